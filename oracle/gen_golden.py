@@ -1,0 +1,796 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE implementation (imported read-only from
+/root/reference) and records inputs / injected randomness / outputs as small .npz fixtures
+under tests/golden/.
+
+Runs ONLY in the build container (the GPU box has no /root/reference).  The fixtures are data:
+inputs, the random draws the reference consumed, and the reference's outputs.  No reference
+source text is stored.
+
+    python oracle/gen_golden.py            # regenerate everything
+    python oracle/gen_golden.py tree nets  # regenerate selected groups
+
+Groups:
+  tree   G1  reference uct_search (mcts.py:302-407) driven by a scripted fake network
+  nets   G2  MuZeroMLPNet / MuZeroBoardGameNet / MuZeroAtariNet initial+recurrent inference
+  search G3  end-to-end uct_search with real (seeded random-weight) networks
+  pipe   G4  pipeline/util/mcts helper functions (incl. the reference's own KATs)
+  env    G5  TicTacToe / Gomoku scripted games (incl. the reference tests' win lines)
+  play   G6  one full reference run_self_play episode on TicTacToe
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+import torch  # noqa: E402
+
+import muzero.mcts as ref_mcts  # noqa: E402
+import muzero.network as ref_network  # noqa: E402
+import muzero.util as ref_util  # noqa: E402
+import muzero.config as ref_config  # noqa: E402
+import muzero.pipeline as ref_pipeline  # noqa: E402
+from muzero.games.tictactoe import TicTacToeEnv  # noqa: E402
+from muzero.games.gomoku import GomokuEnv  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+torch.set_num_threads(1)
+
+
+# --------------------------------------------------------------------------------------------
+# Recording of the global-numpy-RNG draws consumed by the reference (mcts.py:124,245,404).
+# The reference arithmetic is untouched: the real numpy functions are called and their results
+# returned; we only log what they produced.
+# --------------------------------------------------------------------------------------------
+class DrawRecorder:
+    def __init__(self):
+        self.noise = None
+        self.tie_idx = []  # index *within the candidate list* for every tie-break with >1 candidate
+        self.tie_n = []
+        self.final_u = np.nan
+        self.final_action = -1
+        self.visits = None
+        self._orig = {}
+
+    def __enter__(self):
+        self._orig = dict(dirichlet=np.random.dirichlet, choice=np.random.choice, gpp=ref_mcts.generate_play_policy)
+        rec = self
+
+        def dirichlet(alphas, *a, **k):
+            out = rec._orig['dirichlet'](alphas, *a, **k)
+            rec.noise = np.array(out, dtype=np.float64)
+            return out
+
+        def choice(a, *args, **kwargs):
+            p = kwargs.get('p', None)
+            if p is None:
+                cand = np.asarray(a)
+                res = rec._orig['choice'](a, *args, **kwargs)
+                if cand.shape[0] > 1:
+                    rec.tie_idx.append(int(np.where(cand == res)[0][0]))
+                    rec.tie_n.append(int(cand.shape[0]))
+                return res
+            # final sample: recover the uniform double numpy consumed (one random_sample()).
+            st = np.random.get_state()
+            res = rec._orig['choice'](a, *args, **kwargs)
+            st_after = np.random.get_state()
+            np.random.set_state(st)
+            u = np.random.random_sample()
+            assert all(np.array_equal(x, y) for x, y in zip(np.random.get_state()[1:2], st_after[1:2]))
+            np.random.set_state(st_after)
+            rec.final_u = float(u)
+            rec.final_action = int(res)
+            return res
+
+        def gpp(visits_count, temperature):
+            rec.visits = np.array(visits_count, dtype=np.int64)
+            return rec._orig['gpp'](visits_count, temperature)
+
+        np.random.dirichlet = dirichlet
+        np.random.choice = choice
+        ref_mcts.generate_play_policy = gpp
+        return self
+
+    def __exit__(self, *exc):
+        np.random.dirichlet = self._orig['dirichlet']
+        np.random.choice = self._orig['choice']
+        ref_mcts.generate_play_policy = self._orig['gpp']
+
+    def as_dict(self, A, max_ties):
+        assert len(self.tie_idx) <= max_ties, (len(self.tie_idx), max_ties)
+        u_tie = np.full((max_ties,), 0.5, dtype=np.float64)
+        for i, (idx, n) in enumerate(zip(self.tie_idx, self.tie_n)):
+            u_tie[i] = (idx + 0.5) / n
+        return dict(
+            noise=self.noise if self.noise is not None else np.zeros((A,), np.float64),
+            has_noise=np.int32(self.noise is not None),
+            u_tie=u_tie,
+            n_tie=np.int32(len(self.tie_idx)),
+            u_final=np.float64(self.final_u if np.isfinite(self.final_u) else 0.5),
+            visits=self.visits.astype(np.int32),
+        )
+
+
+def make_config(discount, alpha, sims, board, bounds, value_support=1, reward_support=1):
+    return ref_config.MuZeroConfig(
+        discount=discount,
+        dirichlet_alpha=alpha,
+        num_simulations=sims,
+        batch_size=8,
+        td_steps=10,
+        lr_init=0.01,
+        lr_milestones=[10],
+        visit_softmax_temperature_fn=lambda a, b: 1.0,
+        known_bounds=ref_config.KnownBounds(*bounds) if bounds is not None else None,
+        value_support_size=value_support,
+        reward_support_size=reward_support,
+        is_board_game=board,
+    )
+
+
+def cfg_arrays(cfg):
+    kb = cfg.known_bounds
+    return dict(
+        discount=np.float64(cfg.discount),
+        alpha=np.float64(cfg.root_dirichlet_alpha),
+        eps=np.float64(cfg.root_exploration_eps),
+        sims=np.int32(cfg.num_simulations),
+        board=np.int32(cfg.is_board_game),
+        has_bounds=np.int32(kb is not None),
+        kb_min=np.float64(kb.min if kb else 0.0),
+        kb_max=np.float64(kb.max if kb else 0.0),
+        pb_c_base=np.float64(cfg.pb_c_base),
+        pb_c_init=np.float64(cfg.pb_c_init),
+    )
+
+
+# --------------------------------------------------------------------------------------------
+# G1: tree-only.  A fake network scripts (value, reward) per simulation and labels every node's
+# hidden state with its creation index, so the (parent, action) chosen by every simulation can
+# be read back from the arguments of recurrent_inference.
+# --------------------------------------------------------------------------------------------
+class ScriptedNet:
+    def __init__(self, pi0, values, rewards):
+        self.pi0 = pi0.astype(np.float32)
+        self.values = values
+        self.rewards = rewards
+        self.calls = 0
+        self.trace_parent = []
+        self.trace_action = []
+
+    def initial_inference(self, x):
+        return ref_network.NetworkOutputs(
+            hidden_state=np.array([0.0], dtype=np.float32), reward=0.0, pi_probs=self.pi0.copy(), value=0.123
+        )
+
+    def recurrent_inference(self, hidden_state, action):
+        s = self.calls
+        self.calls += 1
+        self.trace_parent.append(int(hidden_state.reshape(-1)[0].item()))
+        self.trace_action.append(int(action.reshape(-1)[0].item()))
+        # value / reward arrive in the tree as Python floats holding float32 values (network.py:107-108).
+        return ref_network.NetworkOutputs(
+            hidden_state=np.array([float(s + 1)], dtype=np.float32),
+            reward=float(np.float32(self.rewards[s])),
+            pi_probs=self.pi0.copy(),
+            value=float(np.float32(self.values[s])),
+        )
+
+
+def gen_tree():
+    rng = np.random.RandomState(1234)
+    cases = []
+    spec = [
+        # A, S, board, bounds, discount, alpha, deterministic, temperature, players, mask_kind, value_kind
+        (2, 50, False, None, 0.997, 0.25, False, 1.0, (1, 1), 'all', 'positive'),
+        (2, 50, False, None, 0.997, 0.25, False, 0.5, (1, 1), 'all', 'positive'),
+        (2, 50, False, None, 0.997, 0.25, True, 0.25, (1, 1), 'all', 'positive'),
+        (2, 50, False, None, 0.997, 0.25, False, 0.0, (1, 1), 'all', 'mixed'),
+        (4, 50, False, None, 0.997, 0.25, False, 1.0, (1, 1), 'all', 'mixed'),
+        (4, 30, False, None, 0.997, 0.25, True, 1.0, (1, 1), 'random', 'mixed'),
+        (6, 30, False, None, 0.997, 0.25, False, 0.25, (1, 1), 'all', 'positive'),
+        (10, 25, True, (-1, 1), 1.0, 0.25, False, 1.0, (1, 2), 'all', 'unit'),
+        (10, 25, True, (-1, 1), 1.0, 0.25, False, 0.1, (2, 1), 'random', 'unit'),
+        (10, 25, True, (-1, 1), 1.0, 0.25, True, 0.1, (1, 2), 'random', 'unit'),
+        (10, 25, True, (-1, 1), 1.0, 0.25, False, 1.0, (1, 2), 'random', 'big'),  # values escape the known bounds
+        (10, 25, True, None, 1.0, 0.25, False, 1.0, (2, 1), 'random', 'unit'),
+        (10, 40, True, (-1, 1), 1.0, 0.0, False, 1.0, (1, 2), 'all', 'zero'),  # alpha=0: no noise, all-zero values => many ties
+        (10, 12, False, None, 0.9, 0.3, False, 0.3, (1, 1), 'random', 'mixed'),  # non-integer exponent 1/T
+        (3, 1, False, None, 0.997, 0.25, False, 1.0, (1, 1), 'all', 'mixed'),  # single simulation
+        (10, 40, True, (-1, 1), 1.0, 0.0, False, 1.0, (1, 2), 'all', 'zero_uniform'),  # uniform prior + zero values: ties at every level
+        (4, 30, False, None, 0.997, 0.0, True, 1.0, (1, 1), 'all', 'zero_uniform'),  # same, deterministic (float32 prior path)
+        (10, 25, True, (-1, 1), 1.0, 0.25, True, 0.0, (1, 2), 'random', 'zero_uniform'),
+        (226, 60, True, (-1, 1), 1.0, 0.03, False, 1.0, (1, 2), 'random', 'unit'),
+        (226, 40, True, (-1, 1), 1.0, 0.03, True, 0.1, (2, 1), 'all', 'unit'),
+        (82, 30, True, (-1, 1), 1.0, 0.03, False, 0.1, (1, 2), 'random', 'unit'),
+    ]
+    # add a few randomised repeats of the two benchmark shapes
+    for r in range(6):
+        spec.append((2, 50, False, None, 0.997, 0.25, False, 1.0, (1, 1), 'all', 'positive'))
+        spec.append((10, 25, True, (-1, 1), 1.0, 0.25, False, 1.0 if r % 2 else 0.1, (1 + r % 2, 2 - r % 2), 'random', 'unit'))
+
+    out = {}
+    for ci, (A, S, board, bounds, disc, alpha, det, T, players, mask_kind, vkind) in enumerate(spec):
+        cfg = make_config(disc, alpha, S, board, bounds)
+        logits = rng.randn(A).astype(np.float32) * 1.5
+        if vkind == 'zero_uniform':
+            logits[:] = 0.0
+        pi0 = torch.softmax(torch.from_numpy(logits), dim=0).numpy()
+        if vkind == 'positive':
+            values = rng.uniform(0.0, 12.0, size=S)
+            rewards = rng.uniform(0.0, 1.5, size=S)
+        elif vkind == 'mixed':
+            values = rng.uniform(-5.0, 5.0, size=S)
+            rewards = rng.uniform(-1.0, 1.0, size=S)
+        elif vkind == 'unit':
+            values = rng.uniform(-1.0, 1.0, size=S)
+            rewards = np.where(rng.rand(S) < 0.2, rng.uniform(-1, 1, size=S), 0.0)
+        elif vkind == 'big':
+            values = rng.uniform(-3.0, 3.0, size=S)
+            rewards = rng.uniform(-2.0, 2.0, size=S)
+        else:
+            values = np.zeros(S)
+            rewards = np.zeros(S)
+        values = values.astype(np.float32)
+        rewards = rewards.astype(np.float32)
+        if mask_kind == 'all':
+            mask = np.ones(A, dtype=bool)
+        else:
+            mask = rng.rand(A) < 0.6
+            mask[rng.randint(A)] = True
+            if mask.sum() < 2 and A > 1:
+                mask[(np.argmax(mask) + 1) % A] = True
+        net = ScriptedNet(pi0, values, rewards)
+        np.random.seed(1000 + ci)
+        with DrawRecorder() as rec:
+            action, pi, root_value = ref_mcts.uct_search(
+                state=np.zeros((1,), np.float32),
+                network=net,
+                device=torch.device('cpu'),
+                config=cfg,
+                temperature=float(T),
+                actions_mask=mask,
+                current_player=players[0],
+                opponent_player=players[1],
+                deterministic=det,
+            )
+        d = dict(
+            A=np.int32(A),
+            pi0=pi0,
+            values=values,
+            rewards=rewards,
+            mask=mask.astype(np.uint8),
+            temperature=np.float64(T),
+            deterministic=np.int32(det),
+            cur_player=np.int32(players[0]),
+            opp_player=np.int32(players[1]),
+            trace_parent=np.array(net.trace_parent, np.int32),
+            trace_action=np.array(net.trace_action, np.int32),
+            out_action=np.int32(action),
+            out_pi=np.asarray(pi, np.float64),
+            out_root_value=np.float64(root_value),
+        )
+        d.update(cfg_arrays(cfg))
+        d.update(rec.as_dict(A, max_ties=4 * S + 8))
+        for k, v in d.items():
+            out[f'c{ci}_{k}'] = v
+        cases.append(ci)
+    out['num_cases'] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'tree_cases.npz'), **out)
+    print(f'tree: {len(cases)} cases')
+
+
+# --------------------------------------------------------------------------------------------
+# Seeded weights: fixtures only store the seed; tests/helpers.py regenerates identical weights.
+# --------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tests'))
+from helpers import MLP_CASES, CONV_CASES, seeded_state_dict  # noqa: E402
+import helpers  # noqa: E402
+
+
+def _infer_case(net, obs, actions, prefix, out):
+    """Run reference initial_inference on obs then a chain of recurrent_inference with `actions`."""
+    with torch.no_grad():
+        o = net.initial_inference(torch.from_numpy(obs).to(torch.float32)[None, ...])
+    out[f'{prefix}_obs'] = obs
+    out[f'{prefix}_init_hidden'] = np.asarray(o.hidden_state, np.float32)
+    out[f'{prefix}_init_pi'] = np.asarray(o.pi_probs, np.float32)
+    out[f'{prefix}_init_value'] = np.float32(o.value)
+    out[f'{prefix}_init_reward'] = np.float32(o.reward)
+    h = o.hidden_state
+    hs, rs_, vs, ps = [], [], [], []
+    for a in actions:
+        with torch.no_grad():
+            o = net.recurrent_inference(torch.from_numpy(h)[None, ...], torch.tensor([[int(a)]], dtype=torch.long))
+        h = o.hidden_state
+        hs.append(np.asarray(h, np.float32))
+        rs_.append(np.float32(o.reward))
+        vs.append(np.float32(o.value))
+        ps.append(np.asarray(o.pi_probs, np.float32))
+    out[f'{prefix}_actions'] = np.asarray(actions, np.int32)
+    out[f'{prefix}_rec_hidden'] = np.stack(hs)
+    out[f'{prefix}_rec_reward'] = np.asarray(rs_, np.float32)
+    out[f'{prefix}_rec_value'] = np.asarray(vs, np.float32)
+    out[f'{prefix}_rec_pi'] = np.stack(ps)
+
+
+def build_mlp(case):
+    return helpers.build_mlp(case, ref_network)
+
+
+def build_conv(case):
+    return helpers.build_conv(case, ref_network)
+
+
+def gen_nets():
+    rng = np.random.RandomState(77)
+    out = {}
+    for case in MLP_CASES:
+        name, ishape, A = case[0], case[1], case[2]
+        net = build_mlp(case)
+        for j in range(3):
+            obs = rng.uniform(-1.0, 1.0, size=ishape).astype(np.float32)
+            actions = rng.randint(0, A, size=6)
+            _infer_case(net, obs, actions, f'mlp_{name}_{j}', out)
+    for case in CONV_CASES:
+        name, kind, ishape, A = case[0], case[1], case[2], case[3]
+        net = build_conv(case)
+        for j in range(2):
+            if kind == 'board':
+                obs = (rng.rand(*ishape) < 0.3).astype(np.float32)
+            else:
+                obs = rng.uniform(0.0, 255.0, size=ishape).astype(np.float32)
+            actions = rng.randint(0, A, size=3)
+            _infer_case(net, obs, actions, f'conv_{name}_{j}', out)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'net_cases.npz'), **out)
+    print('nets: done,', len(out), 'arrays')
+
+
+# --------------------------------------------------------------------------------------------
+# G3: end-to-end search with real networks.
+# --------------------------------------------------------------------------------------------
+def _search_case(net, cfg, obs, mask, players, T, det, seed, prefix, out, A):
+    np.random.seed(seed)
+    with DrawRecorder() as rec:
+        action, pi, root_value = ref_mcts.uct_search(
+            state=obs,
+            network=net,
+            device=torch.device('cpu'),
+            config=cfg,
+            temperature=float(T),
+            actions_mask=mask,
+            current_player=players[0],
+            opponent_player=players[1],
+            deterministic=det,
+        )
+    d = dict(
+        obs=obs,
+        mask=mask.astype(np.uint8),
+        temperature=np.float64(T),
+        deterministic=np.int32(det),
+        cur_player=np.int32(players[0]),
+        opp_player=np.int32(players[1]),
+        out_action=np.int32(action),
+        out_pi=np.asarray(pi, np.float64),
+        out_root_value=np.float64(root_value),
+    )
+    d.update(rec.as_dict(A, max_ties=4 * cfg.num_simulations + 8))
+    for k, v in d.items():
+        out[f'{prefix}_{k}'] = v
+
+
+def gen_search():
+    rng = np.random.RandomState(99)
+    out = {}
+    # C2 shape: CartPole MLP (seeded random weights, full size)
+    case = MLP_CASES[0]
+    net = build_mlp(case)
+    cfg = make_config(0.997, 0.25, 50, False, None, 31, 31)
+    for k, v in cfg_arrays(cfg).items():
+        out[f'cartpole_{k}'] = v
+    n = 0
+    for j in range(12):
+        obs = rng.uniform(-0.5, 0.5, size=(4, 5)).astype(np.float32)
+        obs[:, 4] = (rng.randint(0, 2, size=4) + 1) / 2.0
+        T = [1.0, 0.5, 0.25][j % 3]
+        det = (j % 4 == 3)
+        _search_case(net, cfg, obs, np.ones(2, bool), (1, 1), T, det, 500 + j, f'cartpole_{j}', out, 2)
+        n += 1
+    out['cartpole_n'] = np.int32(n)
+    # C3 shape: TicTacToe MLP
+    case = MLP_CASES[2]
+    net = build_mlp(case)
+    cfg = make_config(1.0, 0.25, 25, True, (-1, 1), 1, 1)
+    for k, v in cfg_arrays(cfg).items():
+        out[f'tictactoe_{k}'] = v
+    n = 0
+    for j in range(12):
+        env = TicTacToeEnv()
+        obs = env.reset()
+        for _ in range(rng.randint(0, 5)):
+            legal = np.where(env.actions_mask[:9])[0]
+            obs, _, done, _ = env.step(int(rng.choice(legal)))
+            if done:
+                break
+        if env.is_game_over:
+            env = TicTacToeEnv()
+            obs = env.reset()
+        T = 1.0 if j % 2 == 0 else 0.1
+        det = (j % 5 == 4)
+        _search_case(
+            net, cfg, obs.astype(np.int8), env.actions_mask.copy(), (env.current_player, env.opponent_player), T, det, 700 + j,
+            f'tictactoe_{j}', out, 10,
+        )
+        n += 1
+    out['tictactoe_n'] = np.int32(n)
+    # LunarLander-shaped 4-action MLP
+    case = MLP_CASES[1]
+    net = build_mlp(case)
+    cfg = make_config(0.997, 0.25, 50, False, None, 31, 31)
+    for k, v in cfg_arrays(cfg).items():
+        out[f'lunar_{k}'] = v
+    for j in range(4):
+        obs = rng.uniform(-1, 1, size=(4, 9)).astype(np.float32)
+        _search_case(net, cfg, obs, np.ones(4, bool), (1, 1), 1.0, False, 800 + j, f'lunar_{j}', out, 4)
+    out['lunar_n'] = np.int32(4)
+    # small conv board net (TicTacToe --nouse_mlp_net shape) and small atari net
+    case = CONV_CASES[0]
+    net = build_conv(case)
+    cfg = make_config(1.0, 0.25, 25, True, (-1, 1), 1, 1)
+    for k, v in cfg_arrays(cfg).items():
+        out[f'board3_{k}'] = v
+    for j in range(4):
+        env = TicTacToeEnv()
+        obs = env.reset()
+        for _ in range(j):
+            legal = np.where(env.actions_mask[:9])[0]
+            obs, _, done, _ = env.step(int(rng.choice(legal)))
+        _search_case(
+            net, cfg, obs.astype(np.int8), env.actions_mask.copy(), (env.current_player, env.opponent_player), 1.0, False, 900 + j,
+            f'board3_{j}', out, 10,
+        )
+    out['board3_n'] = np.int32(4)
+    case = CONV_CASES[3]
+    net = build_conv(case)
+    cfg = make_config(0.997, 0.25, 12, False, None, 11, 11)
+    for k, v in cfg_arrays(cfg).items():
+        out[f'atari_s_{k}'] = v
+    for j in range(2):
+        obs = rng.uniform(0, 255, size=(4, 96, 96)).astype(np.float32)
+        _search_case(net, cfg, obs, np.ones(6, bool), (1, 1), 1.0, False, 950 + j, f'atari_s_{j}', out, 6)
+    out['atari_s_n'] = np.int32(2)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'search_cases.npz'), **out)
+    print('search: done')
+
+    # Shipped-checkpoint searches (checkpoints cannot travel: these fixtures are only usable in the
+    # build container and are therefore NOT committed; the test that uses them is skipped when
+    # /root/reference is absent).
+
+
+# --------------------------------------------------------------------------------------------
+# G4: helpers
+# --------------------------------------------------------------------------------------------
+def gen_pipe():
+    rng = np.random.RandomState(5)
+    out = {}
+    # the reference's own KATs (tests/pipeline_test.py:24-53)
+    out['nstep_kat1_rewards'] = np.ones(5)
+    out['nstep_kat1_roots'] = np.zeros(5)
+    out['nstep_kat1_out'] = np.array(ref_pipeline.compute_n_step_target([1.0] * 5, [0] * 5, 5, 0.997))
+    rv = [0.1 * (i + 1) for i in range(10)]
+    out['nstep_kat2_rewards'] = np.ones(10)
+    out['nstep_kat2_roots'] = np.array(rv)
+    out['nstep_kat2_out'] = np.array(ref_pipeline.compute_n_step_target([1.0] * 10, rv, 5, 0.997))
+    for j, (T, td, disc) in enumerate([(1, 10, 0.997), (7, 10, 0.997), (37, 10, 0.997), (23, 5, 0.9), (12, 0, 1.0), (200, 10, 0.997)]):
+        r = rng.uniform(-1, 2, size=T).astype(np.float32).astype(np.float64)
+        v = rng.uniform(-3, 30, size=T)
+        out[f'nstep_{j}_rewards'] = r
+        out[f'nstep_{j}_roots'] = v
+        out[f'nstep_{j}_td'] = np.int32(td)
+        out[f'nstep_{j}_discount'] = np.float64(disc)
+        out[f'nstep_{j}_out'] = np.array(ref_pipeline.compute_n_step_target(list(r), list(v), td, disc))
+    out['nstep_n'] = np.int32(6)
+    # mc return
+    mc = [
+        ([0, 0, 0, 0, 1.0], [1, 2, 1, 2, 1]),
+        ([0, 0, 0, -1.0], [1, 2, 1, 2]),
+        ([0, 0, 0, 0, 0, 0, 0, 0, 0.0], [1, 2, 1, 2, 1, 2, 1, 2, 1]),
+        ([1.0], [2]),
+        ([0, 0, 0, 0, 0, 1.0], [1, 2, 1, 2, 1, 2]),
+    ]
+    for j, (r, p) in enumerate(mc):
+        out[f'mc_{j}_rewards'] = np.array(r, np.float64)
+        out[f'mc_{j}_players'] = np.array(p, np.int32)
+        out[f'mc_{j}_out'] = np.array(ref_pipeline.compute_mc_return_target(list(r), list(p)), np.float64)
+    out['mc_n'] = np.int32(len(mc))
+    # make_unroll_sequence
+    for j, (T, A, oshape) in enumerate([(1, 2, (4, 5)), (4, 2, (4, 5)), (9, 10, (9, 3, 3)), (13, 4, (4, 9))]):
+        obs = [rng.uniform(-1, 1, size=oshape).astype(np.float32) for _ in range(T)]
+        actions = [int(x) for x in rng.randint(0, A, size=T)]
+        rewards = [float(x) for x in rng.uniform(-1, 1, size=T)]
+        pis = []
+        for _ in range(T):
+            p = rng.rand(A)
+            pis.append(p / p.sum())
+        values = [float(x) for x in rng.uniform(-2, 2, size=T)]
+        prios = np.abs(rng.randn(T))
+        out[f'unroll_{j}_obs'] = np.stack(obs)
+        out[f'unroll_{j}_actions'] = np.array(actions, np.int32)
+        out[f'unroll_{j}_rewards'] = np.array(rewards, np.float64)
+        out[f'unroll_{j}_pis'] = np.stack(pis)
+        out[f'unroll_{j}_values'] = np.array(values, np.float64)
+        out[f'unroll_{j}_prios'] = prios
+        seq = list(ref_pipeline.make_unroll_sequence(list(obs), list(actions), list(rewards), list(pis), list(values), prios, 5))
+        out[f'unroll_{j}_out_state'] = np.stack([t.state for t, _ in seq])
+        out[f'unroll_{j}_out_action'] = np.stack([t.action for t, _ in seq])
+        out[f'unroll_{j}_out_reward'] = np.stack([t.reward for t, _ in seq])
+        out[f'unroll_{j}_out_value'] = np.stack([t.value for t, _ in seq])
+        out[f'unroll_{j}_out_pi'] = np.stack([t.pi_prob for t, _ in seq])
+        out[f'unroll_{j}_out_prio'] = np.array([p for _, p in seq], np.float64)
+    out['unroll_n'] = np.int32(4)
+    # generate_play_policy
+    j = 0
+    for A in (2, 4, 10, 226):
+        for T in (0.0, 0.1, 0.25, 0.3, 0.5, 0.7, 1.0):
+            v = rng.randint(0, 60, size=A).astype(np.int32)
+            v[rng.randint(A)] += 1
+            out[f'policy_{j}_visits'] = v
+            out[f'policy_{j}_T'] = np.float64(T)
+            out[f'policy_{j}_out'] = ref_mcts.generate_play_policy(v, float(T))
+            j += 1
+    out['policy_n'] = np.int32(j)
+    # add_dirichlet_noise + set_illegal_action_probs_to_zero (f32 prior -> f64 noised prior)
+    j = 0
+    for A in (2, 4, 10, 82, 226):
+        for alpha in (0.25, 0.03):
+            p = torch.softmax(torch.from_numpy(rng.randn(A).astype(np.float32)), 0).numpy()
+            np.random.seed(40 + j)
+            with DrawRecorder() as rec:
+                noised = ref_mcts.add_dirichlet_noise(p, eps=0.25, alpha=alpha)
+            mask = rng.rand(A) < 0.7
+            mask[0] = True
+            masked = ref_mcts.set_illegal_action_probs_to_zero(mask, noised)
+            masked32 = ref_mcts.set_illegal_action_probs_to_zero(mask, p)
+            out[f'noise_{j}_p'] = p
+            out[f'noise_{j}_noise'] = rec.noise
+            out[f'noise_{j}_noised'] = noised
+            out[f'noise_{j}_mask'] = mask.astype(np.uint8)
+            out[f'noise_{j}_masked'] = masked
+            out[f'noise_{j}_masked32'] = masked32
+            assert noised.dtype == np.float64 and masked.dtype == np.float64 and masked32.dtype == np.float32
+            j += 1
+    out['noise_n'] = np.int32(j)
+    # util.py: the reference KAT (tests/util_test.py:25-48) and sweeps
+    x = torch.tensor([[3.7], [2.3]], dtype=torch.float32)
+    out['twohot_kat_x'] = x.numpy()
+    out['twohot_kat_out'] = ref_util.transform_to_2hot(x, -5, 5, 11).numpy()
+    xs = torch.from_numpy(np.concatenate([np.linspace(-400, 400, 161), rng.uniform(-20, 20, 200), [0.0, 1e-6, -1e-6]]).astype(np.float32))
+    out['xform_x'] = xs.numpy()
+    out['xform_hyperbolic'] = ref_util.signed_hyperbolic(xs).numpy()
+    out['xform_parabolic'] = ref_util.signed_parabolic(xs).numpy()
+    for j, S in enumerate((31, 61, 601, 5)):
+        lg = torch.from_numpy((rng.randn(16, S) * 3).astype(np.float32))
+        out[f'logits_{j}_in'] = lg.numpy()
+        out[f'logits_{j}_out'] = ref_util.logits_to_transformed_expected_value(lg, S).numpy()
+        sc = torch.from_numpy(rng.uniform(-(S // 2) * 3.0, (S // 2) * 3.0, size=(4, 5)).astype(np.float32))
+        out[f'cat_{j}_in'] = sc.numpy()
+        out[f'cat_{j}_out'] = ref_util.scalar_to_categorical_probabilities(sc, S).numpy()
+    h = torch.from_numpy(rng.randn(5, 64).astype(np.float32))
+    out['norm_mlp_in'] = h.numpy()
+    out['norm_mlp_out'] = ref_util.normalize_hidden_state(h).numpy()
+    h = torch.from_numpy(rng.randn(2, 8, 3, 3).astype(np.float32))
+    out['norm_conv_in'] = h.numpy()
+    out['norm_conv_out'] = ref_util.normalize_hidden_state(h).numpy()
+    # temperature schedules and config factory attributes (API surface, config.py:106-267)
+    sched = []
+    for fn in ('tictactoe', 'gomoku', 'classic', 'atari'):
+        f = getattr(ref_config, f'{fn}_visit_softmax_temperature_fn')
+        sched.append([f(es, ts) for es in (0, 5, 6, 29, 30, 100) for ts in (0, 29999, 30000, 60000, 499999, 500000, 1000000)])
+    out['temperature_table'] = np.array(sched, np.float64)
+    for fn in ('tictactoe', 'gomoku', 'classic', 'atari'):
+        cfg = getattr(ref_config, f'make_{fn}_config')()
+        fields = ['num_planes', 'num_res_blocks', 'value_support_size', 'reward_support_size', 'hidden_dim', 'num_simulations',
+                  'discount', 'acc_seq_length', 'root_dirichlet_alpha', 'root_exploration_eps', 'pb_c_base', 'pb_c_init',
+                  'num_training_steps', 'checkpoint_interval', 'min_replay_size', 'batch_size', 'unroll_steps', 'td_steps',
+                  'weight_decay', 'momentum', 'max_grad_norm', 'lr_init', 'lr_decay_rate', 'train_delay']
+        out[f'config_{fn}'] = np.array([float(getattr(cfg, f)) for f in fields], np.float64)
+        out[f'config_{fn}_milestones'] = np.array(cfg.lr_milestones, np.float64)
+        out[f'config_{fn}_flags'] = np.array([cfg.clip_grad, cfg.use_tensorboard, cfg.is_board_game, cfg.known_bounds is not None], np.int32)
+    out['config_fields'] = np.array(fields)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'pipe_cases.npz'), **out)
+    print('pipe: done')
+
+
+# --------------------------------------------------------------------------------------------
+# G5: board-game env traces
+# --------------------------------------------------------------------------------------------
+def _play_trace(env, actions, prefix, out):
+    obs0 = env.reset()
+    obs, rew, done, mask, cur, winner = [obs0.astype(np.int8)], [], [], [env.actions_mask.copy()], [env.current_player], []
+    for a in actions:
+        o, r, d, _ = env.step(int(a))
+        obs.append(o.astype(np.int8))
+        rew.append(r)
+        done.append(d)
+        mask.append(env.actions_mask.copy())
+        cur.append(env.current_player)
+        winner.append(0 if env.winner is None else env.winner)
+        if d:
+            break
+    n = len(rew)
+    out[f'{prefix}_actions'] = np.array(actions[:n], np.int32)
+    out[f'{prefix}_obs'] = np.stack(obs)
+    out[f'{prefix}_reward'] = np.array(rew, np.float64)
+    out[f'{prefix}_done'] = np.array(done, np.uint8)
+    out[f'{prefix}_mask'] = np.stack(mask).astype(np.uint8)
+    out[f'{prefix}_cur'] = np.array(cur, np.int32)
+    out[f'{prefix}_winner'] = np.array(winner, np.int32)
+
+
+def gen_env():
+    rng = np.random.RandomState(31)
+    out = {}
+    j = 0
+    # the 8 TicTacToe win lines for each colour (tests/games/tictactoe_test.py:25-34): winner plays the line,
+    # the other side plays the remaining cells in index order.
+    lines = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (0, 3, 6), (1, 4, 7), (2, 5, 8), (0, 4, 8), (2, 4, 6)]
+    for line in lines:
+        for colour in (1, 2):
+            others = [c for c in range(9) if c not in line]
+            # pick filler moves that do not themselves complete a line
+            seq = []
+            li, oi = 0, 0
+            filler = [c for c in others]
+            rng.shuffle(filler)
+            mover_is_winner = (colour == 1)
+            while li < 3:
+                if mover_is_winner:
+                    seq.append(line[li])
+                    li += 1
+                else:
+                    seq.append(filler[oi])
+                    oi += 1
+                mover_is_winner = not mover_is_winner
+            env = TicTacToeEnv()
+            _play_trace(env, seq, f'ttt_{j}', out)
+            j += 1
+    # random legal games incl. resign (action 9, tests/games/boardgame_test.py:42-55) and draws
+    for g in range(24):
+        env = TicTacToeEnv()
+        env.reset()
+        seq = []
+        sim = TicTacToeEnv()
+        sim.reset()
+        while not sim.is_game_over:
+            legal = np.where(sim.actions_mask)[0]
+            if g % 6 != 0:
+                legal = legal[legal != 9]
+            a = int(rng.choice(legal))
+            seq.append(a)
+            sim.step(a)
+        _play_trace(env, seq, f'ttt_{j}', out)
+        j += 1
+    out['ttt_n'] = np.int32(j)
+    # Gomoku: 9x9 (launcher default) and 15x15; num_to_win 5, stack 4 (gomoku/run_training.py)
+    j = 0
+    for board_size in (9, 15):
+        for g in range(5):
+            env = GomokuEnv(board_size=board_size, stack_history=4)
+            env.reset()
+            sim = GomokuEnv(board_size=board_size, stack_history=4)
+            sim.reset()
+            seq = []
+            if g < 3:
+                # scripted five-in-row for black / white along row, column, diagonal
+                base = board_size * 2 + 2
+                step = [1, board_size, board_size + 1][g]
+                win = [base + i * step for i in range(5)]
+                other = [board_size * (board_size - 1) + i * 2 for i in range(5)]
+                black_wins = (g % 2 == 0)
+                wi = oi = 0
+                mover_black = True
+                while wi < 5:
+                    if mover_black == black_wins:
+                        seq.append(win[wi])
+                        wi += 1
+                    else:
+                        seq.append(other[oi])
+                        oi += 1
+                    mover_black = not mover_black
+            else:
+                while not sim.is_game_over and len(seq) < 60:
+                    legal = np.where(sim.actions_mask)[0]
+                    legal = legal[legal != board_size * board_size] if g == 3 else legal
+                    a = int(rng.choice(legal))
+                    seq.append(a)
+                    sim.step(a)
+            _play_trace(env, seq, f'gomoku_{j}', out)
+            out[f'gomoku_{j}_board'] = np.int32(board_size)
+            j += 1
+    out['gomoku_n'] = np.int32(j)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'env_cases.npz'), **out)
+    print('env: done')
+
+
+# --------------------------------------------------------------------------------------------
+# G6: one full reference run_self_play episode (pipeline.py:41-167) on TicTacToe with the
+# seeded MLP; every search's draws are recorded so the episode can be replayed exactly.
+# --------------------------------------------------------------------------------------------
+def gen_play():
+    out = {}
+    for ep, seed in enumerate((4242, 4243, 4244)):
+        case = MLP_CASES[2]
+        net = build_mlp(case)
+        cfg = ref_config.make_tictactoe_config(use_tensorboard=False)
+        env = TicTacToeEnv()
+        records = []
+        searches = []
+
+        class Q:
+            def put(self, item):
+                records.append(item)
+                stop.flag = True
+
+        class Stop:
+            flag = False
+
+            def is_set(self):
+                return self.flag
+
+        stop = Stop()
+        counter = types.SimpleNamespace(value=0)
+        orig_search = ref_pipeline.uct_search
+
+        def logged_search(**kw):
+            with DrawRecorder() as rec:
+                res = orig_search(**kw)
+            d = rec.as_dict(10, max_ties=4 * cfg.num_simulations + 8)
+            d.update(
+                obs=np.asarray(kw['state'], np.int8),
+                mask=np.asarray(kw['actions_mask']).astype(np.uint8).copy(),
+                cur=np.int32(kw['current_player']),
+                opp=np.int32(kw['opponent_player']),
+                T=np.float64(kw['temperature']),
+                action=np.int32(res[0]),
+                pi=np.asarray(res[1], np.float64),
+                root=np.float64(res[2]),
+            )
+            searches.append(d)
+            return res
+
+        ref_pipeline.uct_search = logged_search
+        ref_pipeline.handle_exit_signal = lambda: None
+        np.random.seed(seed)
+        try:
+            ref_pipeline.run_self_play(cfg, 0, net, torch.device('cpu'), env, Q(), counter, stop, None)
+        finally:
+            ref_pipeline.uct_search = orig_search
+        n = len(searches)
+        for k in searches[0].keys():
+            out[f'ep{ep}_search_{k}'] = np.stack([np.asarray(s[k]) for s in searches])
+        out[f'ep{ep}_n_moves'] = np.int32(n)
+        out[f'ep{ep}_tr_state'] = np.stack([t.state for t, _ in records])
+        out[f'ep{ep}_tr_action'] = np.stack([t.action for t, _ in records])
+        out[f'ep{ep}_tr_reward'] = np.stack([t.reward for t, _ in records])
+        out[f'ep{ep}_tr_value'] = np.stack([t.value for t, _ in records])
+        out[f'ep{ep}_tr_pi'] = np.stack([t.pi_prob for t, _ in records])
+        out[f'ep{ep}_tr_priority'] = np.array([p for _, p in records], np.float64)
+    out['n_episodes'] = np.int32(3)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'selfplay_cases.npz'), **out)
+    print('play: done')
+
+
+GROUPS = dict(tree=gen_tree, nets=gen_nets, search=gen_search, pipe=gen_pipe, env=gen_env, play=gen_play)
+
+if __name__ == '__main__':
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    which = sys.argv[1:] or list(GROUPS)
+    for g in which:
+        GROUPS[g]()
