@@ -1,0 +1,138 @@
+/*
+ * mzplanner.h -- C ABI of the MI355X-native MuZero self-play planner (libmzplanner_hip.so).
+ *
+ * This is the drop-in boundary for the planning hot path of michaelnny/muzero.  Each entry point names the
+ * reference interface (file:line under /root/reference/muzero/) it replaces.  Plain C: pointers and sizes only,
+ * status-code returns (0 = ok, <0 = error, text via mz_last_error()), no exceptions cross the boundary,
+ * caller-allocated outputs.  One planner handle per GPU; a handle is NOT thread-safe (one host thread per
+ * handle); the handle owns its HIP stream and all device memory.
+ *
+ * Pointer arguments named h_* are host pointers; d_* are device (HBM) pointers on the planner's GPU.
+ */
+#ifndef MZPLANNER_H
+#define MZPLANNER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_OK 0
+#define MZ_E_INVALID (-1)     /* bad argument / unsupported configuration */
+#define MZ_E_HIP (-2)         /* a HIP runtime call failed */
+#define MZ_E_STATE (-3)       /* call out of order (e.g. search before weights were committed) */
+#define MZ_E_TIES (-4)        /* injected tie-break stream exhausted (parity mode only) */
+#define MZ_E_NOMEM (-5)
+
+#define MZ_NET_MLP 0   /* MuZeroMLPNet        network.py:236-267 */
+#define MZ_NET_BOARD 1 /* MuZeroBoardGameNet  network.py:540-574 */
+#define MZ_NET_ATARI 2 /* MuZeroAtariNet      network.py:501-537 */
+
+#define MZ_ENV_NONE 0
+#define MZ_ENV_CARTPOLE 1  /* CartPole-v1 + StackFrameAndAction(4) + PlayerIdAndActionMaskWrapper, gym_env.py:271-365,436-459 */
+#define MZ_ENV_TICTACTOE 2 /* TicTacToeEnv, games/tictactoe.py + games/env.py */
+
+/* Everything uct_search reads from MuZeroConfig (config.py:51-103) and from the network constructors
+ * (network.py:239-247, 504-512, 543-549), plus planner-only sizing knobs. */
+typedef struct {
+    /* network */
+    int32_t net_kind;            /* MZ_NET_* */
+    int32_t obs_c, obs_h, obs_w; /* observation shape; MLP nets flatten it (network.py:153-154) */
+    int32_t num_actions;
+    int32_t num_planes;
+    int32_t hidden_dim;          /* MLP only */
+    int32_t num_res_blocks;      /* conv nets only */
+    int32_t value_support_size;
+    int32_t reward_support_size;
+    /* search: config.py:58-78 */
+    int32_t num_simulations;
+    double discount;
+    double pb_c_base;
+    double pb_c_init;
+    int32_t is_board_game;
+    int32_t has_known_bounds;
+    double known_bounds_min, known_bounds_max;
+    double root_dirichlet_alpha;
+    double root_exploration_eps;
+    /* planner */
+    int32_t num_envs;  /* capacity B: environments searched in lock-step on this GPU */
+    int32_t max_ties;  /* length of the injected tie-break stream per env (parity mode) */
+    uint64_t seed;     /* Philox key for on-device randomness (production mode) */
+} mz_config;
+
+/* Injected randomness for a batch of searches: replaces the reference's global numpy RNG
+ * (np.random.dirichlet mcts.py:245, np.random.choice mcts.py:124 and :404).  All host pointers.
+ * Passing NULL for the whole struct selects on-device Philox randomness. */
+typedef struct {
+    const double* h_noise;   /* [B, A] Dirichlet samples; NULL => draw on device */
+    const double* h_u_tie;   /* [B, max_ties] uniforms in [0,1): k-th real tie among n candidates picks cand[floor(u*n)] */
+    const double* h_u_final; /* [B] uniform for the final inverse-CDF sample of the play policy */
+} mz_rng_inputs;
+
+typedef struct mz_planner mz_planner;
+
+const char* mz_last_error(void);
+const char* mz_version(void);
+
+/* Lifetime.  Replaces: network construction + .to(device) in the launchers (classic/run_training.py:83-99) and the
+ * per-search allocations of Node objects (mcts.py:75-102). */
+int mz_planner_create(const mz_config* cfg, int device_id, mz_planner** out);
+int mz_planner_destroy(mz_planner* p);
+
+/* Weights.  `name` is a state_dict key of the reference module (SURVEY 8b lists them; e.g.
+ * "dynamics_net.transition_net.0.weight"); data is a host float32 tensor in torch layout; it is copied.
+ * Replaces: actor_network.load_state_dict (pipeline.py:266).  Call mz_planner_commit_params after the last tensor:
+ * it packs weights into MFMA fragment order and folds eval-mode BatchNorm. */
+int mz_planner_set_param(mz_planner* p, const char* name, const float* h_data, const int64_t* shape, int32_t ndim);
+int mz_planner_commit_params(mz_planner* p);
+
+/* MuZeroNet.initial_inference (network.py:62-84), batched.  obs float32 [batch, obs_c*obs_h*obs_w];
+ * outputs hidden [batch, hidden_size], pi [batch, A], value [batch]; reward is identically 0 (network.py:76). */
+int mz_planner_initial_inference(mz_planner* p, int32_t batch, const float* h_obs, float* h_hidden, float* h_pi, float* h_value);
+
+/* MuZeroNet.recurrent_inference (network.py:86-111), batched.  action int32 [batch]. */
+int mz_planner_recurrent_inference(mz_planner* p, int32_t batch, const float* h_hidden, const int32_t* h_action, float* h_hidden_out,
+                                   float* h_reward, float* h_pi, float* h_value);
+int32_t mz_planner_hidden_size(const mz_planner* p);
+
+/* uct_search (mcts.py:302-407) for `batch` independent roots in lock-step.
+ *   h_obs float32 [batch, obs]; h_mask uint8 [batch, A] or NULL (actions_mask=None); players int32 [batch];
+ *   h_temperature float64 [batch]; deterministic as mcts.py:311; rng NULL => on-device randomness.
+ *   outputs: action int32 [batch], pi float64 [batch, A], root_value float64 [batch], visits int32 [batch, A] (may be NULL). */
+int mz_planner_search(mz_planner* p, int32_t batch, const float* h_obs, const uint8_t* h_mask, const int32_t* h_current_player,
+                      const int32_t* h_opponent_player, const double* h_temperature, int32_t deterministic, const mz_rng_inputs* rng,
+                      int32_t* h_action, double* h_pi, double* h_root_value, int32_t* h_visits);
+
+/* Tree-only parity entry: the same search with the network replaced by scripted outputs
+ * (h_pi0 float32 [batch, A]; h_values / h_rewards float32 [batch, num_simulations]: simulation s receives
+ * value[s], reward[s]).  Also returns the (parent node, action) expanded by every simulation.  Test hook for the
+ * tree kernels: mcts.py:369-389 with network outputs injected. */
+int mz_planner_search_scripted(mz_planner* p, int32_t batch, const float* h_pi0, const float* h_values, const float* h_rewards,
+                               const uint8_t* h_mask, const int32_t* h_current_player, const int32_t* h_opponent_player,
+                               const double* h_temperature, int32_t deterministic, const mz_rng_inputs* rng, int32_t* h_action,
+                               double* h_pi, double* h_root_value, int32_t* h_visits, int32_t* h_trace_parent, int32_t* h_trace_action);
+
+/* Device-resident self-play: run_self_play's inner loop (pipeline.py:91-113) for num_envs on-device environments.
+ * mz_selfplay_reset seeds/initialises the envs (h_init_state: CartPole float64 [B,4] or NULL => U(-0.05,0.05) from Philox).
+ * mz_selfplay_step performs ONE lock-step move for all envs: search (num_simulations) -> sample action -> env.step ->
+ * record (obs, action, reward, pi, root_value, player) -> auto-reset finished episodes.  Nothing crosses PCIe. */
+int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* h_init_state);
+int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_moves);
+/* Copy out the records of the last `n_moves` moves (newest last): arrays [n_moves, B, ...]; any pointer may be NULL. */
+int mz_selfplay_read(mz_planner* p, int32_t n_moves, float* h_obs, int32_t* h_action, float* h_reward, double* h_pi,
+                     double* h_root_value, int32_t* h_player, uint8_t* h_done);
+/* counters since reset: [0] env steps, [1] simulations, [2] finished episodes, [3] sum of finished episode lengths */
+int mz_selfplay_counters(mz_planner* p, int64_t out[4]);
+
+/* Measurement hooks (bench.py): HIP-event timing on the planner's own stream.
+ * mz_profile_begin/end bracket a region; mz_profile_end returns elapsed milliseconds and the number of
+ * search-kernel launches inside it (the dominant kernel of the path). */
+int mz_profile_begin(mz_planner* p);
+int mz_profile_end(mz_planner* p, double* elapsed_ms, double* search_kernel_ms, int64_t* search_kernel_launches);
+int mz_planner_synchronize(mz_planner* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

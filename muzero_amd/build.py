@@ -1,0 +1,42 @@
+"""Builds libmzplanner_hip.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m muzero_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerical contract: all fused multiply-adds in
+the kernels are explicit (see csrc/mz_device.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libmzplanner_hip.so')
+SOURCES = ['planner.hip']
+HEADERS = ['mz_device.h', 'mz_mlp.h', 'mz_search.h', 'mz_env.h', os.path.join('..', '..', 'include', 'mzplanner.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17', '-Wall', '-Wno-unused-function',
+         '-Wno-pass-failed']
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + FLAGS + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB_PATH]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

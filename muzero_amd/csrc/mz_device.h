@@ -1,0 +1,235 @@
+// mz_device.h -- device-side scalar helpers shared by the planner kernels (gfx950).
+//
+// Built with -ffp-contract=off: every fused multiply-add below is an explicit fmaf()/fma(); plain a*b+c stays
+// two roundings.  sqrtf() and '/' are IEEE-correct (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mz {
+
+__device__ __forceinline__ float bits2f(uint32_t u) { return __uint_as_float(u); }
+
+// exp() used by every softmax on the path (policy network.py:72,100; value/reward util.py:88).
+// Cephes-style: n = rint(x*log2e), r = x - n*ln2 in two fmaf steps, degree-5 polynomial, scale by 2^n.
+// ~1 ulp; deterministic instruction sequence (no libm, no fast-math).
+__device__ __forceinline__ float expf_det(float x) {
+    if (x > 88.5f) return __uint_as_float(0x7f800000u);
+    if (x < -103.5f) return 0.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    if (ni < -126) {
+        y = y * 5.42101086242752217e-20f;  // 2^-64
+        ni += 64;
+    }
+    if (ni > 127) {
+        y = y * 2.0f;
+        ni -= 1;
+    }
+    return y * bits2f((uint32_t)(ni + 127) << 23);
+}
+
+// signed_parabolic, util.py:25-28 (eps = 1e-3), float32 in the op order of the torch expression.
+__device__ __forceinline__ float signed_parabolic(float x) {
+    float ax = fabsf(x);
+    float t = 1.001f + ax;
+    float u = 0.004f * t;
+    float v = 1.0f + u;
+    float s = sqrtf(v);
+    float z = s / 2.0f / 0.001f - 500.0f;
+    float sq = z * z;
+    float m = sq - 1.0f;
+    float sg = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    return sg * m;
+}
+
+// logits_to_transformed_expected_value, util.py:70-93: softmax -> E[linspace(-(S-1)/2, (S-1)/2, S)] -> signed_parabolic.
+// Sequential float32 sums in index order (the order is part of the numerical contract).  S == 1: identity (MSE heads).
+__device__ inline float logits_to_scalar(const float* lg, int S) {
+    if (S == 1) return lg[0];
+    float m = lg[0];
+    for (int i = 1; i < S; i++) m = lg[i] > m ? lg[i] : m;
+    float sum = 0.0f;
+    for (int i = 0; i < S; i++) sum = sum + expf_det(lg[i] - m);
+    int half = (S - 1) / 2;
+    float x = 0.0f;
+    for (int i = 0; i < S; i++) {
+        float p = expf_det(lg[i] - m) / sum;
+        float t = p * (float)(i - half);
+        x = x + t;
+    }
+    return signed_parabolic(x);
+}
+
+// numpy's np.sum on a contiguous 1-D array (pairwise_sum, numpy/core/src/umath/loops_utils.h.src):
+// the reference normalises the masked prior with it (mcts.py:296) and the play policy (mcts.py:279).
+__device__ inline double np_sum_f64(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r = r + a[i];
+        return r;
+    } else if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] = r[j] + a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res = res + a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        // one level of recursion is enough for n <= 256 (both halves <= 128)
+        double lo, hi;
+        {
+            const double* b = a;
+            int m = n2;
+            double r[8];
+            for (int j = 0; j < 8; j++) r[j] = b[j];
+            int i;
+            for (i = 8; i < m - (m % 8); i += 8)
+                for (int j = 0; j < 8; j++) r[j] = r[j] + b[i + j];
+            lo = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < m; i++) lo = lo + b[i];
+        }
+        {
+            const double* b = a + n2;
+            int m = n - n2;
+            double r[8];
+            for (int j = 0; j < 8; j++) r[j] = b[j];
+            int i;
+            for (i = 8; i < m - (m % 8); i += 8)
+                for (int j = 0; j < 8; j++) r[j] = r[j] + b[i + j];
+            hi = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < m; i++) hi = hi + b[i];
+        }
+        return lo + hi;
+    }
+}
+
+__device__ inline float np_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; i++) r = r + a[i];
+        return r;
+    }
+    // n <= 256 supported (two blocks of <= 128)
+    int n2 = n;
+    const float* b = a;
+    float part[2];
+    int parts = 1;
+    int lens[2] = {n, 0};
+    if (n > 128) {
+        n2 = n / 2;
+        n2 -= n2 % 8;
+        lens[0] = n2;
+        lens[1] = n - n2;
+        parts = 2;
+    }
+    for (int p = 0; p < parts; p++) {
+        int m = lens[p];
+        float r[8];
+        for (int j = 0; j < 8; j++) r[j] = b[j];
+        int i;
+        for (i = 8; i < m - (m % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] = r[j] + b[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < m; i++) res = res + b[i];
+        part[p] = res;
+        b += m;
+    }
+    return parts == 1 ? part[0] : part[0] + part[1];
+}
+
+// ---- Philox4x32-10 counter-based RNG (production-mode randomness; parity mode injects recorded draws) ----
+struct Philox {
+    uint32_t key[2];
+    uint32_t ctr[4];
+    __device__ Philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2) {
+        key[0] = (uint32_t)seed;
+        key[1] = (uint32_t)(seed >> 32);
+        ctr[0] = 0; ctr[1] = c0; ctr[2] = c1; ctr[3] = c2;
+    }
+    __device__ void round4(uint32_t* out) {
+        uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+        uint32_t k0 = key[0], k1 = key[1];
+        for (int i = 0; i < 10; i++) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+            uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+            uint32_t n1 = (uint32_t)p1;
+            uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+            uint32_t n3 = (uint32_t)p0;
+            c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+        ctr[0] += 1;  // next block of the same stream
+    }
+    // uniform double in [0,1) with 53 random bits (same construction as numpy's random_sample: (a>>5, b>>6))
+    __device__ double uniform() {
+        uint32_t r[4];
+        round4(r);
+        return ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
+    }
+};
+
+// standard_gamma(alpha) -- numpy legacy algorithm (alpha < 1: Ahrens-Dieter style rejection as in
+// legacy-distributions.c; alpha == 1: exponential; alpha > 1: Marsaglia-Tsang).  Production noise only.
+__device__ inline double gamma_sample(Philox& g, double alpha) {
+    if (alpha == 1.0) return -log(1.0 - g.uniform());
+    if (alpha < 1.0) {
+        for (int it = 0; it < 256; it++) {
+            double U = g.uniform();
+            double V = -log(1.0 - g.uniform());
+            if (U <= 1.0 - alpha) {
+                double X = pow(U, 1.0 / alpha);
+                if (X <= V) return X;
+            } else {
+                double Y = -log((1.0 - U) / alpha);
+                double X = pow(1.0 - alpha + alpha * Y, 1.0 / alpha);
+                if (X <= V + Y) return X;
+            }
+        }
+        return 0.0;
+    }
+    double b = alpha - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * b);
+    for (int it = 0; it < 256; it++) {
+        double X, V;
+        do {
+            double u1 = g.uniform(), u2 = g.uniform();
+            X = sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2);
+            V = 1.0 + c * X;
+        } while (V <= 0.0);
+        V = V * V * V;
+        double U = g.uniform();
+        if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return b * V;
+        if (log(U) < 0.5 * X * X + b * (1.0 - V + log(V))) return b * V;
+    }
+    return b;
+}
+
+// v ** e for the play policy (mcts.py:276-277): integer exponents (every shipped schedule gives 1, 2, 4 or 5) by
+// repeated multiplication (exact while representable, identical to libm pow there); otherwise ocml pow.
+__device__ inline double pow_policy(double v, double e) {
+    if (e == 1.0) return v;
+    if (e == 2.0) return v * v;
+    if (e == 3.0) return v * v * v;
+    if (e == 4.0) { double s = v * v; return s * s; }
+    if (e == 5.0) { double s = v * v; return s * s * v; }
+    return pow(v, e);
+}
+
+}  // namespace mz

@@ -1,0 +1,431 @@
+// mz_search.h -- the fused, persistent-per-move search kernel for MLP-class configs (CartPole / LunarLander /
+// TicTacToe shapes): one 256-thread workgroup owns 16 environments and runs ALL num_simulations of their searches
+// (mcts.py:352-407) without leaving the CU:
+//   * the 16 trees (node statistics, child tables, root priors, min-max stats) live in LDS as structure-of-arrays;
+//   * selection (mcts.py:104-127,159-200) uses 16 lanes per environment (lanes over actions), wavefront-segment
+//     max/ballot reductions for the pUCT argmax and its tie set;
+//   * the leaf evaluation (network.py:86-111) is the MFMA tile pipeline of mz_mlp.h, weights streamed from L2;
+//   * expansion + backup (mcts.py:129-157,386-389) walk the LDS tree in float64 exactly like the reference's
+//     Python floats; hidden states go to an HBM node store hidden[env][node][H] (L2/MALL resident).
+// Environments are independent (mcts.py has no cross-env state), so no inter-workgroup communication exists.
+#pragma once
+#include "mz_mlp.h"
+
+namespace mz {
+
+struct __attribute__((aligned(8))) TreeNode {  // 32 bytes
+    double W;       // sum of backed-up values          (Node.W, mcts.py:69)
+    double vq;      // reward + discount * (+/-)Q, refreshed by backup; it is both the min-max update value
+                    // (mcts.py:147-150) and the un-normalised child_Q term (mcts.py:174)
+    int N;          // visit count                       (Node.N, mcts.py:68)
+    float reward;   // float32 network output, widened on use (mcts.py:96)
+    short parent;
+    short move;
+    int player;
+};
+
+struct SearchParams {
+    MlpNet net;
+    MlpLds o;
+    // LDS byte offsets of the tree part
+    int t_nodes, t_child, t_prior, t_pi0, t_mm, t_sel, t_ftab, t_ptr, t_tmp;
+    int lds_bytes;
+    // search configuration (config.py:58-78)
+    int S, A, NN;
+    double discount;
+    int board, has_bounds;
+    double kb_min, kb_max, alpha, eps;
+    int deterministic, has_mask;
+    int noise_mode;  // 0: none, 1: injected, 2: Philox Dirichlet on device
+    int rng_mode;    // 0: injected tie/final uniforms, 1: Philox
+    int max_ties;
+    // batch
+    int B;
+    const float* obs;       // [B][in_dim]
+    const unsigned char* mask;  // [B][A]
+    const int* cur;
+    const int* opp;
+    const double* temperature;
+    const double* noise;    // [B][A]
+    const double* u_tie;    // [B][max_ties]
+    const double* u_final;  // [B]
+    float* hidden;          // [B][NN][H] node store
+    const double* ftab;     // [(S+1)][(S+1)]: ((log((N+base+1)/base)+c_init)*sqrt(N)) / (n_child+1), host-computed float64
+    int* out_action;
+    double* out_pi;
+    double* out_root;
+    int* out_visits;
+    int* err;
+    // scripted-network test hook
+    const float* s_pi0;
+    const float* s_values;
+    const float* s_rewards;
+    int* trace_parent;
+    int* trace_action;
+    unsigned long long seed;
+    unsigned int move_counter;
+    unsigned int env_offset;  // global id of env 0 (multi-GPU sharding: Philox streams are keyed by global env id)
+};
+
+__device__ __forceinline__ TreeNode* node_at(unsigned char* smem, const SearchParams& P, int e, int i) {
+    return reinterpret_cast<TreeNode*>(smem + P.t_nodes) + (e * P.NN + i);
+}
+__device__ __forceinline__ short* child_row(unsigned char* smem, const SearchParams& P, int e, int i) {
+    return reinterpret_cast<short*>(smem + P.t_child) + (size_t)(e * P.NN + i) * P.A;
+}
+
+__device__ __forceinline__ int nth_set_bit(unsigned m, int idx) {
+    for (int i = 0; i < idx; i++) m &= m - 1;
+    return __ffs(m) - 1;
+}
+
+constexpr int MAX_CH = 4;  // action chunks of 16 lanes: A <= 64 in the LDS-resident kernel
+
+// One descent from the root to an unexpanded child for all 16 envs of the tile (mcts.py:372-379).
+// Every lane of an env's 16-lane segment ends with identical (segment-uniform) results.
+__device__ __forceinline__ void tree_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g) {
+    const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
+    const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
+    const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
+    double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
+    int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
+    const double mn = mm[0], mx = mm[1];
+    const bool norm = mx > mn;
+    const bool prior_f32 = (P.noise_mode == 0);
+    const int nch = (P.A + 15) >> 4;
+    int n = 0, cp = env_ok ? P.cur[env_g] : 0, op = env_ok ? P.opp[env_g] : 0;
+    int ties = sel[3];
+    bool done = !env_ok;
+    int lp = 0, la = 0, lpl = 0, depth = 0;
+    while (__any(!done)) {
+        const int Nn = node_at(smem, P, e, n)->N;
+        const double* frow = ftab + Nn * (P.S + 1);
+        const short* crow = child_row(smem, P, e, n);
+        float u[MAX_CH];
+        float best = __uint_as_float(0xff800000u);
+#pragma unroll
+        for (int ch = 0; ch < MAX_CH; ch++) {
+            u[ch] = __uint_as_float(0xff800000u);
+            const int a = ch * 16 + a0;
+            if (ch < nch && a < P.A) {
+                const int c = crow[a];
+                int cn = 0;
+                float qa = 0.0f;  // child_Q, mcts.py:159-178
+                if (c >= 0) {
+                    const TreeNode* cd = node_at(smem, P, e, c);
+                    cn = cd->N;
+                    if (cn > 0) {
+                        double v = cd->vq;
+                        if (norm) v = (v - mn) / (mx - mn);
+                        qa = (float)v;
+                    }
+                }
+                const double f = frow[cn];  // child_U, mcts.py:180-200
+                const float ua = prior_f32 ? ((float)prior[a] * (float)f) : (float)(prior[a] * f);
+                u[ch] = qa + ua;
+                best = u[ch] > best ? u[ch] : best;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            const float o = __shfl_xor(best, m, 64);
+            best = o > best ? o : best;
+        }
+        // tie set in ascending action order (np.where(ucb == max), mcts.py:124)
+        unsigned msk[MAX_CH];
+        int total = 0;
+#pragma unroll
+        for (int ch = 0; ch < MAX_CH; ch++) {
+            const int a = ch * 16 + a0;
+            const bool eq = (ch < nch) && (a < P.A) && (u[ch] == best);
+            const unsigned long long bal = __ballot(eq);
+            msk[ch] = (unsigned)(bal >> (16 * seg)) & 0xffffu;
+            total += __popc(msk[ch]);
+        }
+        int pick = 0;
+        if (!done && total > 1) {  // np.random.choice consumes randomness only when there is a real tie
+            double uu;
+            if (P.rng_mode == 0) {
+                if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
+                else { uu = 0.5; if (a0 == 0) atomicExch(P.err, 4); }
+            } else {
+                Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
+                uu = g.uniform();
+            }
+            ties++;
+            pick = (int)floor(uu * (double)total);
+            pick = pick >= total ? total - 1 : pick;
+        }
+        int a_sel = 0, cum = 0;
+        bool found = false;
+#pragma unroll
+        for (int ch = 0; ch < MAX_CH; ch++) {
+            const int c = __popc(msk[ch]);
+            if (!found && pick < cum + c) {
+                a_sel = ch * 16 + nth_set_bit(msk[ch], pick - cum);
+                found = true;
+            }
+            cum += c;
+        }
+        const int t = cp; cp = op; op = t;  // mcts.py:379
+        if (!done) {
+            const int c = crow[a_sel];
+            depth++;
+            if (c < 0 || depth > P.NN) {
+                done = true;
+                lp = n; la = a_sel; lpl = cp;
+            } else {
+                n = c;
+            }
+        }
+    }
+    if (a0 == 0) {
+        sel[0] = lp; sel[1] = la; sel[2] = lpl; sel[3] = ties;
+    }
+}
+
+// expand the selected leaf and back its value up to the root (mcts.py:386-389, 129-157); one lane per env
+__device__ __forceinline__ void tree_expand_backup(unsigned char* smem, const SearchParams& P, int e, int s, float r32, float v32) {
+    int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
+    double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
+    const int n = sel[0], a = sel[1], cp = sel[2], nw = s + 1;
+    child_row(smem, P, e, n)[a] = (short)nw;
+    TreeNode* nd = node_at(smem, P, e, nw);
+    nd->W = 0.0; nd->vq = 0.0; nd->N = 0; nd->reward = r32; nd->parent = (short)n; nd->move = (short)a; nd->player = cp;
+    double val = (double)v32, mn = mm[0], mx = mm[1];
+    const double g = P.discount;
+    for (int c = nw; c >= 0;) {
+        TreeNode* x = node_at(smem, P, e, c);
+        const bool same = (x->player == cp);
+        const double W = x->W + (same ? val : -val);
+        const int N = x->N + 1;
+        const double rw = (double)x->reward;
+        const double Q = W / (double)N;
+        const double v = P.board ? (rw + g * -Q) : (rw + g * Q);
+        x->W = W; x->N = N; x->vq = v;
+        mx = v > mx ? v : mx;
+        mn = v < mn ? v : mn;
+        val = (P.board && same) ? (-rw + g * val) : (rw + g * val);
+        c = x->parent;
+    }
+    mm[0] = mn; mm[1] = mx;
+}
+
+// root prior: Dirichlet mix + illegal-action mask + renormalisation (mcts.py:357-365, 244-247, 293-299); one lane per env
+__device__ __forceinline__ void root_prior(unsigned char* smem, const SearchParams& P, int e, int env_g) {
+    double* prior = reinterpret_cast<double*>(smem + P.t_prior) + e * P.A;
+    float* pi0 = reinterpret_cast<float*>(smem + P.t_pi0) + e * P.A;
+    double* tmp = reinterpret_cast<double*>(smem + P.t_tmp) + e * P.A;
+    const unsigned char* mk = P.has_mask ? P.mask + (size_t)env_g * P.A : nullptr;
+    const int A = P.A;
+    if (P.noise_mode != 0) {
+        if (P.noise_mode == 1) {
+            for (int a = 0; a < A; a++) tmp[a] = P.noise[(size_t)env_g * A + a];
+        } else {
+            Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x20000000u);
+            double s = 0.0;
+            for (int a = 0; a < A; a++) { tmp[a] = gamma_sample(g, P.alpha); s += tmp[a]; }
+            for (int a = 0; a < A; a++) tmp[a] = s > 0.0 ? tmp[a] / s : 1.0 / (double)A;
+        }
+        const float om = (float)(1.0 - P.eps);
+        for (int a = 0; a < A; a++) {
+            const float t = om * pi0[a];        // float32 product (python scalar * float32 array)
+            const double en = P.eps * tmp[a];   // float64
+            prior[a] = (double)t + en;
+        }
+        if (mk) {
+            for (int a = 0; a < A; a++)
+                if (!mk[a]) prior[a] = 0.0;
+            const double s = np_sum_f64(prior, A);
+            if (s > 0)
+                for (int a = 0; a < A; a++) prior[a] = prior[a] / s;
+        }
+    } else {
+        if (mk) {
+            for (int a = 0; a < A; a++)
+                if (!mk[a]) pi0[a] = 0.0f;
+            const float s = np_sum_f32(pi0, A);
+            if (s > 0)
+                for (int a = 0; a < A; a++) pi0[a] = pi0[a] / s;
+        }
+        for (int a = 0; a < A; a++) prior[a] = (double)pi0[a];
+    }
+}
+
+// play: visit counts -> policy -> action (mcts.py:391-407); one lane per env
+__device__ __forceinline__ void tree_finish(unsigned char* smem, const SearchParams& P, int e, int env_g) {
+    double* tmp = reinterpret_cast<double*>(smem + P.t_tmp) + e * P.A;
+    const unsigned char* mk = P.has_mask ? P.mask + (size_t)env_g * P.A : nullptr;
+    const short* crow = child_row(smem, P, e, 0);
+    const int A = P.A;
+    const double T = P.temperature[env_g];
+    double ex = 1.0;
+    if (T > 0.0) {
+        ex = 1.0 / T;
+        ex = ex < 5.0 ? ex : 5.0;
+        ex = ex > 1.0 ? ex : 1.0;
+    }
+    int best = 0, bestv = -1;
+    for (int a = 0; a < A; a++) {
+        const int c = crow[a];
+        int v = c >= 0 ? node_at(smem, P, e, c)->N : 0;
+        if (mk && !mk[a]) v = 0;
+        if (P.out_visits) P.out_visits[(size_t)env_g * A + a] = v;
+        if (v > bestv) { bestv = v; best = a; }
+        tmp[a] = (T > 0.0) ? pow_policy((double)v, ex) : (double)v;
+    }
+    const double s = np_sum_f64(tmp, A);
+    double* pi = P.out_pi + (size_t)env_g * A;
+    for (int a = 0; a < A; a++) pi[a] = tmp[a] / s;
+    int action = best;
+    if (!P.deterministic) {
+        double uu;
+        if (P.rng_mode == 0) uu = P.u_final[env_g];
+        else {
+            Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x30000000u);
+            uu = g.uniform();
+        }
+        // np.random.choice(p=pi): cdf = cumsum(pi); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
+        double c = 0.0;
+        for (int a = 0; a < A; a++) { c = c + pi[a]; tmp[a] = c; }
+        const double last = tmp[A - 1];
+        int idx = 0;
+        for (int a = 0; a < A; a++)
+            if (tmp[a] / last <= uu) idx = a + 1;
+        action = idx >= A ? A - 1 : idx;
+    }
+    P.out_action[env_g] = action;
+    const TreeNode* root = node_at(smem, P, e, 0);
+    P.out_root[env_g] = root->N > 0 ? root->W / (double)root->N : 0.0;
+}
+
+template <bool SCRIPTED>
+__global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
+    const int env_g = blockIdx.x * TILE_E + e;
+    const bool env_ok = env_g < P.B;
+    float* pi0 = reinterpret_cast<float*>(smem + P.t_pi0);
+    const float** src = reinterpret_cast<const float**>(smem + P.t_ptr);
+    float** dst = reinterpret_cast<float**>(smem + P.t_ptr) + 16;
+
+    // tables and tree initialisation
+    {
+        double* ft = reinterpret_cast<double*>(smem + P.t_ftab);
+        for (int i = tid; i < (P.S + 1) * (P.S + 1); i += WG_THREADS) ft[i] = P.ftab[i];
+        short* ch = reinterpret_cast<short*>(smem + P.t_child);
+        for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) ch[i] = -1;
+        if (a0 == 0) {
+            TreeNode* r = node_at(smem, P, e, 0);
+            r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
+            r->player = env_ok ? P.cur[env_g] : 0;
+            double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
+            mm[0] = P.has_bounds ? P.kb_min : __longlong_as_double(0x7ff0000000000000LL);   // MinMaxStats, mcts.py:36-38
+            mm[1] = P.has_bounds ? P.kb_max : __longlong_as_double(0xfff0000000000000LL);
+            int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
+            sel[0] = sel[1] = sel[2] = sel[3] = 0;
+            if (!SCRIPTED) {
+                src[e] = env_ok ? P.obs + (size_t)env_g * P.net.in_dim : nullptr;
+                dst[e] = env_ok ? P.hidden + (size_t)env_g * P.NN * P.net.H : nullptr;
+            }
+        }
+    }
+    __syncthreads();
+    if (SCRIPTED) {
+        for (int i = tid; i < TILE_E * P.A; i += WG_THREADS) {
+            const int ee = i / P.A, a = i - ee * P.A, eg = blockIdx.x * TILE_E + ee;
+            pi0[i] = eg < P.B ? P.s_pi0[(size_t)eg * P.A + a] : 1.0f / (float)P.A;
+        }
+    } else {
+        load_obs(P.net, lds + P.o.X, src, tid);
+        __syncthreads();
+        mlp_initial_tile(P.net, P.o, lds, dst, pi0, tid);  // root value is discarded (mcts.py:356-367)
+    }
+    __syncthreads();
+    if (a0 == 0 && env_ok) root_prior(smem, P, e, env_g);
+    __syncthreads();
+
+    for (int s = 0; s < P.S; s++) {
+        tree_select(smem, P, tid, env_ok, env_g);
+        __syncthreads();
+        const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
+        float r32, v32;
+        if (SCRIPTED) {
+            r32 = env_ok ? P.s_rewards[(size_t)env_g * P.S + s] : 0.0f;
+            v32 = env_ok ? P.s_values[(size_t)env_g * P.S + s] : 0.0f;
+            if (a0 == 0 && env_ok) {
+                P.trace_parent[(size_t)env_g * P.S + s] = sel[0];
+                P.trace_action[(size_t)env_g * P.S + s] = sel[1];
+            }
+        } else {
+            int* act = reinterpret_cast<int*>(smem + P.t_sel) + 64;  // [16] leaf actions
+            if (a0 == 0) {
+                float* base = env_ok ? P.hidden + (size_t)env_g * P.NN * P.net.H : nullptr;
+                src[e] = env_ok ? base + (size_t)sel[0] * P.net.H : nullptr;
+                dst[e] = env_ok ? base + (size_t)(s + 1) * P.net.H : nullptr;
+                act[e] = sel[1];
+            }
+            __syncthreads();
+            load_hidden_onehot(P.net, lds + P.o.X, src, act, tid);
+            __syncthreads();
+            mlp_recurrent_tile(P.net, P.o, lds, dst, false, nullptr, tid);
+            r32 = lds[P.o.OUT + e * 4 + 0];
+            v32 = lds[P.o.OUT + e * 4 + 1];
+        }
+        if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
+        __syncthreads();
+    }
+    if (a0 == 0 && env_ok) tree_finish(smem, P, e, env_g);
+}
+
+// ---- stand-alone batched inference (network.py:62-111) on the same tile pipeline ----
+struct InferParams {
+    MlpNet net;
+    MlpLds o;
+    int t_ptr, t_pi, t_act, lds_bytes;
+    int B;
+    const float* in;     // obs [B][in_dim] or hidden [B][H]
+    const int* action;   // [B] (recurrent)
+    float* hidden_out;   // [B][H]
+    float* reward;       // [B]
+    float* value;        // [B]
+    float* pi;           // [B][A]
+};
+
+template <bool INITIAL>
+__global__ __launch_bounds__(WG_THREADS) void k_infer(const InferParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
+    const int env_g = blockIdx.x * TILE_E + e;
+    const bool env_ok = env_g < P.B;
+    const float** src = reinterpret_cast<const float**>(smem + P.t_ptr);
+    float** dst = reinterpret_cast<float**>(smem + P.t_ptr) + 16;
+    float* pi = reinterpret_cast<float*>(smem + P.t_pi);
+    int* act = reinterpret_cast<int*>(smem + P.t_act);
+    if (a0 == 0) {
+        src[e] = env_ok ? P.in + (size_t)env_g * (INITIAL ? P.net.in_dim : P.net.H) : nullptr;
+        dst[e] = env_ok ? P.hidden_out + (size_t)env_g * P.net.H : nullptr;
+        act[e] = (!INITIAL && env_ok) ? P.action[env_g] : 0;
+    }
+    __syncthreads();
+    if (INITIAL) {
+        load_obs(P.net, lds + P.o.X, src, tid);
+        __syncthreads();
+        mlp_initial_tile(P.net, P.o, lds, dst, pi, tid);
+    } else {
+        load_hidden_onehot(P.net, lds + P.o.X, src, act, tid);
+        __syncthreads();
+        mlp_recurrent_tile(P.net, P.o, lds, dst, true, pi, tid);
+    }
+    if (env_ok) {
+        if (a0 == 0) {
+            P.reward[env_g] = lds[P.o.OUT + e * 4 + 0];
+            P.value[env_g] = lds[P.o.OUT + e * 4 + 1];
+        }
+        for (int a = a0; a < P.net.A; a += 16) P.pi[(size_t)env_g * P.net.A + a] = pi[e * P.net.A + a];
+    }
+}
+
+}  // namespace mz

@@ -1,0 +1,587 @@
+// planner.hip -- host side of libmzplanner_hip.so: the C ABI of include/mzplanner.h over the gfx950 kernels
+// in mz_search.h / mz_mlp.h / mz_env.h.  One planner handle == one GPU, one HIP stream, all state in HBM.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mzplanner.h"
+#include "mz_env.h"
+#include "mz_search.h"
+
+using namespace mz;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return fail(MZ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                                      std::to_string(__LINE__) + ")");                                       \
+    } while (0)
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+static const char* kMlpNames[L_COUNT] = {
+    "represent_net.net.0",          "represent_net.net.2",          "dynamics_net.transition_net.0", "dynamics_net.transition_net.2",
+    "dynamics_net.reward_net.0",    "dynamics_net.reward_net.2",    "prediction_net.policy_net.0",   "prediction_net.policy_net.2",
+    "prediction_net.value_net.0",   "prediction_net.value_net.2",
+};
+
+struct mz_planner {
+    mz_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, HostTensor> params;
+    bool committed = false;
+
+    MlpNet net{};
+    MlpLds o{};
+    float* d_w[L_COUNT] = {};
+    float* d_b[L_COUNT] = {};
+    SearchParams sp{};
+    InferParams ip{};
+
+    // per-env device buffers (capacity cfg.num_envs)
+    float* d_obs = nullptr;
+    unsigned char* d_mask = nullptr;
+    int *d_cur = nullptr, *d_opp = nullptr;
+    double* d_temp = nullptr;
+    double *d_noise = nullptr, *d_utie = nullptr, *d_ufinal = nullptr;
+    float* d_hidden = nullptr;
+    double* d_ftab = nullptr;
+    int* d_action = nullptr;
+    double *d_pi = nullptr, *d_root = nullptr;
+    int* d_visits = nullptr;
+    int* d_err = nullptr;
+    // scripted hook
+    float *d_spi0 = nullptr, *d_svalues = nullptr, *d_srewards = nullptr;
+    int *d_tparent = nullptr, *d_taction = nullptr;
+    // inference API buffers
+    float *d_inf_in = nullptr, *d_inf_hidden = nullptr, *d_inf_reward = nullptr, *d_inf_value = nullptr, *d_inf_pi = nullptr;
+    int* d_inf_action = nullptr;
+    int inf_cap = 0;
+
+    // self-play
+    EnvState env{};
+    int env_kind = MZ_ENV_NONE;
+    unsigned int move_counter = 0;
+    int ring_len = 0, ring_pos = 0, ring_count = 0;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    size_t kev_used = 0;
+};
+
+static int obs_dim(const mz_config& c) { return c.obs_c * c.obs_h * c.obs_w; }
+static int pad16(int x) { return (x + 15) & ~15; }
+
+extern "C" const char* mz_last_error(void) { return g_err.c_str(); }
+extern "C" const char* mz_version(void) { return "mzplanner 0.1 (gfx950)"; }
+
+static void compute_layout(mz_planner* p) {
+    const mz_config& c = p->cfg;
+    MlpNet& n = p->net;
+    n.in_dim = obs_dim(c); n.A = c.num_actions; n.P = c.num_planes; n.H = c.hidden_dim;
+    n.Sv = c.value_support_size; n.Sr = c.reward_support_size;
+    n.in_pad = pad16(n.in_dim); n.x_pad = pad16(n.H + n.A); n.p_pad = pad16(n.P); n.h_pad = pad16(n.H);
+    const int dims[L_COUNT][2] = {{n.P, n.in_dim}, {n.H, n.P}, {n.P, n.H + n.A}, {n.H, n.P}, {n.P, n.H},
+                                  {n.Sr, n.P},     {n.P, n.H}, {n.A, n.P},       {n.P, n.H}, {n.Sv, n.P}};
+    for (int l = 0; l < L_COUNT; l++) {
+        MlpLayer& L = n.L[l];
+        L.n = dims[l][0]; L.k = dims[l][1];
+        L.n_tiles = (L.n + 15) / 16; L.k_steps = (L.k + 3) / 4; L.kg = (L.k + 15) / 16;
+    }
+    MlpLds& o = p->o;
+    int off = 0;
+    const int xk = n.in_pad > n.x_pad ? n.in_pad : n.x_pad;
+    o.X = off; off += xk * 16;
+    o.H1 = off; off += n.p_pad * 16;
+    o.V1 = off; off += n.p_pad * 16;
+    o.HN = off; off += n.h_pad * 16;
+    o.HS = off; off += n.h_pad * 16;
+    int mx = n.A; mx = n.Sv > mx ? n.Sv : mx; mx = n.Sr > mx ? n.Sr : mx;
+    o.lg_stride = pad16(mx) + 1;  // odd stride: 16 envs read their logits rows without LDS bank conflicts
+    o.LG = off; off += ((2 * 16 * o.lg_stride + 3) & ~3);
+    o.OUT = off; off += 64;
+    o.total_floats = off;
+
+    // search kernel: tree part after the network part
+    SearchParams& s = p->sp;
+    s.net = n; s.o = o;
+    s.S = c.num_simulations; s.A = c.num_actions; s.NN = c.num_simulations + 1;
+    int b = o.total_floats * 4;
+    auto take = [&](int bytes, int align) { b = (b + align - 1) / align * align; int r = b; b += bytes; return r; };
+    s.t_nodes = take(16 * s.NN * (int)sizeof(TreeNode), 16);
+    s.t_child = take(16 * s.NN * s.A * 2, 16);
+    s.t_prior = take(16 * s.A * 8, 16);
+    s.t_tmp = take(16 * s.A * 8, 16);
+    s.t_pi0 = take(16 * s.A * 4, 16);
+    s.t_mm = take(16 * 2 * 8, 16);
+    s.t_sel = take(128 * 4, 16);
+    s.t_ptr = take(32 * 8, 16);
+    s.t_ftab = take((s.S + 1) * (s.S + 1) * 8, 16);
+    s.lds_bytes = (b + 15) & ~15;
+
+    InferParams& ip = p->ip;
+    ip.net = n; ip.o = o;
+    b = o.total_floats * 4;
+    ip.t_ptr = take(32 * 8, 16);
+    ip.t_pi = take(16 * n.A * 4, 16);
+    ip.t_act = take(16 * 4, 16);
+    ip.lds_bytes = (b + 15) & ~15;
+}
+
+extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner** out) {
+    if (!cfg || !out) return fail(MZ_E_INVALID, "null argument");
+    if (cfg->net_kind != MZ_NET_MLP)
+        return fail(MZ_E_INVALID, "only MZ_NET_MLP is implemented by this build of the HIP planner (conv towers: see DESIGN.md scope)");
+    if (cfg->num_actions < 1 || cfg->num_actions > 16 * MAX_CH) return fail(MZ_E_INVALID, "num_actions must be in [1, 64] for the LDS-resident search kernel");
+    if (cfg->num_simulations < 1 || cfg->num_simulations > 4000) return fail(MZ_E_INVALID, "num_simulations out of range");
+    if (cfg->hidden_dim < 1 || cfg->num_planes < 1 || cfg->num_envs < 1) return fail(MZ_E_INVALID, "bad network/env dimensions");
+    if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1023 || cfg->reward_support_size > 1023)
+        return fail(MZ_E_INVALID, "support sizes must be in [1, 1023]");
+    if (cfg->is_board_game && cfg->discount != 1.0) return fail(MZ_E_INVALID, "board games require discount == 1.0 (mcts.py:349-350)");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(MZ_E_HIP, "no HIP device visible: the planner has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(MZ_E_INVALID, "device_id out of range");
+    mz_planner* p = new mz_planner();
+    p->cfg = *cfg;
+    p->device = device_id;
+    compute_layout(p);
+    if (p->sp.lds_bytes > 160 * 1024) {
+        int need = p->sp.lds_bytes;
+        delete p;
+        return fail(MZ_E_INVALID, "configuration needs " + std::to_string(need) + " bytes of LDS per workgroup (> 160 KiB): tree does not fit the LDS-resident kernel");
+    }
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    const mz_config& c = p->cfg;
+    const size_t B = (size_t)c.num_envs, A = (size_t)c.num_actions, S = (size_t)c.num_simulations;
+    const int mt = c.max_ties > 0 ? c.max_ties : 4 * c.num_simulations + 8;
+    p->cfg.max_ties = mt;
+    HIPCHK(hipMalloc(&p->d_obs, B * obs_dim(c) * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_mask, B * A));
+    HIPCHK(hipMalloc(&p->d_cur, B * sizeof(int)));
+    HIPCHK(hipMalloc(&p->d_opp, B * sizeof(int)));
+    HIPCHK(hipMalloc(&p->d_temp, B * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_noise, B * A * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_utie, B * (size_t)mt * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_ufinal, B * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_hidden, B * (S + 1) * (size_t)c.hidden_dim * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_ftab, (S + 1) * (S + 1) * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_action, B * sizeof(int)));
+    HIPCHK(hipMalloc(&p->d_pi, B * A * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_root, B * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_visits, B * A * sizeof(int)));
+    HIPCHK(hipMalloc(&p->d_err, sizeof(int)));
+    HIPCHK(hipMemset(p->d_err, 0, sizeof(int)));
+    HIPCHK(hipMemset(p->d_mask, 1, B * A));
+    // child_U factor table: pb(N) / (n_child + 1) in float64 with the host libm, i.e. the very values math.log /
+    // math.sqrt give the reference (mcts.py:193-195)
+    std::vector<double> ft((S + 1) * (S + 1));
+    for (size_t N = 0; N <= S; N++) {
+        const double pb = (std::log(((double)N + c.pb_c_base + 1.0) / c.pb_c_base) + c.pb_c_init) * std::sqrt((double)N);
+        for (size_t cn = 0; cn <= S; cn++) ft[N * (S + 1) + cn] = pb / (double)(cn + 1);
+    }
+    HIPCHK(hipMemcpy(p->d_ftab, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreate(&p->ev_begin));
+    HIPCHK(hipEventCreate(&p->ev_end));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
+    *out = p;
+    return MZ_OK;
+}
+
+extern "C" int mz_planner_destroy(mz_planner* p) {
+    if (!p) return MZ_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    void* bufs[] = {p->d_obs, p->d_mask, p->d_cur, p->d_opp, p->d_temp, p->d_noise, p->d_utie, p->d_ufinal, p->d_hidden, p->d_ftab,
+                    p->d_action, p->d_pi, p->d_root, p->d_visits, p->d_err, p->d_spi0, p->d_svalues, p->d_srewards, p->d_tparent,
+                    p->d_taction, p->d_inf_in, p->d_inf_hidden, p->d_inf_reward, p->d_inf_value, p->d_inf_pi, p->d_inf_action};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (int l = 0; l < L_COUNT; l++) {
+        if (p->d_w[l]) (void)hipFree(p->d_w[l]);
+        if (p->d_b[l]) (void)hipFree(p->d_b[l]);
+    }
+    env_free(p->env);
+    for (auto& pr : p->kev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
+    if (p->ev_end) (void)hipEventDestroy(p->ev_end);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return MZ_OK;
+}
+
+extern "C" int32_t mz_planner_hidden_size(const mz_planner* p) { return p ? p->cfg.hidden_dim : 0; }
+
+extern "C" int mz_planner_set_param(mz_planner* p, const char* name, const float* h_data, const int64_t* shape, int32_t ndim) {
+    if (!p || !name || !h_data || !shape || ndim < 1 || ndim > 4) return fail(MZ_E_INVALID, "bad argument to mz_planner_set_param");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; i++) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(h_data, h_data + n);
+    p->params[name] = std::move(t);
+    p->committed = false;
+    return MZ_OK;
+}
+
+extern "C" int mz_planner_commit_params(mz_planner* p) {
+    if (!p) return fail(MZ_E_INVALID, "null planner");
+    HIPCHK(hipSetDevice(p->device));
+    for (int l = 0; l < L_COUNT; l++) {
+        const MlpLayer& L = p->net.L[l];
+        const std::string wn = std::string(kMlpNames[l]) + ".weight", bn = std::string(kMlpNames[l]) + ".bias";
+        auto wi = p->params.find(wn), bi = p->params.find(bn);
+        if (wi == p->params.end() || bi == p->params.end()) return fail(MZ_E_STATE, "missing parameter " + wn + " / " + bn);
+        const HostTensor &W = wi->second, &Bv = bi->second;
+        if (W.shape.size() != 2 || W.shape[0] != L.n || W.shape[1] != L.k || Bv.data.size() != (size_t)L.n)
+            return fail(MZ_E_INVALID, "shape mismatch for " + wn + ": expected [" + std::to_string(L.n) + ", " + std::to_string(L.k) + "]");
+        // A-operand fragment order of v_mfma_f32_16x16x4_f32 (see mz_mlp.h)
+        std::vector<float> pw((size_t)L.n_tiles * L.kg * 256, 0.0f), pb((size_t)L.n_tiles * 16, 0.0f);
+        for (int t = 0; t < L.n_tiles; t++)
+            for (int g = 0; g < L.kg; g++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int s = 0; s < 4; s++) {
+                        const int nn = 16 * t + (lane & 15), kk = 16 * g + 4 * s + (lane >> 4);
+                        if (nn < L.n && kk < L.k) pw[(((size_t)t * L.kg + g) * 64 + lane) * 4 + s] = W.data[(size_t)nn * L.k + kk];
+                    }
+        for (int i = 0; i < L.n; i++) pb[i] = Bv.data[i];
+        if (!p->d_w[l]) HIPCHK(hipMalloc(&p->d_w[l], pw.size() * sizeof(float)));
+        if (!p->d_b[l]) HIPCHK(hipMalloc(&p->d_b[l], pb.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(p->d_w[l], pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->d_b[l], pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
+        p->net.L[l].w = p->d_w[l];
+        p->net.L[l].b = p->d_b[l];
+    }
+    p->sp.net = p->net;
+    p->ip.net = p->net;
+    p->committed = true;
+    return MZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// inference API
+// ---------------------------------------------------------------------------------------------------------
+static int ensure_infer_buffers(mz_planner* p, int batch) {
+    if (batch <= p->inf_cap) return MZ_OK;
+    void* old[] = {p->d_inf_in, p->d_inf_hidden, p->d_inf_reward, p->d_inf_value, p->d_inf_pi, p->d_inf_action};
+    for (void* b : old)
+        if (b) (void)hipFree(b);
+    const size_t B = (size_t)batch;
+    const size_t in = (size_t)(obs_dim(p->cfg) > p->cfg.hidden_dim ? obs_dim(p->cfg) : p->cfg.hidden_dim);
+    HIPCHK(hipMalloc(&p->d_inf_in, B * in * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_inf_hidden, B * p->cfg.hidden_dim * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_inf_reward, B * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_inf_value, B * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_inf_pi, B * p->cfg.num_actions * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_inf_action, B * sizeof(int)));
+    p->inf_cap = batch;
+    return MZ_OK;
+}
+
+static int run_infer(mz_planner* p, bool initial, int batch, const float* h_in, const int32_t* h_action, float* h_hidden, float* h_reward,
+                     float* h_pi, float* h_value) {
+    if (!p || batch < 1 || !h_in) return fail(MZ_E_INVALID, "bad argument to inference call");
+    if (!p->committed) return fail(MZ_E_STATE, "weights not committed: call mz_planner_set_param for every tensor, then mz_planner_commit_params");
+    HIPCHK(hipSetDevice(p->device));
+    int rc = ensure_infer_buffers(p, batch);
+    if (rc) return rc;
+    const size_t in_w = initial ? obs_dim(p->cfg) : p->cfg.hidden_dim;
+    HIPCHK(hipMemcpyAsync(p->d_inf_in, h_in, (size_t)batch * in_w * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    if (!initial) HIPCHK(hipMemcpyAsync(p->d_inf_action, h_action, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    InferParams ip = p->ip;
+    ip.B = batch; ip.in = p->d_inf_in; ip.action = p->d_inf_action; ip.hidden_out = p->d_inf_hidden; ip.reward = p->d_inf_reward;
+    ip.value = p->d_inf_value; ip.pi = p->d_inf_pi;
+    const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
+    if (initial) hipLaunchKernelGGL(k_infer<true>, grid, block, ip.lds_bytes, p->stream, ip);
+    else hipLaunchKernelGGL(k_infer<false>, grid, block, ip.lds_bytes, p->stream, ip);
+    HIPCHK(hipGetLastError());
+    if (h_hidden) HIPCHK(hipMemcpyAsync(h_hidden, p->d_inf_hidden, (size_t)batch * p->cfg.hidden_dim * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    if (h_reward) HIPCHK(hipMemcpyAsync(h_reward, p->d_inf_reward, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    if (h_value) HIPCHK(hipMemcpyAsync(h_value, p->d_inf_value, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    if (h_pi) HIPCHK(hipMemcpyAsync(h_pi, p->d_inf_pi, (size_t)batch * p->cfg.num_actions * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return MZ_OK;
+}
+
+extern "C" int mz_planner_initial_inference(mz_planner* p, int32_t batch, const float* h_obs, float* h_hidden, float* h_pi, float* h_value) {
+    return run_infer(p, true, batch, h_obs, nullptr, h_hidden, nullptr, h_pi, h_value);
+}
+
+extern "C" int mz_planner_recurrent_inference(mz_planner* p, int32_t batch, const float* h_hidden, const int32_t* h_action, float* h_hidden_out,
+                                              float* h_reward, float* h_pi, float* h_value) {
+    if (!h_action) return fail(MZ_E_INVALID, "null action");
+    return run_infer(p, false, batch, h_hidden, h_action, h_hidden_out, h_reward, h_pi, h_value);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------------------------
+static int next_kernel_events(mz_planner* p, hipEvent_t* a, hipEvent_t* b) {
+    if (p->kev_used == p->kev.size()) {
+        hipEvent_t x, y;
+        HIPCHK(hipEventCreate(&x));
+        HIPCHK(hipEventCreate(&y));
+        p->kev.emplace_back(x, y);
+    }
+    *a = p->kev[p->kev_used].first;
+    *b = p->kev[p->kev_used].second;
+    p->kev_used++;
+    return MZ_OK;
+}
+
+// launches the fused search kernel over inputs that are already resident in the planner's device buffers
+static int launch_search(mz_planner* p, int batch, int deterministic, bool has_mask, bool injected_rng, bool scripted) {
+    const mz_config& c = p->cfg;
+    SearchParams s = p->sp;
+    s.discount = c.discount; s.board = c.is_board_game; s.has_bounds = c.has_known_bounds;
+    s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
+    s.deterministic = deterministic; s.has_mask = has_mask ? 1 : 0;
+    const bool want_noise = !deterministic && c.root_dirichlet_alpha > 0.0 && c.root_exploration_eps > 0.0;  // mcts.py:361
+    s.noise_mode = want_noise ? (injected_rng ? 1 : 2) : 0;
+    s.rng_mode = injected_rng ? 0 : 1;
+    s.max_ties = c.max_ties;
+    s.B = batch;
+    s.obs = p->d_obs; s.mask = p->d_mask; s.cur = p->d_cur; s.opp = p->d_opp; s.temperature = p->d_temp;
+    s.noise = p->d_noise; s.u_tie = p->d_utie; s.u_final = p->d_ufinal; s.hidden = p->d_hidden; s.ftab = p->d_ftab;
+    s.out_action = p->d_action; s.out_pi = p->d_pi; s.out_root = p->d_root; s.out_visits = p->d_visits; s.err = p->d_err;
+    s.s_pi0 = p->d_spi0; s.s_values = p->d_svalues; s.s_rewards = p->d_srewards; s.trace_parent = p->d_tparent; s.trace_action = p->d_taction;
+    s.seed = c.seed; s.move_counter = p->move_counter++; s.env_offset = 0;
+    const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (p->profiling) {
+        int rc = next_kernel_events(p, &ea, &eb);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(ea, p->stream));
+    }
+    if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
+    else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
+    HIPCHK(hipGetLastError());
+    if (p->profiling) HIPCHK(hipEventRecord(eb, p->stream));
+    return MZ_OK;
+}
+
+static int upload_roots(mz_planner* p, int batch, const float* h_obs, const uint8_t* h_mask, const int32_t* h_cur, const int32_t* h_opp,
+                        const double* h_temp, const mz_rng_inputs* rng, int deterministic) {
+    const mz_config& c = p->cfg;
+    const size_t B = (size_t)batch, A = (size_t)c.num_actions;
+    if (h_obs) HIPCHK(hipMemcpyAsync(p->d_obs, h_obs, B * obs_dim(c) * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    if (h_mask) HIPCHK(hipMemcpyAsync(p->d_mask, h_mask, B * A, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(p->d_cur, h_cur, B * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(p->d_opp, h_opp, B * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(p->d_temp, h_temp, B * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if (rng) {
+        const bool want_noise = !deterministic && c.root_dirichlet_alpha > 0.0 && c.root_exploration_eps > 0.0;
+        if (want_noise) {
+            if (!rng->h_noise) return fail(MZ_E_INVALID, "rng inputs given but h_noise is NULL while the search mixes Dirichlet noise");
+            HIPCHK(hipMemcpyAsync(p->d_noise, rng->h_noise, B * A * sizeof(double), hipMemcpyHostToDevice, p->stream));
+        }
+        if (!rng->h_u_tie || (!deterministic && !rng->h_u_final)) return fail(MZ_E_INVALID, "rng inputs need h_u_tie and h_u_final");
+        HIPCHK(hipMemcpyAsync(p->d_utie, rng->h_u_tie, B * (size_t)c.max_ties * sizeof(double), hipMemcpyHostToDevice, p->stream));
+        if (rng->h_u_final) HIPCHK(hipMemcpyAsync(p->d_ufinal, rng->h_u_final, B * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    }
+    return MZ_OK;
+}
+
+static int download_results(mz_planner* p, int batch, int32_t* h_action, double* h_pi, double* h_root, int32_t* h_visits) {
+    const size_t B = (size_t)batch, A = (size_t)p->cfg.num_actions;
+    int err = 0;
+    if (h_action) HIPCHK(hipMemcpyAsync(h_action, p->d_action, B * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if (h_pi) HIPCHK(hipMemcpyAsync(h_pi, p->d_pi, B * A * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (h_root) HIPCHK(hipMemcpyAsync(h_root, p->d_root, B * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (h_visits) HIPCHK(hipMemcpyAsync(h_visits, p->d_visits, B * A * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipMemcpyAsync(&err, p->d_err, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (err) {
+        HIPCHK(hipMemset(p->d_err, 0, sizeof(int)));
+        if (err == 4) return fail(MZ_E_TIES, "injected tie-break stream exhausted (raise mz_config.max_ties)");
+        return fail(MZ_E_INVALID, "search kernel reported error " + std::to_string(err));
+    }
+    return MZ_OK;
+}
+
+extern "C" int mz_planner_search(mz_planner* p, int32_t batch, const float* h_obs, const uint8_t* h_mask, const int32_t* h_cur,
+                                 const int32_t* h_opp, const double* h_temp, int32_t deterministic, const mz_rng_inputs* rng,
+                                 int32_t* h_action, double* h_pi, double* h_root, int32_t* h_visits) {
+    if (!p || !h_obs || !h_cur || !h_opp || !h_temp || !h_action || !h_pi || !h_root) return fail(MZ_E_INVALID, "null argument to mz_planner_search");
+    if (batch < 1 || batch > p->cfg.num_envs) return fail(MZ_E_INVALID, "batch exceeds mz_config.num_envs");
+    if (!p->committed) return fail(MZ_E_STATE, "weights not committed");
+    HIPCHK(hipSetDevice(p->device));
+    int rc = upload_roots(p, batch, h_obs, h_mask, h_cur, h_opp, h_temp, rng, deterministic);
+    if (rc) return rc;
+    rc = launch_search(p, batch, deterministic, h_mask != nullptr, rng != nullptr, false);
+    if (rc) return rc;
+    return download_results(p, batch, h_action, h_pi, h_root, h_visits);
+}
+
+extern "C" int mz_planner_search_scripted(mz_planner* p, int32_t batch, const float* h_pi0, const float* h_values, const float* h_rewards,
+                                          const uint8_t* h_mask, const int32_t* h_cur, const int32_t* h_opp, const double* h_temp,
+                                          int32_t deterministic, const mz_rng_inputs* rng, int32_t* h_action, double* h_pi, double* h_root,
+                                          int32_t* h_visits, int32_t* h_tparent, int32_t* h_taction) {
+    if (!p || !h_pi0 || !h_values || !h_rewards || !h_cur || !h_opp || !h_temp || !h_action || !h_pi || !h_root)
+        return fail(MZ_E_INVALID, "null argument to mz_planner_search_scripted");
+    if (batch < 1 || batch > p->cfg.num_envs) return fail(MZ_E_INVALID, "batch exceeds mz_config.num_envs");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t B = (size_t)p->cfg.num_envs, A = (size_t)p->cfg.num_actions, S = (size_t)p->cfg.num_simulations;
+    if (!p->d_spi0) {
+        HIPCHK(hipMalloc(&p->d_spi0, B * A * sizeof(float)));
+        HIPCHK(hipMalloc(&p->d_svalues, B * S * sizeof(float)));
+        HIPCHK(hipMalloc(&p->d_srewards, B * S * sizeof(float)));
+        HIPCHK(hipMalloc(&p->d_tparent, B * S * sizeof(int)));
+        HIPCHK(hipMalloc(&p->d_taction, B * S * sizeof(int)));
+    }
+    const size_t b = (size_t)batch;
+    HIPCHK(hipMemcpyAsync(p->d_spi0, h_pi0, b * A * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(p->d_svalues, h_values, b * S * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(p->d_srewards, h_rewards, b * S * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    int rc = upload_roots(p, batch, nullptr, h_mask, h_cur, h_opp, h_temp, rng, deterministic);
+    if (rc) return rc;
+    rc = launch_search(p, batch, deterministic, h_mask != nullptr, rng != nullptr, true);
+    if (rc) return rc;
+    if (h_tparent) HIPCHK(hipMemcpyAsync(h_tparent, p->d_tparent, b * S * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if (h_taction) HIPCHK(hipMemcpyAsync(h_taction, p->d_taction, b * S * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    return download_results(p, batch, h_action, h_pi, h_root, h_visits);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device-resident self-play
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* h_init_state) {
+    if (!p) return fail(MZ_E_INVALID, "null planner");
+    HIPCHK(hipSetDevice(p->device));
+    const mz_config& c = p->cfg;
+    if (env_kind == MZ_ENV_CARTPOLE) {
+        if (c.num_actions != 2 || obs_dim(c) != 20) return fail(MZ_E_INVALID, "CartPole env needs num_actions == 2 and a (4,5) observation");
+    } else if (env_kind == MZ_ENV_TICTACTOE) {
+        if (c.num_actions != 10 || obs_dim(c) != 81) return fail(MZ_E_INVALID, "TicTacToe env needs num_actions == 10 and a (9,3,3) observation");
+    } else {
+        return fail(MZ_E_INVALID, "unknown env kind");
+    }
+    p->env_kind = env_kind;
+    p->ring_len = 64;
+    p->ring_pos = 0;
+    p->ring_count = 0;
+    hipError_t e = env_alloc(p->env, env_kind, c.num_envs, c.num_actions, obs_dim(c), p->ring_len);
+    if (e != hipSuccess) return fail(MZ_E_HIP, std::string("env_alloc: ") + hipGetErrorString(e));
+    if (h_init_state) HIPCHK(hipMemcpyAsync(p->env.init_state, h_init_state, (size_t)c.num_envs * 4 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    EnvLaunch L{};
+    L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.use_init = h_init_state != nullptr;
+    L.obs = p->d_obs; L.mask = p->d_mask; L.cur = p->d_cur; L.opp = p->d_opp;
+    hipLaunchKernelGGL(k_env_reset, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return MZ_OK;
+}
+
+extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_moves) {
+    if (!p || n_moves < 1) return fail(MZ_E_INVALID, "bad argument to mz_selfplay_step");
+    if (p->env_kind == MZ_ENV_NONE) return fail(MZ_E_STATE, "call mz_selfplay_reset first");
+    if (!p->committed) return fail(MZ_E_STATE, "weights not committed");
+    HIPCHK(hipSetDevice(p->device));
+    const mz_config& c = p->cfg;
+    for (int m = 0; m < n_moves; m++) {
+        EnvLaunch L{};
+        L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.temperature = temperature; L.move_counter = p->move_counter;
+        L.obs = p->d_obs; L.mask = p->d_mask; L.cur = p->d_cur; L.opp = p->d_opp; L.temp_out = p->d_temp;
+        L.action = p->d_action; L.pi = p->d_pi; L.root = p->d_root; L.slot = p->ring_pos; L.sims = c.num_simulations;
+        // temperatures for this move, then the search, then env.step + record + auto-reset
+        hipLaunchKernelGGL(k_env_pre, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+        int rc = launch_search(p, c.num_envs, 0, true, false, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_env_step, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+        HIPCHK(hipGetLastError());
+        p->ring_pos = (p->ring_pos + 1) % p->ring_len;
+        if (p->ring_count < p->ring_len) p->ring_count++;
+    }
+    return MZ_OK;
+}
+
+extern "C" int mz_selfplay_read(mz_planner* p, int32_t n_moves, float* h_obs, int32_t* h_action, float* h_reward, double* h_pi,
+                                double* h_root, int32_t* h_player, uint8_t* h_done) {
+    if (!p || n_moves < 1 || n_moves > p->ring_count) return fail(MZ_E_INVALID, "n_moves exceeds the recorded history");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    const size_t B = (size_t)p->cfg.num_envs, A = (size_t)p->cfg.num_actions, D = (size_t)obs_dim(p->cfg);
+    for (int i = 0; i < n_moves; i++) {
+        const int slot = ((p->ring_pos - n_moves + i) % p->ring_len + p->ring_len) % p->ring_len;
+        if (h_obs) HIPCHK(hipMemcpy(h_obs + (size_t)i * B * D, p->env.r_obs + (size_t)slot * B * D, B * D * sizeof(float), hipMemcpyDeviceToHost));
+        if (h_action) HIPCHK(hipMemcpy(h_action + (size_t)i * B, p->env.r_action + (size_t)slot * B, B * sizeof(int), hipMemcpyDeviceToHost));
+        if (h_reward) HIPCHK(hipMemcpy(h_reward + (size_t)i * B, p->env.r_reward + (size_t)slot * B, B * sizeof(float), hipMemcpyDeviceToHost));
+        if (h_pi) HIPCHK(hipMemcpy(h_pi + (size_t)i * B * A, p->env.r_pi + (size_t)slot * B * A, B * A * sizeof(double), hipMemcpyDeviceToHost));
+        if (h_root) HIPCHK(hipMemcpy(h_root + (size_t)i * B, p->env.r_root + (size_t)slot * B, B * sizeof(double), hipMemcpyDeviceToHost));
+        if (h_player) HIPCHK(hipMemcpy(h_player + (size_t)i * B, p->env.r_player + (size_t)slot * B, B * sizeof(int), hipMemcpyDeviceToHost));
+        if (h_done) HIPCHK(hipMemcpy(h_done + (size_t)i * B, p->env.r_done + (size_t)slot * B, B, hipMemcpyDeviceToHost));
+    }
+    return MZ_OK;
+}
+
+extern "C" int mz_selfplay_counters(mz_planner* p, int64_t out[4]) {
+    if (!p || !out) return fail(MZ_E_INVALID, "null argument");
+    if (p->env_kind == MZ_ENV_NONE) return fail(MZ_E_STATE, "call mz_selfplay_reset first");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    unsigned long long c[4];
+    HIPCHK(hipMemcpy(c, p->env.counters, sizeof(c), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out[i] = (int64_t)c[i];
+    return MZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// measurement hooks
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int mz_planner_synchronize(mz_planner* p) {
+    if (!p) return fail(MZ_E_INVALID, "null planner");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return MZ_OK;
+}
+
+extern "C" int mz_profile_begin(mz_planner* p) {
+    if (!p) return fail(MZ_E_INVALID, "null planner");
+    HIPCHK(hipSetDevice(p->device));
+    p->profiling = true;
+    p->kev_used = 0;
+    HIPCHK(hipEventRecord(p->ev_begin, p->stream));
+    return MZ_OK;
+}
+
+extern "C" int mz_profile_end(mz_planner* p, double* elapsed_ms, double* search_kernel_ms, int64_t* search_kernel_launches) {
+    if (!p || !p->profiling) return fail(MZ_E_STATE, "mz_profile_end without mz_profile_begin");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipEventRecord(p->ev_end, p->stream));
+    HIPCHK(hipEventSynchronize(p->ev_end));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, p->ev_begin, p->ev_end));
+    if (elapsed_ms) *elapsed_ms = ms;
+    double ksum = 0.0;
+    for (size_t i = 0; i < p->kev_used; i++) {
+        float k = 0.0f;
+        HIPCHK(hipEventElapsedTime(&k, p->kev[i].first, p->kev[i].second));
+        ksum += k;
+    }
+    if (search_kernel_ms) *search_kernel_ms = ksum;
+    if (search_kernel_launches) *search_kernel_launches = (int64_t)p->kev_used;
+    p->profiling = false;
+    return MZ_OK;
+}

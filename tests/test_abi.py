@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds (hipcc cross-compiles gfx950 without a GPU), loads,
+and exports every symbol include/mzplanner.h declares.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+from helpers import REPO
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'mzplanner.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mz_[a-z_]+)\s*\(', text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from muzero_amd import build, planner
+
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/mzplanner.h but not exported'
+    assert sorted(planner.ABI_SYMBOLS) == declared
+    planner.load_library()
+    assert b'gfx950' in planner.load_library().mz_version()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under muzero_amd/ may import, link or execute it."""
+    for root, _, files in os.walk(os.path.join(REPO, 'muzero_amd')):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                src = open(os.path.join(root, f), errors='ignore').read()
+                assert 'mz_oracle' not in src and 'libmzoracle' not in src and 'import oracle' not in src, os.path.join(root, f)
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    from muzero_amd import planner
+    from helpers import build_mlp, mlp_case
+
+    net = build_mlp(mlp_case('tiny'))
+    try:
+        planner.Planner(planner.make_mz_config(net.planner_spec(), None, num_envs=4), 0)
+    except planner.PlannerError as e:
+        assert 'HIP' in str(e) or 'hip' in str(e)
+    else:
+        raise AssertionError('planner creation must fail without a GPU (no CPU fallback)')
