@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play planning throughput on MI355X (BASELINE.json metric: self-play env-steps/sec & MCTS sims/sec).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "C2"): CartPole-v1, 50 simulations per move, 4096 parallel environments per GPU,
+MuZeroMLPNet 512/64/31 (seeded random-init weights, synthetic data), device-resident CartPole environments with
+auto-reset, on-device Philox randomness, temperature 1.0.  One "step" = one lock-step self-play move for all
+environments of a rank: temperature kernel -> fused search kernel (root inference + 50 x {select, dynamics/reward/value
+inference, expand, backup} + play policy + action sample) -> env.step/record kernel.  All inputs are resident in HBM.
+
+Multi-GPU: environments are independent (one planner per GPU, envs sharded by rank, no data-path collective);
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.  scaling = "weak".
+
+Output: ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant kernel k_search, fp32 MFMA bound,
+measured live with HIP events on the planner's stream) and `cpu_baseline` (the CPU oracle -- a C port of the reference
+algorithm -- timed on the host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+# CartPole MLP (C2): algorithmic MACs per simulation of the reference-faithful search (the recurrent policy head is
+# dead compute in the reference, mcts.py:386 uses the root prior, so it is not evaluated): SURVEY 8d.
+MAC_TRANSITION = 66 * 512 + 512 * 64
+MAC_REWARD = 64 * 512 + 512 * 31
+MAC_VALUE = 64 * 512 + 512 * 31
+MAC_POLICY = 64 * 512 + 512 * 2
+MAC_REPRESENT = 20 * 512 + 512 * 64
+FLOP_PER_SIM = 2 * (MAC_TRANSITION + MAC_REWARD + MAC_VALUE)          # 327 680
+FLOP_PER_ROOT = 2 * (MAC_REPRESENT + MAC_POLICY + MAC_VALUE)          # 250 880
+PEAK_FP32_MFMA_TFLOPS = 157.3                                         # MI355X_MICROARCH.md, v_mfma_f32_*_f32 dense peak
+
+
+def cpu_baseline(num_sims, sample_envs, budget_s=20.0):
+    """The oracle (oracle/mz_oracle.c, a scalar C port of mcts.py + network.py, one env per host thread with batch-1
+    inference like the reference's one-actor-per-process layout) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import oracle  # test infrastructure, used here only as the reported CPU baseline
+    from helpers import build_mlp, mlp_case
+
+    net = build_mlp(mlp_case('cartpole'))
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    onet = oracle.Net.mlp(sd, 20, 2, 512, 64, 31, 31)
+    cfg = oracle.make_config(2, num_sims, 0.997, False, None, 0.25, 0.25)
+    cores = os.cpu_count() or 1
+    rs = np.random.RandomState(3)
+
+    def run(n_envs, threads):
+        obs = rs.uniform(-0.05, 0.05, size=(n_envs, 4, 5)).astype(np.float32)
+        obs[:, :, 4] = 0.5
+        noise = rs.dirichlet(np.full(2, 0.25), size=n_envs)
+        t0 = time.perf_counter()
+        oracle.uct_search_batch(cfg, onet, obs, np.ones((n_envs, 2), np.uint8), 1, 1, 1.0, False, noise=noise,
+                                u_tie=rs.rand(n_envs, 4 * num_sims + 8), u_final=rs.rand(n_envs), num_threads=threads)
+        return n_envs * num_sims / (time.perf_counter() - t0)
+
+    # pick the thread count that runs fastest on this host (SMT siblings can hurt), on a small probe
+    best_threads, best_rate = 1, run(8, 1)
+    for t in sorted({max(1, cores // 2), cores}):
+        r = run(8 * t, t)
+        if r > best_rate:
+            best_threads, best_rate = t, r
+    n_envs = int(max(best_threads * 8, min(sample_envs, best_rate * budget_s / num_sims)))
+    rate = run(n_envs, best_threads)
+    return dict(value=rate, unit='sims/s', cores=best_threads, kind='port',
+                sample=f'{n_envs} CartPole roots x {num_sims} simulations, oracle/mz_oracle.c, {best_threads} OpenMP threads '
+                       f'of {cores} host CPUs, batch-1 inference per env')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--envs', type=int, default=4096, help='environments per GPU')
+    ap.add_argument('--sims', type=int, default=50)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import build as mz_build
+    from muzero_amd import planner as pl
+
+    mz_build.build()
+    net = build_mlp(mlp_case('cartpole'))  # 512/64/31, seeded random init
+    B, S = args.envs, args.sims
+    cfg = pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=1000 + rank, num_simulations=S, discount=0.997,
+                            root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    p = pl.Planner(cfg, local_rank)
+    p.load_state_dict(net.state_dict())
+    p.selfplay_reset(pl.ENV_CARTPOLE)
+
+    def sync():
+        p.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    p.selfplay_step(1.0, args.warmup)
+    sync()
+    p.profile_begin()
+    t0 = time.perf_counter()
+    p.selfplay_step(1.0, args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = p.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    counters = p.selfplay_counters()
+
+    if rank == 0:
+        total_sims = world * B * S * args.steps
+        sims_per_s = total_sims / elapsed
+        k_ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
+        flop_per_launch = B * (S * FLOP_PER_SIM + FLOP_PER_ROOT)
+        achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+        out = {
+            'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)',
+            'value': sims_per_s,
+            'unit': 'sims/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'C2: CartPole-v1 self-play, 50 sims/move, 4096 parallel envs per MI355X, MuZeroMLPNet 512/64/31, batched tree',
+                'envs_per_gpu': B, 'sims_per_move': S, 'num_actions': 2, 'parallelism': f'env-sharded x{world}',
+                'randomness': 'on-device Philox', 'weights': 'seeded random init',
+            },
+            'env_steps_per_sec': sims_per_s / S,
+            'episodes_finished_rank0': counters['episodes'],
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'mz::k_search<false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,
+                'flop_per_sim': FLOP_PER_SIM, 'timed_with': 'hipEvent pairs on the planner stream',
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(S, sample_envs=B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

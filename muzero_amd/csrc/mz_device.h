@@ -53,22 +53,62 @@ __device__ __forceinline__ float signed_parabolic(float x) {
     return sg * m;
 }
 
-// logits_to_transformed_expected_value, util.py:70-93: softmax -> E[linspace(-(S-1)/2, (S-1)/2, S)] -> signed_parabolic.
-// Sequential float32 sums in index order (the order is part of the numerical contract).  S == 1: identity (MSE heads).
-__device__ inline float logits_to_scalar(const float* lg, int S) {
+// Row reduction order shared with the oracle (row_reduce16 in oracle/mz_oracle.c): each of 16 lanes holds the
+// sequential partial sum of elements j, j+16, j+32, ...; the partials are combined by an xor-butterfly with strides
+// 1, 2, 4, 8.  Every lane of the 16-lane segment returns the same total.
+__device__ __forceinline__ float butterfly16(float part) {
+    part = part + __shfl_xor(part, 1, 64);
+    part = part + __shfl_xor(part, 2, 64);
+    part = part + __shfl_xor(part, 4, 64);
+    part = part + __shfl_xor(part, 8, 64);
+    return part;
+}
+__device__ __forceinline__ float butterfly16_max(float v) {
+    float o;
+    o = __shfl_xor(v, 1, 64); v = o > v ? o : v;
+    o = __shfl_xor(v, 2, 64); v = o > v ? o : v;
+    o = __shfl_xor(v, 4, 64); v = o > v ? o : v;
+    o = __shfl_xor(v, 8, 64); v = o > v ? o : v;
+    return v;
+}
+
+// logits_to_transformed_expected_value, util.py:70-93: softmax -> E[linspace(-(S-1)/2, (S-1)/2, S)] -> signed_parabolic,
+// computed by the 16 lanes of a segment on one row `lg` (LDS, overwritten with the exponentials).  S == 1: identity.
+__device__ __forceinline__ float row_logits_to_scalar(float* lg, int S, int j) {
     if (S == 1) return lg[0];
-    float m = lg[0];
-    for (int i = 1; i < S; i++) m = lg[i] > m ? lg[i] : m;
-    float sum = 0.0f;
-    for (int i = 0; i < S; i++) sum = sum + expf_det(lg[i] - m);
-    int half = (S - 1) / 2;
-    float x = 0.0f;
-    for (int i = 0; i < S; i++) {
-        float p = expf_det(lg[i] - m) / sum;
-        float t = p * (float)(i - half);
-        x = x + t;
+    float m = __uint_as_float(0xff800000u);
+    for (int i = j; i < S; i += 16) m = lg[i] > m ? lg[i] : m;
+    m = butterfly16_max(m);
+    float a = 0.0f;
+    for (int i = j; i < S; i += 16) {
+        const float e = expf_det(lg[i] - m);
+        lg[i] = e;
+        a = a + e;
     }
-    return signed_parabolic(x);
+    const float sum = butterfly16(a);
+    const int half = (S - 1) / 2;
+    float t = 0.0f;
+    for (int i = j; i < S; i += 16) {
+        const float p = lg[i] / sum;
+        const float tt = p * (float)(i - half);
+        t = t + tt;
+    }
+    return signed_parabolic(butterfly16(t));
+}
+
+// softmax of one row of n logits (policy, network.py:72,100) by the 16 lanes of a segment; out may alias lg
+__device__ __forceinline__ void row_softmax(const float* lg, float* out, int n, int j) {
+    float m = __uint_as_float(0xff800000u);
+    for (int i = j; i < n; i += 16) m = lg[i] > m ? lg[i] : m;
+    m = butterfly16_max(m);
+    float a = 0.0f;
+    for (int i = j; i < n; i += 16) {
+        const float e = expf_det(lg[i] - m);
+        out[i] = e;
+        a = a + e;
+    }
+    const float sum = butterfly16(a);
+    for (int i = j; i < n; i += 16) out[i] = out[i] / sum;
 }
 
 // numpy's np.sum on a contiguous 1-D array (pairwise_sum, numpy/core/src/umath/loops_utils.h.src):

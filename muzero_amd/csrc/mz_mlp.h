@@ -229,6 +229,19 @@ __device__ __forceinline__ void zero_packed(float* dst, int k_lo, int k_hi, int 
     }
 }
 
+// reward / value logits rows (LG[head][e][:]) -> scalars OUT[e][head]; 16 lanes per row, 256 threads = 16 rows per pass.
+// with_reward == false (initial inference): reward := 0 (network.py:76), only the value rows are reduced.
+__device__ __forceinline__ void heads_to_scalars(const MlpNet& net, const MlpLds& o, float* lds, int tid, bool with_reward) {
+    const int e = tid >> 4, j = tid & 15;
+    const float v = row_logits_to_scalar(lds + o.LG + (16 + e) * o.lg_stride, net.Sv, j);
+    float r = 0.0f;
+    if (with_reward) r = row_logits_to_scalar(lds + o.LG + e * o.lg_stride, net.Sr, j);
+    if (j == 0) {
+        lds[o.OUT + e * 4 + 0] = r;
+        lds[o.OUT + e * 4 + 1] = v;
+    }
+}
+
 // dynamics + reward + value for the 16 envs of this tile (network.py:86-111 without the dead policy head unless
 // want_policy).  Expects X (packed hidden+onehot) ready in LDS and a barrier already passed.
 //   out: lds OUT[e][0] = reward, OUT[e][1] = value ; HS = normalised next hidden ; grow[e] (optional) global rows.
@@ -248,25 +261,14 @@ __device__ __forceinline__ void mlp_recurrent_tile(const MlpNet& net, const MlpL
     gemm_layer(net.L[L_REW1], lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
     gemm_layer(net.L[L_VAL1], lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
     __syncthreads();
-    if (tid < 32) {
-        const int head = tid >> 4, e = tid & 15;
-        const float v = logits_to_scalar(lds + o.LG + (head * 16 + e) * o.lg_stride, head ? net.Sv : net.Sr);
-        lds[o.OUT + e * 4 + head] = v;
-    }
+    heads_to_scalars(net, o, lds, tid, true);
     if (want_policy) {
         __syncthreads();
         gemm_layer(net.L[L_POL0], lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
         __syncthreads();
         gemm_layer(net.L[L_POL1], lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
         __syncthreads();
-        if (tid < 16) {
-            const float* lg = lds + o.LG + tid * o.lg_stride;
-            float m = lg[0];
-            for (int i = 1; i < net.A; i++) m = lg[i] > m ? lg[i] : m;
-            float s = 0.0f;
-            for (int i = 0; i < net.A; i++) s = s + expf_det(lg[i] - m);
-            for (int i = 0; i < net.A; i++) pi_out[tid * net.A + i] = expf_det(lg[i] - m) / s;
-        }
+        row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
     }
     __syncthreads();
 }
@@ -287,18 +289,8 @@ __device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds
     gemm_layer(net.L[L_POL1], lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
     gemm_layer(net.L[L_VAL1], lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
     __syncthreads();
-    if (tid < 16) {
-        const float* lg = lds + o.LG + tid * o.lg_stride;
-        float m = lg[0];
-        for (int i = 1; i < net.A; i++) m = lg[i] > m ? lg[i] : m;
-        float s = 0.0f;
-        for (int i = 0; i < net.A; i++) s = s + expf_det(lg[i] - m);
-        for (int i = 0; i < net.A; i++) pi_out[tid * net.A + i] = expf_det(lg[i] - m) / s;
-    } else if (tid < 32) {
-        const int e = tid & 15;
-        lds[o.OUT + e * 4 + 1] = logits_to_scalar(lds + o.LG + (16 + e) * o.lg_stride, net.Sv);
-        lds[o.OUT + e * 4 + 0] = 0.0f;  // reward = zeros_like(value), network.py:76
-    }
+    row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
+    heads_to_scalars(net, o, lds, tid, false);
     __syncthreads();
 }
 

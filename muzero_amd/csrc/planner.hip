@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -12,6 +13,7 @@
 #include "../../include/mzplanner.h"
 #include "mz_env.h"
 #include "mz_search.h"
+#include "mz_search_fast.h"
 
 using namespace mz;
 
@@ -54,6 +56,11 @@ struct mz_planner {
     float* d_b[L_COUNT] = {};
     SearchParams sp{};
     InferParams ip{};
+    // tuned kernel for the benchmark shapes (mz_search_fast.h): per-wave weight streams of the wide layers
+    int fast_planes = 0;  // 0: generic kernel only; 256 / 512: k_search_fast<P>
+    bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
+    float* d_stream[3] = {};
+    FastWeights fw{};
 
     // per-env device buffers (capacity cfg.num_envs)
     float* d_obs = nullptr;
@@ -164,6 +171,10 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     mz_planner* p = new mz_planner();
     p->cfg = *cfg;
     p->device = device_id;
+    {
+        const char* fg = getenv("MZ_FORCE_GENERIC");
+        p->force_generic = fg && fg[0] == '1';
+    }
     compute_layout(p);
     if (p->sp.lds_bytes > 160 * 1024) {
         int need = p->sp.lds_bytes;
@@ -207,6 +218,12 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
+    if (c.hidden_dim == 64 && (c.num_planes == 256 || c.num_planes == 512) && c.num_actions <= 16 && c.value_support_size <= 32 &&
+        c.reward_support_size <= 32) {
+        p->fast_planes = c.num_planes;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
+    }
     *out = p;
     return MZ_OK;
 }
@@ -224,6 +241,8 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
         if (p->d_w[l]) (void)hipFree(p->d_w[l]);
         if (p->d_b[l]) (void)hipFree(p->d_b[l]);
     }
+    for (int i = 0; i < 3; i++)
+        if (p->d_stream[i]) (void)hipFree(p->d_stream[i]);
     env_free(p->env);
     for (auto& pr : p->kev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
@@ -276,6 +295,30 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
     }
     p->sp.net = p->net;
     p->ip.net = p->net;
+    if (p->fast_planes) {
+        // per-wave contiguous streams of the wide layers (layout: mz_search_fast.h)
+        const int lay[3] = {L_DYN0, L_REW0, L_VAL0};
+        for (int i = 0; i < 3; i++) {
+            const MlpLayer& L = p->net.L[lay[i]];
+            const int NT = L.n_tiles / WG_WAVES, KG = L.kg;
+            const std::string wn = std::string(kMlpNames[lay[i]]) + ".weight";
+            const HostTensor& W = p->params.find(wn)->second;
+            std::vector<float> st((size_t)WG_WAVES * KG * NT * 256, 0.0f);
+            for (int w = 0; w < WG_WAVES; w++)
+                for (int g = 0; g < KG; g++)
+                    for (int j = 0; j < NT; j++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int q4 = 0; q4 < 4; q4++) {
+                                const int nn = 16 * (w + WG_WAVES * j) + (lane & 15), kk = 16 * g + 4 * q4 + (lane >> 4);
+                                if (nn < L.n && kk < L.k) st[((((size_t)w * KG + g) * NT + j) * 64 + lane) * 4 + q4] = W.data[(size_t)nn * L.k + kk];
+                            }
+            if (!p->d_stream[i]) HIPCHK(hipMalloc(&p->d_stream[i], st.size() * sizeof(float)));
+            HIPCHK(hipMemcpy(p->d_stream[i], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        p->fw.dyn0 = reinterpret_cast<const float4*>(p->d_stream[0]);
+        p->fw.rew0 = reinterpret_cast<const float4*>(p->d_stream[1]);
+        p->fw.val0 = reinterpret_cast<const float4*>(p->d_stream[2]);
+    }
     p->committed = true;
     return MZ_OK;
 }
@@ -376,6 +419,8 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         HIPCHK(hipEventRecord(ea, p->stream));
     }
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
+    else if (p->fast_planes == 512 && !p->force_generic) hipLaunchKernelGGL(k_search_fast<512>, grid, block, s.lds_bytes, p->stream, s, p->fw);
+    else if (p->fast_planes == 256 && !p->force_generic) hipLaunchKernelGGL(k_search_fast<256>, grid, block, s.lds_bytes, p->stream, s, p->fw);
     else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
     HIPCHK(hipGetLastError());
     if (p->profiling) HIPCHK(hipEventRecord(eb, p->stream));

@@ -55,6 +55,7 @@ def load_library():
         raise PlannerError(
             f'{LIB_PATH} not found: build it with `python -m muzero_amd.build` (hipcc, gfx950). The planning path has no CPU fallback.'
         )
+    import torch  # noqa: F401  -- torch bundles its own HIP runtime: load it first so ONE libamdhip64 serves the process
     L = C.CDLL(LIB_PATH)
     vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
     L.mz_last_error.restype = C.c_char_p

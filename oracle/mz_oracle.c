@@ -72,24 +72,39 @@ float mzo_signed_parabolic(float x) {
     return sg * m;
 }
 
+/* Row reduction used by every softmax / expectation on the path.  The ORDER is part of the oracle's numerical
+ * contract (the HIP kernels reproduce it with 16 lanes per row): 16 interleaved partial sums
+ * part[j] = v[j] + v[j+16] + v[j+32] + ... (sequential), then an xor-butterfly over the 16 partials with
+ * strides 1, 2, 4, 8 (IEEE addition is commutative, so every slot ends with the same total). */
+static float row_reduce16(const float* v, int n) {
+    float part[16];
+    for (int j = 0; j < 16; j++) {
+        float a = 0.0f;
+        for (int i = j; i < n; i += 16) a = a + v[i];
+        part[j] = a;
+    }
+    for (int m = 1; m < 16; m <<= 1) {
+        float nxt[16];
+        for (int j = 0; j < 16; j++) nxt[j] = part[j] + part[j ^ m];
+        for (int j = 0; j < 16; j++) part[j] = nxt[j];
+    }
+    return part[0];
+}
+
 /* util.py:70-93: softmax -> expectation over linspace(-(S-1)/2, (S-1)/2, S) -> signed_parabolic */
 float mzo_logits_to_value(const float* logits, int32_t S) {
     float m = logits[0];
     for (int i = 1; i < S; i++) m = logits[i] > m ? logits[i] : m;
-    float e[1024];
-    float sum = 0.0f;
-    for (int i = 0; i < S; i++) {
-        e[i] = mzo_expf(logits[i] - m);
-        sum = sum + e[i];
-    }
+    float e[1024], t[1024];
+    for (int i = 0; i < S; i++) e[i] = mzo_expf(logits[i] - m);
+    float sum = row_reduce16(e, S);
     int maxv = (S - 1) / 2;
-    float x = 0.0f;
     for (int i = 0; i < S; i++) {
         float p = e[i] / sum;
         float sup = (float)(i - maxv); /* linspace(-max, max, S) has unit spacing: exact integers */
-        float t = p * sup;
-        x = x + t;
+        t[i] = p * sup;
     }
+    float x = row_reduce16(t, S);
     return mzo_signed_parabolic(x);
 }
 
@@ -110,11 +125,8 @@ void mzo_normalize_hidden(float* h, int32_t channels, int32_t spatial) {
 static void softmax_f32(const float* logits, int32_t n, float* out) {
     float m = logits[0];
     for (int i = 1; i < n; i++) m = logits[i] > m ? logits[i] : m;
-    float sum = 0.0f;
-    for (int i = 0; i < n; i++) {
-        out[i] = mzo_expf(logits[i] - m);
-        sum = sum + out[i];
-    }
+    for (int i = 0; i < n; i++) out[i] = mzo_expf(logits[i] - m);
+    float sum = row_reduce16(out, n);
     for (int i = 0; i < n; i++) out[i] = out[i] / sum;
 }
 

@@ -184,6 +184,26 @@ def test_batched_search_bit_exact_vs_oracle(oracle, g, B):
     np.testing.assert_array_equal(rd['root_value'], od['root_value'])
 
 
+def test_generic_and_tuned_kernels_agree(monkeypatch):
+    """k_search (shape-generic) and k_search_fast (benchmark shapes) are the same algorithm: identical outputs."""
+    for g, S, board in (('cartpole', 50, False), ('tictactoe', 25, True)):
+        case = mlp_case(g)
+        net = build_mlp(case)
+        A, B = case[2], 70
+        kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+        rs = np.random.RandomState(11)
+        obs = rs.uniform(-1, 1, size=(B,) + tuple(case[1])).astype(np.float32)
+        args = (obs, np.ones((B, A), bool), 1, 2 if board else 1, 1.0, False)
+        rng = dict(noise=rs.dirichlet(np.full(A, 0.25), size=B), u_tie=rs.rand(B, 4 * S + 8), u_final=rs.rand(B))
+        monkeypatch.delenv('MZ_FORCE_GENERIC', raising=False)
+        fast = _planner(net, B, **kw).search(*args, **rng)
+        monkeypatch.setenv('MZ_FORCE_GENERIC', '1')
+        gen = _planner(net, B, **kw).search(*args, **rng)
+        monkeypatch.delenv('MZ_FORCE_GENERIC', raising=False)
+        for k in ('visits', 'pi', 'action', 'root_value'):
+            np.testing.assert_array_equal(fast[k], gen[k])
+
+
 def test_production_rng_properties():
     """On-device Philox mode at the BASELINE size (4096 envs): size-independent properties -- visit counts sum to
     num_simulations, policy is a distribution supported on legal actions, runs are reproducible for a fixed seed."""
