@@ -27,6 +27,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_stamps():
+    """Diagnostic library with per-phase s_memtime stamps (never loaded by the product path)."""
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    out = os.path.join(LIB_DIR, 'libmzplanner_hip_stamps.so')
+    subprocess.check_call([hipcc] + FLAGS + ['-DMZ_STAMPS'] + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out])
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
@@ -39,4 +47,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
+    if '--stamps' in sys.argv:
+        print(build_stamps())
+        sys.exit(0)
     print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

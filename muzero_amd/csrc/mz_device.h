@@ -53,23 +53,64 @@ __device__ __forceinline__ float signed_parabolic(float x) {
     return sg * m;
 }
 
+// DPP row rotation inside each 16-lane row (no LDS crossbar, one VALU op): lane i receives lane (i + n) mod 16.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x120 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + N, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Row reduction order shared with the oracle (row_reduce16 in oracle/mz_oracle.c): each of 16 lanes holds the
-// sequential partial sum of elements j, j+16, j+32, ...; the partials are combined by an xor-butterfly with strides
-// 1, 2, 4, 8.  Every lane of the 16-lane segment returns the same total.
+// sequential partial sum of elements j, j+16, j+32, ...; the partials are combined by a butterfly with strides
+// 8, 4, 2, 1.  Every lane of the 16-lane segment returns the same total.
 __device__ __forceinline__ float butterfly16(float part) {
-    part = part + __shfl_xor(part, 1, 64);
-    part = part + __shfl_xor(part, 2, 64);
-    part = part + __shfl_xor(part, 4, 64);
-    part = part + __shfl_xor(part, 8, 64);
+    part = part + row_ror<8>(part);
+    part = part + row_ror<4>(part);
+    part = part + row_ror<2>(part);
+    part = part + row_ror<1>(part);
     return part;
 }
 __device__ __forceinline__ float butterfly16_max(float v) {
     float o;
-    o = __shfl_xor(v, 1, 64); v = o > v ? o : v;
-    o = __shfl_xor(v, 2, 64); v = o > v ? o : v;
-    o = __shfl_xor(v, 4, 64); v = o > v ? o : v;
-    o = __shfl_xor(v, 8, 64); v = o > v ? o : v;
+    o = row_ror<8>(v); v = o > v ? o : v;
+    o = row_ror<4>(v); v = o > v ? o : v;
+    o = row_ror<2>(v); v = o > v ? o : v;
+    o = row_ror<1>(v); v = o > v ? o : v;
     return v;
+}
+__device__ __forceinline__ float butterfly16_min(float v) {
+    float o;
+    o = row_ror<8>(v); v = o < v ? o : v;
+    o = row_ror<4>(v); v = o < v ? o : v;
+    o = row_ror<2>(v); v = o < v ? o : v;
+    o = row_ror<1>(v); v = o < v ? o : v;
+    return v;
+}
+
+// register-only version for rows of at most 32 values: lane j holds l0 = row[j], l1 = row[j + 16] (has1 says whether
+// the second one exists).  Same arithmetic as row_logits_to_scalar.
+__device__ __forceinline__ float row2_logits_to_scalar(float l0, float l1, bool has0, bool has1, int S, int j) {
+    const float ninf = __uint_as_float(0xff800000u);
+    float m = has0 ? l0 : ninf;
+    m = (has1 && l1 > m) ? l1 : m;
+    m = butterfly16_max(m);
+    const float e0 = has0 ? expf_det(l0 - m) : 0.0f;
+    const float e1 = has1 ? expf_det(l1 - m) : 0.0f;
+    float a = 0.0f;
+    if (has0) a = a + e0;
+    if (has1) a = a + e1;
+    const float sum = butterfly16(a);
+    const int half = (S - 1) / 2;
+    float t = 0.0f;
+    if (has0) { const float p = e0 / sum; const float tt = p * (float)(j - half); t = t + tt; }
+    if (has1) { const float p = e1 / sum; const float tt = p * (float)(j + 16 - half); t = t + tt; }
+    return signed_parabolic(butterfly16(t));
 }
 
 // logits_to_transformed_expected_value, util.py:70-93: softmax -> E[linspace(-(S-1)/2, (S-1)/2, S)] -> signed_parabolic,

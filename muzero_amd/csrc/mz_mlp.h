@@ -37,6 +37,7 @@ struct MlpLayer {
     int n_tiles;     // ceil(n/16)
     int k_steps;     // ceil(k/4)
     int kg;          // ceil(k/16)
+    int b_lds;       // float offset of the LDS copy of b (staged once per kernel by stage_biases)
 };
 
 struct MlpNet {
@@ -55,6 +56,8 @@ struct MlpLds {
     int LG;   // [2][16][lg_stride]            : head logits (0: reward / policy, 1: value)
     int lg_stride;
     int OUT;  // [16][4] : per-env scalars {reward, value, -, -}
+    int BIAS; // all layers' padded biases (MlpLayer::b_lds)
+    int PM;   // [2][4][16] : per-wave min / max partials of the hidden state (fused normalisation)
     int total_floats;
 };
 
@@ -62,14 +65,15 @@ struct MlpLds {
 // (tile = wave_slot + i*WG_WAVES); up to NACC tiles are accumulated concurrently (independent MFMA chains hide the
 // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32).  epi(tile, acc) receives D: acc[r] = Y[16*tile + 4q + r][e].
 template <int NACC, typename Epi>
-__device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __restrict__ Xs, int t0, int lane, Epi& epi) {
+__device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs, int t0, int lane,
+                                           Epi& epi) {
     const int q = lane >> 4;
     f32x4 acc[NACC];
     const float4* wp[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; j++) {
         const int t = t0 + j * WG_WAVES;
-        const float4 bv = *reinterpret_cast<const float4*>(L.b + t * 16 + q * 4);
+        const float4 bv = *reinterpret_cast<const float4*>(lds + L.b_lds + t * 16 + q * 4);
         acc[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
         wp[j] = reinterpret_cast<const float4*>(L.w) + (size_t)t * L.kg * 64 + lane;
     }
@@ -113,21 +117,22 @@ __device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __res
 }
 
 template <typename Epi>
-__device__ __forceinline__ void gemm_layer(const MlpLayer& L, const float* __restrict__ Xs, int wave_slot, int lane, Epi epi) {
+__device__ __forceinline__ void gemm_layer(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs, int wave_slot,
+                                           int lane, Epi epi) {
     int t = wave_slot;
     while (t + 7 * WG_WAVES < L.n_tiles) {
-        gemm_chunk<8>(L, Xs, t, lane, epi);
+        gemm_chunk<8>(L, lds, Xs, t, lane, epi);
         t += 8 * WG_WAVES;
     }
     if (t + 3 * WG_WAVES < L.n_tiles) {
-        gemm_chunk<4>(L, Xs, t, lane, epi);
+        gemm_chunk<4>(L, lds, Xs, t, lane, epi);
         t += 4 * WG_WAVES;
     }
     if (t + 1 * WG_WAVES < L.n_tiles) {
-        gemm_chunk<2>(L, Xs, t, lane, epi);
+        gemm_chunk<2>(L, lds, Xs, t, lane, epi);
         t += 2 * WG_WAVES;
     }
-    if (t < L.n_tiles) gemm_chunk<1>(L, Xs, t, lane, epi);
+    if (t < L.n_tiles) gemm_chunk<1>(L, lds, Xs, t, lane, epi);
 }
 
 // epilogue: ReLU, store to the packed LDS buffer that feeds the next layer (neuron n becomes k = n there)
@@ -172,6 +177,15 @@ struct EpiLogits {
         p[3] = a[3];
     }
 };
+
+// copy every layer's padded bias vector into LDS (once per kernel): bias reads then cost an LDS access, not an
+// exposed L2 round trip at the head of each layer
+__device__ __forceinline__ void stage_biases(const MlpNet& net, float* lds, int tid) {
+    for (int l = 0; l < L_COUNT; l++) {
+        const MlpLayer& L = net.L[l];
+        for (int i = tid; i < L.n_tiles * 16; i += WG_THREADS) lds[L.b_lds + i] = L.b[i];
+    }
+}
 
 // normalize_hidden_state (util.py:31-36) for the MLP nets: min/max over the H features of each env, then
 // (h - min) / (max - min + 1e-8).  Reads HN (packed), writes HS (packed) and, if gdst != nullptr, the row-major
@@ -248,25 +262,25 @@ __device__ __forceinline__ void heads_to_scalars(const MlpNet& net, const MlpLds
 __device__ __forceinline__ void mlp_recurrent_tile(const MlpNet& net, const MlpLds& o, float* lds, float* const* grow, bool want_policy,
                                                    float* pi_out /*LDS [16][A] or null*/, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    gemm_layer(net.L[L_DYN0], lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
+    gemm_layer(net.L[L_DYN0], lds, lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
     __syncthreads();
-    gemm_layer(net.L[L_DYN1], lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
+    gemm_layer(net.L[L_DYN1], lds, lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
     __syncthreads();
     normalize_tile(net, lds + o.HN, lds + o.HS, grow, tid);
     __syncthreads();
     // reward head reads the UN-normalised state (network.py:195-196), value head the normalised one
-    gemm_layer(net.L[L_REW0], lds + o.HN, wave, lane, EpiReluPacked{lds + o.H1, lane});
-    gemm_layer(net.L[L_VAL0], lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
+    gemm_layer(net.L[L_REW0], lds, lds + o.HN, wave, lane, EpiReluPacked{lds + o.H1, lane});
+    gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
     __syncthreads();
-    gemm_layer(net.L[L_REW1], lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-    gemm_layer(net.L[L_VAL1], lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+    gemm_layer(net.L[L_REW1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+    gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
     __syncthreads();
     heads_to_scalars(net, o, lds, tid, true);
     if (want_policy) {
         __syncthreads();
-        gemm_layer(net.L[L_POL0], lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
+        gemm_layer(net.L[L_POL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
         __syncthreads();
-        gemm_layer(net.L[L_POL1], lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+        gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
         __syncthreads();
         row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
     }
@@ -277,17 +291,17 @@ __device__ __forceinline__ void mlp_recurrent_tile(const MlpNet& net, const MlpL
 //   out: HS = normalised hidden (and grow rows), pi_out LDS [16][A] (softmax), OUT[e][1] = value.
 __device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds& o, float* lds, float* const* grow, float* pi_out, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    gemm_layer(net.L[L_REP0], lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
+    gemm_layer(net.L[L_REP0], lds, lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
     __syncthreads();
-    gemm_layer(net.L[L_REP1], lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
+    gemm_layer(net.L[L_REP1], lds, lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
     __syncthreads();
     normalize_tile(net, lds + o.HN, lds + o.HS, grow, tid);
     __syncthreads();
-    gemm_layer(net.L[L_POL0], lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
-    gemm_layer(net.L[L_VAL0], lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
+    gemm_layer(net.L[L_POL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
+    gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
     __syncthreads();
-    gemm_layer(net.L[L_POL1], lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-    gemm_layer(net.L[L_VAL1], lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+    gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+    gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
     __syncthreads();
     row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
     heads_to_scalars(net, o, lds, tid, false);

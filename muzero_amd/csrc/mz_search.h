@@ -65,7 +65,22 @@ struct SearchParams {
     unsigned long long seed;
     unsigned int move_counter;
     unsigned int env_offset;  // global id of env 0 (multi-GPU sharding: Philox streams are keyed by global env id)
+    long long* stamps;        // diagnostic builds (-DMZ_STAMPS) only: per-phase cycle sums of block 0, else unused
 };
+
+// Phase stamps for the diagnostic build (python -m muzero_amd.build --stamps -> libmzplanner_hip_stamps.so): thread 0
+// of block 0 accumulates s_memtime deltas per phase.  Never compiled into the product library; read SHARES, not totals.
+#ifdef MZ_STAMPS
+#define MZ_STAMP_DECL long long _t0 = 0; long long _acc[16] = {0};
+#define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
+#define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); _acc[i] += _t1 - _t0; _t0 = _t1; } } while (0)
+#define MZ_STAMP_FLUSH(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = _acc[_i]; } while (0)
+#else
+#define MZ_STAMP_DECL
+#define MZ_STAMP_START() do {} while (0)
+#define MZ_STAMP(i) do {} while (0)
+#define MZ_STAMP_FLUSH(P) do {} while (0)
+#endif
 
 __device__ __forceinline__ TreeNode* node_at(unsigned char* smem, const SearchParams& P, int e, int i) {
     return reinterpret_cast<TreeNode*>(smem + P.t_nodes) + (e * P.NN + i);
@@ -83,7 +98,8 @@ constexpr int MAX_CH = 4;  // action chunks of 16 lanes: A <= 64 in the LDS-resi
 
 // One descent from the root to an unexpanded child for all 16 envs of the tile (mcts.py:372-379).
 // Every lane of an env's 16-lane segment ends with identical (segment-uniform) results.
-__device__ __forceinline__ void tree_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g) {
+__device__ __forceinline__ void tree_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
+                                            int& leaf_action) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
     const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
     const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
@@ -126,11 +142,7 @@ __device__ __forceinline__ void tree_select(unsigned char* smem, const SearchPar
                 best = u[ch] > best ? u[ch] : best;
             }
         }
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-            const float o = __shfl_xor(best, m, 64);
-            best = o > best ? o : best;
-        }
+        best = butterfly16_max(best);  // DPP row rotations inside the env's 16-lane segment
         // tie set in ascending action order (np.where(ucb == max), mcts.py:124)
         unsigned msk[MAX_CH];
         int total = 0;
@@ -182,6 +194,8 @@ __device__ __forceinline__ void tree_select(unsigned char* smem, const SearchPar
     if (a0 == 0) {
         sel[0] = lp; sel[1] = la; sel[2] = lpl; sel[3] = ties;
     }
+    leaf_parent = lp;
+    leaf_action = la;
 }
 
 // expand the selected leaf and back its value up to the root (mcts.py:386-389, 129-157); one lane per env
@@ -311,6 +325,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     float** dst = reinterpret_cast<float**>(smem + P.t_ptr) + 16;
 
     // tables and tree initialisation
+    if (!SCRIPTED) stage_biases(P.net, lds, tid);
     {
         double* ft = reinterpret_cast<double*>(smem + P.t_ftab);
         for (int i = tid; i < (P.S + 1) * (P.S + 1); i += WG_THREADS) ft[i] = P.ftab[i];
@@ -347,7 +362,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     __syncthreads();
 
     for (int s = 0; s < P.S; s++) {
-        tree_select(smem, P, tid, env_ok, env_g);
+        int lp_unused, la_unused;
+        tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
         __syncthreads();
         const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
         float r32, v32;
@@ -404,6 +420,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_infer(const InferParams P) {
     float** dst = reinterpret_cast<float**>(smem + P.t_ptr) + 16;
     float* pi = reinterpret_cast<float*>(smem + P.t_pi);
     int* act = reinterpret_cast<int*>(smem + P.t_act);
+    stage_biases(P.net, lds, tid);
     if (a0 == 0) {
         src[e] = env_ok ? P.in + (size_t)env_g * (INITIAL ? P.net.in_dim : P.net.H) : nullptr;
         dst[e] = env_ok ? P.hidden_out + (size_t)env_g * P.net.H : nullptr;

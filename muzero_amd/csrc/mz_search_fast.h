@@ -143,9 +143,9 @@ __device__ __forceinline__ void chain_prime(float4 (&ring)[D], const WSrc& wp, i
     for (int d = 0; d < D; d++) ring[d] = bload(wp, lane * 16, d);
 }
 
-template <int KGP, int D, typename Epi>
-__device__ __forceinline__ void chain_layer_ring(float4 (&ring)[D], const WSrc& wp, const float* __restrict__ bias, int tile,
-                                                 const float* __restrict__ Xs, int lane, Epi epi) {
+template <int KGP, int D>
+__device__ __forceinline__ f32x4 chain_layer_ring(float4 (&ring)[D], const WSrc& wp, const float* __restrict__ bias, int tile,
+                                                  const float* __restrict__ Xs, int lane) {
     const int q = lane >> 4;
     const float4 bv = *reinterpret_cast<const float4*>(bias + tile * 16 + q * 4);
     f32x4 acc = f32x4{bv.x, bv.y, bv.z, bv.w};
@@ -164,7 +164,7 @@ __device__ __forceinline__ void chain_layer_ring(float4 (&ring)[D], const WSrc& 
         x1 = x2;
         __builtin_amdgcn_sched_barrier(0);
     }
-    epi(tile, acc);
+    return acc;
 }
 
 // P = num_planes (256 or 512); XG = k-groups of the dynamics input (hidden 64 + one-hot A): 5 for A <= 16
@@ -185,7 +185,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     const float** src = reinterpret_cast<const float**>(smem + Pm.t_ptr);
     float** dst = reinterpret_cast<float**>(smem + Pm.t_ptr) + 16;
 
+    MZ_STAMP_DECL
+    MZ_STAMP_START();
     // ---- tables, tree, root (identical to k_search) ----
+    stage_biases(net, lds, tid);
     {
         double* ft = reinterpret_cast<double*>(smem + Pm.t_ftab);
         for (int i = tid; i < (Pm.S + 1) * (Pm.S + 1); i += WG_THREADS) ft[i] = Pm.ftab[i];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     __syncthreads();
     if (a0 == 0 && env_ok) root_prior(smem, Pm, e, env_g);
 
-    // ---- resident chain weights: dynamics layer 2 tile `wave`; reward layer 2 (waves 0,1) / value layer 2 (waves 2,3) ----
+    // ---- chain-layer weight sources: dynamics layer 2 tile `wave`; reward layer 2 (waves 0,1) / value layer 2 (waves 2,3) ----
     constexpr int HD = 8;  // chain ring depth (groups in flight): shared by the dynamics-2 chain and the head chain
     float4 cring[HD];
     const WSrc pd = make_wsrc(net.L[L_DYN1].w, (unsigned)net.L[L_DYN1].n_tiles * KGP * 1024u, wave * KGP * 1024);
@@ -227,56 +230,103 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     float4 ring[2][NT];
     wload<NT>(ring[0], s_dyn0, lane * 16, 0);
     const int x_last = net.L[L_DYN0].k_steps - 4 * (XG - 1);  // k-steps in the last input group (1..4)
+    // MFMA-side env of this lane (D column) and its hidden-state rows in the HBM node store
+    const int e2 = lane & 15, q = lane >> 4;
+    const int env2 = blockIdx.x * TILE_E + e2;
+    const bool env2_ok = env2 < Pm.B;
+    float* const hid_sel = Pm.hidden + (size_t)(env_ok ? env_g : 0) * Pm.NN * 64;   // select-side env (tid >> 4)
+    float* const hid_mma = Pm.hidden + (size_t)(env2_ok ? env2 : 0) * Pm.NN * 64;  // MFMA-side env (lane & 15)
+    const float* bias = lds;  // biases live in LDS (stage_biases)
     __syncthreads();
+    MZ_STAMP(0);  // root: tables + initial inference + prior
 
     // Ring parity: a layer that starts with its group 0 in ring[PAR] and has KG groups leaves its successor's group 0
     // in ring[(PAR + KG) & 1].  dyn0 has 5 groups, rew0 and val0 4 each, so the parity flips once per simulation:
     // the body is instantiated for both parities and the simulation loop alternates them (no register copies).
     auto sim = [&](auto par_tag, int s) {
         constexpr int PAR = decltype(par_tag)::value;
-        tree_select(smem, Pm, tid, env_ok, env_g);
-        __syncthreads();
-        int* act = reinterpret_cast<int*>(smem + Pm.t_sel) + 64;
+        int lp, la;
+        tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
+        // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
+        // their descent and scatter it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
         {
-            const int* sel = reinterpret_cast<const int*>(smem + Pm.t_sel) + e * 4;
-            if (a0 == 0) {
-                float* base = env_ok ? Pm.hidden + (size_t)env_g * Pm.NN * net.H : nullptr;
-                src[e] = env_ok ? base + (size_t)sel[0] * net.H : nullptr;
-                dst[e] = env_ok ? base + (size_t)(s + 1) * net.H : nullptr;
-                act[e] = sel[1];
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (env_ok) hv = *reinterpret_cast<const float4*>(hid_sel + (size_t)lp * 64 + a0 * 4);
+            float* X = lds + o.X;
+            const int base = ((((a0 >> 2) * 64) + e) << 2) + (a0 & 3);  // pk(4*a0 + j, e) = base + 64 j
+            X[base] = hv.x; X[base + 64] = hv.y; X[base + 128] = hv.z; X[base + 192] = hv.w;
+            X[(((4 * 64) + (a0 & 3) * 16 + e) << 2) + (a0 >> 2)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;  // pk(64 + a0, e)
+        }
+        chain_prime<KGP, HD>(cring, pd, lane);  // dynamics-2 chain weights: first HD groups land during dynamics layer 1
+        __syncthreads();
+        MZ_STAMP(1);  // select + gather
+        // dynamics layer 1 (wide, streamed): X -> H1
+        stream_layer<NT, XG, PAR>(ring, s_dyn0, s_rew0, bias + net.L[L_DYN0].b_lds, lds + o.X, x_last, wave, lane, EpiReluPacked{lds + o.H1, lane});
+        __syncthreads();
+        MZ_STAMP(3);  // dynamics layer 1
+        // dynamics layer 2 (chain): H1 -> h; normalisation (util.py:31-36) fused into the epilogue: per-wave min/max
+        // partials through LDS, then every lane normalises its own 4 neurons in registers
+        {
+            const f32x4 h = chain_layer_ring<KGP, HD>(cring, pd, bias + net.L[L_DYN1].b_lds, wave, lds + o.H1, lane);
+            float mn = h[0] < h[1] ? h[0] : h[1], mx = h[0] > h[1] ? h[0] : h[1];
+            mn = h[2] < mn ? h[2] : mn; mx = h[2] > mx ? h[2] : mx;
+            mn = h[3] < mn ? h[3] : mn; mx = h[3] > mx ? h[3] : mx;
+            float t;
+            t = __shfl_xor(mn, 16, 64); mn = t < mn ? t : mn;
+            t = __shfl_xor(mx, 16, 64); mx = t > mx ? t : mx;
+            t = __shfl_xor(mn, 32, 64); mn = t < mn ? t : mn;
+            t = __shfl_xor(mx, 32, 64); mx = t > mx ? t : mx;
+            float* pm = lds + o.PM;
+            if (q == 0) { pm[wave * 16 + e2] = mn; pm[64 + wave * 16 + e2] = mx; }
+            EpiRawPacked{lds + o.HN, lane}(wave, h);  // un-normalised state feeds the reward head (network.py:195-196)
+            chain_prime<KGP, HD>(cring, ph, lane);    // head-chain weights: land during the two wide layers below
+            __syncthreads();
+            MZ_STAMP(4);  // dynamics layer 2 (chain)
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float a = pm[w * 16 + e2], b = pm[64 + w * 16 + e2];
+                mn = a < mn ? a : mn;
+                mx = b > mx ? b : mx;
+            }
+            const float d = (mx - mn) + 1e-8f;
+            const f32x4 hs = f32x4{(h[0] - mn) / d, (h[1] - mn) / d, (h[2] - mn) / d, (h[3] - mn) / d};
+            EpiRawPacked{lds + o.HS, lane}(wave, hs);
+            if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = make_float4(hs[0], hs[1], hs[2], hs[3]);
+        }
+        __syncthreads();
+        MZ_STAMP(5);  // normalise + hidden store
+        // reward layer 1 (HN -> H1) and value layer 1 (HS -> V1), wide, streamed; the last one requests the next
+        // simulation's dynamics group 0, which then lands during the chain / softmax / tree phases
+        stream_layer<NT, 4, PAR ^ 1>(ring, s_rew0, s_val0, bias + net.L[L_REW0].b_lds, lds + o.HN, 4, wave, lane, EpiReluPacked{lds + o.H1, lane});
+        stream_layer<NT, 4, PAR ^ 1>(ring, s_val0, s_dyn0, bias + net.L[L_VAL0].b_lds, lds + o.HS, 4, wave, lane, EpiReluPacked{lds + o.V1, lane});
+        __syncthreads();
+        MZ_STAMP(6);  // reward + value layer 1
+        // reward layer 2 (waves 0,1) / value layer 2 (waves 2,3): chain, weights through the ring
+        if (head_ok) {
+            if (is_val_wave) {
+                const f32x4 lg = chain_layer_ring<KGP, HD>(cring, ph, bias + net.L[L_VAL1].b_lds, head_tile, lds + o.V1, lane);
+                EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane}(head_tile, lg);
+            } else {
+                const f32x4 lg = chain_layer_ring<KGP, HD>(cring, ph, bias + net.L[L_REW1].b_lds, head_tile, lds + o.H1, lane);
+                EpiLogits{lds + o.LG, o.lg_stride, lane}(head_tile, lg);
             }
         }
         __syncthreads();
-        load_hidden_onehot(net, lds + o.X, src, act, tid);
-        __syncthreads();
-        chain_prime<KGP, HD>(cring, pd, lane);  // dynamics-2 chain weights: first HD groups land during dynamics layer 1
-        // dynamics layer 1 (wide, streamed): X -> H1
-        stream_layer<NT, XG, PAR>(ring, s_dyn0, s_rew0, net.L[L_DYN0].b, lds + o.X, x_last, wave, lane, EpiReluPacked{lds + o.H1, lane});
-        __syncthreads();
-        // dynamics layer 2 (chain): H1 -> HN
-        chain_layer_ring<KGP, HD>(cring, pd, net.L[L_DYN1].b, wave, lds + o.H1, lane, EpiRawPacked{lds + o.HN, lane});
-        __syncthreads();
-        normalize_tile(net, lds + o.HN, lds + o.HS, dst, tid);
-        __syncthreads();
-        chain_prime<KGP, HD>(cring, ph, lane);  // head-chain weights: first HD groups land during the two wide layers below
-        // reward layer 1 (HN -> H1) and value layer 1 (HS -> V1), wide, streamed; the last one requests the next
-        // simulation's dynamics group 0, which then lands during the chain / softmax / tree phases
-        stream_layer<NT, 4, PAR ^ 1>(ring, s_rew0, s_val0, net.L[L_REW0].b, lds + o.HN, 4, wave, lane, EpiReluPacked{lds + o.H1, lane});
-        stream_layer<NT, 4, PAR ^ 1>(ring, s_val0, s_dyn0, net.L[L_VAL0].b, lds + o.HS, 4, wave, lane, EpiReluPacked{lds + o.V1, lane});
-        __syncthreads();
-        // reward layer 2 (waves 0,1) / value layer 2 (waves 2,3): chain, weights through the head ring
-        if (head_ok) {
-            if (is_val_wave)
-                chain_layer_ring<KGP, HD>(cring, ph, net.L[L_VAL1].b, head_tile, lds + o.V1, lane,
-                                          EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
-            else
-                chain_layer_ring<KGP, HD>(cring, ph, net.L[L_REW1].b, head_tile, lds + o.H1, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+        MZ_STAMP(7);  // reward / value layer 2 (chain)
+        // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
+        // the results are segment-uniform, so the env's lane 0 goes straight on to expand + backup
+        {
+            const float* rr = lds + o.LG + e * o.lg_stride;
+            const float* rv = lds + o.LG + (16 + e) * o.lg_stride;
+            const bool r0 = a0 < net.Sr, r1 = a0 + 16 < net.Sr, v0 = a0 < net.Sv, v1 = a0 + 16 < net.Sv;
+            const float lr0 = rr[r0 ? a0 : 0], lr1 = rr[r1 ? a0 + 16 : 0], lv0 = rv[v0 ? a0 : 0], lv1 = rv[v1 ? a0 + 16 : 0];
+            const float rew = net.Sr == 1 ? rr[0] : row2_logits_to_scalar(lr0, lr1, r0, r1, net.Sr, a0);
+            const float val = net.Sv == 1 ? rv[0] : row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
+            MZ_STAMP(8);  // softmax + expectation + transform
+            if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
         __syncthreads();
-        heads_to_scalars(net, o, lds, tid, true);
-        __syncthreads();
-        if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, lds[o.OUT + e * 4 + 0], lds[o.OUT + e * 4 + 1]);
-        __syncthreads();
+        MZ_STAMP(9);  // expand + backup
     };
     int s = 0;
     for (; s + 1 < Pm.S; s += 2) {
@@ -285,6 +335,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     }
     if (s < Pm.S) sim(std::integral_constant<int, 0>{}, s);
     if (a0 == 0 && env_ok) tree_finish(smem, Pm, e, env_g);
+    MZ_STAMP(10);  // play policy + action
+    MZ_STAMP_FLUSH(Pm);
 }
 
 }  // namespace mz

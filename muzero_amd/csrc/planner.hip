@@ -74,6 +74,7 @@ struct mz_planner {
     double *d_pi = nullptr, *d_root = nullptr;
     int* d_visits = nullptr;
     int* d_err = nullptr;
+    long long* d_stamps = nullptr;
     // scripted hook
     float *d_spi0 = nullptr, *d_svalues = nullptr, *d_srewards = nullptr;
     int *d_tparent = nullptr, *d_taction = nullptr;
@@ -126,6 +127,9 @@ static void compute_layout(mz_planner* p) {
     o.lg_stride = pad16(mx) + 1;  // odd stride: 16 envs read their logits rows without LDS bank conflicts
     o.LG = off; off += ((2 * 16 * o.lg_stride + 3) & ~3);
     o.OUT = off; off += 64;
+    o.BIAS = off;
+    for (int l = 0; l < L_COUNT; l++) { n.L[l].b_lds = off; off += n.L[l].n_tiles * 16; }
+    o.PM = off; off += 128;
     o.total_floats = off;
 
     // search kernel: tree part after the network part
@@ -203,6 +207,8 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     HIPCHK(hipMalloc(&p->d_visits, B * A * sizeof(int)));
     HIPCHK(hipMalloc(&p->d_err, sizeof(int)));
     HIPCHK(hipMemset(p->d_err, 0, sizeof(int)));
+    HIPCHK(hipMalloc(&p->d_stamps, 16 * sizeof(long long)));
+    HIPCHK(hipMemset(p->d_stamps, 0, 16 * sizeof(long long)));
     HIPCHK(hipMemset(p->d_mask, 1, B * A));
     // child_U factor table: pb(N) / (n_child + 1) in float64 with the host libm, i.e. the very values math.log /
     // math.sqrt give the reference (mcts.py:193-195)
@@ -233,7 +239,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     void* bufs[] = {p->d_obs, p->d_mask, p->d_cur, p->d_opp, p->d_temp, p->d_noise, p->d_utie, p->d_ufinal, p->d_hidden, p->d_ftab,
-                    p->d_action, p->d_pi, p->d_root, p->d_visits, p->d_err, p->d_spi0, p->d_svalues, p->d_srewards, p->d_tparent,
+                    p->d_action, p->d_pi, p->d_root, p->d_visits, p->d_err, p->d_stamps, p->d_spi0, p->d_svalues, p->d_srewards, p->d_tparent,
                     p->d_taction, p->d_inf_in, p->d_inf_hidden, p->d_inf_reward, p->d_inf_value, p->d_inf_pi, p->d_inf_action};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -410,7 +416,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     s.noise = p->d_noise; s.u_tie = p->d_utie; s.u_final = p->d_ufinal; s.hidden = p->d_hidden; s.ftab = p->d_ftab;
     s.out_action = p->d_action; s.out_pi = p->d_pi; s.out_root = p->d_root; s.out_visits = p->d_visits; s.err = p->d_err;
     s.s_pi0 = p->d_spi0; s.s_values = p->d_svalues; s.s_rewards = p->d_srewards; s.trace_parent = p->d_tparent; s.trace_action = p->d_taction;
-    s.seed = c.seed; s.move_counter = p->move_counter++; s.env_offset = 0;
+    s.seed = c.seed; s.move_counter = p->move_counter++; s.env_offset = 0; s.stamps = p->d_stamps;
     const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
     hipEvent_t ea = nullptr, eb = nullptr;
     if (p->profiling) {
@@ -460,6 +466,8 @@ static int download_results(mz_planner* p, int batch, int32_t* h_action, double*
     HIPCHK(hipStreamSynchronize(p->stream));
     if (err) {
         HIPCHK(hipMemset(p->d_err, 0, sizeof(int)));
+    HIPCHK(hipMalloc(&p->d_stamps, 16 * sizeof(long long)));
+    HIPCHK(hipMemset(p->d_stamps, 0, 16 * sizeof(long long)));
         if (err == 4) return fail(MZ_E_TIES, "injected tie-break stream exhausted (raise mz_config.max_ties)");
         return fail(MZ_E_INVALID, "search kernel reported error " + std::to_string(err));
     }
@@ -595,6 +603,15 @@ extern "C" int mz_selfplay_counters(mz_planner* p, int64_t out[4]) {
 // ---------------------------------------------------------------------------------------------------------
 // measurement hooks
 // ---------------------------------------------------------------------------------------------------------
+// diagnostic builds only (-DMZ_STAMPS): per-phase cycle sums of the last search launch, block 0.  Not part of the ABI header.
+extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
+    if (!p || !out) return fail(MZ_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpy(out, p->d_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return MZ_OK;
+}
+
 extern "C" int mz_planner_synchronize(mz_planner* p) {
     if (!p) return fail(MZ_E_INVALID, "null planner");
     HIPCHK(hipSetDevice(p->device));

@@ -74,8 +74,9 @@ float mzo_signed_parabolic(float x) {
 
 /* Row reduction used by every softmax / expectation on the path.  The ORDER is part of the oracle's numerical
  * contract (the HIP kernels reproduce it with 16 lanes per row): 16 interleaved partial sums
- * part[j] = v[j] + v[j+16] + v[j+32] + ... (sequential), then an xor-butterfly over the 16 partials with
- * strides 1, 2, 4, 8 (IEEE addition is commutative, so every slot ends with the same total). */
+ * part[j] = v[j] + v[j+16] + v[j+32] + ... (sequential), then a butterfly over the 16 partials with strides
+ * 8, 4, 2, 1 (IEEE addition is commutative, so every slot ends with the same total; with descending strides the
+ * xor-butterfly equals the rotate-butterfly the GPU runs as DPP row_ror:8/4/2/1). */
 static float row_reduce16(const float* v, int n) {
     float part[16];
     for (int j = 0; j < 16; j++) {
@@ -83,7 +84,7 @@ static float row_reduce16(const float* v, int n) {
         for (int i = j; i < n; i += 16) a = a + v[i];
         part[j] = a;
     }
-    for (int m = 1; m < 16; m <<= 1) {
+    for (int m = 8; m >= 1; m >>= 1) {
         float nxt[16];
         for (int j = 0; j < 16; j++) nxt[j] = part[j] + part[j ^ m];
         for (int j = 0; j < 16; j++) part[j] = nxt[j];

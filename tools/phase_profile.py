@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the tuned search kernel (block 0), from the -DMZ_STAMPS build.
+    python -m muzero_amd.build --stamps && python tools/phase_profile.py [cartpole|tictactoe]
+Read the SHARES; the stamped build's total time is not a performance number."""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import numpy as np  # noqa: E402
+
+from muzero_amd import planner as pl  # noqa: E402
+
+pl.LIB_PATH = os.path.join(REPO, 'muzero_amd', 'lib', 'libmzplanner_hip_stamps.so')
+from helpers import build_mlp, mlp_case  # noqa: E402
+
+NAMES = ['root', 'select', 'gather', 'dyn1(wide)', 'dyn2(chain)', 'normalise', 'rew1+val1(wide)', 'heads2(chain)', 'softmax', 'backup', 'finish']
+
+
+def main():
+    g = sys.argv[1] if len(sys.argv) > 1 else 'cartpole'
+    board = g == 'tictactoe'
+    net = build_mlp(mlp_case(g))
+    B, S = 4096, 25 if board else 50
+    kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, **kw), 0)
+    p.load_state_dict(net.state_dict())
+    p.selfplay_reset(pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE)
+    p.selfplay_step(-1.0 if board else 1.0, 5)
+    p.lib.mz_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    tot = np.zeros(16)
+    n = 10
+    for _ in range(n):
+        p.selfplay_step(-1.0 if board else 1.0, 1)
+        st = (C.c_longlong * 16)()
+        p.lib.mz_debug_read_stamps(p.h, st)
+        tot += np.array(st[:], dtype=np.float64)
+    tot /= n
+    total = tot.sum()
+    print(f'{g}: total stamped ticks per move (block 0): {total:.0f}  (s_memtime ticks, 100 MHz on gfx950)')
+    for i, name in enumerate(NAMES):
+        per_sim = tot[i] / (S if 1 <= i <= 9 else 1)
+        print(f'  {name:18s} {tot[i]:10.0f}  {100 * tot[i] / total:5.1f}%   per-sim {per_sim:8.1f}')
+
+
+if __name__ == '__main__':
+    main()
