@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmzplanner_hip.so')
 SOURCES = ['planner.hip']
-HEADERS = ['mz_device.h', 'mz_mlp.h', 'mz_search.h', 'mz_search_fast.h', 'mz_env.h', os.path.join('..', '..', 'include', 'mzplanner.h')]
+HEADERS = ['mz_device.h', 'mz_mlp.h', 'mz_search.h', 'mz_tree2.h', 'mz_search_fast.h', 'mz_env.h', os.path.join('..', '..', 'include', 'mzplanner.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-pass-failed']
 

@@ -29,6 +29,10 @@ struct SearchParams {
     MlpLds o;
     // LDS byte offsets of the tree part
     int t_nodes, t_child, t_prior, t_pi0, t_mm, t_sel, t_ftab, t_ptr, t_tmp;
+    // tree_mode 2 layout (mz_tree2.h): 24-byte nodes, per-(node, action) child entries, selection cache, path, version
+    int t2_nodes, t2_entries, t_cache, t_path, t_ver, t2_ftab;
+    int tree_mode;  // 0: reference-order tree walk (mz_search.h); 2: entry table + selection cache + lane-parallel backup (mz_tree2.h, A <= 16)
+    const double* ftab_tri;  // [(S+1)(S+2)/2]: ftab restricted to n_child <= N
     int lds_bytes;
     // search configuration (config.py:58-78)
     int S, A, NN;
@@ -71,11 +75,14 @@ struct SearchParams {
 // Phase stamps for the diagnostic build (python -m muzero_amd.build --stamps -> libmzplanner_hip_stamps.so): thread 0
 // of block 0 accumulates s_memtime deltas per phase.  Never compiled into the product library; read SHARES, not totals.
 #ifdef MZ_STAMPS
+__device__ unsigned long long g_dbg[8];  // [0] levels visited, [1] cache hits, [2] descents, [3] version bumps, [4] max-depth sum per wave-descent
+#define MZ_COUNT(i, v) atomicAdd(&g_dbg[i], (unsigned long long)(v))
 #define MZ_STAMP_DECL long long _t0 = 0; long long _acc[16] = {0};
 #define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); _acc[i] += _t1 - _t0; _t0 = _t1; } } while (0)
 #define MZ_STAMP_FLUSH(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = _acc[_i]; } while (0)
 #else
+#define MZ_COUNT(i, v) do {} while (0)
 #define MZ_STAMP_DECL
 #define MZ_STAMP_START() do {} while (0)
 #define MZ_STAMP(i) do {} while (0)
@@ -96,92 +103,102 @@ __device__ __forceinline__ int nth_set_bit(unsigned m, int idx) {
 
 constexpr int MAX_CH = 4;  // action chunks of 16 lanes: A <= 64 in the LDS-resident kernel
 
+// pUCT evaluation of ONE node for the env's 16-lane segment (best_child, mcts.py:104-127): child_Q (mcts.py:159-178) +
+// child_U (mcts.py:180-200) per action lane, segment max, tie set in ascending action order, np.random.choice among
+// real ties.  `draw` says whether this segment may consume a tie-break draw.  Returns the selected action
+// (segment-uniform).  Must be executed by all 64 lanes of the wave (DPP / ballot inside).
+__device__ __forceinline__ int select_level(unsigned char* smem, const SearchParams& P, int e, int a0, int seg, int n, double mn, double mx,
+                                            bool draw, int& ties, int env_g) {
+    const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
+    const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
+    const bool norm = mx > mn;
+    const bool prior_f32 = (P.noise_mode == 0);
+    const int nch = (P.A + 15) >> 4;
+    const int Nn = node_at(smem, P, e, n)->N;
+    const double* frow = ftab + Nn * (P.S + 1);
+    const short* crow = child_row(smem, P, e, n);
+    float u[MAX_CH];
+    float best = __uint_as_float(0xff800000u);
+#pragma unroll
+    for (int ch = 0; ch < MAX_CH; ch++) {
+        u[ch] = __uint_as_float(0xff800000u);
+        const int a = ch * 16 + a0;
+        if (ch < nch && a < P.A) {
+            const int c = crow[a];
+            int cn = 0;
+            float qa = 0.0f;  // child_Q, mcts.py:159-178
+            if (c >= 0) {
+                const TreeNode* cd = node_at(smem, P, e, c);
+                cn = cd->N;
+                if (cn > 0) {
+                    double v = cd->vq;
+                    if (norm) v = (v - mn) / (mx - mn);
+                    qa = (float)v;
+                }
+            }
+            const double f = frow[cn];  // child_U, mcts.py:180-200
+            const float ua = prior_f32 ? ((float)prior[a] * (float)f) : (float)(prior[a] * f);
+            u[ch] = qa + ua;
+            best = u[ch] > best ? u[ch] : best;
+        }
+    }
+    best = butterfly16_max(best);  // DPP row rotations inside the env's 16-lane segment
+    // tie set in ascending action order (np.where(ucb == max), mcts.py:124)
+    unsigned msk[MAX_CH];
+    int total = 0;
+#pragma unroll
+    for (int ch = 0; ch < MAX_CH; ch++) {
+        const int a = ch * 16 + a0;
+        const bool eq = (ch < nch) && (a < P.A) && (u[ch] == best);
+        const unsigned long long bal = __ballot(eq);
+        msk[ch] = (unsigned)(bal >> (16 * seg)) & 0xffffu;
+        total += __popc(msk[ch]);
+    }
+    int pick = 0;
+    if (draw && total > 1) {  // np.random.choice consumes randomness only when there is a real tie
+        double uu;
+        if (P.rng_mode == 0) {
+            if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
+            else { uu = 0.5; if (a0 == 0) atomicExch(P.err, 4); }
+        } else {
+            Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
+            uu = g.uniform();
+        }
+        ties++;
+        pick = (int)floor(uu * (double)total);
+        pick = pick >= total ? total - 1 : pick;
+    }
+    int a_sel = 0, cum = 0;
+    bool found = false;
+#pragma unroll
+    for (int ch = 0; ch < MAX_CH; ch++) {
+        const int c = __popc(msk[ch]);
+        if (!found && pick < cum + c) {
+            a_sel = ch * 16 + nth_set_bit(msk[ch], pick - cum);
+            found = true;
+        }
+        cum += c;
+    }
+    return a_sel;
+}
+
 // One descent from the root to an unexpanded child for all 16 envs of the tile (mcts.py:372-379).
 // Every lane of an env's 16-lane segment ends with identical (segment-uniform) results.
 __device__ __forceinline__ void tree_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
                                             int& leaf_action) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
-    const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
-    const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
     double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
     int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
     const double mn = mm[0], mx = mm[1];
-    const bool norm = mx > mn;
-    const bool prior_f32 = (P.noise_mode == 0);
-    const int nch = (P.A + 15) >> 4;
     int n = 0, cp = env_ok ? P.cur[env_g] : 0, op = env_ok ? P.opp[env_g] : 0;
     int ties = sel[3];
     bool done = !env_ok;
     int lp = 0, la = 0, lpl = 0, depth = 0;
     while (__any(!done)) {
-        const int Nn = node_at(smem, P, e, n)->N;
-        const double* frow = ftab + Nn * (P.S + 1);
-        const short* crow = child_row(smem, P, e, n);
-        float u[MAX_CH];
-        float best = __uint_as_float(0xff800000u);
-#pragma unroll
-        for (int ch = 0; ch < MAX_CH; ch++) {
-            u[ch] = __uint_as_float(0xff800000u);
-            const int a = ch * 16 + a0;
-            if (ch < nch && a < P.A) {
-                const int c = crow[a];
-                int cn = 0;
-                float qa = 0.0f;  // child_Q, mcts.py:159-178
-                if (c >= 0) {
-                    const TreeNode* cd = node_at(smem, P, e, c);
-                    cn = cd->N;
-                    if (cn > 0) {
-                        double v = cd->vq;
-                        if (norm) v = (v - mn) / (mx - mn);
-                        qa = (float)v;
-                    }
-                }
-                const double f = frow[cn];  // child_U, mcts.py:180-200
-                const float ua = prior_f32 ? ((float)prior[a] * (float)f) : (float)(prior[a] * f);
-                u[ch] = qa + ua;
-                best = u[ch] > best ? u[ch] : best;
-            }
-        }
-        best = butterfly16_max(best);  // DPP row rotations inside the env's 16-lane segment
-        // tie set in ascending action order (np.where(ucb == max), mcts.py:124)
-        unsigned msk[MAX_CH];
-        int total = 0;
-#pragma unroll
-        for (int ch = 0; ch < MAX_CH; ch++) {
-            const int a = ch * 16 + a0;
-            const bool eq = (ch < nch) && (a < P.A) && (u[ch] == best);
-            const unsigned long long bal = __ballot(eq);
-            msk[ch] = (unsigned)(bal >> (16 * seg)) & 0xffffu;
-            total += __popc(msk[ch]);
-        }
-        int pick = 0;
-        if (!done && total > 1) {  // np.random.choice consumes randomness only when there is a real tie
-            double uu;
-            if (P.rng_mode == 0) {
-                if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
-                else { uu = 0.5; if (a0 == 0) atomicExch(P.err, 4); }
-            } else {
-                Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
-                uu = g.uniform();
-            }
-            ties++;
-            pick = (int)floor(uu * (double)total);
-            pick = pick >= total ? total - 1 : pick;
-        }
-        int a_sel = 0, cum = 0;
-        bool found = false;
-#pragma unroll
-        for (int ch = 0; ch < MAX_CH; ch++) {
-            const int c = __popc(msk[ch]);
-            if (!found && pick < cum + c) {
-                a_sel = ch * 16 + nth_set_bit(msk[ch], pick - cum);
-                found = true;
-            }
-            cum += c;
-        }
+        const int a_sel = select_level(smem, P, e, a0, seg, n, mn, mx, !done, ties, env_g);
         const int t = cp; cp = op; op = t;  // mcts.py:379
         if (!done) {
-            const int c = crow[a_sel];
+            const int c = child_row(smem, P, e, n)[a_sel];
             depth++;
             if (c < 0 || depth > P.NN) {
                 done = true;
@@ -267,10 +284,11 @@ __device__ __forceinline__ void root_prior(unsigned char* smem, const SearchPara
 }
 
 // play: visit counts -> policy -> action (mcts.py:391-407); one lane per env
-__device__ __forceinline__ void tree_finish(unsigned char* smem, const SearchParams& P, int e, int env_g) {
+// play: visit counts -> policy -> action (mcts.py:391-407); one lane per env.  raw_visits: the root children's N in LDS.
+__device__ __forceinline__ void play_from_visits(unsigned char* smem, const SearchParams& P, int e, int env_g, const int* raw_visits, double rootW,
+                                                 int rootN) {
     double* tmp = reinterpret_cast<double*>(smem + P.t_tmp) + e * P.A;
     const unsigned char* mk = P.has_mask ? P.mask + (size_t)env_g * P.A : nullptr;
-    const short* crow = child_row(smem, P, e, 0);
     const int A = P.A;
     const double T = P.temperature[env_g];
     double ex = 1.0;
@@ -281,8 +299,7 @@ __device__ __forceinline__ void tree_finish(unsigned char* smem, const SearchPar
     }
     int best = 0, bestv = -1;
     for (int a = 0; a < A; a++) {
-        const int c = crow[a];
-        int v = c >= 0 ? node_at(smem, P, e, c)->N : 0;
+        int v = raw_visits[a];
         if (mk && !mk[a]) v = 0;
         if (P.out_visits) P.out_visits[(size_t)env_g * A + a] = v;
         if (v > bestv) { bestv = v; best = a; }
@@ -309,9 +326,21 @@ __device__ __forceinline__ void tree_finish(unsigned char* smem, const SearchPar
         action = idx >= A ? A - 1 : idx;
     }
     P.out_action[env_g] = action;
-    const TreeNode* root = node_at(smem, P, e, 0);
-    P.out_root[env_g] = root->N > 0 ? root->W / (double)root->N : 0.0;
+    P.out_root[env_g] = rootN > 0 ? rootW / (double)rootN : 0.0;
 }
+
+__device__ __forceinline__ void tree_finish(unsigned char* smem, const SearchParams& P, int e, int env_g) {
+    int* rv = reinterpret_cast<int*>(smem + P.t_pi0) + e * P.A;  // the float32 root policy is no longer needed: reuse as int scratch
+    const short* crow = child_row(smem, P, e, 0);
+    for (int a = 0; a < P.A; a++) {
+        const int c = crow[a];
+        rv[a] = c >= 0 ? node_at(smem, P, e, c)->N : 0;
+    }
+    const TreeNode* root = node_at(smem, P, e, 0);
+    play_from_visits(smem, P, e, env_g, rv, root->W, root->N);
+}
+
+#include "mz_tree2.h"
 
 template <bool SCRIPTED>
 __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
@@ -327,14 +356,20 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     // tables and tree initialisation
     if (!SCRIPTED) stage_biases(P.net, lds, tid);
     {
-        double* ft = reinterpret_cast<double*>(smem + P.t_ftab);
-        for (int i = tid; i < (P.S + 1) * (P.S + 1); i += WG_THREADS) ft[i] = P.ftab[i];
-        short* ch = reinterpret_cast<short*>(smem + P.t_child);
-        for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) ch[i] = -1;
+        if (P.tree_mode == 2) {
+            tree2_init(smem, P, tid, env_ok, env_g);
+        } else {
+            double* ft = reinterpret_cast<double*>(smem + P.t_ftab);
+            for (int i = tid; i < (P.S + 1) * (P.S + 1); i += WG_THREADS) ft[i] = P.ftab[i];
+            short* ch = reinterpret_cast<short*>(smem + P.t_child);
+            for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) ch[i] = -1;
+            if (a0 == 0) {
+                TreeNode* r = node_at(smem, P, e, 0);
+                r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
+                r->player = env_ok ? P.cur[env_g] : 0;
+            }
+        }
         if (a0 == 0) {
-            TreeNode* r = node_at(smem, P, e, 0);
-            r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
-            r->player = env_ok ? P.cur[env_g] : 0;
             double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
             mm[0] = P.has_bounds ? P.kb_min : __longlong_as_double(0x7ff0000000000000LL);   // MinMaxStats, mcts.py:36-38
             mm[1] = P.has_bounds ? P.kb_max : __longlong_as_double(0xfff0000000000000LL);
@@ -363,7 +398,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
 
     for (int s = 0; s < P.S; s++) {
         int lp_unused, la_unused;
-        tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
+        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
+        else tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
         __syncthreads();
         const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
         float r32, v32;
@@ -389,10 +425,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
             r32 = lds[P.o.OUT + e * 4 + 0];
             v32 = lds[P.o.OUT + e * 4 + 1];
         }
-        if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
+        if (P.tree_mode == 2) tree2_backup(smem, P, tid, env_ok, s, r32, v32);
+        else if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
         __syncthreads();
     }
-    if (a0 == 0 && env_ok) tree_finish(smem, P, e, env_g);
+    if (a0 == 0 && env_ok) {
+        if (P.tree_mode == 2) tree2_finish(smem, P, e, env_g);
+        else tree_finish(smem, P, e, env_g);
+    }
 }
 
 // ---- stand-alone batched inference (network.py:62-111) on the same tile pipeline ----

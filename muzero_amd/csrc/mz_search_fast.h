@@ -190,14 +190,20 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     // ---- tables, tree, root (identical to k_search) ----
     stage_biases(net, lds, tid);
     {
-        double* ft = reinterpret_cast<double*>(smem + Pm.t_ftab);
-        for (int i = tid; i < (Pm.S + 1) * (Pm.S + 1); i += WG_THREADS) ft[i] = Pm.ftab[i];
-        short* ch = reinterpret_cast<short*>(smem + Pm.t_child);
-        for (int i = tid; i < TILE_E * Pm.NN * Pm.A; i += WG_THREADS) ch[i] = -1;
+        if (Pm.tree_mode == 2) {
+            tree2_init(smem, Pm, tid, env_ok, env_g);
+        } else {
+            double* ft = reinterpret_cast<double*>(smem + Pm.t_ftab);
+            for (int i = tid; i < (Pm.S + 1) * (Pm.S + 1); i += WG_THREADS) ft[i] = Pm.ftab[i];
+            short* ch = reinterpret_cast<short*>(smem + Pm.t_child);
+            for (int i = tid; i < TILE_E * Pm.NN * Pm.A; i += WG_THREADS) ch[i] = -1;
+            if (a0 == 0) {
+                TreeNode* r = node_at(smem, Pm, e, 0);
+                r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
+                r->player = env_ok ? Pm.cur[env_g] : 0;
+            }
+        }
         if (a0 == 0) {
-            TreeNode* r = node_at(smem, Pm, e, 0);
-            r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
-            r->player = env_ok ? Pm.cur[env_g] : 0;
             double* mm = reinterpret_cast<double*>(smem + Pm.t_mm) + e * 2;
             mm[0] = Pm.has_bounds ? Pm.kb_min : __longlong_as_double(0x7ff0000000000000LL);
             mm[1] = Pm.has_bounds ? Pm.kb_max : __longlong_as_double(0xfff0000000000000LL);
@@ -246,7 +252,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     auto sim = [&](auto par_tag, int s) {
         constexpr int PAR = decltype(par_tag)::value;
         int lp, la;
-        tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
+        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la);
+        else tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and scatter it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
         {
@@ -323,7 +330,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
             const float rew = net.Sr == 1 ? rr[0] : row2_logits_to_scalar(lr0, lr1, r0, r1, net.Sr, a0);
             const float val = net.Sv == 1 ? rv[0] : row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
             MZ_STAMP(8);  // softmax + expectation + transform
-            if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
+            if (Pm.tree_mode == 2) tree2_backup(smem, Pm, tid, env_ok, s, rew, val);
+            else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
         __syncthreads();
         MZ_STAMP(9);  // expand + backup
@@ -334,7 +342,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
         sim(std::integral_constant<int, 1>{}, s + 1);
     }
     if (s < Pm.S) sim(std::integral_constant<int, 0>{}, s);
-    if (a0 == 0 && env_ok) tree_finish(smem, Pm, e, env_g);
+    if (a0 == 0 && env_ok) {
+        if (Pm.tree_mode == 2) tree2_finish(smem, Pm, e, env_g);
+        else tree_finish(smem, Pm, e, env_g);
+    }
     MZ_STAMP(10);  // play policy + action
     MZ_STAMP_FLUSH(Pm);
 }

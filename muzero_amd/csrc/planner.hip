@@ -54,10 +54,15 @@ struct mz_planner {
     MlpLds o{};
     float* d_w[L_COUNT] = {};
     float* d_b[L_COUNT] = {};
-    SearchParams sp{};
+    SearchParams sp{};   // tree_mode 0 layout
+    SearchParams sp2{};  // tree_mode 2 layout (valid if tree2_ok)
+    bool tree2_ok = false;
+    int lds_mode0 = 0, lds_mode2 = 0;
+    double* d_ftab_tri = nullptr;
     InferParams ip{};
     // tuned kernel for the benchmark shapes (mz_search_fast.h): per-wave weight streams of the wide layers
     int fast_planes = 0;  // 0: generic kernel only; 256 / 512: k_search_fast<P>
+    bool tree_old = false;       // MZ_TREE_OLD=1: evaluate every level on every descent (A/B measurements, tests)
     bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
     float* d_stream[3] = {};
     FastWeights fw{};
@@ -148,6 +153,25 @@ static void compute_layout(mz_planner* p) {
     s.t_ptr = take(32 * 8, 16);
     s.t_ftab = take((s.S + 1) * (s.S + 1) * 8, 16);
     s.lds_bytes = (b + 15) & ~15;
+    // tree_mode 2 layout (mz_tree2.h) replaces t_nodes / t_child / t_ftab when it fits in LDS
+    p->lds_mode0 = s.lds_bytes;
+    p->tree2_ok = false;
+    if (s.A <= 16) {
+        b = o.total_floats * 4;
+        const int n2 = take(16 * s.NN * 24, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
+                  p0 = take(16 * s.A * 4, 16), mmo = take(16 * 2 * 8, 16), se = take(128 * 4, 16), pt = take(32 * 8, 16),
+                  ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * s.NN * 8, 16), pa = take(16 * (s.NN + 3) * 2, 16),
+                  ve = take(16 * 4, 16);
+        const int total = (b + 15) & ~15;
+        if (total <= 160 * 1024) {
+            p->tree2_ok = true;
+            p->lds_mode2 = total;
+            p->sp2 = s;
+            SearchParams& q = p->sp2;
+            q.t2_nodes = n2; q.t2_entries = e2; q.t_prior = pr; q.t_tmp = tm; q.t_pi0 = p0; q.t_mm = mmo; q.t_sel = se; q.t_ptr = pt;
+            q.t2_ftab = ft; q.t_cache = ca; q.t_path = pa; q.t_ver = ve; q.lds_bytes = total; q.tree_mode = 2;
+        }
+    }
 
     InferParams& ip = p->ip;
     ip.net = n; ip.o = o;
@@ -178,9 +202,11 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     {
         const char* fg = getenv("MZ_FORCE_GENERIC");
         p->force_generic = fg && fg[0] == '1';
+        const char* to = getenv("MZ_TREE_OLD");
+        p->tree_old = to && to[0] == '1';
     }
     compute_layout(p);
-    if (p->sp.lds_bytes > 160 * 1024) {
+    if (p->sp.lds_bytes > 160 * 1024 && !p->tree2_ok) {
         int need = p->sp.lds_bytes;
         delete p;
         return fail(MZ_E_INVALID, "configuration needs " + std::to_string(need) + " bytes of LDS per workgroup (> 160 KiB): tree does not fit the LDS-resident kernel");
@@ -218,17 +244,27 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         for (size_t cn = 0; cn <= S; cn++) ft[N * (S + 1) + cn] = pb / (double)(cn + 1);
     }
     HIPCHK(hipMemcpy(p->d_ftab, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<double> tri;
+        for (size_t N = 0; N <= S; N++)
+            for (size_t cn = 0; cn <= N; cn++) tri.push_back(ft[N * (S + 1) + cn]);
+        HIPCHK(hipMalloc(&p->d_ftab_tri, tri.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(p->d_ftab_tri, tri.data(), tri.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipEventCreate(&p->ev_begin));
     HIPCHK(hipEventCreate(&p->ev_end));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
+    int max_lds = p->tree2_ok ? p->lds_mode2 : 0;
+    if (p->lds_mode0 <= 160 * 1024 && p->lds_mode0 > max_lds) max_lds = p->lds_mode0;
+    if (p->lds_mode0 > 160 * 1024) p->tree_old = false;  // only the mode-2 layout fits
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     if (c.hidden_dim == 64 && (c.num_planes == 256 || c.num_planes == 512) && c.num_actions <= 16 && c.value_support_size <= 32 &&
         c.reward_support_size <= 32) {
         p->fast_planes = c.num_planes;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512>), hipFuncAttributeMaxDynamicSharedMemorySize, p->sp.lds_bytes));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
     *out = p;
     return MZ_OK;
@@ -238,7 +274,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     if (!p) return MZ_OK;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->d_obs, p->d_mask, p->d_cur, p->d_opp, p->d_temp, p->d_noise, p->d_utie, p->d_ufinal, p->d_hidden, p->d_ftab,
+    void* bufs[] = {p->d_obs, p->d_mask, p->d_cur, p->d_opp, p->d_temp, p->d_noise, p->d_utie, p->d_ufinal, p->d_hidden, p->d_ftab, p->d_ftab_tri,
                     p->d_action, p->d_pi, p->d_root, p->d_visits, p->d_err, p->d_stamps, p->d_spi0, p->d_svalues, p->d_srewards, p->d_tparent,
                     p->d_taction, p->d_inf_in, p->d_inf_hidden, p->d_inf_reward, p->d_inf_value, p->d_inf_pi, p->d_inf_action};
     for (void* b : bufs)
@@ -403,7 +439,11 @@ static int next_kernel_events(mz_planner* p, hipEvent_t* a, hipEvent_t* b) {
 // launches the fused search kernel over inputs that are already resident in the planner's device buffers
 static int launch_search(mz_planner* p, int batch, int deterministic, bool has_mask, bool injected_rng, bool scripted) {
     const mz_config& c = p->cfg;
-    SearchParams s = p->sp;
+    const bool mode2 = p->tree2_ok && !p->tree_old;
+    SearchParams s = mode2 ? p->sp2 : p->sp;
+    s.tree_mode = mode2 ? 2 : 0;
+    s.net = p->net;
+    s.ftab_tri = p->d_ftab_tri;
     s.discount = c.discount; s.board = c.is_board_game; s.has_bounds = c.has_known_bounds;
     s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
     s.deterministic = deterministic; s.has_mask = has_mask ? 1 : 0;
@@ -609,6 +649,11 @@ extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipMemcpy(out, p->d_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+#ifdef MZ_STAMPS
+    unsigned long long dbg[8];
+    HIPCHK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(mz::g_dbg), sizeof(dbg)));
+    for (int i = 0; i < 5; i++) out[11 + i] = (long long)dbg[i];
+#endif
     return MZ_OK;
 }
 

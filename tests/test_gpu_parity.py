@@ -76,10 +76,12 @@ def _tree_case(i):
 TREE_IDS = [i for i in range(int(TREE['num_cases'])) if int(TREE[f'c{i}_A']) <= 64]
 
 
+@pytest.mark.parametrize('tree_old', ['0', '1'], ids=['cached', 'per_level'])
 @pytest.mark.parametrize('i', TREE_IDS)
-def test_tree_kernels_bit_exact_vs_reference(i):
+def test_tree_kernels_bit_exact_vs_reference(i, tree_old, monkeypatch):
     """Scripted network outputs injected: select / expand / backup / min-max / play policy of the HIP kernel against the
     REFERENCE's own tree (golden fixture), every simulation's (parent, action) included."""
+    monkeypatch.setenv('MZ_TREE_OLD', tree_old)  # both tree schedules (selection cache / per-level evaluation)
     c = _tree_case(i)
     A, S = int(c['A']), int(c['sims'])
     net = build_mlp(('x', (4,), A, 16, 1, 1, 16, 1))
@@ -199,9 +201,15 @@ def test_generic_and_tuned_kernels_agree(monkeypatch):
         fast = _planner(net, B, **kw).search(*args, **rng)
         monkeypatch.setenv('MZ_FORCE_GENERIC', '1')
         gen = _planner(net, B, **kw).search(*args, **rng)
+        monkeypatch.setenv('MZ_TREE_OLD', '1')
+        gen_old = _planner(net, B, **kw).search(*args, **rng)
         monkeypatch.delenv('MZ_FORCE_GENERIC', raising=False)
+        fast_old = _planner(net, B, **kw).search(*args, **rng)
+        monkeypatch.delenv('MZ_TREE_OLD', raising=False)
         for k in ('visits', 'pi', 'action', 'root_value'):
             np.testing.assert_array_equal(fast[k], gen[k])
+            np.testing.assert_array_equal(fast[k], gen_old[k])
+            np.testing.assert_array_equal(fast[k], fast_old[k])
 
 
 def test_production_rng_properties():
