@@ -75,14 +75,25 @@ struct SearchParams {
 // Phase stamps for the diagnostic build (python -m muzero_amd.build --stamps -> libmzplanner_hip_stamps.so): thread 0
 // of block 0 accumulates s_memtime deltas per phase.  Never compiled into the product library; read SHARES, not totals.
 #ifdef MZ_STAMPS
-__device__ unsigned long long g_dbg[8];  // [0] levels visited, [1] cache hits, [2] descents, [3] version bumps, [4] max-depth sum per wave-descent
+#ifdef MZ_COUNTERS
 #define MZ_COUNT(i, v) atomicAdd(&g_dbg[i], (unsigned long long)(v))
+#else
+#define MZ_COUNT(i, v) do {} while (0)
+#endif
+__device__ unsigned long long g_dbg[8];
+__device__ long long g_sub[8];  // sub-phase cycle sums written by thread 0 of block 0 only
+#define MZ_SUB_DECL long long _s0 = 0;
+#define MZ_SUB_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _s0 = __builtin_readcyclecounter(); } while (0)
+#define MZ_SUB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _s1 = __builtin_readcyclecounter(); g_sub[i] += _s1 - _s0; _s0 = _s1; } } while (0)  // [0] levels visited, [1] cache hits, [2] descents, [3] version bumps, [4] max-depth sum per wave-descent
 #define MZ_STAMP_DECL long long _t0 = 0; long long _acc[16] = {0};
 #define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); _acc[i] += _t1 - _t0; _t0 = _t1; } } while (0)
 #define MZ_STAMP_FLUSH(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = _acc[_i]; } while (0)
 #else
 #define MZ_COUNT(i, v) do {} while (0)
+#define MZ_SUB_DECL
+#define MZ_SUB_START() do {} while (0)
+#define MZ_SUB(i) do {} while (0)
 #define MZ_STAMP_DECL
 #define MZ_STAMP_START() do {} while (0)
 #define MZ_STAMP(i) do {} while (0)
@@ -397,8 +408,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     __syncthreads();
 
     for (int s = 0; s < P.S; s++) {
-        int lp_unused, la_unused;
-        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
+        int lp_unused, la_unused, mypath = 0;
+        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused, mypath);
         else tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
         __syncthreads();
         const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
             r32 = lds[P.o.OUT + e * 4 + 0];
             v32 = lds[P.o.OUT + e * 4 + 1];
         }
-        if (P.tree_mode == 2) tree2_backup(smem, P, tid, env_ok, s, r32, v32);
+        if (P.tree_mode == 2) tree2_backup(smem, P, tid, env_ok, s, r32, v32, mypath);
         else if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
         __syncthreads();
     }

@@ -251,8 +251,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     // the body is instantiated for both parities and the simulation loop alternates them (no register copies).
     auto sim = [&](auto par_tag, int s) {
         constexpr int PAR = decltype(par_tag)::value;
-        int lp, la;
-        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la);
+        int lp, la, mypath = 0;
+        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, mypath);
         else tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and scatter it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
             const float rew = net.Sr == 1 ? rr[0] : row2_logits_to_scalar(lr0, lr1, r0, r1, net.Sr, a0);
             const float val = net.Sv == 1 ? rv[0] : row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
             MZ_STAMP(8);  // softmax + expectation + transform
-            if (Pm.tree_mode == 2) tree2_backup(smem, Pm, tid, env_ok, s, rew, val);
+            if (Pm.tree_mode == 2) tree2_backup(smem, Pm, tid, env_ok, s, rew, val, mypath);
             else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
         __syncthreads();

@@ -1,20 +1,24 @@
 // mz_tree2.h -- tree_mode 2: the same search tree as mz_search.h's reference-order walk (bit-identical results), laid
-// out and scheduled for the 16-lanes-per-env segments of the search kernels.  Included from mz_search.h.
+// out and scheduled for the 16-lanes-per-env segments of the search kernels.  Included from mz_search.h (inside
+// namespace mz, after SearchParams and the select helpers).
 //
 //   * child ENTRY table: entry[node][action] = {vq, N, child node} of that child, kept up to date by backup.  One
-//     16-byte LDS read per action lane gives everything child_Q / child_U need about a child (mcts.py:159-200); the
-//     per-level dependent chain is {entry, parent N} -> {pb factor table} -> ALU, two LDS round trips.
-//   * selection CACHE: every node caches its current best child {action, child, version}.  A node's pUCT ranking
-//     depends only on its own N, its children's (N, vq), the root prior and the env's min-max pair.  The first three
-//     change only when a backup passes through the node; a min-max change bumps the env's version and invalidates
-//     all of the env's cached entries.  A level is re-evaluated at visit time on a miss, or when the cached evaluation
-//     found a real tie (the tie-break draw must be consumed at visit time, like np.random.choice in mcts.py:124).
+//     16-byte LDS read per action lane gives everything child_Q / child_U need about a child (mcts.py:159-200).
+//   * selection CACHE: every node caches its current best child together with the MARGIN by which it beat the
+//     runner-up.  A node's pUCT ranking depends on its own N, its children's (N, vq), the root prior -- all of which
+//     change only when a backup passes through the node (which refreshes the cache) -- and on the env's min-max pair,
+//     which only rescales the child_Q terms.  Every min-max change k moves each normalised Q by at most
+//     D_k = max(norm_new(min_old), 1 - norm_new(max_old)) (the difference of two affine maps peaks at an endpoint), so
+//     a cached choice is PROVABLY still the unique argmax while 2 * (sum of D_k since it was computed) + rounding slack
+//     < margin.  Otherwise (or if the cached evaluation saw a real tie, whose np.random.choice draw must be consumed at
+//     visit time, mcts.py:124) the level is evaluated at visit time exactly as the reference does.  The cache is a pure
+//     shortcut: it never changes a result.
+//   * a DESCENT is therefore mostly a chain of single 16-byte cache reads; the visited nodes are kept in registers
+//     (lane d of the env's segment holds the node at depth d).
 //   * BACKUP (mcts.py:129-157) runs on the env's 16 lanes: lane i owns the i-th path node from the leaf; the value
-//     recurrence is a DPP shift chain in registers; W/N/Q/vq updates and the min-max reduction are lane-parallel; then
-//     the best child of every path node is re-evaluated lane-parallel (16/A_pad nodes at a time) with the final
-//     statistics and written to the cache.
+//     recurrence is a DPP shift chain in registers; W/N/Q/vq updates, the min-max reduction and the best-child refresh
+//     of every path node (each lane loops over its node's actions) are lane-parallel.
 #pragma once
-// (included inside namespace mz by mz_search.h, after SearchParams / select helpers are defined)
 
 struct __attribute__((aligned(8))) Node2 {  // 24 bytes
     double W;
@@ -29,31 +33,28 @@ struct __attribute__((aligned(16))) Entry2 {  // 16 bytes
     int cn;     // child's visit count (0: never expanded)
     int c;      // child's node index, -1 if unexpanded
 };
-struct SelCache {
-    int packed;  // (best_action & 0xffff) | (best_child_node << 16); best_action == -1: evaluate at visit time
-    int ver;
+struct __attribute__((aligned(8))) SelCache {  // 8 bytes
+    int packed;  // bits 0-7 best action (0xff: evaluate at visit time), bits 8-15 env epoch when computed (mod 256,
+                 // bumped when normalisation switches on), bits 16-31 best child node (signed, -1 unexpanded)
+    float t;     // margin + 2 * drift at compute time, rounded down: valid while 2 * drift_now + slack < t
 };
+struct EnvCacheState {  // per env, 16 bytes
+    double drift;  // sum of D_k
+    int epoch;
+    int pad;
+};
+constexpr float kCacheSlack = 4e-5f;  // float32 rounding of child_Q / child_U / their sum, for |ucb| < 64
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v, int old = 0) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     const long long b = __double_as_longlong(v);
     const int lo = dpp_i<CTRL>((int)(b & 0xffffffffLL)), hi = dpp_i<CTRL>((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_SHR1 = 0x111;
+constexpr int DPP_SHR1 = 0x111;
 
-// max over aligned sub-groups of `width` lanes (2, 4, 8 or 16) inside a 16-lane row
-__device__ __forceinline__ float subgroup_max(float v, int width) {
-    float o = dpp_f<DPP_XOR1>(v); v = o > v ? o : v;
-    if (width > 2) { o = dpp_f<DPP_XOR2>(v); v = o > v ? o : v; }
-    if (width > 4) { o = dpp_f<DPP_HALF_MIRROR>(v); v = o > v ? o : v; }
-    if (width > 8) { o = dpp_f<DPP_MIRROR>(v); v = o > v ? o : v; }
-    return v;
-}
 __device__ __forceinline__ int row_max_i(int v) {
     int o;
     o = dpp_i<0x128>(v); v = o > v ? o : v;
@@ -83,8 +84,11 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     Entry2* en = reinterpret_cast<Entry2*>(smem + P.t2_entries);
     for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].cn = 0; en[i].c = -1; }
     SelCache* c = reinterpret_cast<SelCache*>(smem + P.t_cache);
-    for (int i = tid; i < TILE_E * P.NN; i += WG_THREADS) { c[i].packed = 0xffff; c[i].ver = -1; }  // all stale
-    if (tid < TILE_E) reinterpret_cast<int*>(smem + P.t_ver)[tid] = 0;
+    for (int i = tid; i < TILE_E * P.NN; i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = 0.0f; }  // action 0xff: never a hit
+    if (tid < TILE_E) {
+        EnvCacheState* st = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + tid;
+        st->drift = 0.0; st->epoch = 0; st->pad = 0;
+    }
     if ((tid & 15) == 0) {
         const int e = tid >> 4;
         Node2* r = node2_at(smem, P, e, 0);
@@ -92,9 +96,8 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     }
 }
 
-// pUCT value of action lane `a0` of a node from its entry (child_Q + child_U, mcts.py:159-200)
-__device__ __forceinline__ float puct_entry(const SearchParams& P, const Entry2& en, double f, double prior_a, double mn, double mx, bool norm,
-                                            bool prior_f32) {
+// pUCT value of one action of a node from its entry (child_Q + child_U, mcts.py:159-200)
+__device__ __forceinline__ float puct_entry(const Entry2& en, double f, double prior_a, double mn, double mx, bool norm, bool prior_f32) {
     float qa = 0.0f;
     if (en.cn > 0) {
         double v = en.vq;
@@ -106,14 +109,16 @@ __device__ __forceinline__ float puct_entry(const SearchParams& P, const Entry2&
 }
 
 // One descent (mcts.py:372-379).  Results segment-uniform.  All 64 lanes of every wave must call it.
+// `mypath`: lane d of the segment receives the node visited at depth d (d < 16; deeper levels go to the LDS path row).
 __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
-                                             int& leaf_action) {
+                                             int& leaf_action, int& mypath) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
     const double* mm = reinterpret_cast<const double*>(smem + P.t_mm) + e * 2;
     int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
     short* path = path_row(smem, P, e);
     const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
-    const int cur_ver = reinterpret_cast<const int*>(smem + P.t_ver)[e];
+    const EnvCacheState st = reinterpret_cast<const EnvCacheState*>(smem + P.t_ver)[e];
+    const float drift_up = __double2float_ru(st.drift);
     const double mn = mm[0], mx = mm[1];
     const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0), lane_ok = a0 < P.A;
     const double prior_a = lane_ok ? (reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A)[a0] : 0.0;
@@ -121,18 +126,20 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     int ties = sel[3];
     bool done = !env_ok;
     int lp = 0, la = 0, lpl = 0, depth = 0;
+    mypath = 0;
+    MZ_SUB_DECL
+    MZ_SUB_START();
     while (__any(!done)) {
-        // round 1: everything that depends only on n
         const SelCache cc = *cache_at(smem, P, e, n);
-        const int Np = node2_at(smem, P, e, n)->N;
-        const Entry2 en = entry2_row(smem, P, e, n)[lane_ok ? a0 : 0];
-        const int ba = (int)(short)(cc.packed & 0xffff), bc = cc.packed >> 16;
-        const bool hit = (cc.ver == cur_ver) && (ba >= 0);
+        const int ba = cc.packed & 0xff, bc = cc.packed >> 16;
+        const bool hit = (((cc.packed >> 8) & 0xff) == (st.epoch & 0xff)) && (ba != 0xff) && (2.0f * drift_up + kCacheSlack < cc.t);
         if (a0 == 0 && !done) { MZ_COUNT(0, 1); MZ_COUNT(1, hit ? 1 : 0); }
         int a_sel = ba, c = bc;
         if (__any(!done && !hit)) {  // wave-uniform: some segment has to evaluate this level (best_child, mcts.py:104-127)
-            const double f = ftab[tri(Np) + en.cn];  // round 2
-            const float u = lane_ok ? puct_entry(P, en, f, prior_a, mn, mx, norm, prior_f32) : __uint_as_float(0xff800000u);
+            const int Np = node2_at(smem, P, e, n)->N;
+            const Entry2 en = entry2_row(smem, P, e, n)[lane_ok ? a0 : 0];
+            const double f = ftab[tri(Np) + en.cn];
+            const float u = lane_ok ? puct_entry(en, f, prior_a, mn, mx, norm, prior_f32) : __uint_as_float(0xff800000u);
             const float best = butterfly16_max(u);
             const bool eq = lane_ok && (u == best);
             const unsigned long long bal = __ballot(eq);
@@ -158,7 +165,8 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
         }
         const int t = cp; cp = op; op = t;  // mcts.py:379
         if (!done) {
-            if (a0 == 0) path[depth] = (short)n;
+            if (depth < 16) { if (a0 == depth) mypath = n; }
+            else if (a0 == 0) path[depth] = (short)n;
             depth++;
             if (c < 0 || depth > P.NN) {
                 done = true;
@@ -168,6 +176,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
             }
         }
     }
+    MZ_SUB(3);  // descent loop
     if (a0 == 0 && env_ok) MZ_COUNT(2, 1);
     if (a0 == 0) {
         sel[0] = lp; sel[1] = la; sel[2] = lpl; sel[3] = ties;
@@ -177,30 +186,39 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     leaf_action = la;
 }
 
-// expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform
-__device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32) {
-    const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
+// expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
+// mypath as produced by tree2_select of the same simulation
+__device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
+                                             int mypath) {
+    const int e = tid >> 4, a0 = tid & 15;
     const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
     double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
-    int* ver = reinterpret_cast<int*>(smem + P.t_ver) + e;
-    short* path = path_row(smem, P, e);
+    EnvCacheState* stp = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + e;
+    const short* path = path_row(smem, P, e);
+    const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
+    const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
     const int lp = sel[0], la = sel[1], cp = sel[2], nw = s + 1;
     const int depth = reinterpret_cast<const int*>(smem + P.t_sel)[80 + e];
     const int L = env_ok ? depth + 1 : 0;  // path nodes including the new one
     const double g = P.discount;
     const bool board = P.board != 0;
+    MZ_SUB_DECL
+    MZ_SUB_START();
     if (a0 == 0 && env_ok) {  // expand (mcts.py:386); LDS operations of one wave execute in order: later reads see this
         Node2* nd = node2_at(smem, P, e, nw);
         nd->W = 0.0; nd->N = 0; nd->reward = r32; nd->parent = (short)lp; nd->move = (short)la; nd->player = cp;
-        path[depth] = (short)nw;
     }
     double mn = mm[0], mx = mm[1];
     const double mn0 = mn, mx0 = mx;
     double val_in = (double)v32;
+    // pass 1: statistics (lane i owns the i-th node counted from the leaf)
     for (int base = 0; __any(base < L); base += 16) {
-        const int idx = L - 1 - (base + a0);  // lane i owns the i-th node counted from the leaf
+        const int idx = L - 1 - (base + a0);
         const bool valid = idx >= 0;
-        const int p = valid ? path[idx] : 0;
+        // node at path position idx: the new node, a register of lane idx, or (deep paths) the LDS path row
+        const int from_reg = __shfl(mypath, (tid & 48) | (idx & 15), 64);
+        int p = 0;
+        if (valid) p = (idx == L - 1) ? nw : (idx < 16 ? from_reg : (int)path[idx]);
         Node2* x = node2_at(smem, P, e, p);
         const double rw = valid ? (double)x->reward : 0.0;
         const bool same = valid && (x->player == cp);
@@ -217,6 +235,7 @@ __device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchPa
             const double cand = (board && psame) ? (-prw + g * pv) : (prw + g * pv);
             if (a0 == t) val = cand;
         }
+        MZ_SUB(0);  // loads + value chain
         if (valid) {
             const double W = W0 + (same ? val : -val);
             const int N = N0 + 1;
@@ -242,38 +261,49 @@ __device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchPa
         o = row_ror<2>(mn); mn = o < mn ? o : mn;  o = row_ror<2>(mx); mx = o > mx ? o : mx;
         o = row_ror<1>(mn); mn = o < mn ? o : mn;  o = row_ror<1>(mx); mx = o > mx ? o : mx;
     }
-    int cur_ver = *ver;
-    if (mn != mn0 || mx != mx0) { cur_ver++; if (a0 == 0 && env_ok) MZ_COUNT(3, 1); }
-    if (a0 == 0 && env_ok) { mm[0] = mn; mm[1] = mx; *ver = cur_ver; }
-    // refresh the best child of every node on the path with the final statistics
-    const int Ap = P.A <= 2 ? 2 : (P.A <= 4 ? 4 : (P.A <= 8 ? 8 : 16));
-    const int G = 16 / Ap, gi = a0 / Ap, a = a0 & (Ap - 1);
-    const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
-    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0), lane_ok = a < P.A;
-    const double prior_a = lane_ok ? (reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A)[a] : 0.0;
-    for (int base = 0; __any(base < L); base += G) {
-        const int k = base + gi;
-        const bool valid = k < L;
-        const int p = valid ? path[k] : 0;
-        const int Np = node2_at(smem, P, e, p)->N;
-        const Entry2 en = entry2_row(smem, P, e, p)[lane_ok ? a : 0];
-        const double f = ftab[tri(Np) + en.cn];
-        const float u = (valid && lane_ok) ? puct_entry(P, en, f, prior_a, mn, mx, norm, prior_f32) : __uint_as_float(0xff800000u);
-        const float best = subgroup_max(u, Ap);
-        const bool eq = valid && lane_ok && (u == best);
-        const unsigned long long bal = __ballot(eq);
-        const unsigned bits = (unsigned)(bal >> (16 * seg + Ap * gi)) & ((1u << Ap) - 1u);
-        const int cnt = __popc(bits);
+    // cache-validity bookkeeping for the min-max change of this backup (see header)
+    EnvCacheState st = *stp;
+    if (mn != mn0 || mx != mx0) {
+        if (mx0 > mn0) {
+            const double w = mx - mn;
+            const double d_lo = (mn0 - mn) / w, d_hi = (mx - mx0) / w;
+            st.drift += (d_lo > d_hi ? d_lo : d_hi) * 1.000001 + 1e-12;
+        } else {
+            st.epoch++;  // normalisation may switch on: nothing cached before survives
+        }
+        if (a0 == 0 && env_ok) MZ_COUNT(3, 1);
+    }
+    if (a0 == 0 && env_ok) { mm[0] = mn; mm[1] = mx; *stp = st; }
+    MZ_SUB(1);  // statistics update + min-max reduction
+    // pass 2: best child of every path node with the final statistics (same lane ownership; LDS ops are in order, so the
+    // entry writes of pass 1 -- all from this wave -- are visible)
+    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0);
+    for (int base = 0; __any(base < L); base += 16) {
+        const int idx = L - 1 - (base + a0);
+        const bool valid = idx >= 0;
+        const int from_reg = __shfl(mypath, (tid & 48) | (idx & 15), 64);
+        int p = 0;
+        if (valid) p = (idx == L - 1) ? nw : (idx < 16 ? from_reg : (int)path[idx]);
         if (valid) {
-            SelCache* cc = cache_at(smem, P, e, p);
-            if (cnt == 1) {
-                if (eq) { cc->packed = (a & 0xffff) | (en.c << 16); cc->ver = cur_ver; }
-            } else if (a == 0) {
-                cc->packed = 0xffff;  // real tie: evaluate (and draw) at visit time
-                cc->ver = cur_ver;
+            const int Np = node2_at(smem, P, e, p)->N;
+            const double* frow = ftab + tri(Np);
+            const Entry2* er = entry2_row(smem, P, e, p);
+            float best = __uint_as_float(0xff800000u), second = __uint_as_float(0xff800000u);
+            int besta = 0, bestc = -1, cnt = 0;
+            for (int a = 0; a < P.A; a++) {
+                const Entry2 en = er[a];
+                const float u = puct_entry(en, frow[en.cn], prior[a], mn, mx, norm, prior_f32);
+                if (u > best) { second = best; best = u; besta = a; bestc = en.c; cnt = 1; }
+                else if (u == best) { cnt++; }
+                else if (u > second) { second = u; }
             }
+            SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
+            cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+            cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : 0.0f;
+            *cache_at(smem, P, e, p) = cc;
         }
     }
+    MZ_SUB(2);  // best-child refresh
 }
 
 __device__ __forceinline__ void tree2_finish(unsigned char* smem, const SearchParams& P, int e, int env_g) {
@@ -283,4 +313,3 @@ __device__ __forceinline__ void tree2_finish(unsigned char* smem, const SearchPa
     const Node2* root = node2_at(smem, P, e, 0);
     play_from_visits(smem, P, e, env_g, rv, root->W, root->N);
 }
-

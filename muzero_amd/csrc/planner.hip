@@ -161,7 +161,7 @@ static void compute_layout(mz_planner* p) {
         const int n2 = take(16 * s.NN * 24, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
                   p0 = take(16 * s.A * 4, 16), mmo = take(16 * 2 * 8, 16), se = take(128 * 4, 16), pt = take(32 * 8, 16),
                   ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * s.NN * 8, 16), pa = take(16 * (s.NN + 3) * 2, 16),
-                  ve = take(16 * 4, 16);
+                  ve = take(16 * 16, 16);
         const int total = (b + 15) & ~15;
         if (total <= 160 * 1024) {
             p->tree2_ok = true;
@@ -652,7 +652,10 @@ extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
 #ifdef MZ_STAMPS
     unsigned long long dbg[8];
     HIPCHK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(mz::g_dbg), sizeof(dbg)));
-    for (int i = 0; i < 5; i++) out[11 + i] = (long long)dbg[i];
+    long long sub[8];
+    HIPCHK(hipMemcpyFromSymbol(sub, HIP_SYMBOL(mz::g_sub), sizeof(sub)));
+    for (int i = 0; i < 4; i++) out[11 + i] = sub[i];
+    (void)dbg;
 #endif
     return MZ_OK;
 }

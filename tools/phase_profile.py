@@ -38,12 +38,11 @@ def main():
         p.lib.mz_debug_read_stamps(p.h, st)
         tot += np.array(st[:], dtype=np.float64)
     tot /= n
-    dbg = np.array(st[11:16], dtype=np.float64)  # cumulative counters (whole grid, all launches)
+    sub = np.array(st[11:15], dtype=np.float64) / ((n + 5) * S)  # cumulative over all launches of this process
     tot[11:] = 0
     total = tot.sum()
-    print(f'tree counters: levels={dbg[0]:.0f} hits={dbg[1]:.0f} ({100*dbg[1]/max(dbg[0],1):.1f}%) descents={dbg[2]:.0f} '
-          f'mean depth={dbg[0]/max(dbg[2],1):.2f} version bumps per descent={dbg[3]/max(dbg[2],1):.3f} '
-          f'wave-loop iterations per sim (wave 0, block 0)={dbg[4]/max(1,(n+5)*S):.2f}')
+    print(f'sub-phases per sim (cycles): backup loads+chain {sub[0]:.0f}, update+minmax {sub[1]:.0f}, best-child refresh {sub[2]:.0f}; '
+          f'select descent loop {sub[3]:.0f}')
     print(f'{g}: total stamped ticks per move (block 0): {total:.0f}  (s_memtime ticks, 100 MHz on gfx950)')
     for i, name in enumerate(NAMES):
         per_sim = tot[i] / (S if 1 <= i <= 9 else 1)
