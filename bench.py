@@ -140,6 +140,13 @@ def main():
         k_ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
         flop_per_launch = B * (S * FLOP_PER_SIM + FLOP_PER_ROOT)
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this very
+        # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the profiled workload.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(REPO, 'profiles', 'round1', 'pmc_counters.json')
+        if os.path.exists(pmc) and B == 4096 and S == 50:
+            traffic = json.load(open(pmc))['_hbm_bytes_per_launch']['total']
+            traffic_src = 'profiles/round1/pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)'
         out = {
             'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)',
             'value': sims_per_s,
@@ -161,8 +168,9 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search<false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes of HBM per launch', 'traffic_source': traffic_src,
+                'algorithmic_hbm_bytes_per_launch': B * (S * 2 * 64 * 4 + 20 * 4 + 64 * 4 + 2 * 8 + 16),
                 'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,
                 'flop_per_sim': FLOP_PER_SIM, 'timed_with': 'hipEvent pairs on the planner stream',
             },

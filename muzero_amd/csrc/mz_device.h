@@ -66,7 +66,7 @@ __device__ __forceinline__ double row_ror(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// Row reduction order shared with the oracle (row_reduce16 in oracle/mz_oracle.c): each of 16 lanes holds the
+// Row reduction order (the test oracle restates the same order in its row_reduce16): each of 16 lanes holds the
 // sequential partial sum of elements j, j+16, j+32, ...; the partials are combined by a butterfly with strides
 // 8, 4, 2, 1.  Every lane of the 16-lane segment returns the same total.
 __device__ __forceinline__ float butterfly16(float part) {

@@ -1,0 +1,210 @@
+"""Host-side mirror of the self-play half of muzero/pipeline.py.
+
+The reference runs one Python actor process per environment (pipeline.py:41-167): per step a `uct_search`, an
+`env.step`, a trajectory append, and at episode end target computation + `make_unroll_sequence` + `data_queue.put`.
+Here the per-step part (search, action sampling, env.step, record, auto-reset) is one lock-step move of thousands of
+device-resident environments inside the HIP planner (`mz_selfplay_step`); this module only drains the device record
+ring, cuts it into episodes and emits the same `(Transition, priority)` stream.
+
+Functions with a reference counterpart keep its name, arguments and error behaviour:
+compute_n_step_target (pipeline.py:632-673), compute_mc_return_target (:676-707), make_unroll_sequence (:710-767),
+create_checkpoint / load_checkpoint (:802-807), run_self_play (:41-167).
+"""
+import os
+from typing import Any, Iterable, List, Mapping, NamedTuple, Optional, Text
+
+import numpy as np
+
+
+class Transition(NamedTuple):
+    """Same fields, same order as replay.py:27-32 (the wire format between actors and the learner)."""
+    state: Optional[np.ndarray]
+    action: Optional[np.ndarray]
+    pi_prob: Optional[np.ndarray]
+    value: Optional[np.ndarray]
+    reward: Optional[np.ndarray]
+
+
+def compute_n_step_target(rewards: List[float], root_values: List[float], td_steps: int, discount: float) -> List[float]:
+    """z_t = sum_{i<n} discount^i r_{t+i} + discount^n v_{t+n}, zero padded past the end (pipeline.py:632-673).
+    Sums run left to right in float64 like the reference's Python `sum`, so results are bit-identical."""
+    if len(rewards) != len(root_values):
+        raise ValueError('Arguments `rewards` and `root_values` don have the same length.')
+    T = len(rewards)
+    r = list(rewards) + [0] * td_steps
+    v = list(root_values) + [0] * td_steps
+    pw = [discount**i for i in range(td_steps + 1)]
+    out = []
+    for t in range(T):
+        acc = 0
+        for i in range(td_steps):
+            acc = acc + pw[i] * r[t + i]
+        out.append(acc + pw[td_steps] * v[t + td_steps])
+    return out
+
+
+def compute_mc_return_target(rewards: List[float], player_ids: List[float]) -> List[float]:
+    """Board games: +/- final reward from each mover's perspective, all zeros for a draw (pipeline.py:676-707)."""
+    if len(rewards) != len(player_ids):
+        raise ValueError('Arguments `rewards` and `player_ids` don have the same length.')
+    T = len(rewards)
+    out = [0.0] * T
+    final_reward, final_player = rewards[-1], player_ids[-1]
+    if final_reward != 0.0:
+        for t in range(T):
+            out[t] = final_reward if player_ids[t] == final_player else -final_reward
+    return out
+
+
+def make_unroll_sequence(observations, actions, rewards, pi_probs, values, priorities, unroll_steps) -> Iterable:
+    """Yield (Transition, priority) per step with K-step stacked action / reward / value / policy; steps past the end are
+    absorbing (action 0, reward 0, value 0, uniform policy) (pipeline.py:710-767).
+
+    Differences from the reference, both deliberate: the caller's lists are NOT mutated (the reference extends them in
+    place, pipeline.py:739-747), and actions are stored as int8 only when they fit (A <= 128) -- the reference's
+    unconditional int8 cannot represent Gomoku 15x15 actions; larger action spaces get int16."""
+    T = len(observations)
+    K = unroll_steps
+    n_act = len(pi_probs[-1])
+    acts = list(actions) + ([0] * K if len(actions) == T else [])
+    rews = list(rewards) + ([0] * K if len(rewards) == T else [])
+    vals = list(values) + ([0] * K if len(values) == T else [])
+    pis = list(pi_probs) + ([np.ones_like(pi_probs[-1]) / n_act] * K if len(pi_probs) == T else [])
+    assert len(acts) == len(rews) == len(vals) == len(pis) == T + K
+    act_dtype = np.int8 if n_act <= 128 else np.int16
+    for t in range(T):
+        yield (
+            Transition(
+                state=observations[t],
+                action=np.array(acts[t:t + K], dtype=act_dtype),
+                reward=np.array(rews[t:t + K], dtype=np.float32),
+                value=np.array(vals[t:t + K], dtype=np.float32),
+                pi_prob=np.array(pis[t:t + K], dtype=np.float32),
+            ),
+            priorities[t],
+        )
+
+
+def create_checkpoint(state_to_save: Mapping[Text, Any], ckpt_file: str) -> None:
+    """pipeline.py:802-803: torch.save of {'network', 'optimizer', 'lr_scheduler', 'train_steps'}."""
+    import torch
+
+    torch.save(state_to_save, ckpt_file)
+
+
+def load_checkpoint(ckpt_file: str, device) -> Mapping[Text, Any]:
+    """pipeline.py:806-807 (weights_only=False: the reference checkpoints hold optimizer / scheduler state dicts)."""
+    import torch
+
+    return torch.load(ckpt_file, map_location=torch.device(device), weights_only=False)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU sharding: environments are independent, so ranks own disjoint env ranges and never exchange data
+# ------------------------------------------------------------------------------------------------------------------
+def shard_range(total_envs: int, rank: int, world_size: int):
+    """Contiguous env id range [lo, hi) of `rank` (sizes differ by at most one)."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f'rank {rank} outside world of size {world_size}')
+    base, extra = divmod(total_envs, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def aggregate_throughput(local_units: float, local_seconds: float):
+    """Whole-job rate: total units of all ranks / slowest rank's time (the bench.py contract).  Uses the default
+    torch.distributed group when initialised (RCCL on GPUs, gloo in the CPU tests); a single process otherwise."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_units / local_seconds, local_units, local_seconds
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    units = torch.tensor([float(local_units)], dtype=torch.float64, device=dev)
+    secs = torch.tensor([float(local_seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    dist.all_reduce(secs, op=dist.ReduceOp.MAX)
+    return float(units.item() / secs.item()), float(units.item()), float(secs.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# self-play actor over the device-resident planner
+# ------------------------------------------------------------------------------------------------------------------
+class EpisodeAssembler:
+    """Cuts the lock-step record stream [moves, envs, ...] into per-env episodes and turns finished episodes into
+    (Transition, priority) items exactly like pipeline.py:144-165."""
+
+    def __init__(self, config, num_envs: int):
+        self.config = config
+        self.open = [[] for _ in range(num_envs)]
+
+    def feed(self, rec) -> Iterable:
+        cfg = self.config
+        n_moves, B = rec['action'].shape
+        for m in range(n_moves):
+            for b in range(B):
+                self.open[b].append((rec['obs'][m, b], int(rec['action'][m, b]), float(rec['reward'][m, b]), rec['pi'][m, b],
+                                     float(rec['root_value'][m, b]), int(rec['player'][m, b])))
+                if rec['done'][m, b]:
+                    traj, self.open[b] = self.open[b], []
+                    yield from self._finish(traj)
+                elif (not cfg.is_board_game) and len(self.open[b]) == cfg.acc_seq_length + cfg.unroll_steps + cfg.td_steps:
+                    yield from self._flush_prefix(b)  # pipeline.py:118-142
+
+    def _finish(self, traj):
+        cfg = self.config
+        obs, actions, rewards, pis, roots, players = map(list, zip(*traj))
+        if cfg.is_board_game:
+            targets = compute_mc_return_target(rewards, players)
+        else:
+            targets = compute_n_step_target(rewards, roots, cfg.td_steps, cfg.discount)
+        prios = np.abs(np.array(roots) - np.array(targets))
+        yield from make_unroll_sequence(obs, actions, rewards, pis, targets, prios, cfg.unroll_steps)
+
+    def _flush_prefix(self, b):
+        cfg = self.config
+        n = cfg.acc_seq_length
+        obs, actions, rewards, pis, roots, _ = map(list, zip(*self.open[b]))
+        targets = compute_n_step_target(rewards, roots, cfg.td_steps, cfg.discount)
+        prios = np.abs(np.array(roots) - np.array(targets))
+        k = n + cfg.unroll_steps
+        yield from make_unroll_sequence(obs[:n], actions[:k], rewards[:k], pis[:k], targets[:k], prios[:k], cfg.unroll_steps)
+        del self.open[b][:n]
+
+
+def run_self_play(config, rank, network, device, env, data_queue, train_steps_counter, stop_event, tag: str = None,
+                  moves_per_drain: int = 16, max_moves: Optional[int] = None) -> int:
+    """Self-play until `stop_event` is set (pipeline.py:41-167).  `env` names a device environment ('CartPole-v1' or
+    'TicTacToe'); `config.num_envs` of them advance in lock-step on GPU `device`.  Items put on `data_queue` are the
+    reference's `(Transition, priority)` tuples.  Returns the number of env steps played."""
+    from muzero_amd import planner as pl
+
+    kinds = {'CartPole-v1': pl.ENV_CARTPOLE, 'TicTacToe': pl.ENV_TICTACTOE}
+    name = env if isinstance(env, str) else getattr(env, 'name', None) or getattr(getattr(env, 'spec', None), 'id', None)
+    if name not in kinds:
+        raise ValueError(f'no device environment for {name!r}; available: {sorted(kinds)}')
+    num_envs = int(getattr(config, 'num_envs', 1))
+    idx = device.index if getattr(device, 'index', None) is not None else 0
+    p = pl.Planner(pl.make_mz_config(network.planner_spec(), config, num_envs=num_envs, seed=int(getattr(config, 'planner_seed', 1)) + 7919 * rank), idx)
+    p.load_state_dict(network.state_dict())
+    p.selfplay_reset(kinds[name])
+    asm = EpisodeAssembler(config, num_envs)
+    version = network._weights_version()
+    played = 0
+    while not stop_event.is_set() and (max_moves is None or played < max_moves):
+        if network._weights_version() != version:  # learner pushed new weights (pipeline.py:266)
+            p.load_state_dict(network.state_dict())
+            version = network._weights_version()
+        n = moves_per_drain if max_moves is None else min(moves_per_drain, max_moves - played)
+        # classic/atari schedules depend on train steps only; board games on the env's own step count (config.py:236-267)
+        T = -1.0 if config.is_board_game else float(config.visit_softmax_temperature_fn(0, train_steps_counter.value))
+        p.selfplay_step(T, n)
+        for item in asm.feed(p.selfplay_read(n)):
+            data_queue.put(item)
+        played += n
+    return played * num_envs
+
+
+def rank_env() -> tuple:
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))

@@ -1,0 +1,101 @@
+"""Device-resident self-play (mz_selfplay_*: search + sample + env.step + record + auto-reset in HBM) on an MI355X:
+the recorded trajectories replayed through the oracle environments, and the run_self_play counterpart end to end."""
+import queue
+import types
+
+import numpy as np
+import pytest
+
+from helpers import build_mlp, mlp_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _planner(net, num_envs, seed=3, **search):
+    from muzero_amd import planner as pl
+
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=num_envs, seed=seed, **search), 0)
+    p.load_state_dict(net.state_dict())
+    return p
+
+
+def test_tictactoe_device_env_matches_oracle_env(oracle):
+    """Integer board logic: every recorded (obs, player, reward, done) equals the oracle BoardEnv replaying the recorded
+    actions, across auto-resets; actions are legal; policies are distributions over legal moves."""
+    from muzero_amd import planner as pl
+
+    net = build_mlp(mlp_case('tictactoe'))
+    B, M = 48, 40
+    p = _planner(net, B, num_simulations=25, discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0))
+    p.selfplay_reset(pl.ENV_TICTACTOE)
+    p.selfplay_step(-1.0, M)
+    rec = p.selfplay_read(M)
+    cnt = p.selfplay_counters()
+    assert cnt['env_steps'] == B * M and cnt['simulations'] == B * M * 25
+    assert cnt['episodes'] == int(rec['done'].sum()) and cnt['episode_steps'] > 0
+    for b in range(B):
+        env = oracle.BoardEnv(3, 4, 3)
+        obs = env.reset()
+        for m in range(M):
+            np.testing.assert_array_equal(rec['obs'][m, b].reshape(9, 3, 3), obs.astype(np.float32))
+            assert rec['player'][m, b] == env.current_player
+            a = int(rec['action'][m, b])
+            assert env.actions_mask[a], 'sampled action must be legal'
+            pi = rec['pi'][m, b]
+            assert abs(pi.sum() - 1.0) < 1e-12 and (pi[~env.actions_mask] == 0).all()
+            obs, r, done = env.step(a)
+            assert r == rec['reward'][m, b] and done == bool(rec['done'][m, b])
+            if done:
+                obs = env.reset()
+    assert rec['done'].sum() > B  # several finished games per env slot on average
+
+
+def test_cartpole_device_env_matches_oracle_env(oracle):
+    """float64 physics + float32 stacked observations vs the oracle CartPole from injected initial states (one ulp of the
+    device sin/cos is allowed for: 1e-6 relative on float32 observations) until each env's first reset."""
+    from muzero_amd import planner as pl
+
+    net = build_mlp(mlp_case('cartpole'))
+    B, M = 64, 24
+    rs = np.random.RandomState(4)
+    init = rs.uniform(-0.05, 0.05, size=(B, 4))
+    p = _planner(net, B, num_simulations=50, discount=0.997)
+    p.selfplay_reset(pl.ENV_CARTPOLE, init)
+    p.selfplay_step(1.0, M)
+    rec = p.selfplay_read(M)
+    assert (rec['reward'] == 1.0).all() and (rec['player'] == 1).all()
+    np.testing.assert_array_equal(rec['pi'], np.round(rec['pi'] * 50) / 50)  # T = 1: visit counts / 50
+    for b in range(B):
+        env = oracle.CartPoleEnv(4)
+        obs = env.reset(init[b])
+        for m in range(M):
+            np.testing.assert_allclose(rec['obs'][m, b].reshape(4, 5), obs, rtol=1e-6, atol=1e-7)
+            obs, r, done = env.step(int(rec['action'][m, b]))
+            assert done == bool(rec['done'][m, b])
+            if done:
+                break
+
+
+def test_run_self_play_counterpart_emits_reference_shaped_items():
+    """pipeline.run_self_play: (Transition, priority) stream with the reference's shapes/dtypes and MC-return values."""
+    import torch
+    from muzero_amd import pipeline
+    from muzero_amd.config import make_tictactoe_config
+
+    net = build_mlp(mlp_case('tictactoe'))
+    cfg = make_tictactoe_config(use_tensorboard=False)
+    cfg.num_envs = 32
+    q = queue.SimpleQueue()
+    stop = types.SimpleNamespace(is_set=lambda: False)
+    steps = pipeline.run_self_play(cfg, 0, net, torch.device('cuda', 0), 'TicTacToe', q, types.SimpleNamespace(value=0), stop, max_moves=24)
+    assert steps == 24 * 32
+    items = []
+    while not q.empty():
+        items.append(q.get())
+    assert len(items) > 32
+    for tr, prio in items:
+        assert tr.state.shape == (81,) and tr.action.shape == (5,) and tr.action.dtype == np.int8
+        assert tr.pi_prob.shape == (5, 10) and tr.pi_prob.dtype == np.float32
+        assert tr.value.dtype == np.float32 and tr.reward.dtype == np.float32
+        assert set(np.unique(tr.value)).issubset({-1.0, 0.0, 1.0})  # Monte-Carlo returns of a board game
+        assert np.isfinite(prio) and prio >= 0
