@@ -27,11 +27,13 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_stamps():
-    """Diagnostic library with per-phase s_memtime stamps (never loaded by the product path)."""
+def build_stamps(counters=False):
+    """Diagnostic library with per-phase s_memtime stamps (never loaded by the product path); counters=True adds the
+    atomic tree counters (hit rates, depths), which distort the timings."""
     hipcc = os.environ.get('HIPCC', 'hipcc')
     out = os.path.join(LIB_DIR, 'libmzplanner_hip_stamps.so')
-    subprocess.check_call([hipcc] + FLAGS + ['-DMZ_STAMPS'] + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out])
+    extra = ['-DMZ_STAMPS'] + (['-DMZ_COUNTERS'] if counters else [])
+    subprocess.check_call([hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out])
     return out
 
 
@@ -48,6 +50,6 @@ def build(force=False, verbose=False):
 
 if __name__ == '__main__':
     if '--stamps' in sys.argv:
-        print(build_stamps())
+        print(build_stamps(counters='--counters' in sys.argv))
         sys.exit(0)
     print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

@@ -84,7 +84,7 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     Entry2* en = reinterpret_cast<Entry2*>(smem + P.t2_entries);
     for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].cn = 0; en[i].c = -1; }
     SelCache* c = reinterpret_cast<SelCache*>(smem + P.t_cache);
-    for (int i = tid; i < TILE_E * P.NN; i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = 0.0f; }  // action 0xff: never a hit
+    for (int i = tid; i < TILE_E * P.NN; i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); }  // t = -inf: never a hit
     if (tid < TILE_E) {
         EnvCacheState* st = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + tid;
         st->drift = 0.0; st->epoch = 0; st->pad = 0;
@@ -110,32 +110,49 @@ __device__ __forceinline__ float puct_entry(const Entry2& en, double f, double p
 
 // One descent (mcts.py:372-379).  Results segment-uniform.  All 64 lanes of every wave must call it.
 // `mypath`: lane d of the segment receives the node visited at depth d (d < 16; deeper levels go to the LDS path row).
+// Two alternating phases: (A) a tight pointer chase along valid cache entries -- one 8-byte LDS read, two compares and a
+// few selects per level; (B) when no segment of the wave can advance by its cache, one full evaluation of the current
+// level for the segments that are not done (best_child, mcts.py:104-127).
 __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
                                              int& leaf_action, int& mypath) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
     const double* mm = reinterpret_cast<const double*>(smem + P.t_mm) + e * 2;
     int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
     short* path = path_row(smem, P, e);
+    const SelCache* cb = cache_at(smem, P, e, 0);
     const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
     const EnvCacheState st = reinterpret_cast<const EnvCacheState*>(smem + P.t_ver)[e];
-    const float drift_up = __double2float_ru(st.drift);
+    const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
+    const int ep = st.epoch & 0xff;
     const double mn = mm[0], mx = mm[1];
     const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0), lane_ok = a0 < P.A;
     const double prior_a = lane_ok ? (reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A)[a0] : 0.0;
-    int n = 0, cp = env_ok ? P.cur[env_g] : 0, op = env_ok ? P.opp[env_g] : 0;
-    int ties = sel[3];
+    const int cp0 = env_ok ? P.cur[env_g] : 0, op0 = env_ok ? P.opp[env_g] : 0;
+    int n = 0, ties = sel[3];
     bool done = !env_ok;
-    int lp = 0, la = 0, lpl = 0, depth = 0;
+    int lp = 0, la = 0, k = 0;  // k: levels descended so far
     mypath = 0;
     MZ_SUB_DECL
     MZ_SUB_START();
     while (__any(!done)) {
-        const SelCache cc = *cache_at(smem, P, e, n);
-        const int ba = cc.packed & 0xff, bc = cc.packed >> 16;
-        const bool hit = (((cc.packed >> 8) & 0xff) == (st.epoch & 0xff)) && (ba != 0xff) && (2.0f * drift_up + kCacheSlack < cc.t);
-        if (a0 == 0 && !done) { MZ_COUNT(0, 1); MZ_COUNT(1, hit ? 1 : 0); }
-        int a_sel = ba, c = bc;
-        if (__any(!done && !hit)) {  // wave-uniform: some segment has to evaluate this level (best_child, mcts.py:104-127)
+        // ---- phase A: chase cached best children ----
+        for (;;) {
+            const SelCache cc = cb[n];
+            const bool adv = !done && (((cc.packed >> 8) & 0xff) == ep) && (thr < cc.t);
+            if (a0 == 0 && !done) { MZ_COUNT(0, 1); MZ_COUNT(1, adv ? 1 : 0); }
+            if (!__any(adv)) break;
+            if (adv) {
+                if (k < 16) { if (a0 == k) mypath = n; }
+                else if (a0 == 0) path[k] = (short)n;
+                k++;
+                const int c = cc.packed >> 16;
+                if (c < 0 || k > P.NN) { done = true; lp = n; la = cc.packed & 0xff; }
+                else n = c;
+            }
+        }
+        if (!__any(!done)) break;
+        // ---- phase B: every segment that is not done sits on a level its cache cannot decide: evaluate it ----
+        {
             const int Np = node2_at(smem, P, e, n)->N;
             const Entry2 en = entry2_row(smem, P, e, n)[lane_ok ? a0 : 0];
             const double f = ftab[tri(Np) + en.cn];
@@ -146,7 +163,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
             const unsigned msk = (unsigned)(bal >> (16 * seg)) & 0xffffu;  // tie set in ascending action order
             const int total = __popc(msk);
             int pick = 0;
-            if (!done && !hit && total > 1) {  // np.random.choice consumes randomness only for a real tie
+            if (!done && total > 1) {  // np.random.choice consumes randomness only for a real tie
                 double uu;
                 if (P.rng_mode == 0) {
                     if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
@@ -161,26 +178,21 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
             }
             const int as = nth_set_bit(msk, pick);
             const int cs = row_max_i((a0 == as) ? en.c : -2);  // broadcast the chosen lane's child index
-            if (!hit) { a_sel = as; c = cs; }
-        }
-        const int t = cp; cp = op; op = t;  // mcts.py:379
-        if (!done) {
-            if (depth < 16) { if (a0 == depth) mypath = n; }
-            else if (a0 == 0) path[depth] = (short)n;
-            depth++;
-            if (c < 0 || depth > P.NN) {
-                done = true;
-                lp = n; la = a_sel; lpl = cp;
-            } else {
-                n = c;
+            if (!done) {
+                if (k < 16) { if (a0 == k) mypath = n; }
+                else if (a0 == 0) path[k] = (short)n;
+                k++;
+                if (cs < 0 || k > P.NN) { done = true; lp = n; la = as; }
+                else n = cs;
             }
         }
     }
     MZ_SUB(3);  // descent loop
     if (a0 == 0 && env_ok) MZ_COUNT(2, 1);
     if (a0 == 0) {
-        sel[0] = lp; sel[1] = la; sel[2] = lpl; sel[3] = ties;
-        reinterpret_cast<int*>(smem + P.t_sel)[80 + e] = depth;  // expanded nodes on the path (root .. leaf parent)
+        // players swap at every level (mcts.py:379): the leaf's player follows from the parity of the depth
+        sel[0] = lp; sel[1] = la; sel[2] = (k & 1) ? op0 : cp0; sel[3] = ties;
+        reinterpret_cast<int*>(smem + P.t_sel)[80 + e] = k;  // expanded nodes on the path (root .. leaf parent)
     }
     leaf_parent = lp;
     leaf_action = la;
@@ -299,7 +311,7 @@ __device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchPa
             }
             SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
             cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
-            cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : 0.0f;
+            cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : __uint_as_float(0xff800000u);
             *cache_at(smem, P, e, p) = cc;
         }
     }

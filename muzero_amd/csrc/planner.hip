@@ -660,6 +660,20 @@ extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
     return MZ_OK;
 }
 
+// diagnostic builds only (-DMZ_STAMPS -DMZ_COUNTERS): tree counters [levels, cache hits, descents, min-max changes]
+extern "C" int mz_debug_read_counters(mz_planner* p, long long out[8]) {
+    if (!p || !out) return fail(MZ_E_INVALID, "null argument");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+#ifdef MZ_STAMPS
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    unsigned long long dbg[8];
+    HIPCHK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(mz::g_dbg), sizeof(dbg)));
+    for (int i = 0; i < 8; i++) out[i] = (long long)dbg[i];
+#endif
+    return MZ_OK;
+}
+
 extern "C" int mz_planner_synchronize(mz_planner* p) {
     if (!p) return fail(MZ_E_INVALID, "null planner");
     HIPCHK(hipSetDevice(p->device));

@@ -43,6 +43,12 @@ def main():
     total = tot.sum()
     print(f'sub-phases per sim (cycles): backup loads+chain {sub[0]:.0f}, update+minmax {sub[1]:.0f}, best-child refresh {sub[2]:.0f}; '
           f'select descent loop {sub[3]:.0f}')
+    cn = (C.c_longlong * 8)()
+    p.lib.mz_debug_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    p.lib.mz_debug_read_counters(p.h, cn)
+    if cn[0]:
+        print(f'tree counters (counters build; timings below are distorted): levels {cn[0]}, cache hits {cn[1]} ({100 * cn[1] / cn[0]:.1f}%), '
+              f'descents {cn[2]}, mean depth {cn[0] / max(cn[2], 1):.2f}, min-max changes per descent {cn[3] / max(cn[2], 1):.3f}')
     print(f'{g}: total stamped ticks per move (block 0): {total:.0f}  (s_memtime ticks, 100 MHz on gfx950)')
     for i, name in enumerate(NAMES):
         per_sim = tot[i] / (S if 1 <= i <= 9 else 1)
