@@ -79,7 +79,6 @@ __device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __res
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
     const int full = L.k_steps >> 2;
-#pragma unroll 2
     for (int g = 0; g < full; g++) {
         const float4 x = xp[g * 64];
         float4 w[NACC];
@@ -143,10 +142,12 @@ struct EpiReluPacked {
         const int q = lane >> 4, e = lane & 15;
         // pk(16t + 4q + r, e) = ((t*64 + r*16 + e) << 2) + q
         float* p = dst + ((t * 64 + e) << 2) + q;
-        p[0 * 64] = a[0] > 0.0f ? a[0] : 0.0f;
-        p[1 * 64] = a[1] > 0.0f ? a[1] : 0.0f;
-        p[2 * 64] = a[2] > 0.0f ? a[2] : 0.0f;
-        p[3 * 64] = a[3] > 0.0f ? a[3] : 0.0f;
+        // ReLU as one v_med3_f32 (median of x, 0, +inf == max(x, 0) for every non-NaN x)
+        const float inf = __uint_as_float(0x7f800000u);
+        p[0 * 64] = __builtin_amdgcn_fmed3f(a[0], 0.0f, inf);
+        p[1 * 64] = __builtin_amdgcn_fmed3f(a[1], 0.0f, inf);
+        p[2 * 64] = __builtin_amdgcn_fmed3f(a[2], 0.0f, inf);
+        p[3 * 64] = __builtin_amdgcn_fmed3f(a[3], 0.0f, inf);
     }
 };
 
@@ -289,22 +290,31 @@ __device__ __forceinline__ void mlp_recurrent_tile(const MlpNet& net, const MlpL
 
 // representation + prediction (network.py:62-84).  Expects X (packed obs) in LDS, barrier passed.
 //   out: HS = normalised hidden (and grow rows), pi_out LDS [16][A] (softmax), OUT[e][1] = value.
-__device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds& o, float* lds, float* const* grow, float* pi_out, int tid) {
+__device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds& o, float* lds, float* const* grow, float* pi_out, int tid,
+                                                 bool active = true) {
+    // `active == false`: a wave that only keeps the workgroup barriers uniform (512-thread kernels run this 4-wave
+    // pipeline on waves 0-3)
     const int lane = tid & 63, wave = tid >> 6;
-    gemm_layer(net.L[L_REP0], lds, lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
+    if (active) gemm_layer(net.L[L_REP0], lds, lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
     __syncthreads();
-    gemm_layer(net.L[L_REP1], lds, lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
+    if (active) gemm_layer(net.L[L_REP1], lds, lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
     __syncthreads();
-    normalize_tile(net, lds + o.HN, lds + o.HS, grow, tid);
+    if (active) normalize_tile(net, lds + o.HN, lds + o.HS, grow, tid);
     __syncthreads();
-    gemm_layer(net.L[L_POL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
-    gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
+    if (active) {
+        gemm_layer(net.L[L_POL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
+        gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
+    }
     __syncthreads();
-    gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-    gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+    if (active) {
+        gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+        gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+    }
     __syncthreads();
-    row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
-    heads_to_scalars(net, o, lds, tid, false);
+    if (active) {
+        row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
+        heads_to_scalars(net, o, lds, tid, false);
+    }
     __syncthreads();
 }
 
