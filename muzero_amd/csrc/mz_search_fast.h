@@ -105,6 +105,14 @@ __device__ __forceinline__ void stream_layer(float4 (&buf)[2][NT], const WSrc& c
         const float4 x = xp[g * 64];
         if (g + 1 < KG) wmma4<NT>(acc, buf[(PAR + g) & 1], x);
         else wmma_rem<NT>(acc, buf[(PAR + g) & 1], x, last_steps);
+        // issue order inside the group: the B-operand read, then one weight load per 4 MFMAs (the loads' issue slots hide
+        // under the 32-cycle MFMAs instead of preceding them)
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep the ring 1 group deep: no hoisting of later groups' loads
     }
 #pragma unroll
