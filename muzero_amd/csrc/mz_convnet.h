@@ -1,0 +1,398 @@
+// mz_convnet.h -- host orchestration of the conv networks (board / Atari) and the HBM-resident search for them.
+//
+// MLP-class configs keep everything of a simulation inside one workgroup (mz_search_fast.h).  Conv-class configs do not
+// fit: one Gomoku tree (A = 226, S = 200) is ~0.1 MB and one hidden state 115 KB.  Here a lock-step simulation is a short
+// sequence of kernels over the whole env batch: tree select (HBM tree) -> dynamics tower -> reward head -> normalise ->
+// prediction tower -> value head -> tree expand + backup.  The tree kernels are the SAME device functions as the
+// LDS-resident search (mz_search.h: tree_select / tree_expand_backup / root_prior / tree_finish) pointed at a per-block
+// global-memory region with the identical layout, so their parity with the reference carries over.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mz_conv.h"
+#include "mz_search.h"
+
+namespace mz {
+
+struct HostTensorRef {
+    const float* data;
+    std::vector<int64_t> shape;
+};
+typedef std::map<std::string, HostTensorRef> ParamMap;
+
+struct ConvLayerDev {
+    float* w = nullptr;
+    float* b = nullptr;
+    int cin = 0, cin_real = 0, cout = 0, stride = 1;
+};
+struct ResBlockDev {
+    ConvLayerDev c1, c2;
+};
+struct HeadDev {
+    float *cw = nullptr, *cb = nullptr, *lw = nullptr, *lb = nullptr;
+    int C = 0, oc = 0, n_out = 0;
+};
+
+struct ConvNetDev {
+    int kind = 0;  // MZ_NET_BOARD (1) / MZ_NET_ATARI (2)
+    int in_c = 0, in_h = 0, in_w = 0, A = 0, R = 0, P = 0, Sv = 1, Sr = 1, hh = 0, hw = 0;
+    ConvLayerDev rep_conv, rep_conv2;
+    std::vector<ResBlockDev> rep_res, dyn_res, pred_res;
+    ConvLayerDev dyn_conv;
+    HeadDev reward, policy, value;
+    std::vector<void*> allocs;
+    // work buffers (dense activations), sized by ensure_buffers
+    float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr;
+    size_t buf_elems = 0;
+    int hidden_size() const { return P * hh * hw; }
+};
+
+inline hipError_t dev_upload(ConvNetDev& n, const std::vector<float>& h, float** d) {
+    hipError_t e = hipMalloc(d, h.size() * sizeof(float));
+    if (e != hipSuccess) return e;
+    n.allocs.push_back(*d);
+    return hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+}
+
+// Conv (bias-free) + optional eval-mode BatchNorm folded exactly like the oracle's conv_init: alpha = (1/sqrt(var+eps))*gamma,
+// w' = w*alpha, b' = beta - mean*alpha (float32 operations in that order); weights packed into the MFMA A-fragment order
+// [co_tile][cb][tap][lane][4]:  W'[16t + (lane&15)][cb*16 + 4s + (lane>>4)][tap]
+inline int build_conv(ConvNetDev& n, const ParamMap& pm, const std::string& conv_w, const std::string& bn, int cin, int cin_real, int cout,
+                      int k, int stride, ConvLayerDev* out, std::string* err) {
+    auto wi = pm.find(conv_w);
+    if (wi == pm.end()) { *err = "missing parameter " + conv_w; return -1; }
+    const HostTensorRef& W = wi->second;
+    if (W.shape.size() != 4 || W.shape[0] != cout || W.shape[1] != cin || W.shape[2] != k || W.shape[3] != k) {
+        *err = "shape mismatch for " + conv_w;
+        return -1;
+    }
+    std::vector<float> alpha(cout, 1.0f), bias(((cout + 15) / 16) * 16, 0.0f);
+    if (!bn.empty()) {
+        const char* names[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+        const float* t[4];
+        for (int i = 0; i < 4; i++) {
+            auto it = pm.find(bn + names[i]);
+            if (it == pm.end() || it->second.shape.size() != 1 || it->second.shape[0] != cout) { *err = "missing/mis-shaped " + bn + names[i]; return -1; }
+            t[i] = it->second.data;
+        }
+        for (int co = 0; co < cout; co++) {
+            const float invstd = 1.0f / sqrtf(t[3][co] + 1e-5f);
+            alpha[co] = invstd * t[0][co];
+            const float m = t[2][co] * alpha[co];
+            bias[co] = t[1][co] - m;
+        }
+    }
+    const int taps = k * k, n_cb = (cin + 15) / 16, co_tiles = (cout + 15) / 16;
+    std::vector<float> pw((size_t)co_tiles * n_cb * taps * 256, 0.0f);
+    for (int t = 0; t < co_tiles; t++)
+        for (int cb = 0; cb < n_cb; cb++)
+            for (int tap = 0; tap < taps; tap++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int s = 0; s < 4; s++) {
+                        const int co = 16 * t + (lane & 15), ci = cb * 16 + 4 * s + (lane >> 4);
+                        if (co < cout && ci < cin) {
+                            float v = W.data[((size_t)co * cin + ci) * taps + tap];
+                            if (!bn.empty()) v = v * alpha[co];
+                            pw[((((size_t)t * n_cb + cb) * taps + tap) * 64 + lane) * 4 + s] = v;
+                        }
+                    }
+    out->cin = cin; out->cin_real = cin_real; out->cout = cout; out->stride = stride;
+    if (dev_upload(n, pw, &out->w) != hipSuccess || dev_upload(n, bias, &out->b) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+    return 0;
+}
+
+inline int build_res(ConvNetDev& n, const ParamMap& pm, const std::string& prefix, int planes, ResBlockDev* r, std::string* err) {
+    int rc = build_conv(n, pm, prefix + ".conv_block1.0.weight", prefix + ".conv_block1.1", planes, planes, planes, 3, 1, &r->c1, err);
+    if (rc) return rc;
+    return build_conv(n, pm, prefix + ".conv_block2.0.weight", prefix + ".conv_block2.1", planes, planes, planes, 3, 1, &r->c2, err);
+}
+
+// head: 1x1 conv + BN (folded, plain [oc][C] layout) + Linear
+inline int build_head(ConvNetDev& n, const ParamMap& pm, const std::string& prefix, int C, int oc, int hw, int n_out, HeadDev* h, std::string* err) {
+    auto wi = pm.find(prefix + ".0.weight");
+    auto lw = pm.find(prefix + ".4.weight"), lb = pm.find(prefix + ".4.bias");
+    if (wi == pm.end() || lw == pm.end() || lb == pm.end()) { *err = "missing head parameters " + prefix; return -1; }
+    const char* names[4] = {".1.weight", ".1.bias", ".1.running_mean", ".1.running_var"};
+    const float* t[4];
+    for (int i = 0; i < 4; i++) {
+        auto it = pm.find(prefix + names[i]);
+        if (it == pm.end()) { *err = "missing " + prefix + names[i]; return -1; }
+        t[i] = it->second.data;
+    }
+    if (lw->second.shape.size() != 2 || lw->second.shape[0] != n_out || lw->second.shape[1] != (int64_t)oc * hw) { *err = "shape mismatch for " + prefix + ".4.weight"; return -1; }
+    std::vector<float> cw((size_t)oc * C), cb(oc);
+    for (int o = 0; o < oc; o++) {
+        const float invstd = 1.0f / sqrtf(t[3][o] + 1e-5f);
+        const float alpha = invstd * t[0][o];
+        const float m = t[2][o] * alpha;
+        cb[o] = t[1][o] - m;
+        for (int c = 0; c < C; c++) cw[(size_t)o * C + c] = wi->second.data[(size_t)o * C + c] * alpha;
+    }
+    std::vector<float> l(lw->second.data, lw->second.data + (size_t)n_out * oc * hw), b(lb->second.data, lb->second.data + n_out);
+    h->C = C; h->oc = oc; h->n_out = n_out;
+    if (dev_upload(n, cw, &h->cw) != hipSuccess || dev_upload(n, cb, &h->cb) != hipSuccess || dev_upload(n, l, &h->lw) != hipSuccess ||
+        dev_upload(n, b, &h->lb) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+    return 0;
+}
+
+inline void convnet_free(ConvNetDev& n) {
+    for (void* p : n.allocs) (void)hipFree(p);
+    n.allocs.clear();
+    for (float* p : {n.bufA, n.bufB, n.bufC})
+        if (p) (void)hipFree(p);
+    n.bufA = n.bufB = n.bufC = nullptr;
+    n.buf_elems = 0;
+    n.rep_res.clear(); n.dyn_res.clear(); n.pred_res.clear();
+}
+
+inline int convnet_build(ConvNetDev& n, const ParamMap& pm, std::string* err) {
+    int rc;
+    const int P = n.P, R = n.R;
+    if (n.kind == 1) {  // MuZeroBoardGameNet, network.py:540-574
+        n.hh = n.in_h; n.hw = n.in_w;
+        if ((rc = build_conv(n, pm, "represent_net.conv_block.0.weight", "represent_net.conv_block.1", n.in_c, n.in_c, P, 3, 1, &n.rep_conv, err))) return rc;
+        n.rep_res.resize(R);
+        for (int i = 0; i < R; i++)
+            if ((rc = build_res(n, pm, "represent_net.res_blocks." + std::to_string(i), P, &n.rep_res[i], err))) return rc;
+    } else {  // MuZeroAtariNet, network.py:501-537: conv_1 always has 128 output channels (network.py:324)
+        n.hh = 6; n.hw = 6;
+        if ((rc = build_conv(n, pm, "represent_net.conv_1.weight", "", n.in_c, n.in_c, 128, 3, 2, &n.rep_conv, err))) return rc;
+        n.rep_res.resize(6);
+        for (int i = 0; i < 2; i++)
+            if ((rc = build_res(n, pm, "represent_net.res_blocks_1." + std::to_string(i), 128, &n.rep_res[i], err))) return rc;
+        if ((rc = build_conv(n, pm, "represent_net.conv_2.weight", "", 128, 128, P, 3, 2, &n.rep_conv2, err))) return rc;
+        for (int i = 0; i < 2; i++)
+            if ((rc = build_res(n, pm, "represent_net.res_blocks_2." + std::to_string(i), P, &n.rep_res[2 + i], err))) return rc;
+        for (int i = 0; i < 2; i++)
+            if ((rc = build_res(n, pm, "represent_net.res_blocks_3." + std::to_string(i), P, &n.rep_res[4 + i], err))) return rc;
+    }
+    const int hw = n.hh * n.hw;
+    if ((rc = build_conv(n, pm, "dynamics_net.conv_block.0.weight", "dynamics_net.conv_block.1", P + n.A, P, P, 3, 1, &n.dyn_conv, err))) return rc;
+    n.dyn_res.resize(R);
+    n.pred_res.resize(R);
+    for (int i = 0; i < R; i++) {
+        if ((rc = build_res(n, pm, "dynamics_net.res_blocks." + std::to_string(i), P, &n.dyn_res[i], err))) return rc;
+        if ((rc = build_res(n, pm, "prediction_net.res_blocks." + std::to_string(i), P, &n.pred_res[i], err))) return rc;
+    }
+    if ((rc = build_head(n, pm, "dynamics_net.reward_head", P, 1, hw, n.Sr, &n.reward, err))) return rc;
+    if ((rc = build_head(n, pm, "prediction_net.policy_net", P, 2, hw, n.A, &n.policy, err))) return rc;
+    if ((rc = build_head(n, pm, "prediction_net.value_net", P, 1, hw, n.Sv, &n.value, err))) return rc;
+    return 0;
+}
+
+inline hipError_t convnet_ensure_buffers(ConvNetDev& n, int B) {
+    size_t per = (size_t)n.P * n.hh * n.hw;
+    if (n.kind == 2) {
+        const size_t a = (size_t)128 * ((n.in_h + 1) / 2) * ((n.in_w + 1) / 2);
+        per = a > per ? a : per;
+    }
+    const size_t need = per * B;
+    if (need <= n.buf_elems) return hipSuccess;
+    for (float** p : {&n.bufA, &n.bufB, &n.bufC}) {
+        if (*p) (void)hipFree(*p);
+        hipError_t e = hipMalloc(p, need * sizeof(float));
+        if (e != hipSuccess) return e;
+    }
+    n.buf_elems = need;
+    return hipSuccess;
+}
+
+inline void pick_tile(int oh, int ow, int* th, int* tw, int* npt) {
+    if (oh * ow <= 240 && oh <= 15 && ow <= 16) { *th = oh; *tw = ow; }
+    else { *th = 8; *tw = 8; }
+    const int slots = *th * *tw;
+    const int cands[6] = {1, 2, 3, 4, 6, 15};
+    for (int c : cands)
+        if (slots <= c * 16) { *npt = c; return; }
+    *npt = 15;
+}
+
+// one 3x3 conv launch; input either dense `in` or per-image `in_ptrs`
+inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float* in, const float* const* in_ptrs, const int* action, int A, int ih,
+                     int iw, const float* residual, float* out, bool relu) {
+    ConvLaunch L{};
+    L.in_ptrs = in_ptrs; L.in = in; L.action = action; L.num_actions = A > 0 ? A : 1;
+    L.cin_real = Lr.cin_real; L.cin = Lr.cin; L.ih = ih; L.iw = iw; L.stride = Lr.stride;
+    L.oh = (ih + 2 - 3) / Lr.stride + 1; L.ow = (iw + 2 - 3) / Lr.stride + 1;
+    L.cout = Lr.cout; L.w = Lr.w; L.bias = Lr.b; L.residual = residual; L.out = out; L.relu = relu ? 1 : 0; L.B = B;
+    int npt;
+    pick_tile(L.oh, L.ow, &L.th, &L.tw, &npt);
+    L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
+    const int sih = (L.th - 1) * L.stride + 3, siw = (L.tw - 1) * L.stride + 3;
+    const size_t lds = (size_t)16 * sih * siw * sizeof(float);
+    const dim3 grid(L.tiles_x * L.tiles_y, B, (Lr.cout + 127) / 128), block(256);
+    switch (npt) {
+        case 1: hipLaunchKernelGGL(k_conv3x3<1>, grid, block, lds, st, L); break;
+        case 2: hipLaunchKernelGGL(k_conv3x3<2>, grid, block, lds, st, L); break;
+        case 3: hipLaunchKernelGGL(k_conv3x3<3>, grid, block, lds, st, L); break;
+        case 4: hipLaunchKernelGGL(k_conv3x3<4>, grid, block, lds, st, L); break;
+        case 6: hipLaunchKernelGGL(k_conv3x3<6>, grid, block, lds, st, L); break;
+        default: hipLaunchKernelGGL(k_conv3x3<15>, grid, block, lds, st, L); break;
+    }
+}
+
+// residual tower in place on x (dense), t1/t2 scratch; returns the buffer holding the result
+inline float* tower_run(hipStream_t st, const std::vector<ResBlockDev>& blocks, int first, int count, int B, float* x, float* t1, float* t2, int h, int w) {
+    for (int i = first; i < first + count; i++) {
+        conv_run(st, blocks[i].c1, B, x, nullptr, nullptr, 0, h, w, nullptr, t1, true);
+        conv_run(st, blocks[i].c2, B, t1, nullptr, nullptr, 0, h, w, x, t2, true);
+        float* s = x; x = t2; t2 = s;
+    }
+    return x;
+}
+
+inline void head_run(hipStream_t st, const HeadDev& H, int B, const float* in, const float* const* in_ptrs, int hw, int mode, float* out_scalar,
+                     float* out_probs) {
+    HeadLaunch L{};
+    L.in = in; L.in_ptrs = in_ptrs; L.C = H.C; L.hw = hw; L.oc = H.oc; L.n_out = H.n_out; L.cw = H.cw; L.cb = H.cb; L.lw = H.lw; L.lb = H.lb;
+    L.mode = mode; L.out_scalar = out_scalar; L.out_probs = out_probs; L.B = B;
+    const size_t lds = (((size_t)H.oc * hw + 3) & ~(size_t)3) * 4 + (size_t)H.n_out * 4 + 16;
+    hipLaunchKernelGGL(k_head, dim3(B), dim3(256), lds, st, L);
+}
+
+// the two of {a, b, c} that are not x
+inline void other_two(float* a, float* b, float* c, const float* x, float** o1, float** o2) {
+    float* r[2];
+    int k = 0;
+    for (float* p : {a, b, c})
+        if (p != x && k < 2) r[k++] = p;
+    *o1 = r[0]; *o2 = r[1];
+}
+
+// shared tail of network.py:62-84 and :86-111: normalise x (dense) into the node-store rows / dense destination, run the
+// prediction tower and the heads on the normalised state
+inline void convnet_tail(hipStream_t st, ConvNetDev& n, int B, float* x, float* const* dst_ptrs, float* dst_dense, float* pi, float* value) {
+    const int hw = n.hh * n.hw;
+    float *nrm, *t2;
+    other_two(n.bufA, n.bufB, n.bufC, x, &nrm, &t2);
+    hipLaunchKernelGGL(k_normalize_planes, dim3((B * hw + 255) / 256), dim3(256), 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+    float* f = tower_run(st, n.pred_res, 0, n.R, B, nrm, x, t2, n.hh, n.hw);
+    if (pi) head_run(st, n.policy, B, f, nullptr, hw, 1, nullptr, pi);
+    head_run(st, n.value, B, f, nullptr, hw, 0, value, nullptr);
+}
+
+// network.py:62-84: obs dense [B][c][h][w] -> normalised hidden rows (dst_ptrs[b] and/or dense dst), pi0 [B][A], value [B]
+inline void convnet_initial(hipStream_t st, ConvNetDev& n, int B, const float* obs, float* const* dst_ptrs, float* dst_dense, float* pi,
+                            float* value) {
+    float *a = n.bufA, *b = n.bufB, *c = n.bufC, *o1, *o2;
+    int h = n.in_h, w = n.in_w;
+    float* x;
+    conv_run(st, n.rep_conv, B, obs, nullptr, nullptr, 0, h, w, nullptr, a, true);  // board: conv+BN+ReLU (:389); Atari: conv_1+ReLU (:346)
+    if (n.kind == 1) {
+        x = tower_run(st, n.rep_res, 0, n.R, B, a, b, c, h, w);
+    } else {
+        h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+        x = tower_run(st, n.rep_res, 0, 2, B, a, b, c, h, w);
+        other_two(a, b, c, x, &o1, &o2);
+        conv_run(st, n.rep_conv2, B, x, nullptr, nullptr, 0, h, w, nullptr, o1, true);  // conv_2 + ReLU (:348)
+        h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+        x = tower_run(st, n.rep_res, 2, 2, B, o1, o2, x, h, w);
+        other_two(a, b, c, x, &o1, &o2);
+        int h2 = (h - 1) / 2 + 1, w2 = (w - 1) / 2 + 1;
+        hipLaunchKernelGGL(k_avgpool, dim3(1024), dim3(256), 0, st, x, o1, B, n.P, h, w, h2, w2);
+        h = h2; w = w2;
+        x = tower_run(st, n.rep_res, 4, 2, B, o1, o2, x, h, w);
+        other_two(a, b, c, x, &o1, &o2);
+        h2 = (h - 1) / 2 + 1; w2 = (w - 1) / 2 + 1;
+        hipLaunchKernelGGL(k_avgpool, dim3(1024), dim3(256), 0, st, x, o1, B, n.P, h, w, h2, w2);
+        x = o1;
+    }
+    convnet_tail(st, n, B, x, dst_ptrs, dst_dense, pi, value);
+}
+
+// network.py:86-111: hidden rows src_ptrs[b] + action[b] -> normalised next hidden rows, reward [B], value [B], policy
+// probabilities (optional: dead compute inside the reference search, mcts.py:386 expands with the root prior)
+inline void convnet_recurrent(hipStream_t st, ConvNetDev& n, int B, const float* const* src_ptrs, const float* src_dense, const int* action,
+                              float* const* dst_ptrs, float* dst_dense, float* reward, float* value, float* pi) {
+    const int h = n.hh, w = n.hw, hw = h * w;
+    conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true);
+    float* x = tower_run(st, n.dyn_res, 0, n.R, B, n.bufA, n.bufB, n.bufC, h, w);
+    head_run(st, n.reward, B, x, nullptr, hw, 0, reward, nullptr);  // the reward head reads the un-normalised state (:447-448)
+    convnet_tail(st, n, B, x, dst_ptrs, dst_dense, pi, value);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// HBM-resident tree kernels: the tree_mode-0 device functions of mz_search.h on a per-block global region
+// ---------------------------------------------------------------------------------------------------------------------
+struct GTreeLaunch {
+    SearchParams P;           // tree_mode 0 layout with the network part empty (offsets relative to the block region)
+    unsigned char* regions;   // [blocks][P.lds_bytes]
+    const float* pi0;         // [B][A]   (root policy from the initial inference)
+    int hidden_size;
+    const float** src_ptrs;   // [B] out of select: parent hidden rows
+    float** dst_ptrs;         // [B] out of select: new node's hidden rows
+    int* actions;             // [B] out of select
+    const float* reward;      // in to backup: reward[env * rv_stride], value[env * rv_stride]
+    const float* value;
+    int rv_stride;
+    int sim;
+};
+
+__global__ __launch_bounds__(256) void k_gtree_init(const GTreeLaunch G) {
+    const SearchParams& P = G.P;
+    unsigned char* smem = G.regions + (size_t)blockIdx.x * P.lds_bytes;
+    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
+    const int env_g = blockIdx.x * TILE_E + e;
+    const bool env_ok = env_g < P.B;
+    double* ft = reinterpret_cast<double*>(smem + P.t_ftab);
+    for (int i = tid; i < (P.S + 1) * (P.S + 1); i += 256) ft[i] = P.ftab[i];
+    short* ch = reinterpret_cast<short*>(smem + P.t_child);
+    for (int i = tid; i < TILE_E * P.NN * P.A; i += 256) ch[i] = -1;
+    float* pi0 = reinterpret_cast<float*>(smem + P.t_pi0);
+    for (int i = tid; i < TILE_E * P.A; i += 256) {
+        const int ee = i / P.A, a = i - ee * P.A, eg = blockIdx.x * TILE_E + ee;
+        pi0[i] = eg < P.B ? G.pi0[(size_t)eg * P.A + a] : 1.0f / (float)P.A;
+    }
+    if (a0 == 0) {
+        TreeNode* r = node_at(smem, P, e, 0);
+        r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
+        r->player = env_ok ? P.cur[env_g] : 0;
+        double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
+        mm[0] = P.has_bounds ? P.kb_min : __longlong_as_double(0x7ff0000000000000LL);
+        mm[1] = P.has_bounds ? P.kb_max : __longlong_as_double(0xfff0000000000000LL);
+        int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
+        sel[0] = sel[1] = sel[2] = sel[3] = 0;
+    }
+    __syncthreads();
+    if (a0 == 0 && env_ok) root_prior(smem, P, e, env_g);
+}
+
+__global__ __launch_bounds__(256) void k_gtree_select(const GTreeLaunch G) {
+    const SearchParams& P = G.P;
+    unsigned char* smem = G.regions + (size_t)blockIdx.x * P.lds_bytes;
+    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
+    const int env_g = blockIdx.x * TILE_E + e;
+    const bool env_ok = env_g < P.B;
+    int lp, la;
+    tree_select<16>(smem, P, tid, env_ok, env_g, lp, la);
+    if (a0 == 0 && env_ok) {
+        float* base = P.hidden + (size_t)env_g * P.NN * G.hidden_size;
+        G.src_ptrs[env_g] = base + (size_t)lp * G.hidden_size;
+        G.dst_ptrs[env_g] = base + (size_t)(G.sim + 1) * G.hidden_size;
+        G.actions[env_g] = la;
+        if (P.trace_parent) {
+            P.trace_parent[(size_t)env_g * P.S + G.sim] = lp;
+            P.trace_action[(size_t)env_g * P.S + G.sim] = la;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gtree_backup(const GTreeLaunch G) {
+    const SearchParams& P = G.P;
+    unsigned char* smem = G.regions + (size_t)blockIdx.x * P.lds_bytes;
+    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
+    const int env_g = blockIdx.x * TILE_E + e;
+    if (a0 == 0 && env_g < P.B) tree_expand_backup(smem, P, e, G.sim, G.reward[(size_t)env_g * G.rv_stride], G.value[(size_t)env_g * G.rv_stride]);
+}
+
+__global__ __launch_bounds__(256) void k_gtree_finish(const GTreeLaunch G) {
+    const SearchParams& P = G.P;
+    unsigned char* smem = G.regions + (size_t)blockIdx.x * P.lds_bytes;
+    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
+    const int env_g = blockIdx.x * TILE_E + e;
+    if (a0 == 0 && env_g < P.B) tree_finish(smem, P, e, env_g);
+}
+
+}  // namespace mz

@@ -118,6 +118,7 @@ constexpr int MAX_CH = 4;  // action chunks of 16 lanes: A <= 64 in the LDS-resi
 // child_U (mcts.py:180-200) per action lane, segment max, tie set in ascending action order, np.random.choice among
 // real ties.  `draw` says whether this segment may consume a tie-break draw.  Returns the selected action
 // (segment-uniform).  Must be executed by all 64 lanes of the wave (DPP / ballot inside).
+template <int MAXCH = MAX_CH>
 __device__ __forceinline__ int select_level(unsigned char* smem, const SearchParams& P, int e, int a0, int seg, int n, double mn, double mx,
                                             bool draw, int& ties, int env_g) {
     const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
@@ -128,10 +129,10 @@ __device__ __forceinline__ int select_level(unsigned char* smem, const SearchPar
     const int Nn = node_at(smem, P, e, n)->N;
     const double* frow = ftab + Nn * (P.S + 1);
     const short* crow = child_row(smem, P, e, n);
-    float u[MAX_CH];
+    float u[MAXCH];
     float best = __uint_as_float(0xff800000u);
 #pragma unroll
-    for (int ch = 0; ch < MAX_CH; ch++) {
+    for (int ch = 0; ch < MAXCH; ch++) {
         u[ch] = __uint_as_float(0xff800000u);
         const int a = ch * 16 + a0;
         if (ch < nch && a < P.A) {
@@ -155,10 +156,10 @@ __device__ __forceinline__ int select_level(unsigned char* smem, const SearchPar
     }
     best = butterfly16_max(best);  // DPP row rotations inside the env's 16-lane segment
     // tie set in ascending action order (np.where(ucb == max), mcts.py:124)
-    unsigned msk[MAX_CH];
+    unsigned msk[MAXCH];
     int total = 0;
 #pragma unroll
-    for (int ch = 0; ch < MAX_CH; ch++) {
+    for (int ch = 0; ch < MAXCH; ch++) {
         const int a = ch * 16 + a0;
         const bool eq = (ch < nch) && (a < P.A) && (u[ch] == best);
         const unsigned long long bal = __ballot(eq);
@@ -182,7 +183,7 @@ __device__ __forceinline__ int select_level(unsigned char* smem, const SearchPar
     int a_sel = 0, cum = 0;
     bool found = false;
 #pragma unroll
-    for (int ch = 0; ch < MAX_CH; ch++) {
+    for (int ch = 0; ch < MAXCH; ch++) {
         const int c = __popc(msk[ch]);
         if (!found && pick < cum + c) {
             a_sel = ch * 16 + nth_set_bit(msk[ch], pick - cum);
@@ -195,6 +196,7 @@ __device__ __forceinline__ int select_level(unsigned char* smem, const SearchPar
 
 // One descent from the root to an unexpanded child for all 16 envs of the tile (mcts.py:372-379).
 // Every lane of an env's 16-lane segment ends with identical (segment-uniform) results.
+template <int MAXCH = MAX_CH>
 __device__ __forceinline__ void tree_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
                                             int& leaf_action) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void tree_select(unsigned char* smem, const SearchPar
     bool done = !env_ok;
     int lp = 0, la = 0, lpl = 0, depth = 0;
     while (__any(!done)) {
-        const int a_sel = select_level(smem, P, e, a0, seg, n, mn, mx, !done, ties, env_g);
+        const int a_sel = select_level<MAXCH>(smem, P, e, a0, seg, n, mn, mx, !done, ties, env_g);
         const int t = cp; cp = op; op = t;  // mcts.py:379
         if (!done) {
             const int c = child_row(smem, P, e, n)[a_sel];

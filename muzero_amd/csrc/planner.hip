@@ -1,5 +1,7 @@
 // planner.hip -- host side of libmzplanner_hip.so: the C ABI of include/mzplanner.h over the gfx950 kernels
-// in mz_search.h / mz_mlp.h / mz_env.h.  One planner handle == one GPU, one HIP stream, all state in HBM.
+// in mz_search.h / mz_mlp.h / mz_env.h (MLP nets: one fused LDS-resident kernel per move) and mz_conv.h / mz_convnet.h
+// (conv nets: HBM-resident trees + MFMA conv towers, a short kernel sequence per simulation).
+// One planner handle == one GPU, one HIP stream, all state in HBM.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -14,6 +16,7 @@
 #include "mz_env.h"
 #include "mz_search.h"
 #include "mz_search_fast.h"
+#include "mz_convnet.h"
 
 using namespace mz;
 
@@ -87,6 +90,15 @@ struct mz_planner {
     float *d_inf_in = nullptr, *d_inf_hidden = nullptr, *d_inf_reward = nullptr, *d_inf_value = nullptr, *d_inf_pi = nullptr;
     int* d_inf_action = nullptr;
     int inf_cap = 0;
+
+    // conv nets (MZ_NET_BOARD / MZ_NET_ATARI): network, HBM tree regions and the per-simulation exchange buffers
+    bool conv = false;
+    ConvNetDev cnet{};
+    unsigned char* d_regions = nullptr;
+    float *d_pi0 = nullptr, *d_sim_reward = nullptr, *d_sim_value = nullptr;
+    const float** d_srcptrs = nullptr;
+    float **d_dstptrs = nullptr, **d_rootptrs = nullptr;
+    int* d_sim_action = nullptr;
 
     // self-play
     EnvState env{};
@@ -182,13 +194,43 @@ static void compute_layout(mz_planner* p) {
     ip.lds_bytes = (b + 15) & ~15;
 }
 
+// conv nets: the tree part only, laid out from offset 0 of a per-workgroup HBM region (same structure as tree_mode 0 in LDS)
+static void compute_layout_conv(mz_planner* p) {
+    const mz_config& c = p->cfg;
+    SearchParams& s = p->sp;
+    s.S = c.num_simulations; s.A = c.num_actions; s.NN = c.num_simulations + 1;
+    int b = 0;
+    auto take = [&](int bytes, int align) { b = (b + align - 1) / align * align; int r = b; b += bytes; return r; };
+    s.t_nodes = take(16 * s.NN * (int)sizeof(TreeNode), 16);
+    s.t_child = take(16 * s.NN * s.A * 2, 16);
+    s.t_prior = take(16 * s.A * 8, 16);
+    s.t_tmp = take(16 * s.A * 8, 16);
+    s.t_pi0 = take(16 * s.A * 4, 16);
+    s.t_mm = take(16 * 2 * 8, 16);
+    s.t_sel = take(128 * 4, 16);
+    s.t_ptr = take(32 * 8, 16);
+    s.t_ftab = take((s.S + 1) * (s.S + 1) * 8, 16);
+    s.lds_bytes = (b + 255) & ~255;
+    s.tree_mode = 0;
+    p->lds_mode0 = s.lds_bytes;
+    p->tree2_ok = false;
+}
+
 extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner** out) {
     if (!cfg || !out) return fail(MZ_E_INVALID, "null argument");
-    if (cfg->net_kind != MZ_NET_MLP)
-        return fail(MZ_E_INVALID, "only MZ_NET_MLP is implemented by this build of the HIP planner (conv towers: see DESIGN.md scope)");
-    if (cfg->num_actions < 1 || cfg->num_actions > 16 * MAX_CH) return fail(MZ_E_INVALID, "num_actions must be in [1, 64] for the LDS-resident search kernel");
+    const bool conv = cfg->net_kind == MZ_NET_BOARD || cfg->net_kind == MZ_NET_ATARI;
+    if (cfg->net_kind != MZ_NET_MLP && !conv) return fail(MZ_E_INVALID, "unknown net_kind");
+    if (!conv && (cfg->num_actions < 1 || cfg->num_actions > 16 * MAX_CH))
+        return fail(MZ_E_INVALID, "num_actions must be in [1, 64] for the LDS-resident search kernel (MLP nets)");
+    if (conv && (cfg->num_actions < 1 || cfg->num_actions > 256)) return fail(MZ_E_INVALID, "num_actions must be in [1, 256] for conv nets");
     if (cfg->num_simulations < 1 || cfg->num_simulations > 4000) return fail(MZ_E_INVALID, "num_simulations out of range");
-    if (cfg->hidden_dim < 1 || cfg->num_planes < 1 || cfg->num_envs < 1) return fail(MZ_E_INVALID, "bad network/env dimensions");
+    if (conv) {
+        if (cfg->obs_c < 1 || cfg->obs_h < 1 || cfg->obs_w < 1 || cfg->num_res_blocks < 0) return fail(MZ_E_INVALID, "bad conv network dimensions");
+        if (cfg->net_kind == MZ_NET_ATARI && (cfg->obs_h != 96 || cfg->obs_w != 96))
+            return fail(MZ_E_INVALID, "MuZeroAtariNet takes 96x96 frames (its hidden state is fixed at 6x6, network.py:515)");
+        if (cfg->net_kind == MZ_NET_BOARD && cfg->obs_h * cfg->obs_w > 240) return fail(MZ_E_INVALID, "board larger than 240 points");
+    }
+    if ((!conv && cfg->hidden_dim < 1) || cfg->num_planes < 1 || cfg->num_envs < 1) return fail(MZ_E_INVALID, "bad network/env dimensions");
     if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1023 || cfg->reward_support_size > 1023)
         return fail(MZ_E_INVALID, "support sizes must be in [1, 1023]");
     if (cfg->is_board_game && cfg->discount != 1.0) return fail(MZ_E_INVALID, "board games require discount == 1.0 (mcts.py:349-350)");
@@ -205,8 +247,19 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         const char* to = getenv("MZ_TREE_OLD");
         p->tree_old = to && to[0] == '1';
     }
-    compute_layout(p);
-    if (p->sp.lds_bytes > 160 * 1024 && !p->tree2_ok) {
+    p->conv = conv;
+    if (conv) {
+        ConvNetDev& n = p->cnet;
+        n.kind = cfg->net_kind; n.in_c = cfg->obs_c; n.in_h = cfg->obs_h; n.in_w = cfg->obs_w; n.A = cfg->num_actions;
+        n.R = cfg->num_res_blocks; n.P = cfg->num_planes; n.Sv = cfg->value_support_size; n.Sr = cfg->reward_support_size;
+        n.hh = conv && cfg->net_kind == MZ_NET_ATARI ? 6 : cfg->obs_h;
+        n.hw = conv && cfg->net_kind == MZ_NET_ATARI ? 6 : cfg->obs_w;
+        p->cfg.hidden_dim = n.hidden_size();
+        compute_layout_conv(p);
+    } else {
+        compute_layout(p);
+    }
+    if (!conv && p->sp.lds_bytes > 160 * 1024 && !p->tree2_ok) {
         int need = p->sp.lds_bytes;
         delete p;
         return fail(MZ_E_INVALID, "configuration needs " + std::to_string(need) + " bytes of LDS per workgroup (> 160 KiB): tree does not fit the LDS-resident kernel");
@@ -253,6 +306,22 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     }
     HIPCHK(hipEventCreate(&p->ev_begin));
     HIPCHK(hipEventCreate(&p->ev_end));
+    if (conv) {
+        const size_t blocks = (B + TILE_E - 1) / TILE_E, HS = (size_t)p->cfg.hidden_dim;
+        HIPCHK(hipMalloc(&p->d_regions, blocks * (size_t)p->sp.lds_bytes));
+        HIPCHK(hipMalloc(&p->d_pi0, B * A * sizeof(float)));
+        HIPCHK(hipMalloc(&p->d_sim_reward, B * sizeof(float)));
+        HIPCHK(hipMalloc(&p->d_sim_value, B * sizeof(float)));
+        HIPCHK(hipMalloc(&p->d_srcptrs, B * sizeof(float*)));
+        HIPCHK(hipMalloc(&p->d_dstptrs, B * sizeof(float*)));
+        HIPCHK(hipMalloc(&p->d_rootptrs, B * sizeof(float*)));
+        HIPCHK(hipMalloc(&p->d_sim_action, B * sizeof(int)));
+        std::vector<float*> roots(B);
+        for (size_t i = 0; i < B; i++) roots[i] = p->d_hidden + i * (S + 1) * HS;
+        HIPCHK(hipMemcpy(p->d_rootptrs, roots.data(), B * sizeof(float*), hipMemcpyHostToDevice));
+        *out = p;
+        return MZ_OK;
+    }
     int max_lds = p->tree2_ok ? p->lds_mode2 : 0;
     if (p->lds_mode0 <= 160 * 1024 && p->lds_mode0 > max_lds) max_lds = p->lds_mode0;
     if (p->lds_mode0 > 160 * 1024) p->tree_old = false;  // only the mode-2 layout fits
@@ -285,6 +354,10 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     }
     for (int i = 0; i < 3; i++)
         if (p->d_stream[i]) (void)hipFree(p->d_stream[i]);
+    void* cbufs[] = {p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
+    for (void* b : cbufs)
+        if (b) (void)hipFree(b);
+    convnet_free(p->cnet);
     env_free(p->env);
     for (auto& pr : p->kev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
@@ -310,6 +383,23 @@ extern "C" int mz_planner_set_param(mz_planner* p, const char* name, const float
 extern "C" int mz_planner_commit_params(mz_planner* p) {
     if (!p) return fail(MZ_E_INVALID, "null planner");
     HIPCHK(hipSetDevice(p->device));
+    if (p->conv) {
+        HIPCHK(hipStreamSynchronize(p->stream));
+        ConvNetDev fresh = p->cnet;
+        fresh.allocs.clear(); fresh.rep_res.clear(); fresh.dyn_res.clear(); fresh.pred_res.clear();
+        fresh.bufA = fresh.bufB = fresh.bufC = nullptr; fresh.buf_elems = 0;
+        convnet_free(p->cnet);
+        p->cnet = fresh;
+        ParamMap pm;
+        for (auto& kv : p->params) pm[kv.first] = HostTensorRef{kv.second.data.data(), kv.second.shape};
+        std::string err;
+        const int rc = convnet_build(p->cnet, pm, &err);
+        if (rc) return fail(rc == -2 ? MZ_E_HIP : (err.rfind("missing", 0) == 0 ? MZ_E_STATE : MZ_E_INVALID), err);
+        hipError_t e = convnet_ensure_buffers(p->cnet, p->cfg.num_envs);
+        if (e != hipSuccess) return fail(MZ_E_HIP, std::string("conv work buffers: ") + hipGetErrorString(e));
+        p->committed = true;
+        return MZ_OK;
+    }
     for (int l = 0; l < L_COUNT; l++) {
         const MlpLayer& L = p->net.L[l];
         const std::string wn = std::string(kMlpNames[l]) + ".weight", bn = std::string(kMlpNames[l]) + ".bias";
@@ -395,6 +485,14 @@ static int run_infer(mz_planner* p, bool initial, int batch, const float* h_in, 
     const size_t in_w = initial ? obs_dim(p->cfg) : p->cfg.hidden_dim;
     HIPCHK(hipMemcpyAsync(p->d_inf_in, h_in, (size_t)batch * in_w * sizeof(float), hipMemcpyHostToDevice, p->stream));
     if (!initial) HIPCHK(hipMemcpyAsync(p->d_inf_action, h_action, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    if (p->conv) {
+        hipError_t e = convnet_ensure_buffers(p->cnet, batch);
+        if (e != hipSuccess) return fail(MZ_E_HIP, std::string("conv work buffers: ") + hipGetErrorString(e));
+        if (initial) convnet_initial(p->stream, p->cnet, batch, p->d_inf_in, nullptr, p->d_inf_hidden, p->d_inf_pi, p->d_inf_value);
+        else convnet_recurrent(p->stream, p->cnet, batch, nullptr, p->d_inf_in, p->d_inf_action, nullptr, p->d_inf_hidden, p->d_inf_reward,
+                               p->d_inf_value, p->d_inf_pi);
+        HIPCHK(hipGetLastError());
+    } else {
     InferParams ip = p->ip;
     ip.B = batch; ip.in = p->d_inf_in; ip.action = p->d_inf_action; ip.hidden_out = p->d_inf_hidden; ip.reward = p->d_inf_reward;
     ip.value = p->d_inf_value; ip.pi = p->d_inf_pi;
@@ -402,6 +500,7 @@ static int run_infer(mz_planner* p, bool initial, int batch, const float* h_in, 
     if (initial) hipLaunchKernelGGL(k_infer<true>, grid, block, ip.lds_bytes, p->stream, ip);
     else hipLaunchKernelGGL(k_infer<false>, grid, block, ip.lds_bytes, p->stream, ip);
     HIPCHK(hipGetLastError());
+    }
     if (h_hidden) HIPCHK(hipMemcpyAsync(h_hidden, p->d_inf_hidden, (size_t)batch * p->cfg.hidden_dim * sizeof(float), hipMemcpyDeviceToHost, p->stream));
     if (h_reward) HIPCHK(hipMemcpyAsync(h_reward, p->d_inf_reward, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p->stream));
     if (h_value) HIPCHK(hipMemcpyAsync(h_value, p->d_inf_value, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p->stream));
@@ -464,6 +563,45 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         if (rc) return rc;
         HIPCHK(hipEventRecord(ea, p->stream));
     }
+    if (p->conv) {
+        // HBM-resident trees: root inference -> init -> S x {select, dynamics + prediction towers, expand + backup} -> play
+        s = p->sp;
+        s.tree_mode = 0;
+        s.discount = c.discount; s.board = c.is_board_game; s.has_bounds = c.has_known_bounds;
+        s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
+        s.deterministic = deterministic; s.has_mask = has_mask ? 1 : 0;
+        s.noise_mode = want_noise ? (injected_rng ? 1 : 2) : 0;
+        s.rng_mode = injected_rng ? 0 : 1;
+        s.max_ties = c.max_ties; s.B = batch;
+        s.obs = p->d_obs; s.mask = p->d_mask; s.cur = p->d_cur; s.opp = p->d_opp; s.temperature = p->d_temp;
+        s.noise = p->d_noise; s.u_tie = p->d_utie; s.u_final = p->d_ufinal; s.hidden = p->d_hidden; s.ftab = p->d_ftab;
+        s.out_action = p->d_action; s.out_pi = p->d_pi; s.out_root = p->d_root; s.out_visits = p->d_visits; s.err = p->d_err;
+        s.trace_parent = scripted ? p->d_tparent : nullptr; s.trace_action = scripted ? p->d_taction : nullptr;
+        s.seed = c.seed; s.move_counter = p->move_counter - 1; s.env_offset = 0; s.stamps = nullptr;
+        GTreeLaunch G{};
+        G.P = s; G.regions = p->d_regions; G.hidden_size = c.hidden_dim; G.src_ptrs = p->d_srcptrs; G.dst_ptrs = p->d_dstptrs;
+        G.actions = p->d_sim_action;
+        if (scripted) {
+            G.pi0 = p->d_spi0;
+        } else {
+            convnet_initial(p->stream, p->cnet, batch, p->d_obs, p->d_rootptrs, nullptr, p->d_pi0, p->d_sim_value);  // root value discarded
+            G.pi0 = p->d_pi0;
+        }
+        hipLaunchKernelGGL(k_gtree_init, grid, block, 0, p->stream, G);
+        for (int sim = 0; sim < c.num_simulations; sim++) {
+            G.sim = sim;
+            hipLaunchKernelGGL(k_gtree_select, grid, block, 0, p->stream, G);
+            if (scripted) {
+                G.reward = p->d_srewards + sim; G.value = p->d_svalues + sim; G.rv_stride = c.num_simulations;
+            } else {
+                convnet_recurrent(p->stream, p->cnet, batch, p->d_srcptrs, nullptr, p->d_sim_action, p->d_dstptrs, nullptr, p->d_sim_reward,
+                                  p->d_sim_value, nullptr);
+                G.reward = p->d_sim_reward; G.value = p->d_sim_value; G.rv_stride = 1;
+            }
+            hipLaunchKernelGGL(k_gtree_backup, grid, block, 0, p->stream, G);
+        }
+        hipLaunchKernelGGL(k_gtree_finish, grid, block, 0, p->stream, G);
+    } else
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
     else if (p->fast_planes == 512 && !p->force_generic) hipLaunchKernelGGL(k_search_fast<512>, grid, block, s.lds_bytes, p->stream, s, p->fw);
     else if (p->fast_planes == 256 && !p->force_generic) hipLaunchKernelGGL(k_search_fast<256>, grid, block, s.lds_bytes, p->stream, s, p->fw);
@@ -506,8 +644,6 @@ static int download_results(mz_planner* p, int batch, int32_t* h_action, double*
     HIPCHK(hipStreamSynchronize(p->stream));
     if (err) {
         HIPCHK(hipMemset(p->d_err, 0, sizeof(int)));
-    HIPCHK(hipMalloc(&p->d_stamps, 16 * sizeof(long long)));
-    HIPCHK(hipMemset(p->d_stamps, 0, 16 * sizeof(long long)));
         if (err == 4) return fail(MZ_E_TIES, "injected tie-break stream exhausted (raise mz_config.max_ties)");
         return fail(MZ_E_INVALID, "search kernel reported error " + std::to_string(err));
     }

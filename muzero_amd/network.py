@@ -252,12 +252,17 @@ class MuZeroNet(nn.Module):
             self._engine_version = ver
         return self._engine
 
+    def _shape_hidden(self, flat):
+        """hidden state without the batch dimension, as the reference returns it: [H] for MLP nets, [C, h, w] for conv nets"""
+        shape = getattr(self, 'hidden_shape', None)
+        return flat if shape is None else flat.reshape(shape)
+
     @torch.no_grad()
     def initial_inference(self, x: torch.Tensor) -> NetworkOutputs:
         """network.py:62-84: batch of one in, numpy / python scalars out."""
         eng = self.inference_engine(x.device)
         hidden, pi, value = eng.initial_inference(x.detach().to(torch.float32).cpu().numpy())
-        return NetworkOutputs(hidden_state=hidden[0], reward=0.0, pi_probs=pi[0], value=float(value[0]))
+        return NetworkOutputs(hidden_state=self._shape_hidden(hidden[0]), reward=0.0, pi_probs=pi[0], value=float(value[0]))
 
     @torch.no_grad()
     def recurrent_inference(self, hidden_state: torch.Tensor, action: torch.Tensor) -> NetworkOutputs:
@@ -266,7 +271,7 @@ class MuZeroNet(nn.Module):
         hidden, reward, pi, value = eng.recurrent_inference(
             hidden_state.detach().to(torch.float32).cpu().numpy(), action.detach().cpu().numpy().reshape(-1).astype(np.int32)
         )
-        return NetworkOutputs(hidden_state=hidden[0], reward=float(reward[0]), pi_probs=pi[0], value=float(value[0]))
+        return NetworkOutputs(hidden_state=self._shape_hidden(hidden[0]), reward=float(reward[0]), pi_probs=pi[0], value=float(value[0]))
 
 
 class MuZeroMLPNet(MuZeroNet):
@@ -304,6 +309,7 @@ class MuZeroAtariNet(MuZeroNet):
         self.represent_net = RepresentationConvAtariNet(input_shape, num_planes)
         self.dynamics_net = DynamicsConvNet((num_planes + num_actions, 6, 6), num_actions, num_res_blocks, num_planes, reward_support_size)
         self.prediction_net = PredictionConvNet((num_planes, 6, 6), num_actions, num_res_blocks, num_planes, value_support_size)
+        self.hidden_shape = (num_planes, 6, 6)
         initialize_weights(self)
 
     def planner_spec(self) -> dict:
@@ -326,6 +332,7 @@ class MuZeroBoardGameNet(MuZeroNet):
         self.represent_net = RepresentationConvNet(input_shape, num_planes, num_res_blocks)
         self.dynamics_net = DynamicsConvNet((num_planes + num_actions, h, w), num_actions, num_res_blocks, num_planes, 1)
         self.prediction_net = PredictionConvNet((num_planes, h, w), num_actions, num_res_blocks, num_planes, 1)
+        self.hidden_shape = (num_planes, h, w)
         initialize_weights(self)
 
     def planner_spec(self) -> dict:

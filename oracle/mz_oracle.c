@@ -246,21 +246,25 @@ static void conv_free(conv_t* c) {
 
 static int conv_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
 
-/* y[co][oy][ox] = b[co] + sum_{ky,kx,ci} x[ci][iy][ix]*w ; zero padding contributes fmaf(0,w,acc) (== acc) */
+/* y[co][oy][ox] = b[co] + sum x[ci][iy][ix]*w as ONE fmaf chain in the order: 16-channel block (major), tap (ky, kx),
+ * channel inside the block (minor) -- the order in which the HIP implicit-GEMM kernel stages 16-channel input slabs in LDS.
+ * Zero padding contributes fmaf(0, w, acc) == acc, i.e. nothing. */
 static void conv_fwd(const conv_t* c, const float* x, int h, int w, float* y, int relu, const float* residual) {
     int oh = conv_out(h, c->k, c->stride, c->pad), ow = conv_out(w, c->k, c->stride, c->pad);
     for (int co = 0; co < c->cout; co++)
         for (int oy = 0; oy < oh; oy++)
             for (int ox = 0; ox < ow; ox++) {
                 float acc = c->b[co];
-                for (int ky = 0; ky < c->k; ky++)
-                    for (int kx = 0; kx < c->k; kx++) {
-                        int iy = oy * c->stride + ky - c->pad, ix = ox * c->stride + kx - c->pad;
-                        if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
-                        const float* wp = c->w + (((size_t)co * c->k + ky) * c->k + kx) * c->cin;
-                        const float* xp = x + (size_t)iy * w + ix;
-                        for (int ci = 0; ci < c->cin; ci++) acc = fmaf(xp[(size_t)ci * h * w], wp[ci], acc);
-                    }
+                for (int cb = 0; cb < c->cin; cb += 16)
+                    for (int ky = 0; ky < c->k; ky++)
+                        for (int kx = 0; kx < c->k; kx++) {
+                            int iy = oy * c->stride + ky - c->pad, ix = ox * c->stride + kx - c->pad;
+                            if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+                            const float* wp = c->w + (((size_t)co * c->k + ky) * c->k + kx) * c->cin;
+                            const float* xp = x + (size_t)iy * w + ix;
+                            int ce = cb + 16 < c->cin ? cb + 16 : c->cin;
+                            for (int ci = cb; ci < ce; ci++) acc = fmaf(xp[(size_t)ci * h * w], wp[ci], acc);
+                        }
                 if (residual) acc = acc + residual[((size_t)co * oh + oy) * ow + ox];
                 if (relu && !(acc > 0.0f)) acc = 0.0f;
                 y[((size_t)co * oh + oy) * ow + ox] = acc;

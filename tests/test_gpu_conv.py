@@ -1,0 +1,189 @@
+"""GPU parity for the conv-tower planner (MuZeroBoardGameNet / MuZeroAtariNet): the MFMA implicit-GEMM
+conv kernels + HBM-resident tree kernels, called through the C ABI, against
+  (1) the CPU oracle on the same seeded inputs -- bit-exact (every conv output is one float32 fmaf chain in the order
+      16-channel block -> tap -> channel on both sides), and
+  (2) the golden fixtures recorded from the reference implementation (tolerances of tests/test_oracle_nets.py)."""
+import numpy as np
+import pytest
+
+from helpers import CONV_CASES, build_conv, conv_case, load_golden
+from test_oracle_nets import _oracle_net
+
+pytestmark = pytest.mark.gpu
+
+TREE = load_golden('tree_cases.npz')
+SEARCH = load_golden('search_cases.npz')
+NETS = load_golden('net_cases.npz')
+
+
+def _planner(net, num_envs, **search):
+    from muzero_amd import planner as pl
+
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=num_envs, **search), 0)
+    p.load_state_dict(net.state_dict())
+    return p
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_inference_bit_exact_vs_oracle(oracle, case):
+    net = build_conv(case)
+    onet = _oracle_net(oracle, net, 'conv')
+    B = 5 if case[1] == 'atari' else 19  # ragged batches
+    p = _planner(net, B)
+    rs = np.random.RandomState(7)
+    obs = rs.uniform(0, 1, size=(B,) + tuple(case[2])).astype(np.float32)
+    hidden, pi, value = p.initial_inference(obs)
+    actions = rs.randint(0, case[3], size=B).astype(np.int32)
+    h2, reward, pi2, value2 = p.recurrent_inference(hidden, actions)
+    for b in range(B):
+        oh, _, opi, ov = onet.initial_inference(obs[b])
+        np.testing.assert_array_equal(hidden[b], oh)
+        np.testing.assert_array_equal(pi[b], opi)
+        assert value[b] == np.float32(ov)
+        oh2, orw, opi2, ov2 = onet.recurrent_inference(oh, int(actions[b]))
+        np.testing.assert_array_equal(h2[b], oh2)
+        assert reward[b] == np.float32(orw) and value2[b] == np.float32(ov2)
+        np.testing.assert_array_equal(pi2[b], opi2)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_inference_matches_reference_fixture(case):
+    net = build_conv(case)
+    p = _planner(net, 16)
+    for j in range(2):
+        pre = f'conv_{case[0]}_{j}'
+        hidden, pi, value = p.initial_inference(NETS[f'{pre}_obs'][None])
+        np.testing.assert_allclose(hidden[0], NETS[f'{pre}_init_hidden'].reshape(-1), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(pi[0], NETS[f'{pre}_init_pi'], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(value[0], NETS[f'{pre}_init_value'], rtol=2e-4, atol=2e-4)
+        acts = NETS[f'{pre}_actions']
+        n = len(acts)
+        hin = np.concatenate([NETS[f'{pre}_init_hidden'].reshape(1, -1), NETS[f'{pre}_rec_hidden'].reshape(n, -1)[:-1]])
+        h, r, pi2, v = p.recurrent_inference(hin, acts)
+        np.testing.assert_allclose(h, NETS[f'{pre}_rec_hidden'].reshape(n, -1), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r, np.asarray(NETS[f'{pre}_rec_reward']).reshape(-1), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(v, np.asarray(NETS[f'{pre}_rec_value']).reshape(-1), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(pi2, NETS[f'{pre}_rec_pi'], rtol=2e-5, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------- HBM tree kernels
+def _tree_case(i):
+    return {k[len(f'c{i}_'):]: TREE[k] for k in TREE.files if k.startswith(f'c{i}_')}
+
+
+@pytest.mark.parametrize('i', range(int(TREE['num_cases'])))
+def test_hbm_tree_kernels_bit_exact_vs_reference(i):
+    """Every tree fixture (A up to 226, incl. the Gomoku-sized ones the LDS kernel cannot hold) through the HBM-resident
+    tree kernels with scripted network outputs: per-simulation (parent, action), visits, policy, action, root value."""
+    c = _tree_case(i)
+    A, S = int(c['A']), int(c['sims'])
+    net = build_conv(('x', 'board', (2, 3, 3), A, 0, 16, 1, 1, 1))
+    kb = (float(c['kb_min']), float(c['kb_max'])) if int(c['has_bounds']) else None
+    p = _planner(net, 35, num_simulations=S, discount=float(c['discount']), is_board_game=bool(c['board']), known_bounds=kb,
+                 root_dirichlet_alpha=float(c['alpha']), root_exploration_eps=float(c['eps']), pb_c_base=float(c['pb_c_base']),
+                 pb_c_init=float(c['pb_c_init']))
+    B = 35  # three workgroups, the last one ragged
+    rep = lambda x: np.repeat(np.asarray(x)[None], B, axis=0)  # noqa: E731
+    r = p.search_scripted(rep(c['pi0']), rep(c['values']), rep(c['rewards']), rep(c['mask']), int(c['cur_player']), int(c['opp_player']),
+                          float(c['temperature']), bool(c['deterministic']), noise=rep(c['noise']) if int(c['has_noise']) else rep(np.zeros(A)),
+                          u_tie=rep(c['u_tie']), u_final=float(c['u_final']))
+    T = float(c['temperature'])
+    ex = max(1.0, min(5.0, 1.0 / T)) if T > 0 else 1.0
+    for b in (0, 15, 16, 34):
+        np.testing.assert_array_equal(r['trace_parent'][b], c['trace_parent'])
+        np.testing.assert_array_equal(r['trace_action'][b], c['trace_action'])
+        np.testing.assert_array_equal(r['visits'][b], c['visits'])
+        if ex == int(ex):
+            np.testing.assert_array_equal(r['pi'][b], c['out_pi'])
+        else:
+            np.testing.assert_allclose(r['pi'][b], c['out_pi'], rtol=1e-15, atol=0)
+        assert r['action'][b] == int(c['out_action'])
+        assert r['root_value'][b] == float(c['out_root_value'])
+
+
+# ----------------------------------------------------------------------------------------------- full search
+def _cfg_kwargs(G, g):
+    return dict(
+        num_simulations=int(G[f'{g}_sims']), discount=float(G[f'{g}_discount']), is_board_game=bool(G[f'{g}_board']),
+        known_bounds=(float(G[f'{g}_kb_min']), float(G[f'{g}_kb_max'])) if int(G[f'{g}_has_bounds']) else None,
+        root_dirichlet_alpha=float(G[f'{g}_alpha']), root_exploration_eps=float(G[f'{g}_eps']),
+    )
+
+
+@pytest.mark.parametrize('g', ['board3', 'atari_s'])
+def test_conv_search_matches_reference_fixture_and_oracle(oracle, g):
+    G = SEARCH
+    net = build_conv(conv_case(g))
+    onet = _oracle_net(oracle, net, 'conv')
+    kw = _cfg_kwargs(G, g)
+    A = net.num_actions
+    ocfg = oracle.make_config(A, kw['num_simulations'], kw['discount'], kw['is_board_game'], kw['known_bounds'], kw['root_dirichlet_alpha'],
+                              kw['root_exploration_eps'])
+    p = _planner(net, 16, **kw)
+    for j in range(int(G[f'{g}_n'])):
+        pre = f'{g}_{j}'
+        det = bool(G[f'{pre}_deterministic'])
+        noise = G[f'{pre}_noise'] if int(G[f'{pre}_has_noise']) else None
+        args = (int(G[f'{pre}_cur_player']), int(G[f'{pre}_opp_player']), float(G[f'{pre}_temperature']), det)
+        r = p.search(G[f'{pre}_obs'][None], G[f'{pre}_mask'][None], *args, noise=None if noise is None else noise[None],
+                     u_tie=G[f'{pre}_u_tie'][None], u_final=float(G[f'{pre}_u_final']))
+        o = oracle.uct_search(ocfg, onet, G[f'{pre}_obs'], G[f'{pre}_mask'], *args, noise=noise, u_tie=G[f'{pre}_u_tie'],
+                              u_final=float(G[f'{pre}_u_final']))
+        # oracle: bit-exact
+        assert r['root_value'][0] == o['root_value']
+        np.testing.assert_array_equal(r['pi'][0], o['pi'])
+        np.testing.assert_array_equal(r['visits'][0], o['visits'])
+        assert r['action'][0] == o['action']
+        # reference fixture (same expectations as tests/test_oracle_search.py holds the oracle to)
+        np.testing.assert_array_equal(r['visits'][0], G[f'{pre}_visits'])
+        np.testing.assert_array_equal(r['pi'][0], G[f'{pre}_out_pi'])
+        assert r['action'][0] == int(G[f'{pre}_out_action'])
+        rv = float(G[f'{pre}_out_root_value'])
+        assert abs(r['root_value'][0] - rv) <= 1e-4 * max(1.0, abs(rv))
+
+
+@pytest.mark.parametrize('g,B,S', [('board3', 40, 25), ('board5', 21, 20), ('board9', 18, 12), ('atari_s', 6, 8)])
+def test_conv_batched_search_bit_exact_vs_oracle(oracle, g, B, S):
+    """Lock-step envs with random injected draws: every env equals an independent oracle search."""
+    case = conv_case(g)
+    net = build_conv(case)
+    onet = _oracle_net(oracle, net, 'conv')
+    A = case[3]
+    board = case[1] == 'board'
+    kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None,
+              root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    ocfg = oracle.make_config(A, S, kw['discount'], board, kw['known_bounds'], 0.25, 0.25)
+    p = _planner(net, B, **kw)
+    rs = np.random.RandomState(321)
+    obs = rs.uniform(0, 1, size=(B,) + tuple(case[2])).astype(np.float32)
+    mask = (rs.rand(B, A) < 0.8) if board else np.ones((B, A), bool)
+    mask[np.arange(B), rs.randint(0, A, B)] = True
+    cur = rs.randint(1, 3, B).astype(np.int32) if board else np.ones(B, np.int32)
+    opp = (3 - cur).astype(np.int32) if board else np.ones(B, np.int32)
+    temp = rs.choice([1.0, 0.5, 0.25, 0.1, 0.0], size=B)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    for det in (False, True):
+        r = p.search(obs, mask, cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie, u_final=u_final)
+        o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie,
+                                    u_final=u_final)
+        np.testing.assert_array_equal(r['visits'], o['visits'])
+        np.testing.assert_array_equal(r['pi'], o['pi'])
+        np.testing.assert_array_equal(r['action'], o['action'])
+        np.testing.assert_array_equal(r['root_value'], o['root_value'])
+
+
+def test_conv_network_api_runs_on_planner(oracle):
+    """MuZeroBoardGameNet.initial_inference / recurrent_inference (network.py:62-111) route through the HIP engine."""
+    import torch
+
+    case = conv_case('board3')
+    net = build_conv(case).to('cuda')
+    onet = _oracle_net(oracle, build_conv(case), 'conv')
+    obs = np.random.RandomState(2).uniform(0, 1, size=case[2]).astype(np.float32)
+    out = net.initial_inference(torch.from_numpy(obs[None]).to('cuda'))
+    oh, _, opi, ov = onet.initial_inference(obs)
+    np.testing.assert_array_equal(np.asarray(out.hidden_state).reshape(-1), oh)
+    np.testing.assert_array_equal(out.pi_probs, opi)
+    assert out.value == float(np.float32(ov)) and out.reward == 0.0
