@@ -78,13 +78,99 @@ def cpu_baseline(num_sims, sample_envs, budget_s=20.0):
                        f'of {cores} host CPUs, batch-1 inference per env')
 
 
+# Conv workloads (BASELINE.json configs[3] / configs[4]; not the headline bench line): name -> (case tuple for
+# tests/helpers.build_conv, envs per GPU, sims per move, env kind, search kwargs)
+CONV_WORKLOADS = {
+    'c4': (('c4', 'atari', (8, 96, 96), 6, 8, 128, 61, 61, 41), 512, 50, 'synthetic', dict(discount=0.997, root_dirichlet_alpha=0.25)),
+    'c5': (('c5', 'board', (9, 15, 15), 226, 8, 128, 1, 1, 42), 256, 200, 'gomoku',
+           dict(discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.03)),
+}
+
+
+def conv_flops(case):
+    """Algorithmic FLOPs (2 x MAC) of one simulation (dynamics + prediction towers, reward + value heads; the recurrent
+    policy head is dead compute in the reference search) and of one root inference, SURVEY 8d."""
+    _, kind, (c, h, w), A, R, P, Sv, Sr, _ = case
+    hh, hw = (6, 6) if kind == 'atari' else (h, w)
+    px = hh * hw
+    res = R * 2 * P * P * 9 * px
+    sim = (P + A) * P * 9 * px + res + (P * px + px * Sr) + res + (P * px + px * Sv)
+    if kind == 'atari':
+        rep = c * 128 * 9 * 48 * 48 + 4 * 128 * 128 * 9 * 48 * 48 + 128 * P * 9 * 24 * 24 + 4 * P * P * 9 * 24 * 24 + 4 * P * P * 9 * 12 * 12
+    else:
+        rep = c * P * 9 * px + res
+    root = rep + res + (2 * P * px + 2 * px * A) + (P * px + px * Sv)
+    return 2 * sim, 2 * root
+
+
+def run_conv_workload(args, name, rank, local_rank, world, torch, dist):
+    from helpers import build_conv
+    from muzero_amd import build as mz_build
+    from muzero_amd import planner as pl
+
+    mz_build.build()
+    case, envs, sims, env_kind, kw = CONV_WORKLOADS[name]
+    B = args.envs or envs
+    S = args.sims or sims
+    net = build_conv(case)
+    cfg = pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=1000 + rank, num_simulations=S, root_exploration_eps=0.25, **kw)
+    p = pl.Planner(cfg, local_rank)
+    p.load_state_dict(net.state_dict())
+    p.selfplay_reset(pl.ENV_GOMOKU if env_kind == 'gomoku' else pl.ENV_SYNTHETIC)
+    T = -1.0 if env_kind == 'gomoku' else 1.0
+
+    def sync():
+        p.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    if args.warmup:
+        p.selfplay_step(T, args.warmup)
+    sync()
+    p.profile_begin()
+    t0 = time.perf_counter()
+    p.selfplay_step(T, args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = p.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        f_sim, f_root = conv_flops(case)
+        sims_per_s = world * B * S * args.steps / elapsed
+        ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
+        flop_per_move = B * (S * f_sim + f_root)
+        achieved = flop_per_move / (ms * 1e-3) / 1e12
+        print(json.dumps({
+            'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)', 'value': sims_per_s, 'unit': 'sims/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{name.upper()}: {case[1]} net {case[5]} planes / {case[4]} blocks, obs {case[2]}, A={case[3]}, {S} sims/move, '
+                                   f'{B} envs per MI355X, {env_kind} device env, HBM-resident trees',
+                       'envs_per_gpu': B, 'sims_per_move': S, 'parallelism': f'env-sharded x{world}', 'weights': 'seeded random init'},
+            'env_steps_per_sec': sims_per_s / S,
+            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_conv3x3<NPT> (conv towers; whole per-move kernel sequence timed)', 'achieved': achieved,
+                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'avg_move_ms': ms, 'flop_per_move': flop_per_move, 'flop_per_sim': f_sim,
+                         'timed_with': 'hipEvent pairs on the planner stream around each move\'s kernel sequence'},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--envs', type=int, default=4096, help='environments per GPU')
-    ap.add_argument('--sims', type=int, default=50)
+    ap.add_argument('--envs', type=int, default=0, help='environments per GPU (default: that of the workload)')
+    ap.add_argument('--sims', type=int, default=0, help='simulations per move (default: that of the workload)')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
+                    help='c2 (default, the headline line): CartPole MLP; c4 / c5: the conv-tower configs of BASELINE.json (extra measurements)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -101,13 +187,16 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
+    if args.workload != 'c2':
+        return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist)
+
     from helpers import build_mlp, mlp_case
     from muzero_amd import build as mz_build
     from muzero_amd import planner as pl
 
     mz_build.build()
     net = build_mlp(mlp_case('cartpole'))  # 512/64/31, seeded random init
-    B, S = args.envs, args.sims
+    B, S = args.envs or 4096, args.sims or 50
     cfg = pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=1000 + rank, num_simulations=S, discount=0.997,
                             root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
     p = pl.Planner(cfg, local_rank)

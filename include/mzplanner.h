@@ -32,6 +32,8 @@ extern "C" {
 #define MZ_ENV_NONE 0
 #define MZ_ENV_CARTPOLE 1  /* CartPole-v1 + StackFrameAndAction(4) + PlayerIdAndActionMaskWrapper, gym_env.py:271-365,436-459 */
 #define MZ_ENV_TICTACTOE 2 /* TicTacToeEnv, games/tictactoe.py + games/env.py */
+#define MZ_ENV_GOMOKU 3    /* GomokuEnv (board = obs_h, stack 4, five in a row), games/gomoku.py + games/env.py */
+#define MZ_ENV_SYNTHETIC 4 /* stand-in for the Atari emulator (absent dependency): fresh U[0,1) frames, reward 0, 1000-step episodes */
 
 /* Everything uct_search reads from MuZeroConfig (config.py:51-103) and from the network constructors
  * (network.py:239-247, 504-512, 543-549), plus planner-only sizing knobs. */
@@ -116,7 +118,9 @@ int mz_planner_search_scripted(mz_planner* p, int32_t batch, const float* h_pi0,
 /* Device-resident self-play: run_self_play's inner loop (pipeline.py:91-113) for num_envs on-device environments.
  * mz_selfplay_reset seeds/initialises the envs (h_init_state: CartPole float64 [B,4] or NULL => U(-0.05,0.05) from Philox).
  * mz_selfplay_step performs ONE lock-step move for all envs: search (num_simulations) -> sample action -> env.step ->
- * record (obs, action, reward, pi, root_value, player) -> auto-reset finished episodes.  Nothing crosses PCIe. */
+ * record (obs, action, reward, pi, root_value, player) -> auto-reset finished episodes.  Nothing crosses PCIe.
+ * temperature >= 0: the same value for every env (classic / Atari schedules depend on training steps only, config.py:252-267);
+ * temperature < 0: the board game's own per-env schedule by episode step (config.py:236-249). */
 int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* h_init_state);
 int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_moves);
 /* Copy out the records of the last `n_moves` moves (newest last): arrays [n_moves, B, ...]; any pointer may be NULL. */

@@ -6,9 +6,11 @@
 //   CartPole-v1   : gym 0.23.1 equations (un-vendored dependency of the reference, requirements.txt:7),
 //                   float64 state, float32 observation, StackFrameAndAction(4) rows [obs_t-k, (a_t-k + 1)/A] newest
 //                   first (gym_env.py:306-353), players 1/1 and an all-true mask (gym_env.py:356-365), TimeLimit 500.
-//   TicTacToe     : BoardGameEnv semantics (games/env.py:117-154,242-310; games/tictactoe.py:33-77): per-player
-//                   own-stone history planes, resign action 9, win test through the last move, player switches only
-//                   if the game is not over.
+//   TicTacToe /   : BoardGameEnv semantics (games/env.py:117-154,242-310; games/tictactoe.py:33-77 == games/gomoku.py:72-116):
+//   Gomoku          N x N board, per-player own-stone history planes (stack 4), resign action N*N, win test (num_to_win
+//                   in a row) through the last move only, player switches only if the game is not over.
+//   Synthetic     : stand-in for the Atari emulator (ale-py is an absent third-party dependency): every step draws a fresh
+//                   U[0,1) observation from Philox, reward 0, episode ends every 1000 steps.
 #pragma once
 #include "mz_device.h"
 
@@ -16,15 +18,18 @@ namespace mz {
 
 constexpr int ENV_CARTPOLE = 1;
 constexpr int ENV_TICTACTOE = 2;
+constexpr int ENV_GOMOKU = 3;
+constexpr int ENV_SYNTHETIC = 4;
 
 struct EnvState {
     int kind, B, A, D, ring_len;
+    int bn, nn, win;       // board games: side length, points (bn * bn), stones in a row to win
     double* cp_state;      // [B][4]
     int* steps;            // [B] steps in the current episode
     unsigned int* episode; // [B] episode index (keys the reset RNG)
     double* init_state;    // [B][4] optional externally supplied reset states (tests)
-    signed char* board;    // [B][9]
-    signed char* planes;   // [B][2][4][9]
+    signed char* board;    // [B][nn]
+    signed char* planes;   // [B][2][4][nn]
     int* player;           // [B] side to move (1 black, 2 white)
     // record ring, slot-major
     float* r_obs;          // [ring][B][D]
@@ -42,7 +47,7 @@ struct EnvLaunch {
     int B;
     unsigned long long seed;
     int use_init;
-    double temperature;  // >= 0: constant; < 0: board-game schedule (1.0 for the first 6 moves, then 0.1; config.py:236-241)
+    double temperature;  // >= 0: constant; < 0: the board game's own schedule (1.0 for the first 6 (TicTacToe) / 30 (Gomoku) moves, then 0.1; config.py:236-249)
     unsigned int move_counter;
     int slot, sims;
     float* obs;
@@ -63,9 +68,10 @@ inline void env_free(EnvState& e) {
     e = EnvState{};
 }
 
-inline hipError_t env_alloc(EnvState& e, int kind, int B, int A, int D, int ring_len) {
+inline hipError_t env_alloc(EnvState& e, int kind, int B, int A, int D, int ring_len, int board_n = 3, int num_to_win = 3) {
     env_free(e);
     e.kind = kind; e.B = B; e.A = A; e.D = D; e.ring_len = ring_len;
+    e.bn = board_n; e.nn = board_n * board_n; e.win = num_to_win;
     hipError_t r;
 #define MZ_ALLOC(ptr, bytes)                                  \
     if ((r = hipMalloc(&(ptr), (bytes))) != hipSuccess) return r; \
@@ -74,8 +80,8 @@ inline hipError_t env_alloc(EnvState& e, int kind, int B, int A, int D, int ring
     MZ_ALLOC(e.steps, (size_t)B * sizeof(int));
     MZ_ALLOC(e.episode, (size_t)B * sizeof(unsigned int));
     MZ_ALLOC(e.init_state, (size_t)B * 4 * sizeof(double));
-    MZ_ALLOC(e.board, (size_t)B * 9);
-    MZ_ALLOC(e.planes, (size_t)B * 72);
+    MZ_ALLOC(e.board, (size_t)B * e.nn);
+    MZ_ALLOC(e.planes, (size_t)B * 8 * e.nn);
     MZ_ALLOC(e.player, (size_t)B * sizeof(int));
     MZ_ALLOC(e.r_obs, (size_t)ring_len * B * D * sizeof(float));
     MZ_ALLOC(e.r_action, (size_t)ring_len * B * sizeof(int));
@@ -126,35 +132,50 @@ __device__ inline bool cartpole_physics(double s[4], int action) {
     return (x < -x_threshold) || (x > x_threshold) || (theta < -theta_threshold) || (theta > theta_threshold);
 }
 
-// ---- TicTacToe ----
-__device__ inline void ttt_write_obs(const EnvLaunch& L, int e) {
+// ---- board games (TicTacToe, Gomoku) ----
+__device__ inline void board_write_obs(const EnvLaunch& L, int e) {
     // [X_t, Y_t, X_t-1, Y_t-1, ..., C] from the side to move (games/env.py:242-271)
-    float* o = L.obs + (size_t)e * 81;
-    const signed char* pl = L.env.planes + (size_t)e * 72;
+    const int nn = L.env.nn;
+    float* o = L.obs + (size_t)e * 9 * nn;
+    const signed char* pl = L.env.planes + (size_t)e * 8 * nn;
     const int me = L.env.player[e], opp = 3 - me;
     for (int t = 0; t < 4; t++)
-        for (int i = 0; i < 9; i++) {
-            o[(2 * t) * 9 + i] = (float)pl[((me - 1) * 4 + t) * 9 + i];
-            o[(2 * t + 1) * 9 + i] = (float)pl[((opp - 1) * 4 + t) * 9 + i];
+        for (int i = 0; i < nn; i++) {
+            o[(2 * t) * nn + i] = (float)pl[((me - 1) * 4 + t) * nn + i];
+            o[(2 * t + 1) * nn + i] = (float)pl[((opp - 1) * 4 + t) * nn + i];
         }
-    for (int i = 0; i < 9; i++) o[72 + i] = me == 1 ? 1.0f : 0.0f;
+    for (int i = 0; i < nn; i++) o[8 * nn + i] = me == 1 ? 1.0f : 0.0f;
     L.cur[e] = me;
     L.opp[e] = opp;
 }
 
-__device__ inline void ttt_fresh(const EnvLaunch& L, int e) {
-    for (int i = 0; i < 9; i++) L.env.board[(size_t)e * 9 + i] = 0;
-    for (int i = 0; i < 72; i++) L.env.planes[(size_t)e * 72 + i] = 0;
-    for (int a = 0; a < 10; a++) L.mask[(size_t)e * 10 + a] = 1;
+__device__ inline void board_fresh(const EnvLaunch& L, int e) {
+    const int nn = L.env.nn;
+    for (int i = 0; i < nn; i++) L.env.board[(size_t)e * nn + i] = 0;
+    for (int i = 0; i < 8 * nn; i++) L.env.planes[(size_t)e * 8 * nn + i] = 0;
+    for (int a = 0; a <= nn; a++) L.mask[(size_t)e * (nn + 1) + a] = 1;
     L.env.player[e] = 1;
-    ttt_write_obs(L, e);
+    board_write_obs(L, e);
 }
 
-__device__ inline int ttt_line(const signed char* b, int r, int c, int dr, int dc, int colour) {
-    int n = 0;
+__device__ inline int board_line(const signed char* b, int n, int r, int c, int dr, int dc, int colour) {
+    int k = 0;
     r += dr; c += dc;
-    while (r >= 0 && r < 3 && c >= 0 && c < 3 && b[r * 3 + c] == colour) { n++; r += dr; c += dc; }
-    return n;
+    while (r >= 0 && r < n && c >= 0 && c < n && b[r * n + c] == colour) { k++; r += dr; c += dc; }
+    return k;
+}
+
+// ---- synthetic frames: one thread per 4 observation values, keyed by (env, episode, step) ----
+__global__ void k_env_synth_obs(const EnvLaunch L) {
+    const int D4 = (L.env.D + 3) >> 2;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (size_t)L.B * D4) return;
+    const int e = (int)(i / D4), q = (int)(i - (size_t)e * D4);
+    Philox g(L.seed, (unsigned)e, L.env.episode[e] * 1000u + (unsigned)L.env.steps[e], 0x50000000u + (unsigned)q);
+    uint32_t v[4];
+    g.round4(v);
+    float* o = L.obs + (size_t)e * L.env.D + 4 * q;
+    for (int k = 0; k < 4 && 4 * q + k < L.env.D; k++) o[k] = (float)(v[k] >> 8) * (1.0f / 16777216.0f);
 }
 
 __global__ void k_env_reset(const EnvLaunch L) {
@@ -171,8 +192,11 @@ __global__ void k_env_reset(const EnvLaunch L) {
         cartpole_obs_reset(L, e, s);
         L.mask[(size_t)e * 2] = 1; L.mask[(size_t)e * 2 + 1] = 1;
         L.cur[e] = 1; L.opp[e] = 1;
+    } else if (L.env.kind == ENV_SYNTHETIC) {
+        for (int a = 0; a < L.env.A; a++) L.mask[(size_t)e * L.env.A + a] = 1;
+        L.cur[e] = 1; L.opp[e] = 1;
     } else {
-        ttt_fresh(L, e);
+        board_fresh(L, e);
     }
 }
 
@@ -181,12 +205,8 @@ __global__ void k_env_pre(const EnvLaunch L) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= L.B) return;
     double T = L.temperature;
-    if (T < 0.0) T = L.env.steps[e] < 6 ? 1.0 : 0.1;
-    L.temp_out[e] = T;
-    const int D = L.env.D;
-    float* ro = L.env.r_obs + ((size_t)L.slot * L.B + e) * D;
-    const float* o = L.obs + (size_t)e * D;
-    for (int i = 0; i < D; i++) ro[i] = o[i];
+    if (T < 0.0) T = L.env.steps[e] < (L.env.kind == ENV_GOMOKU ? 30 : 6) ? 1.0 : 0.1;  // config.py:236-249
+    L.temp_out[e] = T;  // (the observation half of the record is one device-to-device copy enqueued by the host)
     L.env.r_player[(size_t)L.slot * L.B + e] = L.cur[e];
 }
 
@@ -222,43 +242,54 @@ __global__ void k_env_step(const EnvLaunch L) {
             for (int i = 0; i < 4; i++) L.env.cp_state[e * 4 + i] = s[i];
             cartpole_obs_reset(L, e, s);
         }
+    } else if (L.env.kind == ENV_SYNTHETIC) {
+        const int st = L.env.steps[e] + 1;
+        done = st >= 1000;
+        if (done) {
+            atomicAdd(&L.env.counters[2], 1ULL);
+            atomicAdd(&L.env.counters[3], (unsigned long long)st);
+            L.env.episode[e] += 1;
+        }
+        L.env.steps[e] = done ? 0 : st;  // the next observation is drawn by k_env_synth_obs
     } else {
-        signed char* b = L.env.board + (size_t)e * 9;
-        signed char* pl = L.env.planes + (size_t)e * 72;
+        const int n = L.env.bn, nn = L.env.nn;
+        signed char* b = L.env.board + (size_t)e * nn;
+        signed char* pl = L.env.planes + (size_t)e * 8 * nn;
         const int me = L.env.player[e], opp = 3 - me;
         const int st = L.env.steps[e];
         int winner = 0;
-        L.mask[(size_t)e * 10 + a] = 0;
-        if (a == 9) {  // resign (games/env.py:134-136)
+        L.mask[(size_t)e * (nn + 1) + a] = 0;
+        if (a == nn) {  // resign (games/env.py:134-136)
             reward = -1.0f;
             winner = opp;
         } else {
             b[a] = (signed char)me;
-            signed char* mine = pl + (me - 1) * 36;
+            signed char* mine = pl + (me - 1) * 4 * nn;
             for (int k = 3; k > 0; k--)
-                for (int i = 0; i < 9; i++) mine[k * 9 + i] = mine[(k - 1) * 9 + i];
-            for (int i = 0; i < 9; i++) mine[i] = b[i] == me;
-            if (st >= 4) {  // games/tictactoe.py:37-38 with the pre-increment step count
-                const int r = a / 3, c = a % 3;
+                for (int i = 0; i < nn; i++) mine[k * nn + i] = mine[(k - 1) * nn + i];
+            for (int i = 0; i < nn; i++) mine[i] = b[i] == me;
+            if (st >= (L.env.win - 1) * 2) {  // games/tictactoe.py:37-38, games/gomoku.py:76-77 with the pre-increment step count
+                const int r = a / n, c = a % n;
                 const int dirs[4][2] = {{0, 1}, {1, 0}, {1, 1}, {-1, 1}};
                 for (int d = 0; d < 4; d++)
-                    if (1 + ttt_line(b, r, c, dirs[d][0], dirs[d][1], me) + ttt_line(b, r, c, -dirs[d][0], -dirs[d][1], me) >= 3) winner = me;
+                    if (1 + board_line(b, n, r, c, dirs[d][0], dirs[d][1], me) + board_line(b, n, r, c, -dirs[d][0], -dirs[d][1], me) >= L.env.win)
+                        winner = me;
             }
             if (winner) reward = 1.0f;
         }
         bool full = true;
-        for (int i = 0; i < 9; i++) full = full && b[i] != 0;
+        for (int i = 0; i < nn; i++) full = full && b[i] != 0;
         done = winner != 0 || full;
         if (!done) {
             L.env.player[e] = opp;
             L.env.steps[e] = st + 1;
-            ttt_write_obs(L, e);
+            board_write_obs(L, e);
         } else {
             atomicAdd(&L.env.counters[2], 1ULL);
             atomicAdd(&L.env.counters[3], (unsigned long long)(st + 1));
             L.env.steps[e] = 0;
             L.env.episode[e] += 1;
-            ttt_fresh(L, e);
+            board_fresh(L, e);
         }
     }
     L.env.r_action[rec] = a;

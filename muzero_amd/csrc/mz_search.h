@@ -318,7 +318,25 @@ __device__ __forceinline__ void play_from_visits(unsigned char* smem, const Sear
         if (v > bestv) { bestv = v; best = a; }
         tmp[a] = (T > 0.0) ? pow_policy((double)v, ex) : (double)v;
     }
-    const double s = np_sum_f64(tmp, A);
+    double s = np_sum_f64(tmp, A);
+    if (!(s > 0.0)) {
+        // Every visit went to an illegal root child: the first simulation of a search ties ALL actions (U == 0 while the
+        // root has N == 0, mcts.py:193-195) and may pick an illegal one, which then keeps winning on Q alone when simulations
+        // are few.  The reference divides 0/0 here (a NaN policy) and np.random.choice then raises ValueError
+        // (mcts.py:279,404).  Parity mode (injected draws) returns the same NaN policy -- the Python mirror raises the
+        // ValueError; production self-play plays uniformly over the legal actions instead of stopping the actor.
+        if (P.rng_mode != 0) {
+            s = 0.0;
+            best = -1;
+            for (int a = 0; a < A; a++) {
+                const bool legal = !mk || mk[a];
+                tmp[a] = legal ? 1.0 : 0.0;
+                s = s + tmp[a];
+                if (legal && best < 0) best = a;
+            }
+            best = best < 0 ? 0 : best;
+        }
+    }
     double* pi = P.out_pi + (size_t)env_g * A;
     for (int a = 0; a < A; a++) pi[a] = tmp[a] / s;
     int action = best;

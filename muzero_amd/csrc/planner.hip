@@ -700,24 +700,34 @@ extern "C" int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* 
     if (!p) return fail(MZ_E_INVALID, "null planner");
     HIPCHK(hipSetDevice(p->device));
     const mz_config& c = p->cfg;
+    int board_n = 3, num_to_win = 3;
     if (env_kind == MZ_ENV_CARTPOLE) {
         if (c.num_actions != 2 || obs_dim(c) != 20) return fail(MZ_E_INVALID, "CartPole env needs num_actions == 2 and a (4,5) observation");
     } else if (env_kind == MZ_ENV_TICTACTOE) {
         if (c.num_actions != 10 || obs_dim(c) != 81) return fail(MZ_E_INVALID, "TicTacToe env needs num_actions == 10 and a (9,3,3) observation");
+    } else if (env_kind == MZ_ENV_GOMOKU) {
+        if (c.net_kind != MZ_NET_BOARD || c.obs_c != 9 || c.obs_h != c.obs_w || c.num_actions != c.obs_h * c.obs_w + 1 || c.obs_h < 5)
+            return fail(MZ_E_INVALID, "Gomoku env needs a board net with a (9,N,N) observation, N >= 5, and num_actions == N*N + 1");
+        board_n = c.obs_h;
+        num_to_win = 5;
+    } else if (env_kind == MZ_ENV_SYNTHETIC) {
+        if (h_init_state) return fail(MZ_E_INVALID, "the synthetic env takes no initial state");
     } else {
         return fail(MZ_E_INVALID, "unknown env kind");
     }
     p->env_kind = env_kind;
-    p->ring_len = 64;
+    p->ring_len = (size_t)c.num_envs * obs_dim(c) * sizeof(float) * 64 > ((size_t)4 << 30) ? 16 : 64;  // record ring: at most a few GB
     p->ring_pos = 0;
     p->ring_count = 0;
-    hipError_t e = env_alloc(p->env, env_kind, c.num_envs, c.num_actions, obs_dim(c), p->ring_len);
+    hipError_t e = env_alloc(p->env, env_kind, c.num_envs, c.num_actions, obs_dim(c), p->ring_len, board_n, num_to_win);
     if (e != hipSuccess) return fail(MZ_E_HIP, std::string("env_alloc: ") + hipGetErrorString(e));
     if (h_init_state) HIPCHK(hipMemcpyAsync(p->env.init_state, h_init_state, (size_t)c.num_envs * 4 * sizeof(double), hipMemcpyHostToDevice, p->stream));
     EnvLaunch L{};
     L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.use_init = h_init_state != nullptr;
     L.obs = p->d_obs; L.mask = p->d_mask; L.cur = p->d_cur; L.opp = p->d_opp;
     hipLaunchKernelGGL(k_env_reset, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+    if (env_kind == MZ_ENV_SYNTHETIC)
+        hipLaunchKernelGGL(k_env_synth_obs, dim3(((size_t)c.num_envs * ((obs_dim(c) + 3) / 4) + 255) / 256), dim3(256), 0, p->stream, L);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
     return MZ_OK;
@@ -736,9 +746,13 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
         L.action = p->d_action; L.pi = p->d_pi; L.root = p->d_root; L.slot = p->ring_pos; L.sims = c.num_simulations;
         // temperatures for this move, then the search, then env.step + record + auto-reset
         hipLaunchKernelGGL(k_env_pre, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+        HIPCHK(hipMemcpyAsync(p->env.r_obs + (size_t)p->ring_pos * c.num_envs * obs_dim(c), p->d_obs, (size_t)c.num_envs * obs_dim(c) * sizeof(float),
+                              hipMemcpyDeviceToDevice, p->stream));
         int rc = launch_search(p, c.num_envs, 0, true, false, false);
         if (rc) return rc;
         hipLaunchKernelGGL(k_env_step, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+        if (p->env_kind == MZ_ENV_SYNTHETIC)
+            hipLaunchKernelGGL(k_env_synth_obs, dim3(((size_t)c.num_envs * ((obs_dim(c) + 3) / 4) + 255) / 256), dim3(256), 0, p->stream, L);
         HIPCHK(hipGetLastError());
         p->ring_pos = (p->ring_pos + 1) % p->ring_len;
         if (p->ring_count < p->ring_len) p->ring_count++;

@@ -115,4 +115,7 @@ def uct_search(state, network, device, config, temperature, actions_mask, curren
     mask = None if actions_mask is None else np.asarray(actions_mask)[None, ...]
     a, pi, v = batched_uct_search(np.asarray(state)[None, ...], network, device, config, temperature, mask, current_player, opponent_player,
                                   deterministic, rng)
+    if not deterministic and np.isnan(pi[0]).any():
+        # every visit fell on illegal root children: the reference's 0/0 policy makes np.random.choice raise (mcts.py:279,404)
+        raise ValueError('probabilities contain NaN')
     return int(a[0]), pi[0], float(v[0])

@@ -174,12 +174,12 @@ class EpisodeAssembler:
 
 def run_self_play(config, rank, network, device, env, data_queue, train_steps_counter, stop_event, tag: str = None,
                   moves_per_drain: int = 16, max_moves: Optional[int] = None) -> int:
-    """Self-play until `stop_event` is set (pipeline.py:41-167).  `env` names a device environment ('CartPole-v1' or
-    'TicTacToe'); `config.num_envs` of them advance in lock-step on GPU `device`.  Items put on `data_queue` are the
+    """Self-play until `stop_event` is set (pipeline.py:41-167).  `env` names a device environment ('CartPole-v1',
+    'TicTacToe', 'Gomoku', or 'Synthetic-Atari': random frames standing in for the absent emulator); `config.num_envs` of them advance in lock-step on GPU `device`.  Items put on `data_queue` are the
     reference's `(Transition, priority)` tuples.  Returns the number of env steps played."""
     from muzero_amd import planner as pl
 
-    kinds = {'CartPole-v1': pl.ENV_CARTPOLE, 'TicTacToe': pl.ENV_TICTACTOE}
+    kinds = {'CartPole-v1': pl.ENV_CARTPOLE, 'TicTacToe': pl.ENV_TICTACTOE, 'Gomoku': pl.ENV_GOMOKU, 'Synthetic-Atari': pl.ENV_SYNTHETIC}
     name = env if isinstance(env, str) else getattr(env, 'name', None) or getattr(getattr(env, 'spec', None), 'id', None)
     if name not in kinds:
         raise ValueError(f'no device environment for {name!r}; available: {sorted(kinds)}')

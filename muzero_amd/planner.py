@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmzplanner_hip.so')
 
 NET_MLP, NET_BOARD, NET_ATARI = 0, 1, 2
-ENV_NONE, ENV_CARTPOLE, ENV_TICTACTOE = 0, 1, 2
+ENV_NONE, ENV_CARTPOLE, ENV_TICTACTOE, ENV_GOMOKU, ENV_SYNTHETIC = 0, 1, 2, 3, 4
 _NET_KINDS = {'mlp': NET_MLP, 'board': NET_BOARD, 'atari': NET_ATARI}
 
 # every symbol include/mzplanner.h declares (tests/test_abi.py checks the library exports all of them)

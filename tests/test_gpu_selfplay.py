@@ -99,3 +99,58 @@ def test_run_self_play_counterpart_emits_reference_shaped_items():
         assert tr.value.dtype == np.float32 and tr.reward.dtype == np.float32
         assert set(np.unique(tr.value)).issubset({-1.0, 0.0, 1.0})  # Monte-Carlo returns of a board game
         assert np.isfinite(prio) and prio >= 0
+
+
+def test_gomoku_device_env_matches_oracle_env(oracle):
+    """Gomoku (9x9 board, five in a row, A = 82) on a conv planner: the recorded trajectories replayed through the oracle
+    BoardEnv -- bit-exact integer board logic across auto-resets."""
+    from helpers import build_conv, conv_case
+    from muzero_amd import planner as pl
+
+    net = build_conv(conv_case('board9'))
+    B, M = 24, 60
+    p = _planner(net, B, num_simulations=12, discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.03)
+    p.selfplay_reset(pl.ENV_GOMOKU)
+    done_total = 0
+    envs = [oracle.BoardEnv(9, 4, 5) for _ in range(B)]
+    obs = [e.reset() for e in envs]
+    steps = [0] * B
+    for _ in range(M // 12):
+        p.selfplay_step(-1.0, 12)
+        rec = p.selfplay_read(12)
+        for m in range(12):
+            for b in range(B):
+                env = envs[b]
+                np.testing.assert_array_equal(rec['obs'][m, b].reshape(9, 9, 9), obs[b].astype(np.float32))
+                assert rec['player'][m, b] == env.current_player
+                a = int(rec['action'][m, b])
+                assert env.actions_mask[a], 'sampled action must be legal'
+                pi = rec['pi'][m, b]
+                assert abs(pi.sum() - 1.0) < 1e-12 and (pi[~env.actions_mask] == 0).all()
+                obs[b], r, done = env.step(a)
+                steps[b] += 1
+                assert r == rec['reward'][m, b] and done == bool(rec['done'][m, b])
+                if done:
+                    done_total += 1
+                    obs[b] = env.reset()
+                    steps[b] = 0
+    cnt = p.selfplay_counters()
+    assert cnt['env_steps'] == B * M and cnt['episodes'] == done_total
+
+
+def test_synthetic_frame_env_runs_atari_net():
+    """The Atari stand-in env: observations are fresh U[0,1) frames each step, reward 0, search output is a distribution."""
+    from helpers import build_conv, conv_case
+    from muzero_amd import planner as pl
+
+    net = build_conv(conv_case('atari_s'))
+    B, M = 5, 3
+    p = _planner(net, B, num_simulations=4, discount=0.997)
+    p.selfplay_reset(pl.ENV_SYNTHETIC)
+    p.selfplay_step(1.0, M)
+    rec = p.selfplay_read(M)
+    assert (rec['reward'] == 0).all() and (rec['done'] == 0).all() and (rec['player'] == 1).all()
+    assert rec['obs'].min() >= 0.0 and rec['obs'].max() < 1.0 and 0.45 < rec['obs'].mean() < 0.55
+    assert not np.array_equal(rec['obs'][0], rec['obs'][1])
+    np.testing.assert_allclose(rec['pi'].sum(-1), 1.0, atol=1e-12)
+    np.testing.assert_array_equal(rec['pi'], np.round(rec['pi'] * 4) / 4)
