@@ -1,15 +1,19 @@
 // mz_conv.h -- conv-tower inference kernels (MuZeroBoardGameNet network.py:540-574, MuZeroAtariNet :501-537) for gfx950.
 //
-// k_conv3x3<NPT>: 3x3 convolution (stride 1 or 2, pad 1) with eval-mode BatchNorm folded into weight/bias, optional
+// k_conv3x3<NPT, NCT>: 3x3 convolution (stride 1 or 2, pad 1) with eval-mode BatchNorm folded into weight/bias, optional
 // residual add and ReLU (ResNetBlock network.py:293-299), as an implicit GEMM on v_mfma_f32_16x16x4_f32:
 //     D[co][pixel] = bias[co] + sum_k W[co][k] * X[k][pixel],   k = (16-channel block, tap (ky,kx), channel in block)
-// A operand = 16 output channels x 4 k of the weights (pre-packed fragment order, streamed from L2), B operand =
-// 4 channels x 16 output pixels read from an LDS-staged input slab (16 channels x tile-with-halo).  The k order is ONE
-// fmaf chain per output in exactly the oracle's order, so results equal the oracle bit for bit; zero padding contributes
-// fma(w, 0, acc) == acc.
-//   workgroup = 256 threads = one image (blockIdx.y) x one spatial tile of up to NPT*16 output pixels (blockIdx.x) x one
-//   slice of 128 output channels (blockIdx.z; wave w owns channel tiles w and w + 4 of the slice); accumulators:
-//   2 x NPT tiles of 16x16 per wave.
+// A operand = 16 output channels x 4 k of the weights (pre-packed fragment order, a linear stream per wave out of L2),
+// B operand = 4 channels x 16 output pixels read from an LDS-staged input slab (tile-with-halo x 16 channels, one
+// 16-byte read per lane and tap).  The k
+// order is ONE fmaf chain per output in exactly the oracle's order, so results equal the oracle bit for bit; zero padding
+// contributes fma(w, 0, acc) == acc.
+//   workgroup = 256 threads = a group of G images (blockIdx.y) x one spatial tile (blockIdx.x) = up to NPT*16 output
+//   pixel slots x one slice of 64*NCT output channels (blockIdx.z; wave w owns channel tiles w, w+4 of the slice).
+//   Small boards pack several images into the pixel dimension (6x6: 4 images = 144 pixels = 9 full MFMA tiles).
+//   Pipeline per 16-channel block: the NEXT block's slab is fetched global -> registers before the MFMA loop and written
+//   to the other LDS buffer after it (one barrier per block); weights run 2 taps ahead in a register ring; B operands are
+//   read one pixel tile ahead of the MFMAs that consume them.  All staging index arithmetic is hoisted out of the loop.
 // The dynamics net's action planes (network.py:440-444: element f = c*h*w + y*w + x of the [A,h,w] block is 1 iff
 // f % A == action) are generated while staging, never materialised.
 #pragma once
@@ -21,106 +25,212 @@ struct ConvLaunch {
     // input: per-image base pointers (gather from the node store) or a dense buffer
     const float* const* in_ptrs;  // [B] or null
     const float* in;              // dense [B][cin_real][ih][iw] if in_ptrs == null
+    const float* in_base;         // with in_ptrs and G > 1: the node store's base; every in_ptrs[b] - in_base must be < 1 Gi floats
     const int* action;            // [B] or null: channels >= cin_real are action planes over num_actions
     int num_actions;
     int cin_real;                 // channels present in memory
     int cin;                      // logical input channels (cin_real + num_actions planes), k runs over pad16(cin)
     int ih, iw, oh, ow, stride;
-    int cout;                     // output channels; blockIdx.z selects a slice of 128 (8 tiles of 16)
+    int cout;                     // output channels; blockIdx.z selects a slice of 64*NCT
     const float* w;               // packed [co_tile][cb][tap][64 lanes][4]
     const float* bias;            // [pad16(cout)]
     const float* residual;        // dense [B][cout][oh][ow] or null
     float* out;                   // dense [B][cout][oh][ow]
     int relu;
-    int th, tw;                   // spatial tile (th*tw <= NPT*16)
+    int th, tw;                   // spatial tile of one image (G * th * tw <= NPT*16)
     int tiles_x, tiles_y;
+    int G;                        // images per workgroup (> 1 only when one tile covers the whole image)
+    int cstride;                  // LDS floats per slab buffer (>= G * sih * siw * CONV_PS)
     int B;
 };
 
-template <int NPT>
-__global__ __launch_bounds__(256) void k_conv3x3(const ConvLaunch L) {
+constexpr int CONV_RK = 2;    // slab positions per thread: G * sih * siw <= 384
+constexpr int CONV_PS = 20;   // LDS floats per slab position: 16 channels + 4 pad (80 B: 16-byte reads and writes spread over the banks)
+
+typedef unsigned int conv_u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef MZC_NO_XS  // diagnostic variants (tools/micro/conv_bench.hip), never defined in the product build
+#define MZC_XS_READ 0
+#else
+#define MZC_XS_READ 1
+#endif
+
+// All global reads of the main loop are buffer loads: address = descriptor base (SGPRs, workgroup- or wave-uniform) +
+// per-lane byte offset (ONE VGPR, loop-invariant) + uniform byte offset (SGPR: channel or weight step).  With plain
+// pointers hipcc keeps one 64-bit VGPR address per unrolled load alive across the loop (or emits flat loads that also
+// tick lgkmcnt and serialise against the LDS reads).
+template <int NPT, int NCT>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // slab[2][positions][CONV_PS]: position r = g * plane + sy * siw + sx holds its 16 channels permuted so that the float4
+    // at r * CONV_PS + 4q is {ch q, ch 4+q, ch 8+q, ch 12+q}: the B operands of the four k-steps of lane group q
     float* slab = reinterpret_cast<float*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
-    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
     const int tile = blockIdx.x, ty0 = (tile / L.tiles_x) * L.th, tx0 = (tile % L.tiles_x) * L.tw;
     const int sih = (L.th - 1) * L.stride + 3, siw = (L.tw - 1) * L.stride + 3, plane = sih * siw;
-    const float* src = L.in_ptrs ? L.in_ptrs[b] : L.in + (size_t)b * L.cin_real * L.ih * L.iw;
-    const int act = L.action ? L.action[b] : 0;
-    const int co_tiles = (L.cout + 15) >> 4, n_cb = (L.cin + 15) >> 4;
-    // this lane's output pixels: slot p = pt*16 + j -> (py, px) inside the tile; slab offset of its top-left tap
-    int off[NPT];
+    const int img0 = blockIdx.y * L.G, TP = L.th * L.tw, ihw = L.ih * L.iw;
+    const int co_tiles = (L.cout + 15) >> 4, n_cb = (L.cin + 15) >> 4, bufsz = L.cstride;  // floats per slab buffer
+    const int iy0 = ty0 * L.stride - 1, ix0 = tx0 * L.stride - 1;
+
+    // ---- staging plan (hoisted): positions r = tid, tid + 256; out-of-image positions read a clamped address and are zeroed ----
+    const int img0c = img0 < L.B ? img0 : L.B - 1;
+    const float* ibase = L.in_ptrs ? (L.G == 1 ? L.in_ptrs[img0c] : L.in_base) : L.in;  // workgroup-uniform
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ibase), 0, -1, 0x00020000);
+    unsigned voff[CONV_RK];
+    int am[CONV_RK], sact[CONV_RK];
+    bool swrite[CONV_RK], sval[CONV_RK];
+    const int ihwA = ihw % L.num_actions;
+#pragma unroll
+    for (int k = 0; k < CONV_RK; k++) {
+        const int r = tid + 256 * k;
+        swrite[k] = r < L.G * plane;
+        const int rc = swrite[k] ? r : 0;
+        const int g = rc / plane, rr = rc - g * plane, sy = rr / siw, sx = rr - sy * siw;
+        const int gy = iy0 + sy, gx = ix0 + sx, bimg = img0 + g;
+        sval[k] = swrite[k] && bimg < L.B && gy >= 0 && gy < L.ih && gx >= 0 && gx < L.iw;
+        const int cy = gy < 0 ? 0 : (gy >= L.ih ? L.ih - 1 : gy), cx = gx < 0 ? 0 : (gx >= L.iw ? L.iw - 1 : gx);
+        const int cimg = bimg < L.B ? bimg : L.B - 1;
+        size_t o = (size_t)(cy * L.iw + cx);
+        if (!L.in_ptrs) o += (size_t)cimg * L.cin_real * ihw;
+        else if (L.G != 1) o += (size_t)(L.in_ptrs[cimg] - L.in_base);
+        voff[k] = (unsigned)(o * sizeof(float));
+        am[k] = (cy * L.iw + cx) % L.num_actions;  // flat index of the first action channel at this pixel, mod A
+        sact[k] = (sval[k] && L.action) ? L.action[cimg] : -1;
+    }
+    float sv[CONV_RK][16];
+    auto fetch = [&](int cb) {  // global -> registers for channel block cb (action planes generated)
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int ch = cb * 16 + c;  // workgroup-uniform
+#pragma unroll
+            for (int k = 0; k < CONV_RK; k++) {
+                float v = 0.0f;
+#ifdef MZC_NO_FETCH
+                if (false) {
+#else
+                if (ch < L.cin_real) {  // raw value from the clamped address; out-of-image positions are zeroed in store()
+                    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[k], ch * ihw * (int)sizeof(float), 0));
+#endif
+                } else if (ch < L.cin) {
+                    v = (am[k] == sact[k]) ? 1.0f : 0.0f;
+                    am[k] += ihwA;
+                    am[k] = am[k] >= L.num_actions ? am[k] - L.num_actions : am[k];
+                }
+                sv[k][c] = v;
+            }
+        }
+    };
+    auto store = [&](int buf, int cb) {
+        float* d = slab + buf * bufsz;
+#pragma unroll
+        for (int k = 0; k < CONV_RK; k++)
+            if (swrite[k]) {
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    if (cb * 16 + c < L.cin_real && !sval[k]) sv[k][c] = 0.0f;  // zero padding of the real channels
+                float4* o = reinterpret_cast<float4*>(d + (tid + 256 * k) * CONV_PS);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) o[g4] = make_float4(sv[k][g4], sv[k][4 + g4], sv[k][8 + g4], sv[k][12 + g4]);
+            }
+    };
+
+    // ---- this lane's output pixels: slot p = pt*16 + j -> image g of the group, (py, px) inside the tile ----
+    int off[NPT];   // float offset of the lane's float4 for tap (0,0)
     bool pv[NPT];
 #pragma unroll
     for (int pt = 0; pt < NPT; pt++) {
-        const int p = pt * 16 + j, py = p / L.tw, px = p - py * L.tw;
-        pv[pt] = (p < L.th * L.tw) && (ty0 + py < L.oh) && (tx0 + px < L.ow);
-        off[pt] = pv[pt] ? (py * L.stride) * siw + px * L.stride : 0;
+        const int p = pt * 16 + j, g = p / TP, pp = p - g * TP, py = pp / L.tw, px = pp - py * L.tw;
+        pv[pt] = (g < L.G) && (img0 + g < L.B) && (ty0 + py < L.oh) && (tx0 + px < L.ow);
+        off[pt] = (g < L.G ? g * plane + (py * L.stride) * siw + px * L.stride : 0) * CONV_PS + q * 4;
     }
-    f32x4 acc[2][NPT];
-    int cot[2];
+    // ---- accumulators start at the bias; the weight stream of channel tile c is linear in (cb, tap): 1 KiB per step ----
+    f32x4 acc[NCT][NPT];
+    int cot[NCT], wbase[NCT];
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.w), 0, -1, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        cot[c] = blockIdx.z * 8 + wave + 4 * c;
-        const bool ok = cot[c] < co_tiles;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) bv = *reinterpret_cast<const float4*>(L.bias + cot[c] * 16 + q * 4);
+    for (int c = 0; c < NCT; c++) {
+        cot[c] = blockIdx.z * 4 * NCT + wave + 4 * c;
+        const int ct = cot[c] < co_tiles ? cot[c] : co_tiles - 1;  // out-of-range tiles compute a duplicate that is never stored
+        const float4 bv = *reinterpret_cast<const float4*>(L.bias + ct * 16 + q * 4);
 #pragma unroll
         for (int pt = 0; pt < NPT; pt++) acc[c][pt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        wbase[c] = ct * n_cb * 9 * 1024;  // bytes; wave-uniform
     }
-    const int iy0 = ty0 * L.stride - 1, ix0 = tx0 * L.stride - 1;
+    const int n_steps = n_cb * 9;  // weight steps (cb, tap)
+    auto wload = [&](int c, int step) {
+        const int sc = step < n_steps ? step : n_steps - 1;
+        const conv_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, wbase[c] + sc * 1024, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    float4 wr[3][NCT];  // ring: step s lives in wr[s % 3]
+#pragma unroll
+    for (int c = 0; c < NCT; c++) {
+        wr[0][c] = wload(c, 0);
+        wr[1][c] = wload(c, 1);
+    }
+    fetch(0);
+    store(0, 0);
+    __syncthreads();
+    // B operands run two pixel tiles ahead of the MFMAs in a 3-slot ring; step n = tap * NPT + pt lives in xr[n % 3]
+    float4 xr[3];
     for (int cb = 0; cb < n_cb; cb++) {
-        __syncthreads();
-        for (int i = tid; i < 16 * plane; i += 256) {
-            const int c = i / plane, r = i - c * plane, sy = r / siw, sx = r - sy * siw;
-            const int ch = cb * 16 + c, gy = iy0 + sy, gx = ix0 + sx;
-            float v = 0.0f;
-            if (ch < L.cin && gy >= 0 && gy < L.ih && gx >= 0 && gx < L.iw) {
-                if (ch < L.cin_real) v = src[((size_t)ch * L.ih + gy) * L.iw + gx];
-                else v = ((((ch - L.cin_real) * L.ih + gy) * L.iw + gx) % L.num_actions == act) ? 1.0f : 0.0f;
-            }
-            slab[i] = v;
-        }
-        __syncthreads();
+        const float* sb = slab + (cb & 1) * bufsz;
+        if (cb + 1 < n_cb) fetch(cb + 1);
+        xr[0] = *reinterpret_cast<const float4*>(sb + off[0]);
+        xr[1] = *reinterpret_cast<const float4*>(sb + (NPT > 1 ? off[NPT > 1 ? 1 : 0] : off[0] + CONV_PS));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const int toff = (tap / 3) * siw + (tap % 3);
-            float4 wv[2];
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                wv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cot[c] < co_tiles) wv[c] = reinterpret_cast<const float4*>(L.w)[(((size_t)cot[c] * n_cb + cb) * 9 + tap) * 64 + lane];
-            }
+            for (int c = 0; c < NCT; c++) wr[(tap + 2) % 3][c] = wload(c, cb * 9 + tap + 2);  // weights two steps ahead
 #pragma unroll
             for (int pt = 0; pt < NPT; pt++) {
-                const float* xp = slab + q * plane + off[pt] + toff;
-                const float x0 = xp[0], x1 = xp[4 * plane], x2 = xp[8 * plane], x3 = xp[12 * plane];
+                const int n = tap * NPT + pt, n2 = n + 2;
+                if (MZC_XS_READ && n2 < 9 * NPT) {  // B operand two steps ahead
+                    const int tap2 = n2 / NPT, pt2 = n2 - tap2 * NPT;
+                    xr[n2 % 3] = *reinterpret_cast<const float4*>(sb + off[pt2] + ((tap2 / 3) * siw + (tap2 % 3)) * CONV_PS);
+                }
+                const float4 x4 = xr[MZC_XS_READ ? n % 3 : 0];
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    if (cot[c] < co_tiles) {
-                        acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].x, x0, acc[c][pt], 0, 0, 0);
-                        acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].y, x1, acc[c][pt], 0, 0, 0);
-                        acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].z, x2, acc[c][pt], 0, 0, 0);
-                        acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].w, x3, acc[c][pt], 0, 0, 0);
-                    }
+                for (int c = 0; c < NCT; c++) {
+                    const float4 w4 = wr[tap % 3][c];
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x4.x, acc[c][pt], 0, 0, 0);
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x4.y, acc[c][pt], 0, 0, 0);
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x4.z, acc[c][pt], 0, 0, 0);
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x4.w, acc[c][pt], 0, 0, 0);
                 }
             }
-        }
-    }
-    // epilogue: D row 4q + r = output channel inside the tile, column j = pixel slot
+            // schedule: the weight loads first, then one LDS read per pixel tile's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x020, NCT, 0);
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
+            for (int pt = 0; pt < NPT; pt++) {
+                if (MZC_XS_READ && tap * NPT + pt + 2 < 9 * NPT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCT, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifndef MZC_NO_STORE
+        if (cb + 1 < n_cb) store((cb + 1) & 1, cb + 1);
+#endif
+        __syncthreads();
+    }
+    // ---- epilogue: D row 4q + r = output channel inside the tile, column j = pixel slot ----
+#pragma unroll
+    for (int c = 0; c < NCT; c++) {
         if (cot[c] >= co_tiles) continue;
 #pragma unroll
         for (int pt = 0; pt < NPT; pt++) {
             if (!pv[pt]) continue;
-            const int p = pt * 16 + j, py = p / L.tw, px = p - py * L.tw;
+            const int p = pt * 16 + j, g = p / TP, pp = p - g * TP, py = pp / L.tw, px = pp - py * L.tw;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int co = cot[c] * 16 + q * 4 + r;
                 if (co < L.cout) {
-                    const size_t o = (((size_t)b * L.cout + co) * L.oh + ty0 + py) * L.ow + tx0 + px;
+                    const size_t o = (((size_t)(img0 + g) * L.cout + co) * L.oh + ty0 + py) * L.ow + tx0 + px;
                     float v = acc[c][pt][r];
+#ifdef MZC_NO_EPI
+                    if (v != 123.456f) continue;
+#endif
                     if (L.residual) v = v + L.residual[o];
                     if (L.relu && !(v > 0.0f)) v = 0.0f;
                     L.out[o] = v;

@@ -189,6 +189,7 @@ inline hipError_t convnet_ensure_buffers(ConvNetDev& n, int B) {
         per = a > per ? a : per;
     }
     const size_t need = per * B;
+    if (need * sizeof(float) >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // 32-bit buffer offsets in k_conv3x3: split the batch
     if (need <= n.buf_elems) return hipSuccess;
     for (float** p : {&n.bufA, &n.bufB, &n.bufC}) {
         if (*p) (void)hipFree(*p);
@@ -199,38 +200,86 @@ inline hipError_t convnet_ensure_buffers(ConvNetDev& n, int B) {
     return hipSuccess;
 }
 
-inline void pick_tile(int oh, int ow, int* th, int* tw, int* npt) {
-    if (oh * ow <= 240 && oh <= 15 && ow <= 16) { *th = oh; *tw = ow; }
-    else { *th = 8; *tw = 8; }
-    const int slots = *th * *tw;
-    const int cands[6] = {1, 2, 3, 4, 6, 15};
-    for (int c : cands)
-        if (slots <= c * 16) { *npt = c; return; }
-    *npt = 15;
+// Launch geometry of one 3x3 conv: spatial tile, images per workgroup (small boards share a workgroup so that the pixel
+// dimension fills whole 16-wide MFMA tiles), pixel tiles per wave (NPT) and channel tiles per wave (NCT).
+struct ConvGeom {
+    int th, tw, G, npt, nct, cstride;
+};
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && v[0] ? atoi(v) : dflt;
+}
+
+inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool allow_group = true) {
+    static const int kNpt[9] = {1, 2, 3, 4, 5, 6, 9, 12, 15};
+    auto round_npt = [&](int tiles) {
+        for (int c : kNpt)
+            if (tiles <= c) return c;
+        return 0;
+    };
+    ConvGeom g{};
+    const bool whole = oh * ow <= 240 && ((oh - 1) * stride + 3) * ((ow - 1) * stride + 3) <= 384;
+    g.th = whole ? oh : 8; g.tw = whole ? ow : 8;
+    const int plane = ((g.th - 1) * stride + 3) * ((g.tw - 1) * stride + 3), TP = g.th * g.tw;
+    const int zs1 = (cout + 63) / 64;  // channel slices with NCT = 1
+    g.G = 1;
+    if (whole && allow_group) {
+        // best MFMA fill among group sizes that keep at least ~2 workgroups per CU busy (when the batch allows it)
+        double best = -1.0;
+        for (int G = 1; G <= 16 && G <= B && G * plane <= 384; G++) {
+            const int npt = round_npt((G * TP + 15) / 16);
+            if (!npt || (G > 1 && npt > 9)) continue;
+            const long wgs = (long)((B + G - 1) / G) * zs1;
+            double fill = (double)(G * TP) / (16.0 * npt);
+            if (wgs < 256) fill *= (double)wgs / 256.0;
+            if (fill > best + 1e-9) { best = fill; g.G = G; }
+        }
+    }
+    g.G = env_int("MZ_CONV_G", g.G);
+    g.npt = round_npt((g.G * TP + 15) / 16);
+    const long tiles = (long)((oh + g.th - 1) / g.th) * ((ow + g.tw - 1) / g.tw);
+    const long wgs1 = tiles * ((B + g.G - 1) / g.G) * zs1;
+    g.nct = (cout > 64 && wgs1 >= 1024) ? 2 : 1;  // two channel tiles per wave halve the staging work when there are workgroups to spare
+    g.nct = env_int("MZ_CONV_NCT", g.nct);
+    g.cstride = g.G * plane * CONV_PS;
+    return g;
+}
+
+template <int NCT>
+inline void conv_launch_npt(int npt, dim3 grid, size_t lds, hipStream_t st, const ConvLaunch& L) {
+    const dim3 block(256);
+    switch (npt) {
+        case 1: hipLaunchKernelGGL((k_conv3x3<1, NCT>), grid, block, lds, st, L); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<2, NCT>), grid, block, lds, st, L); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<3, NCT>), grid, block, lds, st, L); break;
+        case 4: hipLaunchKernelGGL((k_conv3x3<4, NCT>), grid, block, lds, st, L); break;
+        case 5: hipLaunchKernelGGL((k_conv3x3<5, NCT>), grid, block, lds, st, L); break;
+        case 6: hipLaunchKernelGGL((k_conv3x3<6, NCT>), grid, block, lds, st, L); break;
+        case 9: hipLaunchKernelGGL((k_conv3x3<9, NCT>), grid, block, lds, st, L); break;
+        case 12: hipLaunchKernelGGL((k_conv3x3<12, NCT>), grid, block, lds, st, L); break;
+        default: hipLaunchKernelGGL((k_conv3x3<15, NCT>), grid, block, lds, st, L); break;
+    }
 }
 
 // one 3x3 conv launch; input either dense `in` or per-image `in_ptrs`
+// (gathered input: in_base / in_span_floats describe the store the row pointers point into)
 inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float* in, const float* const* in_ptrs, const int* action, int A, int ih,
-                     int iw, const float* residual, float* out, bool relu) {
+                     int iw, const float* residual, float* out, bool relu, const float* in_base = nullptr, size_t in_span_floats = 0) {
     ConvLaunch L{};
-    L.in_ptrs = in_ptrs; L.in = in; L.action = action; L.num_actions = A > 0 ? A : 1;
+    L.in_ptrs = in_ptrs; L.in = in; L.in_base = in_base; L.action = action; L.num_actions = A > 0 ? A : 1;
     L.cin_real = Lr.cin_real; L.cin = Lr.cin; L.ih = ih; L.iw = iw; L.stride = Lr.stride;
     L.oh = (ih + 2 - 3) / Lr.stride + 1; L.ow = (iw + 2 - 3) / Lr.stride + 1;
     L.cout = Lr.cout; L.w = Lr.w; L.bias = Lr.b; L.residual = residual; L.out = out; L.relu = relu ? 1 : 0; L.B = B;
-    int npt;
-    pick_tile(L.oh, L.ow, &L.th, &L.tw, &npt);
+    // images of one workgroup share a buffer descriptor: their rows must lie within 32-bit byte offsets of the store base
+    const bool group_ok = !in_ptrs || (in_base && in_span_floats < ((size_t)1 << 30));
+    const ConvGeom g = conv_geometry(B, L.oh, L.ow, Lr.stride, Lr.cout, group_ok);
+    L.th = g.th; L.tw = g.tw; L.G = g.G; L.cstride = g.cstride;
     L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
-    const int sih = (L.th - 1) * L.stride + 3, siw = (L.tw - 1) * L.stride + 3;
-    const size_t lds = (size_t)16 * sih * siw * sizeof(float);
-    const dim3 grid(L.tiles_x * L.tiles_y, B, (Lr.cout + 127) / 128), block(256);
-    switch (npt) {
-        case 1: hipLaunchKernelGGL(k_conv3x3<1>, grid, block, lds, st, L); break;
-        case 2: hipLaunchKernelGGL(k_conv3x3<2>, grid, block, lds, st, L); break;
-        case 3: hipLaunchKernelGGL(k_conv3x3<3>, grid, block, lds, st, L); break;
-        case 4: hipLaunchKernelGGL(k_conv3x3<4>, grid, block, lds, st, L); break;
-        case 6: hipLaunchKernelGGL(k_conv3x3<6>, grid, block, lds, st, L); break;
-        default: hipLaunchKernelGGL(k_conv3x3<15>, grid, block, lds, st, L); break;
-    }
+    const size_t lds = (size_t)2 * g.cstride * sizeof(float);
+    const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));
+    if (g.nct == 2) conv_launch_npt<2>(g.npt, grid, lds, st, L);
+    else conv_launch_npt<1>(g.npt, grid, lds, st, L);
 }
 
 // residual tower in place on x (dense), t1/t2 scratch; returns the buffer holding the result
@@ -305,9 +354,10 @@ inline void convnet_initial(hipStream_t st, ConvNetDev& n, int B, const float* o
 // network.py:86-111: hidden rows src_ptrs[b] + action[b] -> normalised next hidden rows, reward [B], value [B], policy
 // probabilities (optional: dead compute inside the reference search, mcts.py:386 expands with the root prior)
 inline void convnet_recurrent(hipStream_t st, ConvNetDev& n, int B, const float* const* src_ptrs, const float* src_dense, const int* action,
-                              float* const* dst_ptrs, float* dst_dense, float* reward, float* value, float* pi) {
+                              float* const* dst_ptrs, float* dst_dense, float* reward, float* value, float* pi, const float* store_base = nullptr,
+                              size_t store_floats = 0) {
     const int h = n.hh, w = n.hw, hw = h * w;
-    conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true);
+    conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true, store_base, store_floats);
     float* x = tower_run(st, n.dyn_res, 0, n.R, B, n.bufA, n.bufB, n.bufC, h, w);
     head_run(st, n.reward, B, x, nullptr, hw, 0, reward, nullptr);  // the reward head reads the un-normalised state (:447-448)
     convnet_tail(st, n, B, x, dst_ptrs, dst_dense, pi, value);

@@ -595,7 +595,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
                 G.reward = p->d_srewards + sim; G.value = p->d_svalues + sim; G.rv_stride = c.num_simulations;
             } else {
                 convnet_recurrent(p->stream, p->cnet, batch, p->d_srcptrs, nullptr, p->d_sim_action, p->d_dstptrs, nullptr, p->d_sim_reward,
-                                  p->d_sim_value, nullptr);
+                                  p->d_sim_value, nullptr, p->d_hidden, (size_t)c.num_envs * (c.num_simulations + 1) * (size_t)c.hidden_dim);
                 G.reward = p->d_sim_reward; G.value = p->d_sim_value; G.rv_stride = 1;
             }
             hipLaunchKernelGGL(k_gtree_backup, grid, block, 0, p->stream, G);
