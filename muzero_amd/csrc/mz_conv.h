@@ -2,9 +2,9 @@
 //
 // k_conv3x3<NPT, NCT>: 3x3 convolution (stride 1 or 2, pad 1) with eval-mode BatchNorm folded into weight/bias, optional
 // residual add and ReLU (ResNetBlock network.py:293-299), as an implicit GEMM on v_mfma_f32_16x16x4_f32:
-//     D[co][pixel] = bias[co] + sum_k W[co][k] * X[k][pixel],   k = (16-channel block, tap (ky,kx), channel in block)
-// A operand = 16 output channels x 4 k of the weights (pre-packed fragment order, a linear stream per wave out of L2),
-// B operand = 4 channels x 16 output pixels read from an LDS-staged input slab (tile-with-halo x 16 channels, one
+//     D[pixel][co] = bias[co] + sum_k X[pixel][k] * W[co][k],   k = (16-channel block, tap (ky,kx), channel in block)
+// B operand = 4 k x 16 output channels of the weights (pre-packed fragment order, a linear stream per wave out of L2),
+// A operand = 16 output pixels x 4 channels read from an LDS-staged input slab (tile-with-halo x 16 channels, one
 // 16-byte read per lane and tap).  The k
 // order is ONE fmaf chain per output in exactly the oracle's order, so results equal the oracle bit for bit; zero padding
 // contributes fma(w, 0, acc) == acc.
@@ -42,12 +42,27 @@ struct ConvLaunch {
     int G;                        // images per workgroup (> 1 only when one tile covers the whole image)
     int cstride;                  // LDS floats per slab buffer (>= G * sih * siw * CONV_PS)
     int B;
+    long long* stamps;            // diagnostic builds (-DMZC_STAMPS) only
 };
 
 constexpr int CONV_RK = 2;    // slab positions per thread: G * sih * siw <= 384
 constexpr int CONV_PS = 20;   // LDS floats per slab position: 16 channels + 4 pad (80 B: 16-byte reads and writes spread over the banks)
 
 typedef unsigned int conv_u32x4 __attribute__((ext_vector_type(4)));
+
+// floor(p / d) for 0 <= p < 4096 via a float reciprocal (index arithmetic only): (p + 0.5) / d is at least 0.5 / d away from
+// an integer, far more than float rounding, so the truncation is exact
+__device__ __forceinline__ int conv_idiv(int p, float rcp_d) { return (int)(((float)p + 0.5f) * rcp_d); }
+
+#ifdef MZC_STAMPS  // per-phase cycle sums of wave 0 of workgroup (0,0,0): [0] prologue [1] fetch issue + first B reads [2] tap loop [3] store [4] barrier [5] epilogue
+#define MZC_T_DECL long long _ct0 = __builtin_readcyclecounter(), _cacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MZC_T(i) do { const long long _t = __builtin_readcyclecounter(); _cacc[i] += _t - _ct0; _ct0 = _t; } while (0)
+#define MZC_T_FLUSH(L) do { if (L.stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) for (int _i = 0; _i < 8; _i++) L.stamps[_i] = _cacc[_i]; } while (0)
+#else
+#define MZC_T_DECL
+#define MZC_T(i) do {} while (0)
+#define MZC_T_FLUSH(L) do {} while (0)
+#endif
 
 #ifdef MZC_NO_XS  // diagnostic variants (tools/micro/conv_bench.hip), never defined in the product build
 #define MZC_XS_READ 0
@@ -60,7 +75,8 @@ typedef unsigned int conv_u32x4 __attribute__((ext_vector_type(4)));
 // pointers hipcc keeps one 64-bit VGPR address per unrolled load alive across the loop (or emits flat loads that also
 // tick lgkmcnt and serialise against the LDS reads).
 template <int NPT, int NCT>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
+__global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const ConvLaunch L) {
+    MZC_T_DECL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // slab[2][positions][CONV_PS]: position r = g * plane + sy * siw + sx holds its 16 channels permuted so that the float4
     // at r * CONV_PS + 4q is {ch q, ch 4+q, ch 8+q, ch 12+q}: the B operands of the four k-steps of lane group q
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
     const int img0 = blockIdx.y * L.G, TP = L.th * L.tw, ihw = L.ih * L.iw;
     const int co_tiles = (L.cout + 15) >> 4, n_cb = (L.cin + 15) >> 4, bufsz = L.cstride;  // floats per slab buffer
     const int iy0 = ty0 * L.stride - 1, ix0 = tx0 * L.stride - 1;
+    const float r_plane = 1.0f / (float)plane, r_siw = 1.0f / (float)siw, r_tp = 1.0f / (float)TP, r_tw = 1.0f / (float)L.tw;
 
     // ---- staging plan (hoisted): positions r = tid, tid + 256; out-of-image positions read a clamped address and are zeroed ----
     const int img0c = img0 < L.B ? img0 : L.B - 1;
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
         const int r = tid + 256 * k;
         swrite[k] = r < L.G * plane;
         const int rc = swrite[k] ? r : 0;
-        const int g = rc / plane, rr = rc - g * plane, sy = rr / siw, sx = rr - sy * siw;
+        const int g = conv_idiv(rc, r_plane), rr = rc - g * plane, sy = conv_idiv(rr, r_siw), sx = rr - sy * siw;
         const int gy = iy0 + sy, gx = ix0 + sx, bimg = img0 + g;
         sval[k] = swrite[k] && bimg < L.B && gy >= 0 && gy < L.ih && gx >= 0 && gx < L.iw;
         const int cy = gy < 0 ? 0 : (gy >= L.ih ? L.ih - 1 : gy), cx = gx < 0 ? 0 : (gx >= L.iw ? L.iw - 1 : gx);
@@ -94,21 +111,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
         if (!L.in_ptrs) o += (size_t)cimg * L.cin_real * ihw;
         else if (L.G != 1) o += (size_t)(L.in_ptrs[cimg] - L.in_base);
         voff[k] = (unsigned)(o * sizeof(float));
-        am[k] = (cy * L.iw + cx) % L.num_actions;  // flat index of the first action channel at this pixel, mod A
+        am[k] = L.cin > L.cin_real ? (cy * L.iw + cx) % L.num_actions : 0;  // flat index of the first action channel at this pixel, mod A
         sact[k] = (sval[k] && L.action) ? L.action[cimg] : -1;
     }
     float sv[CONV_RK][16];
-    auto fetch = [&](int cb) {  // global -> registers for channel block cb (action planes generated)
+    // global -> registers for channel block cb.  A block of 16 real channels is a straight run of 16 * CONV_RK independent
+    // buffer loads (per-channel branches make hipcc wait for every load before the next); inside the main loop those loads
+    // are issued a few per tap between the MFMAs (fetch_part), because the memory pipeline accepts them slowly and a wave
+    // that issues all of them at once leaves its MFMA pipe idle meanwhile.  Blocks holding action planes / padding channels
+    // take the generic path.
+    auto fetch_part = [&](int cb, int c_lo, int c_hi) {  // channels [c_lo, c_hi) of block cb, clamped to a valid channel
+#ifndef MZC_NO_FETCH
+#pragma unroll
+        for (int c = c_lo; c < c_hi; c++) {
+            const int ch = cb * 16 + c, chc = ch < L.cin_real ? ch : 0;  // workgroup-uniform
+#pragma unroll
+            for (int k = 0; k < CONV_RK; k++)  // raw value from the clamped address; out-of-image positions are zeroed in store()
+                sv[k][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[k], chc * ihw * (int)sizeof(float), 0));
+        }
+#endif
+    };
+    auto pure_real = [&](int cb) { return cb * 16 + 16 <= L.cin_real; };
+    auto fetch_generic = [&](int cb) {  // blocks with action planes (network.py:440-444) and / or the zero channels padding cin to 16
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            const int ch = cb * 16 + c;  // workgroup-uniform
+            const int ch = cb * 16 + c;
 #pragma unroll
             for (int k = 0; k < CONV_RK; k++) {
                 float v = 0.0f;
-#ifdef MZC_NO_FETCH
-                if (false) {
-#else
-                if (ch < L.cin_real) {  // raw value from the clamped address; out-of-image positions are zeroed in store()
+                if (ch < L.cin_real) {
+#ifndef MZC_NO_FETCH
                     v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[k], ch * ihw * (int)sizeof(float), 0));
 #endif
                 } else if (ch < L.cin) {
@@ -134,16 +166,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
             }
     };
 
-    // ---- this lane's output pixels: slot p = pt*16 + j -> image g of the group, (py, px) inside the tile ----
+    // ---- A-operand rows of this lane: pixel slot p = pt*16 + j -> image g of the group, (py, px) inside the tile ----
     int off[NPT];   // float offset of the lane's float4 for tap (0,0)
-    bool pv[NPT];
 #pragma unroll
     for (int pt = 0; pt < NPT; pt++) {
-        const int p = pt * 16 + j, g = p / TP, pp = p - g * TP, py = pp / L.tw, px = pp - py * L.tw;
-        pv[pt] = (g < L.G) && (img0 + g < L.B) && (ty0 + py < L.oh) && (tx0 + px < L.ow);
+        const int p = pt * 16 + j, g = conv_idiv(p, r_tp), pp = p - g * TP, py = conv_idiv(pp, r_tw), px = pp - py * L.tw;
         off[pt] = (g < L.G ? g * plane + (py * L.stride) * siw + px * L.stride : 0) * CONV_PS + q * 4;
     }
-    // ---- accumulators start at the bias; the weight stream of channel tile c is linear in (cb, tap): 1 KiB per step ----
+    // ---- accumulators D[pixel slot 4q + r][channel j] start at the bias; the weight stream of channel tile c is linear in
+    // (cb, tap): 1 KiB per step ----
     f32x4 acc[NCT][NPT];
     int cot[NCT], wbase[NCT];
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.w), 0, -1, 0x00020000);
@@ -151,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
     for (int c = 0; c < NCT; c++) {
         cot[c] = blockIdx.z * 4 * NCT + wave + 4 * c;
         const int ct = cot[c] < co_tiles ? cot[c] : co_tiles - 1;  // out-of-range tiles compute a duplicate that is never stored
-        const float4 bv = *reinterpret_cast<const float4*>(L.bias + ct * 16 + q * 4);
+        const float bv = L.bias[ct * 16 + j];
 #pragma unroll
-        for (int pt = 0; pt < NPT; pt++) acc[c][pt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        for (int pt = 0; pt < NPT; pt++) acc[c][pt] = f32x4{bv, bv, bv, bv};
         wbase[c] = ct * n_cb * 9 * 1024;  // bytes; wave-uniform
     }
     const int n_steps = n_cb * 9;  // weight steps (cb, tap)
@@ -162,82 +193,150 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvLaunch L) {
         const conv_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, wbase[c] + sc * 1024, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
-    float4 wr[3][NCT];  // ring: step s lives in wr[s % 3]
+    // weight ring: step s lives in wr[s % WD], WD - 1 steps ahead of its use.  An L2 hit takes ~1 us: short taps (few pixel
+    // tiles) need the deep ring; 9 % WD == 0 keeps the ring index static under the unrolled tap loop
+    constexpr int WD = (NPT * NCT <= 9) ? 9 : 3;
+    float4 wr[WD][NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) {
-        wr[0][c] = wload(c, 0);
-        wr[1][c] = wload(c, 1);
+#pragma unroll
+        for (int s0 = 0; s0 < WD - 1; s0++) wr[s0][c] = wload(c, s0);
     }
-    fetch(0);
+    if (pure_real(0)) fetch_part(0, 0, 16);
+    else fetch_generic(0);
     store(0, 0);
     __syncthreads();
+    MZC_T(0);
     // B operands run two pixel tiles ahead of the MFMAs in a 3-slot ring; step n = tap * NPT + pt lives in xr[n % 3]
     float4 xr[3];
+    constexpr int FL = 2 * CONV_RK;                 // staging loads per tap (2 channels), taps 0..7
+    constexpr int FS = FL < NPT ? FL : NPT;         // of which this many go one per pixel tile, the rest in front
     for (int cb = 0; cb < n_cb; cb++) {
         const float* sb = slab + (cb & 1) * bufsz;
-        if (cb + 1 < n_cb) fetch(cb + 1);
         xr[0] = *reinterpret_cast<const float4*>(sb + off[0]);
         xr[1] = *reinterpret_cast<const float4*>(sb + (NPT > 1 ? off[NPT > 1 ? 1 : 0] : off[0] + CONV_PS));
         __builtin_amdgcn_sched_barrier(0);
+        MZC_T(1);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
-            for (int c = 0; c < NCT; c++) wr[(tap + 2) % 3][c] = wload(c, cb * 9 + tap + 2);  // weights two steps ahead
+            for (int c = 0; c < NCT; c++) wr[(tap + WD - 1) % WD][c] = wload(c, cb * 9 + tap + WD - 1);  // weights WD - 1 steps ahead
+            if (tap < 8) fetch_part(cb + 1 < n_cb ? cb + 1 : cb, 2 * tap, 2 * tap + 2);  // next block's slab, 2 channels per tap
 #pragma unroll
             for (int pt = 0; pt < NPT; pt++) {
                 const int n = tap * NPT + pt, n2 = n + 2;
-                if (MZC_XS_READ && n2 < 9 * NPT) {  // B operand two steps ahead
+                if (MZC_XS_READ && n2 < 9 * NPT) {  // A operand two steps ahead
                     const int tap2 = n2 / NPT, pt2 = n2 - tap2 * NPT;
                     xr[n2 % 3] = *reinterpret_cast<const float4*>(sb + off[pt2] + ((tap2 / 3) * siw + (tap2 % 3)) * CONV_PS);
                 }
                 const float4 x4 = xr[MZC_XS_READ ? n % 3 : 0];
 #pragma unroll
                 for (int c = 0; c < NCT; c++) {
-                    const float4 w4 = wr[tap % 3][c];
-                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x4.x, acc[c][pt], 0, 0, 0);
-                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x4.y, acc[c][pt], 0, 0, 0);
-                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x4.z, acc[c][pt], 0, 0, 0);
-                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x4.w, acc[c][pt], 0, 0, 0);
+                    const float4 w4 = wr[tap % WD][c];
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x, w4.x, acc[c][pt], 0, 0, 0);
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y, w4.y, acc[c][pt], 0, 0, 0);
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.z, w4.z, acc[c][pt], 0, 0, 0);
+                    acc[c][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.w, w4.w, acc[c][pt], 0, 0, 0);
                 }
             }
-            // schedule: the weight loads first, then one LDS read per pixel tile's MFMAs
+            // schedule: the weight loads (and staging loads that have no pixel tile to hide behind) first, then per pixel tile
+            // one LDS read, one staging load, its MFMAs
+#ifdef MZC_NO_FETCH
             __builtin_amdgcn_sched_group_barrier(0x020, NCT, 0);
+#else
+            __builtin_amdgcn_sched_group_barrier(0x020, NCT + FL - FS, 0);  // (tap 8 has no staging loads: the group just comes up short)
+#endif
 #pragma unroll
             for (int pt = 0; pt < NPT; pt++) {
                 if (MZC_XS_READ && tap * NPT + pt + 2 < 9 * NPT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#ifndef MZC_NO_FETCH
+                if (tap < 8 && pt < FS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (cb + 1 < n_cb && !pure_real(cb + 1)) fetch_generic(cb + 1);
+        MZC_T(2);
 #ifndef MZC_NO_STORE
         if (cb + 1 < n_cb) store((cb + 1) & 1, cb + 1);
 #endif
+        MZC_T(3);
         __syncthreads();
+        MZC_T(4);
     }
-    // ---- epilogue: D row 4q + r = output channel inside the tile, column j = pixel slot ----
+    // ---- epilogue: lane (q, j) holds pixel slots pt*16 + 4q + r (r = 0..3) of output channel 16*tile + j.  Slots that are
+    // four consecutive pixels of one image row go out as one 16-byte buffer store (residual: one 16-byte load), others one
+    // by one; residual values are fetched EC pixel tiles at a time ----
+    const int ohw = L.oh * L.ow;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(L.out, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.residual ? L.residual : L.out), 0, -1, 0x00020000);
+    constexpr int EC = NPT < 4 ? NPT : 4;
 #pragma unroll
     for (int c = 0; c < NCT; c++) {
-        if (cot[c] >= co_tiles) continue;
+        if (cot[c] >= co_tiles) continue;  // wave-uniform
+        const int co = cot[c] * 16 + j;
+        const bool co_ok = co < L.cout;
+        const unsigned soff = (unsigned)((size_t)img0 * L.cout * ohw * sizeof(float));
 #pragma unroll
-        for (int pt = 0; pt < NPT; pt++) {
-            if (!pv[pt]) continue;
-            const int p = pt * 16 + j, g = p / TP, pp = p - g * TP, py = pp / L.tw, px = pp - py * L.tw;
+        for (int p0 = 0; p0 < NPT; p0 += EC) {
+            unsigned vo[EC][4];
+            bool ok[EC][4], vec[EC];
+            f32x4 rv[EC];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int co = cot[c] * 16 + q * 4 + r;
-                if (co < L.cout) {
-                    const size_t o = (((size_t)(img0 + g) * L.cout + co) * L.oh + ty0 + py) * L.ow + tx0 + px;
-                    float v = acc[c][pt][r];
-#ifdef MZC_NO_EPI
-                    if (v != 123.456f) continue;
+            for (int e = 0; e < EC; e++) {
+                const int pt = p0 + e < NPT ? p0 + e : NPT - 1;
+                const int p = pt * 16 + 4 * q;
+                int g = conv_idiv(p, r_tp), pp = p - g * TP, py = conv_idiv(pp, r_tw), px = pp - py * L.tw;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    ok[e][r] = co_ok && (p0 + e < NPT) && (g < L.G) && (img0 + g < L.B) && (ty0 + py < L.oh) && (tx0 + px < L.ow);
+                    vo[e][r] = (unsigned)((g * L.cout + co) * ohw + (ty0 + py) * L.ow + tx0 + px) * (unsigned)sizeof(float);
+                    px++;
+                    if (px == L.tw) { px = 0; py++; }
+                    if (py == L.th) { py = 0; g++; }
+                }
+                vec[e] = ok[e][0] && ok[e][1] && ok[e][2] && ok[e][3] && vo[e][1] == vo[e][0] + 4 && vo[e][2] == vo[e][0] + 8 && vo[e][3] == vo[e][0] + 12;
+                rv[e] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef MZC_NO_EPI
+                if (L.residual) {
+                    if (vec[e]) {
+                        const conv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, vo[e][0], soff, 0);
+                        rv[e] = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (ok[e][r]) rv[e][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, vo[e][r], soff, 0));
+                    }
+                }
 #endif
-                    if (L.residual) v = v + L.residual[o];
-                    if (L.relu && !(v > 0.0f)) v = 0.0f;
-                    L.out[o] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < EC; e++) {
+                if (p0 + e >= NPT) continue;
+                f32x4 v = acc[c][p0 + e];
+#ifdef MZC_NO_EPI
+                if (v[0] != 123.456f) continue;
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float t = v[r] + rv[e][r];  // (+ 0 without a residual: exact; -0 + 0 = +0 is clamped the same way)
+                    if (L.relu && !(t > 0.0f)) t = 0.0f;
+                    v[r] = t;
+                }
+                if (vec[e]) {
+                    __builtin_amdgcn_raw_buffer_store_b128(conv_u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                           rs_out, vo[e][0], soff, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (ok[e][r]) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_out, vo[e][r], soff, 0);
                 }
             }
         }
     }
+    MZC_T(5);
+    MZC_T_FLUSH(L);
 }
 
 // nn.AvgPool2d(3, 2, 1), count_include_pad (network.py:337,342): taps summed row-major, then / 9

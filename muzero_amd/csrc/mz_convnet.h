@@ -262,6 +262,8 @@ inline void conv_launch_npt(int npt, dim3 grid, size_t lds, hipStream_t st, cons
     }
 }
 
+static long long* g_conv_stamps = nullptr;  // diagnostic builds only (tools/micro/conv_bench.hip)
+
 // one 3x3 conv launch; input either dense `in` or per-image `in_ptrs`
 // (gathered input: in_base / in_span_floats describe the store the row pointers point into)
 inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float* in, const float* const* in_ptrs, const int* action, int A, int ih,
@@ -274,7 +276,7 @@ inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     // images of one workgroup share a buffer descriptor: their rows must lie within 32-bit byte offsets of the store base
     const bool group_ok = !in_ptrs || (in_base && in_span_floats < ((size_t)1 << 30));
     const ConvGeom g = conv_geometry(B, L.oh, L.ow, Lr.stride, Lr.cout, group_ok);
-    L.th = g.th; L.tw = g.tw; L.G = g.G; L.cstride = g.cstride;
+    L.th = g.th; L.tw = g.tw; L.G = g.G; L.cstride = g.cstride; L.stamps = g_conv_stamps;
     L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
     const size_t lds = (size_t)2 * g.cstride * sizeof(float);
     const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));

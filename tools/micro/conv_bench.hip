@@ -43,6 +43,22 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / reps, flop = 2.0 * B * C * (double)cin * 9 * H * W;
     const ConvGeom g = conv_geometry(B, H, W, 1, C);
+#ifdef MZC_STAMPS
+    {
+        long long* d_st;
+        CK(hipMalloc(&d_st, 64));
+        CK(hipMemset(d_st, 0, 64));
+        g_conv_stamps = d_st;
+        conv_run(st, L, B, d_in, nullptr, nullptr, 0, H, W, residual ? d_res : nullptr, d_out, true);
+        CK(hipStreamSynchronize(st));
+        long long h[8];
+        CK(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
+        long long tot = 0;
+        for (int i = 0; i < 6; i++) tot += h[i];
+        printf("  stamps (cycles, wave 0 of WG 0): prologue %lld | per cb: fetch-issue+first-B %lld, taps %lld, store %lld, barrier %lld | epilogue %lld | total %lld\n", h[0],
+               h[1] / n_cb, h[2] / n_cb, h[3] / n_cb, h[4] / n_cb, h[5], tot);
+    }
+#endif
     printf("B=%d C=%d cin=%d %dx%d G=%d npt=%d nct=%d res=%d : %8.1f us  %6.1f TFLOP/s  (%.1f%% of 157.3)\n", B, C, cin, H, W, g.G, g.npt, g.nct, residual, us,
            flop / us / 1e6, 100.0 * flop / us / 1e6 / 157.3);
     return 0;
