@@ -74,7 +74,7 @@ __device__ __forceinline__ int conv_idiv(int p, float rcp_d) { return (int)(((fl
 // per-lane byte offset (ONE VGPR, loop-invariant) + uniform byte offset (SGPR: channel or weight step).  With plain
 // pointers hipcc keeps one 64-bit VGPR address per unrolled load alive across the loop (or emits flat loads that also
 // tick lgkmcnt and serialise against the LDS reads).
-template <int NPT, int NCT>
+template <int NPT, int NCT, bool WHOLE>
 __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const ConvLaunch L) {
     MZC_T_DECL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -89,10 +89,69 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
     const int iy0 = ty0 * L.stride - 1, ix0 = tx0 * L.stride - 1;
     const float r_plane = 1.0f / (float)plane, r_siw = 1.0f / (float)siw, r_tp = 1.0f / (float)TP, r_tw = 1.0f / (float)L.tw;
 
-    // ---- staging plan (hoisted): positions r = tid, tid + 256; out-of-image positions read a clamped address and are zeroed ----
     const int img0c = img0 < L.B ? img0 : L.B - 1;
     const float* ibase = L.in_ptrs ? (L.G == 1 ? L.in_ptrs[img0c] : L.in_base) : L.in;  // workgroup-uniform
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ibase), 0, -1, 0x00020000);
+    auto pure_real = [&](int cb) { return cb * 16 + 16 <= L.cin_real; };
+    // ---- staging plan, tile == whole image (stride 1): a channel of an image is hw contiguous floats.  Lane t of every wave
+    // owns pixel quad t of the group (4 consecutive pixels, one 16-byte load per channel); wave w owns the channels
+    // {w, 4+w, 8+w, 12+w} of each 16-channel block, i.e. exactly the float4 at slot 4w of each slab position: per block and
+    // thread 4 loads and 4 16-byte LDS writes.  The halo is zeroed once; it is never written again. ----
+    const int QP = (ihw + 3) >> 2;  // quads per image; the host guarantees G * QP <= 64
+    unsigned w_voff = 0;
+    int w_spos[4], w_pm[4], w_act = -1;
+    bool w_ok = false;
+    f32x4 w_sv[4];  // [i]: channel 4i + wave of the block, pixels p0 .. p0+3
+    if constexpr (WHOLE) {
+        const float r_qp = 1.0f / (float)QP, r_iw = 1.0f / (float)L.iw;
+        const int g = conv_idiv(lane, r_qp), qd = lane - g * QP, p0 = qd * 4, bimg = img0 + g;
+        w_ok = lane < L.G * QP && bimg < L.B;
+        const int cimg = bimg < L.B ? bimg : L.B - 1;
+        size_t o = (size_t)(w_ok ? p0 : 0);
+        if (!L.in_ptrs) o += (size_t)cimg * L.cin_real * ihw;
+        else if (L.G != 1) o += (size_t)(L.in_ptrs[cimg] - L.in_base);
+        w_voff = (unsigned)(o * sizeof(float));
+        w_act = (w_ok && L.action) ? L.action[cimg] : -1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int pp = p0 + e, py = conv_idiv(pp, r_iw), px = pp - py * L.iw;
+            w_spos[e] = (w_ok && pp < ihw) ? ((g < L.G ? g : 0) * plane + (py + 1) * siw + px + 1) * CONV_PS + 4 * wave : -1;
+            w_pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
+        }
+        for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers
+        __syncthreads();
+    }
+    auto wfetch_real = [&](int cb, int i) {  // channel 4i + wave of block cb, clamped to a valid channel (branch-free)
+#ifndef MZC_NO_FETCH
+        const int ch = cb * 16 + 4 * i + wave, chc = ch < L.cin_real ? ch : 0;
+        const conv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_in, w_voff, chc * ihw * (int)sizeof(float), 0);
+        w_sv[i] = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+#else
+        w_sv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+    };
+    auto wfix_generic = [&](int cb) {  // overwrite the lanes of action-plane (network.py:440-444) and padding channels of block cb
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ch = cb * 16 + 4 * i + wave;  // wave-uniform
+            if (ch >= L.cin_real) {
+                const int t = ch < L.cin ? (int)(((long long)(ch - L.cin_real) * ihw) % L.num_actions) : 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    int m = w_pm[e] + t;
+                    m = m >= L.num_actions ? m - L.num_actions : m;
+                    w_sv[i][e] = (ch < L.cin && m == w_act) ? 1.0f : 0.0f;
+                }
+            }
+        }
+    };
+    auto wstore = [&](int buf) {
+        float* d = slab + buf * bufsz;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (w_spos[e] >= 0) *reinterpret_cast<float4*>(d + w_spos[e]) = make_float4(w_sv[0][e], w_sv[1][e], w_sv[2][e], w_sv[3][e]);
+    };
+    // ---- staging plan, tiled images (any stride): positions r = tid, tid + 256; out-of-image positions read a clamped address and are zeroed ----
     unsigned voff[CONV_RK];
     int am[CONV_RK], sact[CONV_RK];
     bool swrite[CONV_RK], sval[CONV_RK];
@@ -100,7 +159,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
 #pragma unroll
     for (int k = 0; k < CONV_RK; k++) {
         const int r = tid + 256 * k;
-        swrite[k] = r < L.G * plane;
+        swrite[k] = !WHOLE && r < L.G * plane;
         const int rc = swrite[k] ? r : 0;
         const int g = conv_idiv(rc, r_plane), rr = rc - g * plane, sy = conv_idiv(rr, r_siw), sx = rr - sy * siw;
         const int gy = iy0 + sy, gx = ix0 + sx, bimg = img0 + g;
@@ -131,7 +190,6 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
         }
 #endif
     };
-    auto pure_real = [&](int cb) { return cb * 16 + 16 <= L.cin_real; };
     auto fetch_generic = [&](int cb) {  // blocks with action planes (network.py:440-444) and / or the zero channels padding cin to 16
 #pragma unroll
         for (int c = 0; c < 16; c++) {
@@ -202,14 +260,22 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
 #pragma unroll
         for (int s0 = 0; s0 < WD - 1; s0++) wr[s0][c] = wload(c, s0);
     }
-    if (pure_real(0)) fetch_part(0, 0, 16);
-    else fetch_generic(0);
-    store(0, 0);
+    if constexpr (WHOLE) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) wfetch_real(0, i);
+        if (!pure_real(0)) wfix_generic(0);
+        wstore(0);
+    } else {
+        if (pure_real(0)) fetch_part(0, 0, 16);
+        else fetch_generic(0);
+        store(0, 0);
+    }
     __syncthreads();
     MZC_T(0);
     // B operands run two pixel tiles ahead of the MFMAs in a 3-slot ring; step n = tap * NPT + pt lives in xr[n % 3]
     float4 xr[3];
-    constexpr int FL = 2 * CONV_RK;                 // staging loads per tap (2 channels), taps 0..7
+    constexpr int FL = WHOLE ? 1 : 2 * CONV_RK;     // staging loads per tap: whole images 1 (taps 0..3), tiled 2 channels (taps 0..7)
+    constexpr int FT = WHOLE ? 4 : 8;               // taps that carry staging loads
     constexpr int FS = FL < NPT ? FL : NPT;         // of which this many go one per pixel tile, the rest in front
     for (int cb = 0; cb < n_cb; cb++) {
         const float* sb = slab + (cb & 1) * bufsz;
@@ -221,7 +287,11 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
         for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
             for (int c = 0; c < NCT; c++) wr[(tap + WD - 1) % WD][c] = wload(c, cb * 9 + tap + WD - 1);  // weights WD - 1 steps ahead
-            if (tap < 8) fetch_part(cb + 1 < n_cb ? cb + 1 : cb, 2 * tap, 2 * tap + 2);  // next block's slab, 2 channels per tap
+            if constexpr (WHOLE) {
+                if (tap < 4) wfetch_real(cb + 1 < n_cb ? cb + 1 : cb, tap);  // next block's slab, one channel per tap
+            } else {
+                if (tap < 8) fetch_part(cb + 1 < n_cb ? cb + 1 : cb, 2 * tap, 2 * tap + 2);  // next block's slab, 2 channels per tap
+            }
 #pragma unroll
             for (int pt = 0; pt < NPT; pt++) {
                 const int n = tap * NPT + pt, n2 = n + 2;
@@ -250,16 +320,22 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
             for (int pt = 0; pt < NPT; pt++) {
                 if (MZC_XS_READ && tap * NPT + pt + 2 < 9 * NPT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #ifndef MZC_NO_FETCH
-                if (tap < 8 && pt < FS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (tap < FT && pt < FS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
 #endif
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCT, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (cb + 1 < n_cb && !pure_real(cb + 1)) fetch_generic(cb + 1);
+        if (cb + 1 < n_cb && !pure_real(cb + 1)) {
+            if constexpr (WHOLE) wfix_generic(cb + 1);
+            else fetch_generic(cb + 1);
+        }
         MZC_T(2);
 #ifndef MZC_NO_STORE
-        if (cb + 1 < n_cb) store((cb + 1) & 1, cb + 1);
+        if (cb + 1 < n_cb) {
+            if constexpr (WHOLE) wstore((cb + 1) & 1);
+            else store((cb + 1) & 1, cb + 1);
+        }
 #endif
         MZC_T(3);
         __syncthreads();

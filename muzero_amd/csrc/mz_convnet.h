@@ -193,7 +193,7 @@ inline hipError_t convnet_ensure_buffers(ConvNetDev& n, int B) {
     if (need <= n.buf_elems) return hipSuccess;
     for (float** p : {&n.bufA, &n.bufB, &n.bufC}) {
         if (*p) (void)hipFree(*p);
-        hipError_t e = hipMalloc(p, need * sizeof(float));
+        hipError_t e = hipMalloc(p, (need + 64) * sizeof(float));  // + slack: the last pixel quad of a channel is read as 16 bytes
         if (e != hipSuccess) return e;
     }
     n.buf_elems = need;
@@ -204,6 +204,7 @@ inline hipError_t convnet_ensure_buffers(ConvNetDev& n, int B) {
 // dimension fills whole 16-wide MFMA tiles), pixel tiles per wave (NPT) and channel tiles per wave (NCT).
 struct ConvGeom {
     int th, tw, G, npt, nct, cstride;
+    bool whole;  // tile == whole image, stride 1: quad-based staging (k_conv3x3<.., true>)
 };
 
 inline int env_int(const char* name, int dflt) {
@@ -219,7 +220,8 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
         return 0;
     };
     ConvGeom g{};
-    const bool whole = oh * ow <= 240 && ((oh - 1) * stride + 3) * ((ow - 1) * stride + 3) <= 384;
+    const bool whole = stride == 1 && oh * ow <= 240 && (oh + 2) * (ow + 2) <= 384;
+    const int QP = (oh * ow + 3) / 4;  // pixel quads per image: one lane each
     g.th = whole ? oh : 8; g.tw = whole ? ow : 8;
     const int plane = ((g.th - 1) * stride + 3) * ((g.tw - 1) * stride + 3), TP = g.th * g.tw;
     const int zs1 = (cout + 63) / 64;  // channel slices with NCT = 1
@@ -227,7 +229,7 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
     if (whole && allow_group) {
         // best MFMA fill among group sizes that keep at least ~2 workgroups per CU busy (when the batch allows it)
         double best = -1.0;
-        for (int G = 1; G <= 16 && G <= B && G * plane <= 384; G++) {
+        for (int G = 1; G <= 16 && G <= B && G * plane <= 384 && G * QP <= 64; G++) {
             const int npt = round_npt((G * TP + 15) / 16);
             if (!npt || (G > 1 && npt > 9)) continue;
             const long wgs = (long)((B + G - 1) / G) * zs1;
@@ -237,6 +239,7 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
         }
     }
     g.G = env_int("MZ_CONV_G", g.G);
+    g.whole = whole;
     g.npt = round_npt((g.G * TP + 15) / 16);
     const long tiles = (long)((oh + g.th - 1) / g.th) * ((ow + g.tw - 1) / g.tw);
     const long wgs1 = tiles * ((B + g.G - 1) / g.G) * zs1;
@@ -246,19 +249,25 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
     return g;
 }
 
-template <int NCT>
+template <int NCT, bool WHOLE>
 inline void conv_launch_npt(int npt, dim3 grid, size_t lds, hipStream_t st, const ConvLaunch& L) {
     const dim3 block(256);
     switch (npt) {
-        case 1: hipLaunchKernelGGL((k_conv3x3<1, NCT>), grid, block, lds, st, L); break;
-        case 2: hipLaunchKernelGGL((k_conv3x3<2, NCT>), grid, block, lds, st, L); break;
-        case 3: hipLaunchKernelGGL((k_conv3x3<3, NCT>), grid, block, lds, st, L); break;
-        case 4: hipLaunchKernelGGL((k_conv3x3<4, NCT>), grid, block, lds, st, L); break;
-        case 5: hipLaunchKernelGGL((k_conv3x3<5, NCT>), grid, block, lds, st, L); break;
-        case 6: hipLaunchKernelGGL((k_conv3x3<6, NCT>), grid, block, lds, st, L); break;
-        case 9: hipLaunchKernelGGL((k_conv3x3<9, NCT>), grid, block, lds, st, L); break;
-        case 12: hipLaunchKernelGGL((k_conv3x3<12, NCT>), grid, block, lds, st, L); break;
-        default: hipLaunchKernelGGL((k_conv3x3<15, NCT>), grid, block, lds, st, L); break;
+        case 1: hipLaunchKernelGGL((k_conv3x3<1, NCT, WHOLE>), grid, block, lds, st, L); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<2, NCT, WHOLE>), grid, block, lds, st, L); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<3, NCT, WHOLE>), grid, block, lds, st, L); break;
+        case 4: hipLaunchKernelGGL((k_conv3x3<4, NCT, WHOLE>), grid, block, lds, st, L); break;
+        default:
+            if constexpr (WHOLE) {
+                switch (npt) {
+                    case 5: hipLaunchKernelGGL((k_conv3x3<5, NCT, true>), grid, block, lds, st, L); break;
+                    case 6: hipLaunchKernelGGL((k_conv3x3<6, NCT, true>), grid, block, lds, st, L); break;
+                    case 9: hipLaunchKernelGGL((k_conv3x3<9, NCT, true>), grid, block, lds, st, L); break;
+                    case 12: hipLaunchKernelGGL((k_conv3x3<12, NCT, true>), grid, block, lds, st, L); break;
+                    default: hipLaunchKernelGGL((k_conv3x3<15, NCT, true>), grid, block, lds, st, L); break;
+                }
+            }
+            break;  // tiled images use 8x8 tiles: npt == 4
     }
 }
 
@@ -280,8 +289,13 @@ inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
     const size_t lds = (size_t)2 * g.cstride * sizeof(float);
     const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));
-    if (g.nct == 2) conv_launch_npt<2>(g.npt, grid, lds, st, L);
-    else conv_launch_npt<1>(g.npt, grid, lds, st, L);
+    if (g.whole) {
+        if (g.nct == 2) conv_launch_npt<2, true>(g.npt, grid, lds, st, L);
+        else conv_launch_npt<1, true>(g.npt, grid, lds, st, L);
+    } else {
+        if (g.nct == 2) conv_launch_npt<2, false>(g.npt, grid, lds, st, L);
+        else conv_launch_npt<1, false>(g.npt, grid, lds, st, L);
+    }
 }
 
 // residual tower in place on x (dense), t1/t2 scratch; returns the buffer holding the result

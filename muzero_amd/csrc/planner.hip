@@ -270,7 +270,7 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     const size_t B = (size_t)c.num_envs, A = (size_t)c.num_actions, S = (size_t)c.num_simulations;
     const int mt = c.max_ties > 0 ? c.max_ties : 4 * c.num_simulations + 8;
     p->cfg.max_ties = mt;
-    HIPCHK(hipMalloc(&p->d_obs, B * obs_dim(c) * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_obs, B * obs_dim(c) * sizeof(float) + 256));  // + slack: conv staging reads whole 16-byte pixel quads
     HIPCHK(hipMalloc(&p->d_mask, B * A));
     HIPCHK(hipMalloc(&p->d_cur, B * sizeof(int)));
     HIPCHK(hipMalloc(&p->d_opp, B * sizeof(int)));
@@ -278,7 +278,7 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     HIPCHK(hipMalloc(&p->d_noise, B * A * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_utie, B * (size_t)mt * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_ufinal, B * sizeof(double)));
-    HIPCHK(hipMalloc(&p->d_hidden, B * (S + 1) * (size_t)c.hidden_dim * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_hidden, B * (S + 1) * (size_t)c.hidden_dim * sizeof(float) + 256));
     HIPCHK(hipMalloc(&p->d_ftab, (S + 1) * (S + 1) * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_action, B * sizeof(int)));
     HIPCHK(hipMalloc(&p->d_pi, B * A * sizeof(double)));
@@ -465,7 +465,7 @@ static int ensure_infer_buffers(mz_planner* p, int batch) {
         if (b) (void)hipFree(b);
     const size_t B = (size_t)batch;
     const size_t in = (size_t)(obs_dim(p->cfg) > p->cfg.hidden_dim ? obs_dim(p->cfg) : p->cfg.hidden_dim);
-    HIPCHK(hipMalloc(&p->d_inf_in, B * in * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_inf_in, B * in * sizeof(float) + 256));
     HIPCHK(hipMalloc(&p->d_inf_hidden, B * p->cfg.hidden_dim * sizeof(float)));
     HIPCHK(hipMalloc(&p->d_inf_reward, B * sizeof(float)));
     HIPCHK(hipMalloc(&p->d_inf_value, B * sizeof(float)));
