@@ -432,34 +432,60 @@ __global__ void k_avgpool(const float* in, float* out, int B, int C, int ih, int
     }
 }
 
-// normalize_hidden_state for conv states (util.py:31-36): min/max over the channels of each pixel.
-// in dense [B][C][hw]; written to every non-null destination: out_ptrs[b] (node store rows), dense out_a, dense out_b.
-__global__ void k_normalize_planes(const float* in, float* const* out_ptrs, float* out_a, float* out_b, int B, int C, int hw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * hw) return;
-    const int b = i / hw, p = i - b * hw;
-    const float* s = in + (size_t)b * C * hw + p;
-    float mn = s[0], mx = s[0];
-    for (int c = 1; c < C; c++) {
-        const float v = s[(size_t)c * hw];
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
+// normalize_hidden_state for conv states (util.py:31-36): min/max over the channels of each pixel (exact, so any reduction
+// order gives the reference's result).  in dense [B][C][hw]; written to every non-null destination: out_ptrs[b] (node store
+// rows), dense out_a, dense out_b.  Workgroup = one image x 32 pixels; thread (pixel, channel group of 8): its C/8 channels
+// stay in registers between the min/max pass and the scaling pass; HBM traffic = one read + one write per destination.
+// CPT = channels per thread held in registers (C <= 8 * CPT)
+template <int CPT>
+__global__ __launch_bounds__(256) void k_normalize_planes(const float* in, float* const* out_ptrs, float* out_a, float* out_b, int B, int C, int hw) {
+    __shared__ float s_mn[8][32], s_mx[8][32];
+    const int b = blockIdx.y, px = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + px;
+    const bool ok = p < hw;
+    const int cpt = (C + 7) >> 3;  // channels per thread: cg * cpt .. +cpt
+    const float* s = in + (size_t)b * C * hw + (ok ? p : 0);
+    float v[CPT];
+    float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        if (i < cpt && c < C) {
+            v[i] = s[(size_t)c * hw];
+            mn = v[i] < mn ? v[i] : mn;
+            mx = v[i] > mx ? v[i] : mx;
+        }
     }
+    s_mn[cg][px] = mn; s_mx[cg][px] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        mn = s_mn[g][px] < mn ? s_mn[g][px] : mn;
+        mx = s_mx[g][px] > mx ? s_mx[g][px] : mx;
+    }
+    if (!ok) return;
     const float d = (mx - mn) + 1e-8f;
     float* o0 = out_ptrs ? out_ptrs[b] + p : nullptr;
     float* o1 = out_a ? out_a + (size_t)b * C * hw + p : nullptr;
     float* o2 = out_b ? out_b + (size_t)b * C * hw + p : nullptr;
-    for (int c = 0; c < C; c++) {
-        const float v = (s[(size_t)c * hw] - mn) / d;
-        if (o0) o0[(size_t)c * hw] = v;
-        if (o1) o1[(size_t)c * hw] = v;
-        if (o2) o2[(size_t)c * hw] = v;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        if (i < cpt && c < C) {
+            const float r = (v[i] - mn) / d;
+            if (o0) o0[(size_t)c * hw] = r;
+            if (o1) o1[(size_t)c * hw] = r;
+            if (o2) o2[(size_t)c * hw] = r;
+        }
     }
 }
 
 // Head (network.py:424-430, 472-486): 1x1 conv (C -> oc planes, BN folded) + ReLU + flatten + Linear(oc*hw -> n_out),
 // then for value/reward heads softmax-expectation-transform (util.py:70-93) or, for the policy head, softmax.
-// One workgroup of 256 threads per image; chains in the oracle's order.
+// One workgroup of 256 threads per image; every dot product is one fmaf chain in the oracle's order (channels ascending,
+// then features ascending).  The input is staged through LDS in chunks of HEAD_CK channels by all threads (coalesced,
+// independent loads) so that the chains run from LDS instead of paying a global-memory latency per channel.
+constexpr int HEAD_CK = 16;
+
 struct HeadLaunch {
     const float* in;       // dense [B][C][hw]
     const float* const* in_ptrs;  // or per-image pointers
@@ -478,21 +504,44 @@ __global__ __launch_bounds__(256) void k_head(const HeadLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* feat = reinterpret_cast<float*>(smem);     // [oc*hw]
     float* lg = feat + ((L.oc * L.hw + 3) & ~3);      // [n_out]
+    float* stage = lg + ((L.n_out + 3) & ~3);         // [HEAD_CK][hw]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = L.in_ptrs ? L.in_ptrs[b] : L.in + (size_t)b * L.C * L.hw;
-    for (int i = tid; i < L.oc * L.hw; i += 256) {
-        const int o = i / L.hw, p = i - o * L.hw;
-        float acc = L.cb[o];
-        for (int c = 0; c < L.C; c++) acc = fmaf(src[(size_t)c * L.hw + p], L.cw[o * L.C + c], acc);
-        feat[i] = acc > 0.0f ? acc : 0.0f;
+    const int nf = L.oc * L.hw;
+    // 1x1 conv: feature i = (plane o, pixel p); threads stride over features (at most 2 * 240 of them)
+    float acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tid + 256 * u;
+        acc[u] = i < nf ? L.cb[i / L.hw] : 0.0f;
+    }
+    for (int c0 = 0; c0 < L.C; c0 += HEAD_CK) {
+        const int nc = L.C - c0 < HEAD_CK ? L.C - c0 : HEAD_CK;
+        __syncthreads();
+        for (int i = tid; i < nc * L.hw; i += 256) stage[i] = src[(size_t)c0 * L.hw + i];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = tid + 256 * u;
+            if (i < nf) {
+                const int o = i / L.hw, p = i - o * L.hw;
+                const float* w = L.cw + o * L.C + c0;
+                for (int c = 0; c < nc; c++) acc[u] = fmaf(stage[c * L.hw + p], w[c], acc[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tid + 256 * u;
+        if (i < nf) feat[i] = acc[u] > 0.0f ? acc[u] : 0.0f;
     }
     __syncthreads();
-    const int K = L.oc * L.hw;
+    const int K = nf;
     for (int n = tid; n < L.n_out; n += 256) {
-        float acc = L.lb[n];
+        float a = L.lb[n];
         const float* w = L.lw + (size_t)n * K;
-        for (int k = 0; k < K; k++) acc = fmaf(feat[k], w[k], acc);
-        lg[n] = acc;
+        for (int k = 0; k < K; k++) a = fmaf(feat[k], w[k], a);
+        lg[n] = a;
     }
     __syncthreads();
     if (tid < 16) {  // one 16-lane row (DPP butterflies need the whole row active)

@@ -313,7 +313,7 @@ inline void head_run(hipStream_t st, const HeadDev& H, int B, const float* in, c
     HeadLaunch L{};
     L.in = in; L.in_ptrs = in_ptrs; L.C = H.C; L.hw = hw; L.oc = H.oc; L.n_out = H.n_out; L.cw = H.cw; L.cb = H.cb; L.lw = H.lw; L.lb = H.lb;
     L.mode = mode; L.out_scalar = out_scalar; L.out_probs = out_probs; L.B = B;
-    const size_t lds = (((size_t)H.oc * hw + 3) & ~(size_t)3) * 4 + (size_t)H.n_out * 4 + 16;
+    const size_t lds = ((((size_t)H.oc * hw + 3) & ~(size_t)3) + (((size_t)H.n_out + 3) & ~(size_t)3) + (size_t)HEAD_CK * hw) * sizeof(float);
     hipLaunchKernelGGL(k_head, dim3(B), dim3(256), lds, st, L);
 }
 
@@ -332,7 +332,15 @@ inline void convnet_tail(hipStream_t st, ConvNetDev& n, int B, float* x, float* 
     const int hw = n.hh * n.hw;
     float *nrm, *t2;
     other_two(n.bufA, n.bufB, n.bufC, x, &nrm, &t2);
-    hipLaunchKernelGGL(k_normalize_planes, dim3((B * hw + 255) / 256), dim3(256), 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+    {
+        const dim3 grid((hw + 31) / 32, B), block(256);
+        const int cpt = (n.P + 7) / 8;
+        if (cpt <= 2) hipLaunchKernelGGL(k_normalize_planes<2>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+        else if (cpt <= 8) hipLaunchKernelGGL(k_normalize_planes<8>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+        else if (cpt <= 16) hipLaunchKernelGGL(k_normalize_planes<16>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+        else if (cpt <= 32) hipLaunchKernelGGL(k_normalize_planes<32>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+        else hipLaunchKernelGGL(k_normalize_planes<64>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
+    }
     float* f = tower_run(st, n.pred_res, 0, n.R, B, nrm, x, t2, n.hh, n.hw);
     if (pi) head_run(st, n.policy, B, f, nullptr, hw, 1, nullptr, pi);
     head_run(st, n.value, B, f, nullptr, hw, 0, value, nullptr);

@@ -229,6 +229,7 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         if (cfg->net_kind == MZ_NET_ATARI && (cfg->obs_h != 96 || cfg->obs_w != 96))
             return fail(MZ_E_INVALID, "MuZeroAtariNet takes 96x96 frames (its hidden state is fixed at 6x6, network.py:515)");
         if (cfg->net_kind == MZ_NET_BOARD && cfg->obs_h * cfg->obs_w > 240) return fail(MZ_E_INVALID, "board larger than 240 points");
+        if (cfg->num_planes > 512) return fail(MZ_E_INVALID, "conv nets: num_planes must be <= 512");
     }
     if ((!conv && cfg->hidden_dim < 1) || cfg->num_planes < 1 || cfg->num_envs < 1) return fail(MZ_E_INVALID, "bad network/env dimensions");
     if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1023 || cfg->reward_support_size > 1023)
