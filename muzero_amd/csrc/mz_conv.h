@@ -40,13 +40,13 @@ struct ConvLaunch {
     int th, tw;                   // spatial tile of one image (G * th * tw <= NPT*16)
     int tiles_x, tiles_y;
     int G;                        // images per workgroup (> 1 only when one tile covers the whole image)
-    int cstride;                  // LDS floats per slab buffer (>= G * sih * siw * CONV_PS)
+    int cstride;                  // LDS floats per slab buffer = 4 * qstride
+    int qstride;                  // LDS floats per channel-slot plane (>= 4 * G * sih * siw, multiple of 64: see the slab layout)
     int B;
     long long* stamps;            // diagnostic builds (-DMZC_STAMPS) only
 };
 
 constexpr int CONV_RK = 2;    // slab positions per thread: G * sih * siw <= 384
-constexpr int CONV_PS = 20;   // LDS floats per slab position: 16 channels + 4 pad (80 B: 16-byte reads and writes spread over the banks)
 
 typedef unsigned int conv_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -78,8 +78,11 @@ template <int NPT, int NCT, bool WHOLE>
 __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const ConvLaunch L) {
     MZC_T_DECL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // slab[2][positions][CONV_PS]: position r = g * plane + sy * siw + sx holds its 16 channels permuted so that the float4
-    // at r * CONV_PS + 4q is {ch q, ch 4+q, ch 8+q, ch 12+q}: the B operands of the four k-steps of lane group q
+    // slab[2][4 slots][qstride]: position r = g * plane + sy * siw + sx keeps its 16 channels as four float4s, slot q at
+    // q * qstride + 4r = {ch q, ch 4+q, ch 8+q, ch 12+q}: the A operands of the four k-steps of lane group q.  The 16 lanes
+    // of a group read consecutive positions = 64 consecutive dwords, and qstride is a multiple of 64 dwords, which makes
+    // the 16-byte reads of ds_read_b128's mixed-q lane groups conflict-free (PMC: 65 % of LDS cycles were conflicts with a
+    // position-major [r][16 + 4] layout)
     float* slab = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
     const int tile = blockIdx.x, ty0 = (tile / L.tiles_x) * L.th, tx0 = (tile % L.tiles_x) * L.tw;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int pp = p0 + e, py = conv_idiv(pp, r_iw), px = pp - py * L.iw;
-            w_spos[e] = (w_ok && pp < ihw) ? ((g < L.G ? g : 0) * plane + (py + 1) * siw + px + 1) * CONV_PS + 4 * wave : -1;
+            w_spos[e] = (w_ok && pp < ihw) ? ((g < L.G ? g : 0) * plane + (py + 1) * siw + px + 1) * 4 + wave * L.qstride : -1;
             w_pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
         }
         for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers
@@ -218,9 +221,10 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
 #pragma unroll
                 for (int c = 0; c < 16; c++)
                     if (cb * 16 + c < L.cin_real && !sval[k]) sv[k][c] = 0.0f;  // zero padding of the real channels
-                float4* o = reinterpret_cast<float4*>(d + (tid + 256 * k) * CONV_PS);
+                float* o = d + (tid + 256 * k) * 4;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) o[g4] = make_float4(sv[k][g4], sv[k][4 + g4], sv[k][8 + g4], sv[k][12 + g4]);
+                for (int g4 = 0; g4 < 4; g4++)
+                    *reinterpret_cast<float4*>(o + g4 * L.qstride) = make_float4(sv[k][g4], sv[k][4 + g4], sv[k][8 + g4], sv[k][12 + g4]);
             }
     };
 
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
 #pragma unroll
     for (int pt = 0; pt < NPT; pt++) {
         const int p = pt * 16 + j, g = conv_idiv(p, r_tp), pp = p - g * TP, py = conv_idiv(pp, r_tw), px = pp - py * L.tw;
-        off[pt] = (g < L.G ? g * plane + (py * L.stride) * siw + px * L.stride : 0) * CONV_PS + q * 4;
+        off[pt] = (g < L.G ? g * plane + (py * L.stride) * siw + px * L.stride : 0) * 4 + q * L.qstride;
     }
     // ---- accumulators D[pixel slot 4q + r][channel j] start at the bias; the weight stream of channel tile c is linear in
     // (cb, tap): 1 KiB per step ----
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
     for (int cb = 0; cb < n_cb; cb++) {
         const float* sb = slab + (cb & 1) * bufsz;
         xr[0] = *reinterpret_cast<const float4*>(sb + off[0]);
-        xr[1] = *reinterpret_cast<const float4*>(sb + (NPT > 1 ? off[NPT > 1 ? 1 : 0] : off[0] + CONV_PS));
+        xr[1] = *reinterpret_cast<const float4*>(sb + (NPT > 1 ? off[NPT > 1 ? 1 : 0] : off[0] + 4));
         __builtin_amdgcn_sched_barrier(0);
         MZC_T(1);
 #pragma unroll
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
                 const int n = tap * NPT + pt, n2 = n + 2;
                 if (MZC_XS_READ && n2 < 9 * NPT) {  // A operand two steps ahead
                     const int tap2 = n2 / NPT, pt2 = n2 - tap2 * NPT;
-                    xr[n2 % 3] = *reinterpret_cast<const float4*>(sb + off[pt2] + ((tap2 / 3) * siw + (tap2 % 3)) * CONV_PS);
+                    xr[n2 % 3] = *reinterpret_cast<const float4*>(sb + off[pt2] + ((tap2 / 3) * siw + (tap2 % 3)) * 4);
                 }
                 const float4 x4 = xr[MZC_XS_READ ? n % 3 : 0];
 #pragma unroll

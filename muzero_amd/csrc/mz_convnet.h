@@ -203,7 +203,7 @@ inline hipError_t convnet_ensure_buffers(ConvNetDev& n, int B) {
 // Launch geometry of one 3x3 conv: spatial tile, images per workgroup (small boards share a workgroup so that the pixel
 // dimension fills whole 16-wide MFMA tiles), pixel tiles per wave (NPT) and channel tiles per wave (NCT).
 struct ConvGeom {
-    int th, tw, G, npt, nct, cstride;
+    int th, tw, G, npt, nct, cstride, qstride;
     bool whole;  // tile == whole image, stride 1: quad-based staging (k_conv3x3<.., true>)
 };
 
@@ -245,7 +245,8 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
     const long wgs1 = tiles * ((B + g.G - 1) / g.G) * zs1;
     g.nct = (cout > 64 && wgs1 >= 1024) ? 2 : 1;  // two channel tiles per wave halve the staging work when there are workgroups to spare
     g.nct = env_int("MZ_CONV_NCT", g.nct);
-    g.cstride = g.G * plane * CONV_PS;
+    g.qstride = (g.G * plane * 4 + 63) & ~63;
+    g.cstride = 4 * g.qstride;
     return g;
 }
 
@@ -285,7 +286,7 @@ inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     // images of one workgroup share a buffer descriptor: their rows must lie within 32-bit byte offsets of the store base
     const bool group_ok = !in_ptrs || (in_base && in_span_floats < ((size_t)1 << 30));
     const ConvGeom g = conv_geometry(B, L.oh, L.ow, Lr.stride, Lr.cout, group_ok);
-    L.th = g.th; L.tw = g.tw; L.G = g.G; L.cstride = g.cstride; L.stamps = g_conv_stamps;
+    L.th = g.th; L.tw = g.tw; L.G = g.G; L.cstride = g.cstride; L.qstride = g.qstride; L.stamps = g_conv_stamps;
     L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
     const size_t lds = (size_t)2 * g.cstride * sizeof(float);
     const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));
