@@ -16,6 +16,7 @@ Groups:
   search G3  end-to-end uct_search with real (seeded random-weight) networks
   pipe   G4  pipeline/util/mcts helper functions (incl. the reference's own KATs)
   env    G5  TicTacToe / Gomoku scripted games (incl. the reference tests' win lines)
+  learn  L   PrioritizedReplay sampling, calc_loss (loss, priorities, gradients), 3 optimizer steps, 2-hot projection
   play   G6  one full reference run_self_play episode on TicTacToe
 """
 import os
@@ -787,7 +788,101 @@ def gen_play():
     print('play: done')
 
 
-GROUPS = dict(tree=gen_tree, nets=gen_nets, search=gen_search, pipe=gen_pipe, env=gen_env, play=gen_play)
+# --------------------------------------------------------------------------------------------
+# L: learner side: the reference's PrioritizedReplay and calc_loss / optimizer steps run here
+# --------------------------------------------------------------------------------------------
+LEARN_CASES = [
+    # name, kind, case, batch
+    ('mlp_cat', 'mlp', 'tiny', 6),             # categorical value / reward heads
+    ('mlp_mse', 'mlp', 'tiny_mse', 5),         # MSE heads
+    ('conv_board3', 'conv', 'board3', 4),      # BatchNorm in train mode
+]
+
+
+def _learn_batch(rng, net, ishape, A, B, K=5):
+    state = rng.uniform(-1.0, 1.0, size=(B,) + tuple(ishape)).astype(np.float32)
+    action = rng.randint(0, A, size=(B, K)).astype(np.int8)
+    pi = rng.dirichlet(np.ones(A), size=(B, K)).astype(np.float32)
+    value = rng.uniform(-3.0, 3.0, size=(B, K)).astype(np.float32)
+    reward = rng.uniform(-1.0, 1.0, size=(B, K)).astype(np.float32)
+    weights = rng.uniform(0.2, 1.0, size=B).astype(np.float32)
+    return ref_replay.Transition(state=state, action=action, pi_prob=pi, value=value, reward=reward), weights
+
+
+def gen_learn():
+    import muzero.replay as _rr
+    global ref_replay
+    ref_replay = _rr
+    out = {}
+    rng = np.random.RandomState(909)
+    # ---- replay: uniform (exponent 0: RandomState.uniform) and prioritized (global np.random.choice) sampling
+    for j, (cap, n_add, pexp, isexp) in enumerate([(16, 11, 0.0, 0.0), (8, 21, 0.0, 0.0), (16, 16, 0.6, 0.4), (8, 13, 1.0, 1.0)]):
+        rp = ref_replay.PrioritizedReplay(cap, pexp, isexp, np.random.RandomState(5 + j))
+        items, prios = [], []
+        for i in range(n_add):
+            tr = ref_replay.Transition(state=rng.uniform(-1, 1, size=(3, 4)).astype(np.float32), action=rng.randint(0, 4, size=5).astype(np.int8),
+                                       pi_prob=rng.dirichlet(np.ones(4), size=5).astype(np.float32), value=rng.uniform(-1, 1, size=5).astype(np.float32),
+                                       reward=rng.uniform(-1, 1, size=5).astype(np.float32))
+            pr = float(rng.uniform(0.01, 2.0))
+            rp.add(tr, pr)
+            items.append(tr)
+            prios.append(pr)
+        np.random.seed(100 + j)
+        batch, idx, w = rp.sample(6)
+        rp.update_priorities(idx[:3], [0.5, 1.5, 2.5])
+        np.random.seed(200 + j)
+        batch2, idx2, w2 = rp.sample(4)
+        pre = f'replay_{j}'
+        out[f'{pre}_cfg'] = np.array([cap, n_add, pexp, isexp], np.float64)
+        for f in ref_replay.Transition._fields:
+            out[f'{pre}_items_{f}'] = np.stack([getattr(t, f) for t in items])
+            out[f'{pre}_s1_{f}'] = getattr(batch, f)
+            out[f'{pre}_s2_{f}'] = getattr(batch2, f)
+        out[f'{pre}_prios'] = np.array(prios, np.float64)
+        out[f'{pre}_s1_idx'], out[f'{pre}_s1_w'] = np.asarray(idx, np.int64), np.asarray(w, np.float32)
+        out[f'{pre}_s2_idx'], out[f'{pre}_s2_w'] = np.asarray(idx2, np.int64), np.asarray(w2, np.float32)
+        out[f'{pre}_size'] = np.int64(rp.size)
+    out['replay_n'] = np.int32(4)
+    # ---- calc_loss + 3 Adam / MultiStepLR steps (pipeline.py:170-286,541-629)
+    for name, kind, cname, B in LEARN_CASES:
+        case = helpers.mlp_case(cname) if kind == 'mlp' else helpers.conv_case(cname)
+        net = build_mlp(case) if kind == 'mlp' else build_conv(case)
+        ishape, A = (case[1], case[2]) if kind == 'mlp' else (case[2], case[3])
+        net.train()
+        tr, weights = _learn_batch(rng, net, ishape, A, B)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2], gamma=0.1)
+        pre = f'learn_{name}'
+        for f in ref_replay.Transition._fields:
+            out[f'{pre}_{f}'] = getattr(tr, f)
+        out[f'{pre}_weights'] = weights
+        losses = []
+        for step in range(3):
+            opt.zero_grad()
+            loss, prio = ref_pipeline.calc_loss(net, torch.device('cpu'), tr, torch.from_numpy(weights))
+            loss.backward()
+            if step == 0:
+                out[f'{pre}_prio'] = np.asarray(prio, np.float32)
+                for pn, pp in net.named_parameters():
+                    out[f'{pre}_grad_{pn}'] = pp.grad.detach().numpy().copy()
+            if step == 1:
+                torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+            opt.step()
+            sched.step()
+            losses.append(float(loss.detach()))
+        out[f'{pre}_losses'] = np.array(losses, np.float64)
+        for pn, pp in net.state_dict().items():
+            out[f'{pre}_final_{pn}'] = pp.detach().numpy().copy()
+    # ---- target projection (util.py:96-116): scalar -> 2-hot categorical
+    xs = torch.tensor([[-12.3, -1.0, -0.2, 0.0], [0.3, 1.0, 7.7, 300.0]])
+    for S in (31, 61, 601):
+        out[f'proj_{S}'] = ref_util.scalar_to_categorical_probabilities(xs, S).numpy()
+    out['proj_x'] = xs.numpy()
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'learn_cases.npz'), **out)
+    print('learn: done,', len(out), 'arrays')
+
+
+GROUPS = dict(tree=gen_tree, nets=gen_nets, search=gen_search, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
 
 if __name__ == '__main__':
     os.makedirs(GOLDEN_DIR, exist_ok=True)

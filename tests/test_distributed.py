@@ -60,3 +60,67 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _learner_worker(rank, world, port, out):
+    """Data-parallel learner: each rank computes gradients on its own batch; after
+    learner.allreduce_gradients every rank holds the mean gradient, and a train_step keeps the weights identical."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import types
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import learner
+    from muzero_amd.replay import Transition
+
+    torch.set_num_threads(1)
+    net = build_mlp(mlp_case('tiny'))
+    net.train()
+    rs = np.random.RandomState(100 + rank)  # different data per rank
+    B, K, A = 4, 5, 3
+    tr = Transition(rs.uniform(-1, 1, (B, 3, 4)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
+                    rs.dirichlet(np.ones(A), (B, K)).astype(np.float32), rs.uniform(-2, 2, (B, K)).astype(np.float32),
+                    rs.uniform(-1, 1, (B, K)).astype(np.float32))
+    w = torch.ones(B)
+    loss, _ = learner.calc_loss(net, torch.device('cpu'), tr, w)
+    loss.backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    learner.allreduce_gradients(net, bucket_bytes=4096)  # several buckets
+    reduced = [p.grad.clone() for p in net.parameters()]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [g.numpy() for g in local])
+    mean = [np.mean([gathered[r][i] for r in range(world)], axis=0) for i in range(len(local))]
+    ok_mean = all(np.allclose(reduced[i].numpy(), mean[i], rtol=1e-6, atol=1e-8) for i in range(len(local)))
+    # one full update on different batches: weights stay in lock-step across ranks
+    cfg = types.SimpleNamespace(clip_grad=True, max_grad_norm=5.0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10], gamma=0.1)
+    learner.train_step(cfg, net, opt, sched, torch.device('cpu'), tr, w)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [None] * world
+    dist.all_gather_object(both, flat.numpy())
+    if rank == 0:
+        out.put(dict(ok_mean=ok_mean, same=bool(np.array_equal(both[0], both[1])), differ_local=not np.allclose(gathered[0][0], gathered[1][0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_learner_gradient_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = out.get()
+    assert res['differ_local'] and res['ok_mean'] and res['same']

@@ -1,0 +1,85 @@
+"""Learner side on the GPU: HBM-resident replay, calc_loss on the ROCm device against the reference
+fixture, and the closed loop actor (HIP planner self-play) -> replay -> learner update -> planner weight reload."""
+import queue
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_mlp, load_golden, mlp_case
+from muzero_amd import learner
+from muzero_amd.replay import PrioritizedReplay, Transition
+
+pytestmark = pytest.mark.gpu
+G = load_golden('learn_cases.npz')
+
+
+def test_device_replay_matches_reference_draws():
+    j = 2  # prioritized case
+    cap, n_add, pexp, isexp = G[f'replay_{j}_cfg']
+    rp = PrioritizedReplay(int(cap), float(pexp), float(isexp), np.random.RandomState(5 + j), device='cuda')
+    items = Transition(*[G[f'replay_{j}_items_{f}'] for f in Transition._fields])
+    rp.add_batch(items, G[f'replay_{j}_prios'])
+    np.random.seed(100 + j)
+    batch, idx, w = rp.sample_tensors(6)
+    assert all(x.is_cuda for x in batch)
+    np.testing.assert_array_equal(idx, G[f'replay_{j}_s1_idx'])
+    np.testing.assert_array_equal(w, G[f'replay_{j}_s1_w'])
+    for f in Transition._fields:
+        np.testing.assert_array_equal(getattr(batch, f).cpu().numpy(), G[f'replay_{j}_s1_{f}'])
+
+
+@pytest.mark.parametrize('name,cname', [('mlp_cat', 'tiny'), ('mlp_mse', 'tiny_mse')])
+def test_calc_loss_on_device_matches_reference(name, cname):
+    pre = f'learn_{name}'
+    dev = torch.device('cuda', 0)
+    net = build_mlp(mlp_case(cname)).to(dev)
+    net.train()
+    tr = Transition(*[G[f'{pre}_{f}'] for f in Transition._fields])
+    loss, prio = learner.calc_loss(net, dev, tr, torch.from_numpy(G[f'{pre}_weights']).to(dev))
+    loss.backward()
+    assert abs(float(loss) - G[f'{pre}_losses'][0]) <= 1e-4 * max(1.0, abs(G[f'{pre}_losses'][0]))
+    np.testing.assert_allclose(prio, G[f'{pre}_prio'], rtol=1e-4, atol=1e-5)
+    for pn, pp in net.named_parameters():
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), G[f'{pre}_grad_{pn}'], rtol=2e-3, atol=2e-6, err_msg=pn)
+
+
+def test_closed_loop_selfplay_replay_learner_reload():
+    """Actor and learner around one network object: device self-play fills the HBM replay, two learner steps change the
+    weights, and the next self-play call runs on the reloaded weights (parameter-version bump, pipeline.py:266)."""
+    from muzero_amd import pipeline
+    from muzero_amd.config import make_tictactoe_config
+
+    dev = torch.device('cuda', 0)
+    net = build_mlp(mlp_case('tictactoe'))
+    cfg = make_tictactoe_config(use_tensorboard=False, batch_size=32, min_replay_size=32)
+    cfg.num_envs = 32
+    q = queue.SimpleQueue()
+    stop = types.SimpleNamespace(is_set=lambda: False)
+    counter = types.SimpleNamespace(value=0)
+    pipeline.run_self_play(cfg, 0, net, dev, 'TicTacToe', q, counter, stop, max_moves=16)
+    rp = PrioritizedReplay(4096, 0.0, 0.0, np.random.RandomState(3), device='cuda')
+    n = 0
+    while not q.empty():
+        tr, pr = q.get()
+        rp.add(tr, pr)
+        n += 1
+    assert n >= 32 and rp.size == n
+    lnet = build_mlp(mlp_case('tictactoe')).to(dev)
+    lnet.load_state_dict(net.state_dict())
+    lnet.train()
+    opt = torch.optim.Adam(lnet.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.1)
+    losses = []
+    for _ in range(2):
+        batch, idx, w = rp.sample_tensors(cfg.batch_size)
+        loss, prio = learner.train_step(cfg, lnet, opt, sched, dev, batch, w)
+        rp.update_priorities(idx, prio)
+        losses.append(loss)
+    assert np.isfinite(losses).all()
+    before = net._weights_version()
+    net.load_state_dict({k: v.cpu() for k, v in lnet.state_dict().items()})  # learner -> actor (pipeline.py:266)
+    assert net._weights_version() != before
+    steps = pipeline.run_self_play(cfg, 0, net, dev, 'TicTacToe', q, counter, stop, max_moves=4)
+    assert steps == 4 * 32 and not q.empty()
