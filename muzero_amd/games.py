@@ -1,0 +1,141 @@
+"""Host-side board games for evaluators and tools: `BoardGameEnv` semantics of the reference (`games/env.py:40-365`)
+with the win test of `games/tictactoe.py:33-77` / `games/gomoku.py:72-116` (n in a row through the last move only).
+Self-play does not use this class -- its environments live on the device (`csrc/mz_env.h`, same rules)."""
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+class BoardGameEnv:
+    """N x N board, players 1 (black, moves first) and 2 (white); action N*N resigns (`enable_resign`)."""
+
+    def __init__(self, board_size: int = 15, stack_history: int = 4, num_to_win: int = 5, black_player_id: int = 1, white_player_id: int = 2,
+                 enable_resign: bool = True, name: str = '') -> None:
+        assert black_player_id != white_player_id != 0, 'player ids can not be the same, and can not be zero'
+        self.name = name
+        self.board_size, self.stack_history, self.num_to_win = board_size, stack_history, num_to_win
+        self.black_player_id, self.white_player_id = black_player_id, white_player_id
+        self.black_color, self.white_color = 1, 2
+        self.num_actions = board_size ** 2 + 1 if enable_resign else board_size ** 2
+        self.resign_action: Optional[int] = self.num_actions - 1 if enable_resign else None
+        self.observation_shape = (stack_history * 2 + 1, board_size, board_size)
+        self.reset()
+
+    def reset(self, **kwargs) -> np.ndarray:
+        n = self.board_size
+        self.board = np.zeros((n, n), dtype=np.int8)
+        self.actions_mask = np.ones(self.num_actions, dtype=np.bool_)
+        self.current_player = self.black_player_id
+        self.steps = 0
+        self.winner: Optional[int] = None
+        self.last_actions = {self.black_player_id: None, self.white_player_id: None}
+        # own-stone history planes per player, most recent first (games/env.py:294-310)
+        self.feature_planes = {p: np.zeros((self.stack_history, n, n), dtype=np.int8) for p in (self.black_player_id, self.white_player_id)}
+        return self.observation()
+
+    # ---- properties (games/env.py:312-365) ----
+    @property
+    def opponent_player(self) -> int:
+        return self.white_player_id if self.current_player == self.black_player_id else self.black_player_id
+
+    @property
+    def current_player_color(self) -> int:
+        return self.black_color if self.current_player == self.black_player_id else self.white_color
+
+    @property
+    def is_board_full(self) -> bool:
+        return bool(np.all(self.board != 0))
+
+    @property
+    def is_game_over(self) -> bool:
+        return self.winner is not None or self.is_board_full
+
+    @property
+    def loser(self) -> Optional[int]:
+        if self.winner is None:
+            return None
+        return self.white_player_id if self.winner == self.black_player_id else self.black_player_id
+
+    def action_to_coords(self, action: int) -> Tuple[int, int]:
+        return action // self.board_size, action % self.board_size
+
+    def coords_to_action(self, coords: Tuple[int, int]) -> int:
+        return coords[0] * self.board_size + coords[1]
+
+    def is_action_valid(self, action: int) -> bool:
+        return 0 <= action < self.num_actions and bool(self.actions_mask[action])
+
+    # ---- dynamics ----
+    def step(self, action: int):
+        """games/env.py:117-154: returns (observation, reward, done, info); the player is not switched on the final move."""
+        if not 0 <= action <= self.num_actions - 1:
+            raise ValueError(f'Invalid action. Expect action to be in range [0, {self.num_actions}], got {action}')
+        if not self.actions_mask[action]:
+            raise ValueError(f'Invalid action. The action {action} has alread been taken.')
+        if self.is_game_over:
+            raise RuntimeError('Game is over, call reset before using step method.')
+        action = int(action)
+        reward = 0.0
+        self.actions_mask[action] = False
+        self.last_actions[self.current_player] = action
+        if action == self.resign_action:
+            reward = -1.0
+            self.winner = self.opponent_player
+        else:
+            r, c = self.action_to_coords(action)
+            self.board[r, c] = self.current_player_color
+            planes = self.feature_planes[self.current_player]
+            planes[1:] = planes[:-1].copy()
+            planes[0] = (self.board == self.current_player_color)
+            if self.is_current_player_won():
+                reward = 1.0
+                self.winner = self.current_player
+        done = self.is_game_over
+        if not done:
+            self.current_player = self.opponent_player
+        self.steps += 1
+        return self.observation(), reward, done, {}
+
+    def is_current_player_won(self) -> bool:
+        """Lines through the last move only; needs at least 2 * (num_to_win - 1) earlier plies (steps not yet incremented)."""
+        if self.steps < (self.num_to_win - 1) * 2:
+            return False
+        last = self.last_actions[self.current_player]
+        if last is None or last == self.resign_action:
+            return False
+        r0, c0 = self.action_to_coords(last)
+        colour, n = self.current_player_color, self.board_size
+        for dr, dc in ((0, 1), (1, 0), (1, 1), (-1, 1)):
+            count = 1
+            for sgn in (1, -1):
+                r, c = r0 + sgn * dr, c0 + sgn * dc
+                while 0 <= r < n and 0 <= c < n and self.board[r, c] == colour:
+                    count += 1
+                    r, c = r + sgn * dr, c + sgn * dc
+            if count >= self.num_to_win:
+                return True
+        return False
+
+    def observation(self) -> np.ndarray:
+        """[X_t, Y_t, X_t-1, Y_t-1, ..., C] from the side to move, int8 (games/env.py:242-271)."""
+        me, opp = self.current_player, self.opponent_player
+        n = self.board_size
+        out = np.zeros(self.observation_shape, dtype=np.int8)
+        out[0:2 * self.stack_history:2] = self.feature_planes[me]
+        out[1:2 * self.stack_history:2] = self.feature_planes[opp]
+        out[-1] = 1 if me == self.black_player_id else 0
+        return out.reshape(self.observation_shape) if n else out
+
+
+class TicTacToeEnv(BoardGameEnv):
+    """games/tictactoe.py:25-31"""
+
+    def __init__(self, stack_history: int = 4) -> None:
+        super().__init__(board_size=3, stack_history=stack_history, num_to_win=3, name='TicTacToe')
+
+
+class GomokuEnv(BoardGameEnv):
+    """games/gomoku.py:25-70"""
+
+    def __init__(self, board_size: int = 15, stack_history: int = 4, num_to_win: int = 5) -> None:
+        super().__init__(board_size=board_size, stack_history=stack_history, num_to_win=num_to_win, name='Gomoku')

@@ -11,6 +11,7 @@ compute_n_step_target (pipeline.py:632-673), compute_mc_return_target (:676-707)
 create_checkpoint / load_checkpoint (:802-807), run_self_play (:41-167).
 """
 import os
+import time
 from typing import Any, Iterable, List, Mapping, NamedTuple, Optional, Text
 
 import numpy as np
@@ -203,6 +204,51 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
             data_queue.put(item)
         played += n
     return played * num_envs
+
+
+def run_board_game_evaluator(config, old_checkpoint_network, new_ckpt_network, device, env, temperature, checkpoint_files, stop_event,
+                             initial_elo: int = -2000, tag: str = None, on_result=None) -> float:
+    """pipeline.py:289-397: for every new checkpoint, one deterministic game new (black) vs previous (white) checkpoint on a
+    host `games.BoardGameEnv`, searches through the HIP planner; Elo update as the reference does (white inherits black's
+    rating).  `on_result(black_elo, env.steps, train_steps)` stands in for the tensorboard trackers.  Returns the final Elo."""
+    from muzero_amd import mcts
+    from muzero_amd.games import BoardGameEnv
+    from muzero_amd.rating import compute_elo_rating
+
+    if not isinstance(env, BoardGameEnv):
+        raise ValueError(f'Expect env to be a valid BoardGameEnv instance, got {env}')
+    for net in (old_checkpoint_network, new_ckpt_network):
+        for p in net.parameters():
+            p.requires_grad = False
+    black_elo = white_elo = initial_elo
+    while True:
+        if stop_event.is_set() and len(checkpoint_files) == 0:
+            break
+        if len(checkpoint_files) == 0:
+            time.sleep(0.001)
+            continue
+        loaded_state = load_checkpoint(checkpoint_files.pop(0), device)
+        new_ckpt_network.load_state_dict(loaded_state['network'])
+        train_steps = loaded_state['train_steps']
+        new_ckpt_network.eval()
+        old_checkpoint_network.eval()
+        obs = env.reset()
+        done = False
+        while not done:
+            network = new_ckpt_network if env.current_player == env.black_player_id else old_checkpoint_network
+            action, *_ = mcts.uct_search(state=obs, network=network, device=device, config=config, temperature=temperature,
+                                         actions_mask=env.actions_mask, current_player=env.current_player, opponent_player=env.opponent_player,
+                                         deterministic=True)
+            obs, _, done, _ = env.step(action)
+        if env.winner == env.black_player_id:
+            black_elo, _ = compute_elo_rating(0, black_elo, white_elo)
+        elif env.winner == env.white_player_id:
+            black_elo, _ = compute_elo_rating(1, black_elo, white_elo)
+        white_elo = black_elo
+        if on_result is not None:
+            on_result(black_elo, env.steps, train_steps)
+        old_checkpoint_network.load_state_dict(new_ckpt_network.state_dict())
+    return black_elo
 
 
 def rank_env() -> tuple:

@@ -84,3 +84,29 @@ def test_closed_loop_selfplay_replay_learner_reload():
     assert net._weights_version() != before
     steps = pipeline.run_self_play(cfg, 0, net, dev, 'TicTacToe', q, counter, stop, max_moves=4)
     assert steps == 4 * 32 and not q.empty()
+
+
+def test_board_game_evaluator_plays_checkpoints(tmp_path):
+    """pipeline.py:289-397: new checkpoint (black) vs previous (white), deterministic searches on the HIP planner, Elo from
+    -2000: identical networks -> black either wins (+16), loses (-16) or draws (0); ratings chain over checkpoints."""
+    import threading
+
+    from muzero_amd import pipeline
+    from muzero_amd.config import make_tictactoe_config
+    from muzero_amd.games import TicTacToeEnv
+
+    dev = torch.device('cuda', 0)
+    cfg = make_tictactoe_config(use_tensorboard=False)
+    old, new = build_mlp(mlp_case('tictactoe')), build_mlp(mlp_case('tictactoe'))
+    files = []
+    for k in (1, 2):
+        f = tmp_path / f'train_steps_{k}'
+        pipeline.create_checkpoint({'network': new.state_dict(), 'optimizer': {}, 'lr_scheduler': {}, 'train_steps': 100 * k}, f)
+        files.append(f)
+    stop = threading.Event()
+    stop.set()  # evaluator drains the list, then exits
+    results = []
+    elo = pipeline.run_board_game_evaluator(cfg, old, new, dev, TicTacToeEnv(), 0.1, files, stop, on_result=lambda *a: results.append(a))
+    assert len(results) == 2 and [r[2] for r in results] == [100, 200] and files == []
+    assert all(1 <= r[1] <= 9 for r in results)  # at most 9 plies; untrained nets may resign (action 9) early
+    assert results[0][0] in (-2000, -1984.0, -2016.0) and elo == results[1][0]
