@@ -187,3 +187,75 @@ def test_conv_network_api_runs_on_planner(oracle):
     np.testing.assert_array_equal(np.asarray(out.hidden_state).reshape(-1), oh)
     np.testing.assert_array_equal(out.pi_probs, opi)
     assert out.value == float(np.float32(ov)) and out.reward == 0.0
+
+
+# ----------------------------------------------------------------------------------------------- BASELINE sizes
+FULL = {
+    # BASELINE.json configs[3] / configs[4]: network, envs per GPU, sims per move, search kwargs
+    'c4': (('c4', 'atari', (8, 96, 96), 6, 8, 128, 61, 61, 41), 512, 50, dict(discount=0.997, root_dirichlet_alpha=0.25)),
+    'c5': (('c5', 'board', (9, 15, 15), 226, 8, 128, 1, 1, 42), 256, 200,
+           dict(discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.03)),
+}
+
+
+@pytest.mark.parametrize('name', ['c4', 'c5'])
+def test_full_size_conv_search_properties(name):
+    """At BASELINE.json's full sizes the oracle is too slow to shadow every env; size-independent properties instead:
+    visit counts sum to the simulation count (minus visits on illegal root children), the policy is visits / sum (T = 1),
+    only legal actions are played, root values are finite, and the search is a pure function of (inputs, injected draws):
+    two runs give identical results, and a batch of copies of one root gives identical rows."""
+    case, B, S, kw = FULL[name]
+    net = build_conv(case)
+    A = case[3]
+    p = _planner(net, B, num_simulations=S, root_exploration_eps=0.25, **kw)
+    rs = np.random.RandomState(17)
+    obs = rs.uniform(0, 1, size=(B,) + tuple(case[2])).astype(np.float32)
+    obs[B // 2:] = obs[0]  # second half: copies of root 0 ...
+    board = case[1] == 'board'
+    mask = (rs.rand(B, A) < 0.9) if board else np.ones((B, A), bool)
+    mask[:, 0] = True
+    mask[B // 2:] = mask[0]
+    noise = rs.dirichlet(np.full(A, kw['root_dirichlet_alpha']), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    noise[B // 2:], u_tie[B // 2:], u_final[B // 2:] = noise[0], u_tie[0], u_final[0]  # ... with the same draws
+    args = (obs, mask, 1, 2 if board else 1, 1.0, False)
+    r1 = p.search(*args, noise=noise, u_tie=u_tie, u_final=u_final)
+    r2 = p.search(*args, noise=noise, u_tie=u_tie, u_final=u_final)
+    for k in ('visits', 'pi', 'action', 'root_value'):
+        np.testing.assert_array_equal(r1[k], r2[k])
+        np.testing.assert_array_equal(r1[k][B // 2:], np.broadcast_to(r1[k][0], r1[k][B // 2:].shape))
+    v = r1['visits']
+    assert (v[~mask] == 0).all() and (v.sum(1) <= S).all() and (v.sum(1) >= S - 1 - S // 4).all()
+    np.testing.assert_array_equal(r1['pi'], v / v.sum(1, keepdims=True))
+    assert mask[np.arange(B), r1['action']].all() and np.isfinite(r1['root_value']).all()
+    assert len({tuple(x) for x in v[:B // 2]}) > 1  # different roots search differently
+
+
+@pytest.mark.parametrize('name,S,envs', [('c4', 50, (1, 4)), ('c5', 16, (3,))])
+def test_full_size_spot_check_vs_oracle(oracle, name, S, envs):
+    """Envs of the full-size nets (C4: Atari net, 128 planes, 8 blocks, 96x96 frames, all 50 simulations; C5: Gomoku 15x15
+    net, A = 226, the first 16 of its 200 simulations -- the scalar oracle needs ~1 s per simulation there) inside a ragged
+    batch, bit-exact against the oracle: the deepest towers and widest trees the path has."""
+    case, _, _, kw = FULL[name]
+    net = build_conv(case)
+    onet = _oracle_net(oracle, net, 'conv')
+    A, B = case[3], 5
+    board = case[1] == 'board'
+    p = _planner(net, B, num_simulations=S, root_exploration_eps=0.25, **kw)
+    rs = np.random.RandomState(23)
+    obs = rs.uniform(0, 1, size=(B,) + tuple(case[2])).astype(np.float32)
+    mask = (rs.rand(B, A) < 0.9) if board else np.ones((B, A), bool)
+    mask[:, 0] = True
+    noise = rs.dirichlet(np.full(A, kw['root_dirichlet_alpha']), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    players = (1, 2) if board else (1, 1)
+    r = p.search(obs, mask, *players, 1.0, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    ocfg = oracle.make_config(A, S, kw['discount'], board, kw.get('known_bounds'), kw['root_dirichlet_alpha'], 0.25)
+    for b in envs:
+        o = oracle.uct_search(ocfg, onet, obs[b], mask[b].astype(np.uint8), *players, 1.0, False, noise=noise[b], u_tie=u_tie[b],
+                              u_final=float(u_final[b]))
+        np.testing.assert_array_equal(r['visits'][b], o['visits'])
+        np.testing.assert_array_equal(r['pi'][b], o['pi'])
+        assert r['action'][b] == o['action'] and r['root_value'][b] == o['root_value']
