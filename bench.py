@@ -103,7 +103,7 @@ def conv_flops(case):
     return 2 * sim, 2 * root
 
 
-def run_conv_workload(args, name, rank, local_rank, world, torch, dist):
+def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev='cuda'):
     from helpers import build_conv
     from muzero_amd import build as mz_build
     from muzero_amd import planner as pl
@@ -135,7 +135,7 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist):
     elapsed = time.perf_counter() - t0
     prof = p.profile_end()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -180,15 +180,24 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # MZ_BENCH_BACKEND=gloo: control-flow check of the N > 1 path on a box with fewer GPUs than ranks (ranks then share
+    # devices and the barrier / MAX run on CPU tensors); the driver's multi-GPU runs use the default, RCCL.
+    backend = os.environ.get('MZ_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    red_dev = 'cuda' if backend == 'nccl' else 'cpu'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
 
     if args.workload != 'c2':
-        return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist)
+        return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist, red_dev)
 
     from helpers import build_mlp, mlp_case
     from muzero_amd import build as mz_build
@@ -218,7 +227,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = p.profile_end()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     counters = p.selfplay_counters()
