@@ -1,19 +1,20 @@
 // mz_conv.h -- conv-tower inference kernels (MuZeroBoardGameNet network.py:540-574, MuZeroAtariNet :501-537) for gfx950.
 //
-// k_conv3x3<NPT, NCT>: 3x3 convolution (stride 1 or 2, pad 1) with eval-mode BatchNorm folded into weight/bias, optional
-// residual add and ReLU (ResNetBlock network.py:293-299), as an implicit GEMM on v_mfma_f32_16x16x4_f32:
+// k_conv3x3<NPT, NCT, WHOLE>: 3x3 convolution (stride 1 or 2, pad 1) with eval-mode BatchNorm folded into weight/bias,
+// optional residual add and ReLU (ResNetBlock network.py:293-299), as an implicit GEMM on v_mfma_f32_16x16x4_f32:
 //     D[pixel][co] = bias[co] + sum_k X[pixel][k] * W[co][k],   k = (16-channel block, tap (ky,kx), channel in block)
-// B operand = 4 k x 16 output channels of the weights (pre-packed fragment order, a linear stream per wave out of L2),
-// A operand = 16 output pixels x 4 channels read from an LDS-staged input slab (tile-with-halo x 16 channels, one
-// 16-byte read per lane and tap).  The k
-// order is ONE fmaf chain per output in exactly the oracle's order, so results equal the oracle bit for bit; zero padding
-// contributes fma(w, 0, acc) == acc.
+// B operand = 4 k x 16 output channels of the weights (pre-packed fragment order, a linear 1 KiB-per-step stream per wave
+// out of L2), A operand = 16 output pixels x 4 channels read from an LDS-staged input slab (tile + halo, one 16-byte read
+// per lane and (tap, pixel tile)).  The k order is ONE fmaf chain per output in exactly the oracle's order, so results
+// equal the oracle bit for bit; zero padding contributes fma(0, w, acc) == acc.
 //   workgroup = 256 threads = a group of G images (blockIdx.y) x one spatial tile (blockIdx.x) = up to NPT*16 output
 //   pixel slots x one slice of 64*NCT output channels (blockIdx.z; wave w owns channel tiles w, w+4 of the slice).
 //   Small boards pack several images into the pixel dimension (6x6: 4 images = 144 pixels = 9 full MFMA tiles).
-//   Pipeline per 16-channel block: the NEXT block's slab is fetched global -> registers before the MFMA loop and written
-//   to the other LDS buffer after it (one barrier per block); weights run 2 taps ahead in a register ring; B operands are
-//   read one pixel tile ahead of the MFMAs that consume them.  All staging index arithmetic is hoisted out of the loop.
+//   Pipeline per 16-channel block: the NEXT block's slab is fetched global -> registers between the MFMAs of this block
+//   (a few buffer loads per tap) and written to the other LDS buffer after the tap loop (one barrier per block); weights
+//   run 2 or 8 steps ahead in a register ring; A operands are read two pixel tiles ahead of the MFMAs that consume them;
+//   sched_group_barrier pins that order.  All index arithmetic is hoisted out of the loop.
+//   WHOLE = the tile is the whole image (stride 1; the shapes of the search): lanes stage pixel quads with 16-byte loads.
 // The dynamics net's action planes (network.py:440-444: element f = c*h*w + y*w + x of the [A,h,w] block is 1 iff
 // f % A == action) are generated while staging, never materialised.
 #pragma once
@@ -54,7 +55,7 @@ typedef unsigned int conv_u32x4 __attribute__((ext_vector_type(4)));
 // an integer, far more than float rounding, so the truncation is exact
 __device__ __forceinline__ int conv_idiv(int p, float rcp_d) { return (int)(((float)p + 0.5f) * rcp_d); }
 
-#ifdef MZC_STAMPS  // per-phase cycle sums of wave 0 of workgroup (0,0,0): [0] prologue [1] fetch issue + first B reads [2] tap loop [3] store [4] barrier [5] epilogue
+#ifdef MZC_STAMPS  // per-phase cycle sums of wave 0 of workgroup (0,0,0): [0] prologue [1] first A reads of the block [2] tap loop [3] store [4] barrier [5] epilogue
 #define MZC_T_DECL long long _ct0 = __builtin_readcyclecounter(), _cacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define MZC_T(i) do { const long long _t = __builtin_readcyclecounter(); _cacc[i] += _t - _ct0; _ct0 = _t; } while (0)
 #define MZC_T_FLUSH(L) do { if (L.stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) for (int _i = 0; _i < 8; _i++) L.stamps[_i] = _cacc[_i]; } while (0)
