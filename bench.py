@@ -104,20 +104,26 @@ def conv_flops(case):
 
 
 def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev='cuda'):
-    from helpers import build_conv
+    from helpers import build_conv, build_mlp, mlp_case
     from muzero_amd import build as mz_build
     from muzero_amd import planner as pl
 
     mz_build.build()
-    case, envs, sims, env_kind, kw = CONV_WORKLOADS[name]
+    if name == 'c3':  # BASELINE.json configs[2]: TicTacToe MLP 256/64, MSE heads, two-player backup, 25 sims, 4096 envs
+        envs, sims, env_kind = 4096, 25, 'tictactoe'
+        kw = dict(discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.25)
+        net = build_mlp(mlp_case('tictactoe'))
+        case = ('c3', 'mlp', (9, 3, 3), 10, 0, 256, 1, 1, 13)
+    else:
+        case, envs, sims, env_kind, kw = CONV_WORKLOADS[name]
+        net = build_conv(case)
     B = args.envs or envs
     S = args.sims or sims
-    net = build_conv(case)
     cfg = pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=1000 + rank, num_simulations=S, root_exploration_eps=0.25, **kw)
     p = pl.Planner(cfg, local_rank)
     p.load_state_dict(net.state_dict())
-    p.selfplay_reset(pl.ENV_GOMOKU if env_kind == 'gomoku' else pl.ENV_SYNTHETIC)
-    T = -1.0 if env_kind == 'gomoku' else 1.0
+    p.selfplay_reset({'gomoku': pl.ENV_GOMOKU, 'tictactoe': pl.ENV_TICTACTOE}.get(env_kind, pl.ENV_SYNTHETIC))
+    T = -1.0 if env_kind in ('gomoku', 'tictactoe') else 1.0
 
     def sync():
         p.synchronize()
@@ -139,7 +145,8 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        f_sim, f_root = conv_flops(case)
+        # C3: transition 35 328 + reward 16 640 + value 16 640 MAC per simulation; root 37 120 + 18 944 + 16 640
+        f_sim, f_root = (2 * 68608, 2 * 72704) if name == 'c3' else conv_flops(case)
         sims_per_s = world * B * S * args.steps / elapsed
         ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
         flop_per_move = B * (S * f_sim + f_root)
@@ -149,10 +156,10 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{name.upper()}: {case[1]} net {case[5]} planes / {case[4]} blocks, obs {case[2]}, A={case[3]}, {S} sims/move, '
-                                   f'{B} envs per MI355X, {env_kind} device env, HBM-resident trees',
+                                   f'{B} envs per MI355X, {env_kind} device env, ' + ('LDS-resident trees' if name == 'c3' else 'HBM-resident trees'),
                        'envs_per_gpu': B, 'sims_per_move': S, 'parallelism': f'env-sharded x{world}', 'weights': 'seeded random init'},
             'env_steps_per_sec': sims_per_s / S,
-            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_conv3x3<NPT> (conv towers; whole per-move kernel sequence timed)', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<256>' if name == 'c3' else 'mz::k_conv3x3<NPT,NCT,WHOLE> (conv towers; whole per-move kernel sequence timed)', 'achieved': achieved,
                          'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                          'avg_move_ms': ms, 'flop_per_move': flop_per_move, 'flop_per_sim': f_sim,
                          'timed_with': 'hipEvent pairs on the planner stream around each move\'s kernel sequence'},
@@ -169,8 +176,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--envs', type=int, default=0, help='environments per GPU (default: that of the workload)')
     ap.add_argument('--sims', type=int, default=0, help='simulations per move (default: that of the workload)')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
-                    help='c2 (default, the headline line): CartPole MLP; c4 / c5: the conv-tower configs of BASELINE.json (extra measurements)')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
+                    help='c2 (default, the headline line): CartPole MLP; c3: TicTacToe MLP; c4 / c5: the conv-tower configs of BASELINE.json (extra measurements)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
