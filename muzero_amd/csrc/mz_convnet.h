@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256) void k_gtree_init(const GTreeLaunch G) {
         int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
         sel[0] = sel[1] = sel[2] = sel[3] = 0;
     }
+    root_noise_lanes(smem, P, e, a0, env_g, env_ok);
     __syncthreads();
     if (a0 == 0 && env_ok) root_prior(smem, P, e, env_g);
 }

@@ -255,6 +255,18 @@ __device__ __forceinline__ void tree_expand_backup(unsigned char* smem, const Se
     mm[0] = mn; mm[1] = mx;
 }
 
+// Production randomness (noise_mode 2): the gamma(alpha) draws of the root's Dirichlet noise (mcts.py:245), one action per
+// lane of the env's 16-lane segment, each from its own Philox stream keyed by (seed, env, move, action) -- the rejection
+// sampler is ~10 k cycles per draw when one lane does all A of them.  Call with every thread, then barrier, then root_prior.
+__device__ __forceinline__ void root_noise_lanes(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g, bool env_ok) {
+    if (P.noise_mode != 2 || !env_ok) return;
+    double* tmp = reinterpret_cast<double*>(smem + P.t_tmp) + e * P.A;
+    for (int a = a0; a < P.A; a += 16) {
+        Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x20000000u + (unsigned)a);
+        tmp[a] = gamma_sample(g, P.alpha);
+    }
+}
+
 // root prior: Dirichlet mix + illegal-action mask + renormalisation (mcts.py:357-365, 244-247, 293-299); one lane per env
 __device__ __forceinline__ void root_prior(unsigned char* smem, const SearchParams& P, int e, int env_g) {
     double* prior = reinterpret_cast<double*>(smem + P.t_prior) + e * P.A;
@@ -265,10 +277,9 @@ __device__ __forceinline__ void root_prior(unsigned char* smem, const SearchPara
     if (P.noise_mode != 0) {
         if (P.noise_mode == 1) {
             for (int a = 0; a < A; a++) tmp[a] = P.noise[(size_t)env_g * A + a];
-        } else {
-            Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x20000000u);
+        } else {  // tmp[] holds the gamma draws of root_noise_lanes
             double s = 0.0;
-            for (int a = 0; a < A; a++) { tmp[a] = gamma_sample(g, P.alpha); s += tmp[a]; }
+            for (int a = 0; a < A; a++) s += tmp[a];
             for (int a = 0; a < A; a++) tmp[a] = s > 0.0 ? tmp[a] / s : 1.0 / (double)A;
         }
         const float om = (float)(1.0 - P.eps);
@@ -423,6 +434,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
         __syncthreads();
         mlp_initial_tile(P.net, P.o, lds, dst, pi0, tid);  // root value is discarded (mcts.py:356-367)
     }
+    root_noise_lanes(smem, P, e, a0, env_g, env_ok);
     __syncthreads();
     if (a0 == 0 && env_ok) root_prior(smem, P, e, env_g);
     __syncthreads();

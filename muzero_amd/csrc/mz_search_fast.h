@@ -222,6 +222,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
         }
     }
     __syncthreads();
+    root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
     load_obs(net, lds + o.X, src, tid);
     __syncthreads();
     mlp_initial_tile(net, o, lds, dst, pi0, tid);

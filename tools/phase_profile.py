@@ -25,6 +25,8 @@ def main():
     net = build_mlp(mlp_case(g))
     B, S = 4096, 25 if board else 50
     kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+    if len(sys.argv) > 2 and sys.argv[2] == 'nonoise':
+        kw['root_dirichlet_alpha'] = 0.0  # root prior without Dirichlet sampling: isolates its cost in the root phase
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, **kw), 0)
     p.load_state_dict(net.state_dict())
     p.selfplay_reset(pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE)
