@@ -6,6 +6,7 @@ Randomness: the reference draws from the process-global numpy RNG inside the sea
 draws are explicit inputs: by default the planner generates them on device (Philox keyed by planner seed, env id and
 move counter); tests inject recorded draws through `rng=dict(noise=..., u_tie=..., u_final=...)`.
 """
+import math
 from typing import Optional, Tuple
 
 import numpy as np
@@ -30,6 +31,192 @@ class MinMaxStats:
         if self.maximum > self.minimum:
             return (value - self.minimum) / (self.maximum - self.minimum)
         return value
+
+
+class _TreeArrays:
+    """Structure-of-arrays storage behind `Node` handles: the host-side twin of the planner's device tree (per node N, W,
+    reward, parent, move, player, prior; per expanded node a contiguous run of A child slots)."""
+
+    def __init__(self):
+        self.N = np.zeros(64, np.int64)
+        self.W = np.zeros(64, np.float64)
+        self.reward = np.zeros(64, np.float64)
+        self.parent = np.full(64, -1, np.int64)
+        self.move = np.full(64, -1, np.int64)
+        self.player = np.zeros(64, np.int64)
+        self.first_child = np.full(64, -1, np.int64)
+        self.num_children = np.zeros(64, np.int64)
+        self.prior = [None] * 64          # the reference keeps whatever scalar type the prior array had (float32 / float64)
+        self.hidden = {}
+        self.player_set = np.zeros(64, bool)
+        self.size = 0
+
+    def alloc(self, n):
+        while self.size + n > self.N.shape[0]:
+            for name in ('N', 'W', 'reward', 'parent', 'move', 'player', 'first_child', 'num_children', 'player_set'):
+                a = getattr(self, name)
+                fill = -1 if name in ('parent', 'move', 'first_child') else 0
+                setattr(self, name, np.concatenate([a, np.full(a.shape[0], fill, a.dtype)]))
+            self.prior.extend([None] * len(self.prior))
+        first = self.size
+        self.size += n
+        return first
+
+
+class Node:
+    """mcts.py:51-217: the reference's tree-node type (constructor, attributes `N, W, reward, hidden_state, children,
+    is_expanded, player_id, prior, move, parent`, properties `Q, child_N, has_parent`, methods `expand / best_child / backup /
+    child_Q / child_U`, same exceptions) as a handle into structure-of-arrays storage, with the children's statistics
+    evaluated as vectors.  This is the host-side view for tools and tests; `uct_search` does not build Python nodes --
+    its trees live in LDS / HBM and are walked by the HIP kernels, which implement exactly these formulas."""
+
+    def __init__(self, prior: float = None, move: int = None, parent: 'Node' = None, _tree=None, _index=None) -> None:
+        if _tree is not None:
+            self._t, self._i = _tree, _index
+            return
+        self._t = parent._t if parent is not None else _TreeArrays()
+        self._i = self._t.alloc(1)
+        t, i = self._t, self._i
+        t.prior[i] = prior
+        t.move[i] = -1 if move is None else move
+        t.parent[i] = -1 if parent is None else parent._i
+
+    # ---- attributes (plain fields in the reference) ----
+    def _get(name):  # noqa: N805
+        return property(lambda self: getattr(self._t, name)[self._i].item(), lambda self, v: getattr(self._t, name).__setitem__(self._i, v))
+
+    N = _get('N')
+    W = _get('W')
+    reward = _get('reward')
+    del _get
+
+    @property
+    def prior(self):
+        return self._t.prior[self._i]
+
+    @property
+    def move(self):
+        m = int(self._t.move[self._i])
+        return None if m < 0 else m
+
+    @property
+    def parent(self):
+        p = int(self._t.parent[self._i])
+        return None if p < 0 else Node(_tree=self._t, _index=p)
+
+    @property
+    def player_id(self):
+        return int(self._t.player[self._i]) if self._t.player_set[self._i] else None
+
+    @player_id.setter
+    def player_id(self, v):
+        self._t.player[self._i] = v
+        self._t.player_set[self._i] = True
+
+    @property
+    def hidden_state(self):
+        return self._t.hidden.get(self._i)
+
+    @hidden_state.setter
+    def hidden_state(self, v):
+        self._t.hidden[self._i] = v
+
+    @property
+    def is_expanded(self) -> bool:
+        return bool(self._t.first_child[self._i] >= 0)
+
+    @property
+    def children(self):
+        f, n = int(self._t.first_child[self._i]), int(self._t.num_children[self._i])
+        return [Node(_tree=self._t, _index=f + k) for k in range(n)] if f >= 0 else []
+
+    def __eq__(self, other):
+        return isinstance(other, Node) and other._t is self._t and other._i == self._i
+
+    def __hash__(self):
+        return hash((id(self._t), self._i))
+
+    def _child_slice(self):
+        f = int(self._t.first_child[self._i])
+        return slice(f, f + int(self._t.num_children[self._i]))
+
+    # ---- methods ----
+    def expand(self, prior: np.ndarray, player_id: int, hidden_state: np.ndarray, reward: float) -> None:
+        """mcts.py:75-102: one child slot per action, priors as given (illegal actions already zeroed by the caller)."""
+        if self.is_expanded:
+            raise RuntimeError("Node already expanded.")
+        if not isinstance(prior, np.ndarray) or len(prior.shape) != 1 or prior.dtype not in (np.float32, np.float64):
+            raise ValueError(f"Expect `prior` to be a 1D float numpy.array, got {prior}")
+        t = self._t
+        self.hidden_state = hidden_state
+        self.reward = reward
+        self.player_id = player_id
+        n = prior.shape[0]
+        f = t.alloc(n)
+        t.first_child[self._i], t.num_children[self._i] = f, n
+        t.parent[f:f + n] = self._i
+        t.move[f:f + n] = np.arange(n)
+        for a in range(n):
+            t.prior[f + a] = prior[a]
+
+    def best_child(self, min_max_stats: MinMaxStats, config: MuZeroConfig) -> 'Node':
+        """mcts.py:104-127: argmax of child_Q + child_U (float32), ties broken by the global numpy RNG."""
+        if not self.is_expanded:
+            raise ValueError('Expand leaf node first.')
+        ucb_results = self.child_Q(min_max_stats, config) + self.child_U(config)
+        action_index = np.random.choice(np.where(ucb_results == ucb_results.max())[0])
+        return Node(_tree=self._t, _index=int(self._t.first_child[self._i]) + int(action_index))
+
+    def backup(self, value: float, player_id: int, min_max_stats: MinMaxStats, config: MuZeroConfig) -> None:
+        """mcts.py:129-157: leaf -> root; the value flips sign for the other player, min-max sees reward + discount * (+/-)Q."""
+        t, i = self._t, self._i
+        while i >= 0:
+            same = self._t.player_set[i] and t.player[i] == player_id
+            t.W[i] += value if same else -value
+            t.N[i] += 1
+            q = float(t.W[i] / t.N[i])
+            r = float(t.reward[i])
+            min_max_stats.update(r + config.discount * -q if config.is_board_game else r + config.discount * q)
+            value = (-r + config.discount * value) if (config.is_board_game and same) else (r + config.discount * value)
+            i = int(t.parent[i])
+
+    def child_Q(self, min_max_stats: MinMaxStats, config: MuZeroConfig) -> np.ndarray:
+        """mcts.py:159-178: normalised reward + discount * p * Q for visited children, 0 otherwise; float32."""
+        t, s = self._t, self._child_slice()
+        n = t.N[s]
+        q = np.divide(t.W[s], n, out=np.zeros(n.shape[0]), where=n > 0)
+        v = t.reward[s] + (config.discount * (-1.0 if config.is_board_game else 1.0)) * q
+        if min_max_stats.maximum > min_max_stats.minimum:
+            v = (v - min_max_stats.minimum) / (min_max_stats.maximum - min_max_stats.minimum)
+        return np.where(n > 0, v, 0.0).astype(np.float32)
+
+    def child_U(self, config: MuZeroConfig) -> np.ndarray:
+        """mcts.py:180-200: prior * ((ln((N + c_base + 1) / c_base) + c_init) * sqrt(N) / (N_child + 1)); float32.  The prior
+        keeps its scalar type: a float32 prior multiplies in float32 (the scalar promotion numpy applies in the reference's
+        per-child expression), a float64 (noised) prior in float64."""
+        t, s = self._t, self._child_slice()
+        n_self = int(t.N[self._i])
+        f = (math.log((n_self + config.pb_c_base + 1) / config.pb_c_base) + config.pb_c_init) * math.sqrt(n_self) / (t.N[s] + 1)
+        pri = t.prior[s]
+        out = np.empty(len(pri), np.float32)
+        for k, p in enumerate(pri):
+            out[k] = np.float32(p) * np.float32(f[k]) if isinstance(p, np.float32) else np.float32(p * f[k])
+        return out
+
+    @property
+    def Q(self) -> float:
+        """mcts.py:202-207"""
+        n = int(self._t.N[self._i])
+        return 0.0 if n == 0 else float(self._t.W[self._i] / n)
+
+    @property
+    def child_N(self) -> np.ndarray:
+        """mcts.py:209-212"""
+        return self._t.N[self._child_slice()].astype(np.int32)
+
+    @property
+    def has_parent(self) -> bool:
+        return self._t.parent[self._i] >= 0
 
 
 def add_dirichlet_noise(prob: np.ndarray, eps: float = 0.25, alpha: float = 0.03, noise: Optional[np.ndarray] = None):

@@ -1,0 +1,84 @@
+"""`muzero_amd.mcts.Node` (the reference's tree-node API over structure-of-arrays storage) driven
+through the reference's search loop (mcts.py:352-407) with scripted network outputs, against the per-simulation traces
+recorded from the reference itself (tests/golden/tree_cases.npz): selected (parent, action) of every simulation, visit
+counts, policy, root value -- exact."""
+import types
+
+import numpy as np
+import pytest
+
+from helpers import load_golden
+from muzero_amd import mcts
+from muzero_amd.mcts import MinMaxStats, Node
+
+TREE = load_golden('tree_cases.npz')
+
+
+def _case(i):
+    return {k[len(f'c{i}_'):]: TREE[k] for k in TREE.files if k.startswith(f'c{i}_')}
+
+
+@pytest.mark.parametrize('i', range(int(TREE['num_cases'])))
+def test_node_search_loop_matches_reference_traces(i, monkeypatch):
+    c = _case(i)
+    A, S = int(c['A']), int(c['sims'])
+    kb = mcts.KnownBounds(float(c['kb_min']), float(c['kb_max'])) if int(c['has_bounds']) else None
+    cfg = types.SimpleNamespace(discount=float(c['discount']), pb_c_base=float(c['pb_c_base']), pb_c_init=float(c['pb_c_init']),
+                                is_board_game=bool(c['board']))
+    ties = iter(c['u_tie'])
+
+    def choice(cand, *a, **k):  # np.random.choice on the tie set: the recorded draw picks floor(u * n)
+        cand = np.asarray(cand)
+        if cand.shape[0] == 1:
+            return cand[0]
+        return cand[int(next(ties) * cand.shape[0])]
+
+    monkeypatch.setattr(np.random, 'choice', choice)
+    mm = MinMaxStats(kb)
+    prior = c['pi0'].astype(np.float32)
+    if int(c['has_noise']):
+        prior = mcts.add_dirichlet_noise(prior, eps=float(c['eps']), alpha=float(c['alpha']), noise=c['noise'])
+    mask = c['mask'].astype(bool)
+    prior = mcts.set_illegal_action_probs_to_zero(mask, prior)
+    root = Node(prior=0.0)
+    root.expand(prior, int(c['cur_player']), np.zeros(1, np.float32), 0.0)
+    index_of = {root: 0}
+    for s in range(S):
+        node, cp, op = root, int(c['cur_player']), int(c['opp_player'])
+        while node.is_expanded:
+            node = node.best_child(mm, cfg)
+            cp, op = op, cp
+        assert index_of[node.parent] == int(c['trace_parent'][s]) and node.move == int(c['trace_action'][s])
+        node.expand(prior, cp, np.zeros(1, np.float32), float(c['rewards'][s]))
+        index_of[node] = s + 1
+        node.backup(float(c['values'][s]), cp, mm, cfg)
+    visits = np.where(mask, root.child_N, 0)
+    np.testing.assert_array_equal(visits, c['visits'])
+    np.testing.assert_array_equal(mcts.generate_play_policy(visits, float(c['temperature'])), c['out_pi'])
+    assert root.Q == float(c['out_root_value'])
+
+
+def test_node_api_surface_and_errors():
+    root = Node(prior=0.0)
+    assert root.N == 0 and root.W == 0.0 and root.reward == 0.0 and root.parent is None and root.move is None
+    assert root.hidden_state is None and root.children == [] and not root.is_expanded and root.player_id is None and not root.has_parent
+    with pytest.raises(ValueError):
+        root.best_child(MinMaxStats(None), None)
+    with pytest.raises(ValueError):
+        root.expand(np.ones(3, np.int32), 1, None, 0.0)
+    with pytest.raises(ValueError):
+        root.expand(np.ones((3, 1), np.float32), 1, None, 0.0)
+    h = np.arange(4, dtype=np.float32)
+    root.expand(np.array([0.2, 0.3, 0.5], np.float32), 1, h, 0.25)
+    with pytest.raises(RuntimeError):
+        root.expand(np.ones(3, np.float32), 1, None, 0.0)
+    kids = root.children
+    assert len(kids) == 3 and [k.move for k in kids] == [0, 1, 2] and all(k.parent == root and k.has_parent for k in kids)
+    assert kids[1].prior == np.float32(0.3) and root.hidden_state is h and root.reward == 0.25 and root.player_id == 1
+    assert root.child_N.dtype == np.int32 and root.child_N.tolist() == [0, 0, 0]
+    cfg = types.SimpleNamespace(discount=0.997, pb_c_base=19652, pb_c_init=1.25, is_board_game=False)
+    assert root.child_Q(MinMaxStats(None), cfg).dtype == np.float32 and root.child_U(cfg).dtype == np.float32
+    assert (root.child_U(cfg) == 0).all()  # sqrt(N_parent) == 0 on the first simulation: the uniform-tie quirk
+    grown = Node(prior=0.0)
+    grown.expand(np.full(200, 1 / 200, np.float64), 1, None, 0.0)  # storage grows past its initial capacity
+    assert len(grown.children) == 200 and grown.children[199].move == 199
