@@ -13,6 +13,7 @@
 
 #include "mz_conv.h"
 #include "mz_search.h"
+#include "mz_tower.h"
 
 namespace mz {
 
@@ -40,6 +41,10 @@ struct ConvNetDev {
     int in_c = 0, in_h = 0, in_w = 0, A = 0, R = 0, P = 0, Sv = 1, Sr = 1, hh = 0, hw = 0;
     ConvLayerDev rep_conv, rep_conv2;
     std::vector<ResBlockDev> rep_res, dyn_res, pred_res;
+    // fused-tower launch tables (mz_tower.h): device arrays of per-conv weight / bias pointers, [2 * blocks] each
+    const float** tw_rep = nullptr; const float** tb_rep = nullptr;
+    const float** tw_dyn = nullptr; const float** tb_dyn = nullptr;
+    const float** tw_pred = nullptr; const float** tb_pred = nullptr;
     ConvLayerDev dyn_conv;
     HeadDev reward, policy, value;
     std::vector<void*> allocs;
@@ -179,6 +184,21 @@ inline int convnet_build(ConvNetDev& n, const ParamMap& pm, std::string* err) {
     if ((rc = build_head(n, pm, "dynamics_net.reward_head", P, 1, hw, n.Sr, &n.reward, err))) return rc;
     if ((rc = build_head(n, pm, "prediction_net.policy_net", P, 2, hw, n.A, &n.policy, err))) return rc;
     if ((rc = build_head(n, pm, "prediction_net.value_net", P, 1, hw, n.Sv, &n.value, err))) return rc;
+    auto table = [&](const std::vector<ResBlockDev>& blocks, const float*** w, const float*** b) -> int {
+        std::vector<const float*> hw_, hb_;
+        for (const ResBlockDev& r : blocks) { hw_.push_back(r.c1.w); hw_.push_back(r.c2.w); hb_.push_back(r.c1.b); hb_.push_back(r.c2.b); }
+        if (hw_.empty()) return 0;
+        for (auto pr : {std::make_pair(&hw_, w), std::make_pair(&hb_, b)}) {
+            void* d = nullptr;
+            if (hipMalloc(&d, pr.first->size() * sizeof(float*)) != hipSuccess) return -2;
+            n.allocs.push_back(d);
+            if (hipMemcpy(d, pr.first->data(), pr.first->size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess) return -2;
+            *pr.second = reinterpret_cast<const float**>(d);
+        }
+        return 0;
+    };
+    if (n.kind == 1 && table(n.rep_res, &n.tw_rep, &n.tb_rep)) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+    if (table(n.dyn_res, &n.tw_dyn, &n.tb_dyn) || table(n.pred_res, &n.tw_pred, &n.tb_pred)) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
     return 0;
 }
 
@@ -299,8 +319,63 @@ inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     }
 }
 
-// residual tower in place on x (dense), t1/t2 scratch; returns the buffer holding the result
-inline float* tower_run(hipStream_t st, const std::vector<ResBlockDev>& blocks, int first, int count, int B, float* x, float* t1, float* t2, int h, int w) {
+// Geometry of the fused LDS-resident tower (mz_tower.h) for a P-channel tower on h x w images, or npt == 0 if it does not apply
+struct TowerGeom {
+    int G, npt, nposp;
+    size_t lds;
+};
+
+inline TowerGeom tower_geometry(int B, int P, int h, int w) {
+    TowerGeom best{0, 0, 0, 0};
+    if (P > 128 || (P & 15) || env_int("MZ_TOWER", 1) == 0) return best;
+    const int hw = h * w, n_cb = P / 16;
+    double best_score = -1.0;
+    for (int G = 1; G <= 16 && G <= B; G++) {
+        const int npt = (G * hw + 15) / 16;
+        if (npt > 6) break;
+        const int nposp = npt * 16;
+        const size_t lds = ((size_t)3 * n_cb * 4 * nposp * 4 + 4) * sizeof(float);
+        if (lds > 156 * 1024) break;
+        const long wgs = (B + G - 1) / G;
+        double score = (double)(G * hw) / (16.0 * npt);
+        if (wgs < 256) score *= (double)wgs / 256.0;
+        if (score > best_score + 1e-9) { best_score = score; best = TowerGeom{G, npt, nposp, lds}; }
+    }
+    return best;
+}
+
+template <int NPT>
+inline void tower_launch_npt(hipStream_t st, const TowerLaunch& L, int wgs, size_t lds) {
+    static bool attr_set = false;  // one planner thread per process configures this instantiation once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res_tower<NPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_res_tower<NPT>, dim3(wgs), dim3(512), lds, st, L);
+}
+
+// residual tower on x (dense), t1/t2 scratch; returns the buffer holding the result.  Small images take the fused
+// LDS-resident kernel (tables tw / tb: per-conv weight / bias pointers of `blocks`), the rest one k_conv3x3 launch per conv.
+inline float* tower_run(hipStream_t st, const std::vector<ResBlockDev>& blocks, int first, int count, int B, float* x, float* t1, float* t2, int h, int w,
+                        const float** tw = nullptr, const float** tb = nullptr) {
+    if (count > 0 && tw && tb) {
+        const TowerGeom g = tower_geometry(B, blocks[first].c1.cout, h, w);
+        if (g.npt) {
+            TowerLaunch L{};
+            L.in = x; L.out = t1; L.w = tw + 2 * first; L.bias = tb + 2 * first; L.n_convs = 2 * count;
+            L.P = blocks[first].c1.cout; L.h = h; L.w_img = w; L.G = g.G; L.B = B; L.nposp = g.nposp; L.stamps = nullptr;
+            const int wgs = (B + g.G - 1) / g.G;
+            switch (g.npt) {
+                case 1: tower_launch_npt<1>(st, L, wgs, g.lds); break;
+                case 2: tower_launch_npt<2>(st, L, wgs, g.lds); break;
+                case 3: tower_launch_npt<3>(st, L, wgs, g.lds); break;
+                case 4: tower_launch_npt<4>(st, L, wgs, g.lds); break;
+                case 5: tower_launch_npt<5>(st, L, wgs, g.lds); break;
+                default: tower_launch_npt<6>(st, L, wgs, g.lds); break;
+            }
+            return t1;
+        }
+    }
     for (int i = first; i < first + count; i++) {
         conv_run(st, blocks[i].c1, B, x, nullptr, nullptr, 0, h, w, nullptr, t1, true);
         conv_run(st, blocks[i].c2, B, t1, nullptr, nullptr, 0, h, w, x, t2, true);
@@ -342,7 +417,7 @@ inline void convnet_tail(hipStream_t st, ConvNetDev& n, int B, float* x, float* 
         else if (cpt <= 32) hipLaunchKernelGGL(k_normalize_planes<32>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
         else hipLaunchKernelGGL(k_normalize_planes<64>, grid, block, 0, st, x, dst_ptrs, dst_dense, nrm, B, n.P, hw);
     }
-    float* f = tower_run(st, n.pred_res, 0, n.R, B, nrm, x, t2, n.hh, n.hw);
+    float* f = tower_run(st, n.pred_res, 0, n.R, B, nrm, x, t2, n.hh, n.hw, n.tw_pred, n.tb_pred);
     if (pi) head_run(st, n.policy, B, f, nullptr, hw, 1, nullptr, pi);
     head_run(st, n.value, B, f, nullptr, hw, 0, value, nullptr);
 }
@@ -355,7 +430,7 @@ inline void convnet_initial(hipStream_t st, ConvNetDev& n, int B, const float* o
     float* x;
     conv_run(st, n.rep_conv, B, obs, nullptr, nullptr, 0, h, w, nullptr, a, true);  // board: conv+BN+ReLU (:389); Atari: conv_1+ReLU (:346)
     if (n.kind == 1) {
-        x = tower_run(st, n.rep_res, 0, n.R, B, a, b, c, h, w);
+        x = tower_run(st, n.rep_res, 0, n.R, B, a, b, c, h, w, n.tw_rep, n.tb_rep);
     } else {
         h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
         x = tower_run(st, n.rep_res, 0, 2, B, a, b, c, h, w);
@@ -383,7 +458,7 @@ inline void convnet_recurrent(hipStream_t st, ConvNetDev& n, int B, const float*
                               size_t store_floats = 0) {
     const int h = n.hh, w = n.hw, hw = h * w;
     conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true, store_base, store_floats);
-    float* x = tower_run(st, n.dyn_res, 0, n.R, B, n.bufA, n.bufB, n.bufC, h, w);
+    float* x = tower_run(st, n.dyn_res, 0, n.R, B, n.bufA, n.bufB, n.bufC, h, w, n.tw_dyn, n.tb_dyn);
     head_run(st, n.reward, B, x, nullptr, hw, 0, reward, nullptr);  // the reward head reads the un-normalised state (:447-448)
     convnet_tail(st, n, B, x, dst_ptrs, dst_dense, pi, value);
 }

@@ -389,6 +389,7 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
         ConvNetDev fresh = p->cnet;
         fresh.allocs.clear(); fresh.rep_res.clear(); fresh.dyn_res.clear(); fresh.pred_res.clear();
         fresh.bufA = fresh.bufB = fresh.bufC = nullptr; fresh.buf_elems = 0;
+        fresh.tw_rep = fresh.tb_rep = fresh.tw_dyn = fresh.tb_dyn = fresh.tw_pred = fresh.tb_pred = nullptr;
         convnet_free(p->cnet);
         p->cnet = fresh;
         ParamMap pm;
