@@ -41,10 +41,8 @@ struct ConvNetDev {
     int in_c = 0, in_h = 0, in_w = 0, A = 0, R = 0, P = 0, Sv = 1, Sr = 1, hh = 0, hw = 0;
     ConvLayerDev rep_conv, rep_conv2;
     std::vector<ResBlockDev> rep_res, dyn_res, pred_res;
-    // fused-tower launch tables (mz_tower.h): device arrays of per-conv weight / bias pointers, [2 * blocks] each
-    const float** tw_rep = nullptr; const float** tb_rep = nullptr;
-    const float** tw_dyn = nullptr; const float** tb_dyn = nullptr;
-    const float** tw_pred = nullptr; const float** tb_pred = nullptr;
+    // fused-tower copies (mz_tower.h): the packed weights / biases of a tower's 2 * blocks convs back to back
+    const float *tw_rep = nullptr, *tb_rep = nullptr, *tw_dyn = nullptr, *tb_dyn = nullptr, *tw_pred = nullptr, *tb_pred = nullptr;
     ConvLayerDev dyn_conv;
     HeadDev reward, policy, value;
     std::vector<void*> allocs;
@@ -184,17 +182,21 @@ inline int convnet_build(ConvNetDev& n, const ParamMap& pm, std::string* err) {
     if ((rc = build_head(n, pm, "dynamics_net.reward_head", P, 1, hw, n.Sr, &n.reward, err))) return rc;
     if ((rc = build_head(n, pm, "prediction_net.policy_net", P, 2, hw, n.A, &n.policy, err))) return rc;
     if ((rc = build_head(n, pm, "prediction_net.value_net", P, 1, hw, n.Sv, &n.value, err))) return rc;
-    auto table = [&](const std::vector<ResBlockDev>& blocks, const float*** w, const float*** b) -> int {
-        std::vector<const float*> hw_, hb_;
-        for (const ResBlockDev& r : blocks) { hw_.push_back(r.c1.w); hw_.push_back(r.c2.w); hb_.push_back(r.c1.b); hb_.push_back(r.c2.b); }
-        if (hw_.empty()) return 0;
-        for (auto pr : {std::make_pair(&hw_, w), std::make_pair(&hb_, b)}) {
-            void* d = nullptr;
-            if (hipMalloc(&d, pr.first->size() * sizeof(float*)) != hipSuccess) return -2;
-            n.allocs.push_back(d);
-            if (hipMemcpy(d, pr.first->data(), pr.first->size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess) return -2;
-            *pr.second = reinterpret_cast<const float**>(d);
-        }
+    auto table = [&](const std::vector<ResBlockDev>& blocks, const float** w, const float** b) -> int {
+        if (blocks.empty() || P > 128 || (P & 15)) return 0;
+        const size_t wn = (size_t)(P / 16) * (P / 16) * 9 * 256, n_convs = 2 * blocks.size();
+        float *dw = nullptr, *db = nullptr;
+        if (hipMalloc(&dw, n_convs * wn * sizeof(float)) != hipSuccess || hipMalloc(&db, n_convs * P * sizeof(float)) != hipSuccess) return -2;
+        n.allocs.push_back(dw); n.allocs.push_back(db);
+        size_t i = 0;
+        for (const ResBlockDev& r : blocks)
+            for (const ConvLayerDev* c : {&r.c1, &r.c2}) {
+                if (c->cin != P || c->cout != P) return 0;  // (Atari's 128-plane stage with another P: separate launches)
+                if (hipMemcpy(dw + i * wn, c->w, wn * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return -2;
+                if (hipMemcpy(db + i * P, c->b, P * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return -2;
+                i++;
+            }
+        *w = dw; *b = db;
         return 0;
     };
     if (n.kind == 1 && table(n.rep_res, &n.tw_rep, &n.tb_rep)) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
@@ -333,8 +335,8 @@ inline TowerGeom tower_geometry(int B, int P, int h, int w) {
     for (int G = 1; G <= 16 && G <= B; G++) {
         const int npt = (G * hw + 15) / 16;
         if (npt > 6) break;
-        const int nposp = npt * 16;
-        const size_t lds = ((size_t)3 * n_cb * 4 * nposp * 4 + 4) * sizeof(float);
+        const int nposp = npt * 16 + ((G * hw) % 16 == 0 ? 16 : 0);  // at least one padding position (it stays zero: the halo reads)
+        const size_t lds = (size_t)3 * n_cb * 4 * nposp * 4 * sizeof(float);
         if (lds > 156 * 1024) break;
         const long wgs = (B + G - 1) / G;
         double score = (double)(G * hw) / (16.0 * npt);
@@ -357,13 +359,14 @@ inline void tower_launch_npt(hipStream_t st, const TowerLaunch& L, int wgs, size
 // residual tower on x (dense), t1/t2 scratch; returns the buffer holding the result.  Small images take the fused
 // LDS-resident kernel (tables tw / tb: per-conv weight / bias pointers of `blocks`), the rest one k_conv3x3 launch per conv.
 inline float* tower_run(hipStream_t st, const std::vector<ResBlockDev>& blocks, int first, int count, int B, float* x, float* t1, float* t2, int h, int w,
-                        const float** tw = nullptr, const float** tb = nullptr) {
+                        const float* tw = nullptr, const float* tb = nullptr) {
     if (count > 0 && tw && tb) {
         const TowerGeom g = tower_geometry(B, blocks[first].c1.cout, h, w);
         if (g.npt) {
             TowerLaunch L{};
-            L.in = x; L.out = t1; L.w = tw + 2 * first; L.bias = tb + 2 * first; L.n_convs = 2 * count;
-            L.P = blocks[first].c1.cout; L.h = h; L.w_img = w; L.G = g.G; L.B = B; L.nposp = g.nposp; L.stamps = nullptr;
+            const int Pc = blocks[first].c1.cout;
+            L.in = x; L.out = t1; L.w = tw + (size_t)2 * first * (Pc / 16) * (Pc / 16) * 9 * 256; L.bias = tb + 2 * first * Pc; L.n_convs = 2 * count;
+            L.P = Pc; L.h = h; L.w_img = w; L.G = g.G; L.B = B; L.nposp = g.nposp; L.stamps = nullptr;
             const int wgs = (B + g.G - 1) / g.G;
             switch (g.npt) {
                 case 1: tower_launch_npt<1>(st, L, wgs, g.lds); break;
