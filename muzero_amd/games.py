@@ -139,3 +139,52 @@ class GomokuEnv(BoardGameEnv):
 
     def __init__(self, board_size: int = 15, stack_history: int = 4, num_to_win: int = 5) -> None:
         super().__init__(board_size=board_size, stack_history=stack_history, num_to_win=num_to_win, name='Gomoku')
+
+
+class CartPoleEnv:
+    """Host-side CartPole-v1 as the reference's `create_classic_environment('CartPole-v1', stack_history=4)` presents it
+    (`gym_env.py:271-365,436-459`): gym 0.23.1's published equations (an un-vendored dependency of the reference), float64
+    state, float32 observation rows [obs, (action + 1) / A] stacked newest first (reset fills every row with the first
+    observation and action 0), reward 1 per step, TimeLimit 500, players 1 / 1, all actions legal.  Same rules as the device
+    environment in `csrc/mz_env.h`; for evaluators and tools."""
+
+    num_actions = 2
+
+    def __init__(self, stack_history: int = 4, seed: int = 1) -> None:
+        self.stack_history = stack_history
+        self._rs = np.random.RandomState(seed)
+        self.current_player = self.opponent_player = 1
+        self.actions_mask = np.ones(self.num_actions, dtype=np.bool_)
+        self.observation_shape = (stack_history, 5)
+        self.reset()
+
+    def _row(self, action: int) -> np.ndarray:
+        return np.concatenate([self.state.astype(np.float32), np.array([(action + 1) / self.num_actions], np.float32)])
+
+    def reset(self, state=None) -> np.ndarray:
+        self.state = np.asarray(state, np.float64).copy() if state is not None else self._rs.uniform(-0.05, 0.05, size=4)
+        self.steps, self.done = 0, False
+        self._rows = [self._row(0) for _ in range(self.stack_history)]
+        return np.stack(self._rows, axis=0)
+
+    def step(self, action: int):
+        if self.done:
+            raise RuntimeError('Episode is over, call reset before using step method.')
+        if action not in (0, 1):
+            raise ValueError(f'Invalid action {action}')
+        gravity, masscart, masspole, length, force_mag, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
+        total_mass, polemass_length = masspole + masscart, masspole * length
+        x, x_dot, theta, theta_dot = self.state
+        force = force_mag if action == 1 else -force_mag
+        costheta, sintheta = np.cos(theta), np.sin(theta)
+        temp = (force + polemass_length * theta_dot * theta_dot * sintheta) / total_mass
+        thetaacc = (gravity * sintheta - costheta * temp) / (length * (4.0 / 3.0 - masspole * costheta * costheta / total_mass))
+        xacc = temp - polemass_length * thetaacc * costheta / total_mass
+        x, x_dot = x + tau * x_dot, x_dot + tau * xacc
+        theta, theta_dot = theta + tau * theta_dot, theta_dot + tau * thetaacc
+        self.state = np.array([x, x_dot, theta, theta_dot], np.float64)
+        self.steps += 1
+        failed = x < -2.4 or x > 2.4 or theta < -12 * 2 * np.pi / 360 or theta > 12 * 2 * np.pi / 360
+        self.done = bool(failed or self.steps >= 500)
+        self._rows = [self._row(int(action))] + self._rows[:-1]
+        return np.stack(self._rows, axis=0), 1.0, self.done, {}

@@ -251,6 +251,46 @@ def run_board_game_evaluator(config, old_checkpoint_network, new_ckpt_network, d
     return black_elo
 
 
+def run_evaluator(config, new_ckpt_network, device, env, temperature, checkpoint_files, stop_event, tag: str = None, num_episodes: int = 1,
+                  on_result=None) -> List:
+    """pipeline.py:400-488: for every new checkpoint, `num_episodes` deterministic episodes on a host environment exposing
+    `reset / step / actions_mask / current_player / opponent_player` (e.g. `games.CartPoleEnv`), searches through the HIP
+    planner.  `on_result(eval_returns, eval_steps, train_steps)` stands in for the tensorboard trackers; the list of those
+    triples is returned."""
+    from muzero_amd import mcts
+
+    for p in new_ckpt_network.parameters():
+        p.requires_grad = False
+    results = []
+    while True:
+        if stop_event.is_set() and len(checkpoint_files) == 0:
+            break
+        if len(checkpoint_files) == 0:
+            time.sleep(0.001)
+            continue
+        loaded_state = load_checkpoint(checkpoint_files.pop(0), device)
+        new_ckpt_network.load_state_dict(loaded_state['network'])
+        train_steps = loaded_state['train_steps']
+        new_ckpt_network.eval()
+        eval_returns, eval_steps = [], []
+        for _ in range(num_episodes):
+            obs = env.reset()
+            done, steps, returns = False, 0, 0.0
+            while not done:
+                action, *_ = mcts.uct_search(state=obs, network=new_ckpt_network, device=device, config=config, temperature=temperature,
+                                             actions_mask=env.actions_mask, current_player=env.current_player,
+                                             opponent_player=env.opponent_player, deterministic=True)
+                obs, reward, done, _ = env.step(action)
+                steps += 1
+                returns += reward
+            eval_returns.append(returns)
+            eval_steps.append(steps)
+        results.append((eval_returns, eval_steps, train_steps))
+        if on_result is not None:
+            on_result(eval_returns, eval_steps, train_steps)
+    return results
+
+
 def rank_env() -> tuple:
     """(rank, local_rank, world_size) from the torchrun environment."""
     return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))

@@ -110,3 +110,25 @@ def test_board_game_evaluator_plays_checkpoints(tmp_path):
     assert len(results) == 2 and [r[2] for r in results] == [100, 200] and files == []
     assert all(1 <= r[1] <= 9 for r in results)  # at most 9 plies; untrained nets may resign (action 9) early
     assert results[0][0] in (-2000, -1984.0, -2016.0) and elo == results[1][0]
+
+
+def test_classic_evaluator_runs_cartpole_checkpoints(tmp_path):
+    """pipeline.py:400-488 on the host CartPole env: deterministic searches through the HIP planner until the pole falls."""
+    import threading
+
+    from muzero_amd import pipeline
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.games import CartPoleEnv
+
+    dev = torch.device('cuda', 0)
+    cfg = make_classic_config(use_tensorboard=False)
+    cfg.num_simulations = 10
+    net = build_mlp(mlp_case('cartpole'))
+    f = tmp_path / 'train_steps_7'
+    pipeline.create_checkpoint({'network': net.state_dict(), 'optimizer': {}, 'lr_scheduler': {}, 'train_steps': 7}, f)
+    files, stop = [f], threading.Event()
+    stop.set()
+    res = pipeline.run_evaluator(cfg, build_mlp(mlp_case('cartpole')), dev, CartPoleEnv(4, seed=3), 0.0, files, stop, num_episodes=2)
+    assert len(res) == 1 and res[0][2] == 7 and len(res[0][0]) == 2
+    for ret, steps in zip(res[0][0], res[0][1]):
+        assert ret == float(steps) and 8 <= steps <= 500  # reward 1 per step; an untrained net drops the pole quickly
