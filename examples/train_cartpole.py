@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""End-to-end MuZero on CartPole-v1 with the MI355X planner: device-resident self-play (search + env + records in HBM) ->
+host episode assembly (the reference's n-step targets / unroll sequences) -> HBM-resident replay -> learner step (the
+reference's calc_loss, Adam, MultiStepLR) -> weights back into the planner.  One process, one GPU, no actor processes:
+the roles of classic/run_training.py's six actors, data collector thread and learner thread are interleaved in one loop.
+
+    python examples/train_cartpole.py --train-steps 3000 --envs 128
+
+Hyper-parameters are the reference's classic config (config.py:170-201, classic/run_training.py:33-56): 50 simulations,
+discount 0.997, td_steps 10, unroll 5, Adam lr 5e-3 / weight decay 1e-4, batch 128, replay 50 000, uniform sampling,
+temperature 1.0 for the first 30 k training steps.  Prints one JSON line per report with the mean length of the episodes
+that finished since the previous report (500 is the environment's cap)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--train-steps', type=int, default=3000)
+    ap.add_argument('--envs', type=int, default=128)
+    ap.add_argument('--moves-per-iter', type=int, default=8)
+    ap.add_argument('--updates-per-iter', type=int, default=16)
+    ap.add_argument('--report-every', type=int, default=250)
+    ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--eval-episodes', type=int, default=3)
+    ap.add_argument('--out', default='')
+    args = ap.parse_args()
+
+    from muzero_amd import learner
+    from muzero_amd import planner as pl
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.network import MuZeroMLPNet
+    from muzero_amd.pipeline import EpisodeAssembler
+    from muzero_amd.replay import PrioritizedReplay
+
+    torch.manual_seed(args.seed)
+    dev = torch.device('cuda', 0)
+    cfg = make_classic_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
+    cfg.num_envs = args.envs
+    net = MuZeroMLPNet((4, 5), 2, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    replay = PrioritizedReplay(50000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
+
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
+    net.eval()
+    p.load_state_dict(net.state_dict())
+    p.selfplay_reset(pl.ENV_CARTPOLE)
+    asm = EpisodeAssembler(cfg, args.envs)
+
+    steps, t0, last = 0, time.time(), dict(episodes=0, episode_steps=0)
+    log = []
+    while steps < args.train_steps:
+        T = float(cfg.visit_softmax_temperature_fn(0, steps))
+        p.selfplay_step(T, args.moves_per_iter)
+        for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
+            replay.add(tr, prio)
+        if replay.size < cfg.min_replay_size:
+            continue
+        net.train()
+        for _ in range(args.updates_per_iter):
+            batch, idx, w = replay.sample_tensors(cfg.batch_size)
+            loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
+            replay.update_priorities(idx, prio)
+            steps += 1
+            if steps % args.report_every == 0:
+                c = p.selfplay_counters()
+                de, ds = c['episodes'] - last['episodes'], c['episode_steps'] - last['episode_steps']
+                last = dict(episodes=c['episodes'], episode_steps=c['episode_steps'])
+                rec = dict(train_steps=steps, env_steps=c['env_steps'], episodes_finished=de, mean_episode_length=(ds / de) if de else None,
+                           loss=loss, replay=replay.size, seconds=round(time.time() - t0, 1))
+                log.append(rec)
+                print(json.dumps(rec), flush=True)
+        net.eval()
+        p.load_state_dict(net.state_dict())  # actor <- learner (the reference does this every checkpoint_interval steps)
+    # deterministic evaluation episodes (pipeline.py:400-488: argmax of the visit counts, no root noise) on the host env
+    from muzero_amd import mcts
+    from muzero_amd.games import CartPoleEnv
+
+    net.eval()
+    lengths = []
+    for ep in range(args.eval_episodes):
+        env = CartPoleEnv(4, seed=1000 + ep)
+        obs, done = env.reset(), False
+        while not done:
+            action, *_ = mcts.uct_search(obs, net, dev, cfg, 0.0, env.actions_mask, 1, 1, deterministic=True)
+            obs, _, done, _ = env.step(action)
+        lengths.append(env.steps)
+    print(json.dumps(dict(eval_episode_lengths=lengths)), flush=True)
+    if args.out:
+        json.dump(dict(args=vars(args), log=log, eval_episode_lengths=lengths), open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
