@@ -236,6 +236,41 @@ def test_production_rng_properties():
     assert abs(r['action'].mean() - r['pi'][:, 1].mean()) < 0.03
 
 
+def test_full_size_c3_properties_and_oracle_sample(oracle):
+    """BASELINE configs[2] at full size (TicTacToe MLP, 4096 envs, 25 simulations, two-player backup, bounds (-1, 1)) in
+    parity mode: every 64th env is checked bit-exactly against the oracle, all envs against the size-independent properties
+    (masked visit counts, policy = visits^(1/T) normalised, legal actions, a pure function of inputs and draws)."""
+    case = mlp_case('tictactoe')
+    net = build_mlp(case)
+    onet = _oracle_net(oracle, net, 'mlp')
+    B, S, A = 4096, 25, 10
+    kw = dict(num_simulations=S, discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    rs = np.random.RandomState(31)
+    obs = (rs.rand(B, 9, 3, 3) < 0.3).astype(np.float32)
+    mask = rs.rand(B, A) < 0.7
+    mask[np.arange(B), rs.randint(0, A, B)] = True
+    cur = rs.randint(1, 3, B).astype(np.int32)
+    opp = (3 - cur).astype(np.int32)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie, u_final = rs.rand(B, 4 * S + 8), rs.rand(B)
+    p = _planner(net, B, **kw)
+    r1 = p.search(obs, mask, cur, opp, 1.0, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    r2 = p.search(obs, mask, cur, opp, 1.0, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    for k in ('visits', 'pi', 'action', 'root_value'):
+        np.testing.assert_array_equal(r1[k], r2[k])
+    v = r1['visits']
+    ok = v.sum(1) > 0  # (all visits on illegal root children: the reference's 0/0 policy, see DESIGN.md)
+    assert (v[~mask] == 0).all() and (v.sum(1) <= S).all() and ok.mean() > 0.95
+    np.testing.assert_array_equal(r1['pi'][ok], v[ok] / v[ok].sum(1, keepdims=True))
+    assert mask[np.arange(B), r1['action']][ok].all()
+    sub = np.arange(0, B, 64)
+    ocfg = oracle.make_config(A, S, 1.0, True, (-1.0, 1.0), 0.25, 0.25)
+    o = oracle.uct_search_batch(ocfg, onet, obs[sub], mask[sub].astype(np.uint8), cur[sub], opp[sub], np.ones(len(sub)), False, noise=noise[sub],
+                                u_tie=u_tie[sub], u_final=u_final[sub])
+    for k in ('visits', 'pi', 'action', 'root_value'):
+        np.testing.assert_array_equal(r1[k][sub], o[k])
+
+
 def test_selfplay_episode_matches_reference_fixture(oracle):
     """pipeline.py:41-167 on TicTacToe replayed through uct_search (B=1 API) with the recorded draws."""
     from muzero_amd import mcts
