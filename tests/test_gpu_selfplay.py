@@ -154,3 +154,29 @@ def test_synthetic_frame_env_runs_atari_net():
     assert not np.array_equal(rec['obs'][0], rec['obs'][1])
     np.testing.assert_allclose(rec['pi'].sum(-1), 1.0, atol=1e-12)
     np.testing.assert_array_equal(rec['pi'], np.round(rec['pi'] * 4) / 4)
+
+
+def test_run_self_play_gomoku_conv_net_emits_mc_return_items():
+    """pipeline.run_self_play on the device Gomoku env with a conv (board) network: reference-shaped items, Monte-Carlo
+    returns in {-1, 0, 1}, observations are the 9-plane board stacks."""
+    import torch
+    from helpers import build_conv, conv_case
+    from muzero_amd import pipeline
+    from muzero_amd.config import make_gomoku_config
+
+    net = build_conv(conv_case('board9'))
+    cfg = make_gomoku_config(use_tensorboard=False)
+    cfg.num_envs, cfg.num_simulations = 16, 8
+    q = queue.SimpleQueue()
+    stop = types.SimpleNamespace(is_set=lambda: False)
+    steps = pipeline.run_self_play(cfg, 0, net, torch.device('cuda', 0), 'Gomoku', q, types.SimpleNamespace(value=0), stop, max_moves=96,
+                                   moves_per_drain=16)
+    assert steps == 96 * 16
+    items = []
+    while not q.empty():
+        items.append(q.get())
+    assert len(items) > 16  # at least one finished game per env slot on average (81 points, random-ish play)
+    for tr, prio in items:
+        assert tr.state.shape == (9 * 9 * 9,) and set(np.unique(tr.state)).issubset({0.0, 1.0})
+        assert tr.action.shape == (5,) and tr.pi_prob.shape == (5, 82) and tr.value.shape == (5,)
+        assert set(np.unique(tr.value)).issubset({-1.0, 0.0, 1.0}) and np.isfinite(prio)
