@@ -103,6 +103,44 @@ def conv_flops(case):
     return 2 * sim, 2 * root
 
 
+def conv_cpu_baseline(name, case, net, kw, full_sims):
+    """The oracle (scalar C port, one env per OpenMP thread, batch-1 inference like the reference's actors) on a bounded
+    sample of the same network.  MLP nets: whole searches.  Conv nets: one root per thread searched with 2 and with 6
+    simulations; the difference gives the cost of a simulation, the rest the root inference, and the reported rate is that of
+    whole moves of `full_sims` simulations (root inference included once per move, as in the reference)."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import oracle  # test infrastructure, used here only as the reported CPU baseline
+    from test_oracle_nets import _oracle_net
+
+    onet = _oracle_net(oracle, net, 'mlp' if name == 'c3' else 'conv')
+    A = case[3]
+    threads = max(1, (os.cpu_count() or 2) // 2)
+    rs = np.random.RandomState(5)
+    board = bool(kw.get('is_board_game', False))
+
+    def run(n_envs, sims):
+        obs = rs.uniform(0, 1, size=(n_envs,) + tuple(case[2])).astype(np.float32)
+        cfg = oracle.make_config(A, sims, kw['discount'], board, kw.get('known_bounds'), kw['root_dirichlet_alpha'], 0.25)
+        noise = rs.dirichlet(np.full(A, kw['root_dirichlet_alpha']), size=n_envs)
+        t0 = time.perf_counter()
+        oracle.uct_search_batch(cfg, onet, obs, np.ones((n_envs, A), np.uint8), 1, 2 if board else 1, 1.0, False, noise=noise,
+                                u_tie=rs.rand(n_envs, 4 * sims + 8), u_final=rs.rand(n_envs), num_threads=threads)
+        return time.perf_counter() - t0
+
+    if name == 'c3':
+        n = threads * 8
+        dt = run(n, full_sims)
+        return dict(value=n * full_sims / dt, unit='sims/s', cores=threads, kind='port',
+                    sample=f'{n} roots x {full_sims} simulations, oracle/mz_oracle.c, {threads} OpenMP threads, {dt:.1f} s')
+    t2, t6 = run(threads, 2), run(threads, 6)
+    t_sim = max(1e-9, (t6 - t2) / 4.0)
+    t_root = max(0.0, t2 - 2.0 * t_sim)
+    rate = threads * full_sims / (t_root + full_sims * t_sim)
+    return dict(value=rate, unit='sims/s', cores=threads, kind='port',
+                sample=f'{threads} roots (one per OpenMP thread) searched with 2 and 6 simulations, oracle/mz_oracle.c: {t_sim:.3f} s per simulation, '
+                       f'{t_root:.2f} s per root inference per thread; rate of whole {full_sims}-simulation moves')
+
+
 def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev='cuda'):
     from helpers import build_conv, build_mlp, mlp_case
     from muzero_amd import build as mz_build
@@ -151,7 +189,11 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
         ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
         flop_per_move = B * (S * f_sim + f_root)
         achieved = flop_per_move / (ms * 1e-3) / 1e12
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = conv_cpu_baseline(name, case, net, kw, S)
         print(json.dumps({
+            'cpu_baseline': cpu,
             'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)', 'value': sims_per_s, 'unit': 'sims/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
