@@ -32,114 +32,110 @@ TransitionStructure = Transition(state=None, action=None, pi_prob=None, value=No
 class PrioritizedReplay:
     """replay.py:39-142 with array storage.  `priority_exponent == 0` is uniform replay (all launchers' default)."""
 
+    FIELDS = Transition._fields
+
     def __init__(self, capacity: int, priority_exponent: float, importance_sampling_exponent: float, random_state: np.random.RandomState,
                  device='cpu'):
         if capacity <= 0:
             raise ValueError(f'Expect capacity to be a positive integer, got {capacity}')
         self.structure = TransitionStructure
-        self._capacity = int(capacity)
-        self._random_state = random_state
-        self._num_added = 0
-        self._priority_exponent = priority_exponent
-        self._importance_sampling_exponent = importance_sampling_exponent
-        self._priorities = np.zeros((capacity,), dtype=np.float32)
-        self._device = torch.device(device)
-        self._store = None  # dict field -> tensor [capacity, ...], allocated on the first add (shapes come from the data)
+        self._cap, self._count = int(capacity), 0
+        self._rng = random_state
+        self._alpha, self._beta = priority_exponent, importance_sampling_exponent
+        self._prio = np.zeros(self._cap, dtype=np.float32)
+        self._dev = torch.device(device)
+        self._ring = None  # field -> tensor [capacity, ...]; allocated on the first add, when the shapes are known
 
     # ---- storage ----
-    def _allocate(self, item: Transition) -> None:
-        self._store = {}
-        for name, x in zip(Transition._fields, item):
-            a = np.asarray(x)
-            self._store[name] = torch.zeros((self._capacity,) + a.shape, dtype=torch.from_numpy(np.zeros(1, a.dtype)).dtype, device=self._device)
-
-    def add(self, item: Transition, priority: float) -> None:
-        """Adds single item to replay (replay.py:67-75)."""
-        if not np.isfinite(priority) or priority < 0.0:
-            raise ValueError('Priority must be finite and positive.')
-        if self._store is None:
-            self._allocate(item)
-        index = self._num_added % self._capacity
-        for name, x in zip(Transition._fields, item):
-            self._store[name][index] = torch.from_numpy(np.ascontiguousarray(x))
-        self._priorities[index] = priority
-        self._num_added += 1
-
-    def add_batch(self, items: Transition, priorities: Sequence[float]) -> None:
-        """Adds n items at once (fields stacked on axis 0): the form the device-resident actor produces."""
-        pr = np.asarray(priorities, np.float64)
+    @staticmethod
+    def _check_priorities(pr) -> None:
+        pr = np.asarray(pr, np.float64)
         if not np.isfinite(pr).all() or (pr < 0.0).any():
             raise ValueError('Priority must be finite and positive.')
-        n = len(pr)
-        if self._store is None:
+
+    def _allocate(self, item: Transition) -> None:
+        self._ring = {}
+        for name, x in zip(self.FIELDS, item):
+            a = np.asarray(x)
+            self._ring[name] = torch.zeros((self._cap,) + a.shape, dtype=torch.from_numpy(np.zeros(1, a.dtype)).dtype, device=self._dev)
+
+    def add(self, item: Transition, priority: float) -> None:
+        """One item into the ring slot `num_added % capacity` (replay.py:67-75)."""
+        self._check_priorities(priority)
+        if self._ring is None:
+            self._allocate(item)
+        slot = self._count % self._cap
+        for name, x in zip(self.FIELDS, item):
+            self._ring[name][slot] = torch.from_numpy(np.ascontiguousarray(x))
+        self._prio[slot] = priority
+        self._count += 1
+
+    def add_batch(self, items: Transition, priorities: Sequence[float]) -> None:
+        """n items at once (fields stacked on axis 0): the form the device-resident actor produces."""
+        self._check_priorities(priorities)
+        n = len(priorities)
+        if self._ring is None:
             self._allocate(Transition(*[np.asarray(x)[0] for x in items]))
-        idx = (self._num_added + np.arange(n)) % self._capacity
-        tidx = torch.from_numpy(idx).to(self._device)
-        for name, x in zip(Transition._fields, items):
+        slots = (self._count + np.arange(n)) % self._cap
+        tslots = torch.from_numpy(slots).to(self._dev)
+        for name, x in zip(self.FIELDS, items):
             x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
-            self._store[name][tidx] = x.to(self._device, dtype=self._store[name].dtype)
-        self._priorities[idx] = pr
-        self._num_added += n
+            self._ring[name][tslots] = x.to(self._dev, dtype=self._ring[name].dtype)
+        self._prio[slots] = np.asarray(priorities, np.float32)
+        self._count += n
 
     def get(self, indices: Sequence[int]) -> List[Transition]:
-        """Retrieves items by indices (replay.py:77-79)."""
-        return [Transition(*[self._store[f][int(i)].cpu().numpy() for f in Transition._fields]) for i in indices]
+        """Items by index (replay.py:77-79)."""
+        return [Transition(*[self._ring[f][int(i)].cpu().numpy() for f in self.FIELDS]) for i in indices]
 
     # ---- sampling ----
     def _draw(self, batch_size: int) -> Tuple[np.ndarray, np.ndarray]:
-        if self.size < batch_size:
-            raise RuntimeError(f'Replay only have {self.size} samples, got sample batch size {batch_size}')
-        if self._priority_exponent == 0:
-            indices = self._random_state.uniform(0, self.size, size=batch_size).astype(np.int64)
-            weights = np.ones_like(indices, dtype=np.float32)
-        else:
-            priorities = self._priorities[: self.size] ** self._priority_exponent
-            probs = priorities / np.sum(priorities)
-            indices = np.random.choice(np.arange(probs.shape[0]), size=batch_size, replace=True, p=probs)
-            weights = ((1.0 / self.size) / probs[indices]) ** self._importance_sampling_exponent
-            weights /= np.max(weights)
-        return indices, weights
+        n = self.size
+        if n < batch_size:
+            raise RuntimeError(f'Replay only have {n} samples, got sample batch size {batch_size}')
+        if self._alpha == 0:  # uniform: the RandomState handed to the constructor (replay.py:87-89)
+            picks = self._rng.uniform(0, n, size=batch_size).astype(np.int64)
+            return picks, np.ones_like(picks, dtype=np.float32)
+        # proportional: the process-global numpy RNG, as upstream (replay.py:90-98)
+        scaled = self._prio[:n] ** self._alpha
+        probs = scaled / np.sum(scaled)
+        picks = np.random.choice(np.arange(probs.shape[0]), size=batch_size, replace=True, p=probs)
+        is_w = ((1.0 / n) / probs[picks]) ** self._beta
+        is_w /= np.max(is_w)
+        return picks, is_w
 
     def sample_tensors(self, batch_size: int) -> Tuple[Transition, np.ndarray, np.ndarray]:
         """Like `sample`, but the batch stays on the replay's device as torch tensors (no host copy)."""
-        indices, weights = self._draw(batch_size)
-        tidx = torch.from_numpy(indices).to(self._device)
-        return Transition(*[self._store[f].index_select(0, tidx) for f in Transition._fields]), indices, weights
+        picks, is_w = self._draw(batch_size)
+        tpicks = torch.from_numpy(picks).to(self._dev)
+        return Transition(*[self._ring[f].index_select(0, tpicks) for f in self.FIELDS]), picks, is_w
 
     def sample(self, batch_size: int) -> Tuple[Transition, np.ndarray, np.ndarray]:
-        """Samples batch of items from replay, with replacement (replay.py:81-104): numpy arrays stacked on axis 0."""
-        batch, indices, weights = self.sample_tensors(batch_size)
-        return Transition(*[x.cpu().numpy() for x in batch]), indices, weights
+        """A batch with replacement (replay.py:81-104): numpy arrays stacked on axis 0, the indices, the IS weights."""
+        batch, picks, is_w = self.sample_tensors(batch_size)
+        return Transition(*[x.cpu().numpy() for x in batch]), picks, is_w
 
     def update_priorities(self, indices: Sequence[int], priorities: Sequence[float]) -> None:
-        """replay.py:106-113"""
-        priorities = np.asarray(priorities)
-        if not np.isfinite(priorities).all() or (priorities < 0.0).any():
+        """replay.py:106-113 (a repeated index keeps the last value, like the reference's loop)."""
+        pr = np.asarray(priorities)
+        if not np.isfinite(pr).all() or (pr < 0.0).any():
             raise ValueError('Priorities must be finite and positive.')
-        for i, p in zip(indices, priorities):
-            self._priorities[i] = p
+        for i, v in zip(indices, pr):
+            self._prio[i] = v
 
     # ---- bookkeeping (replay.py:115-142) ----
-    @property
-    def num_added(self) -> int:
-        return self._num_added
-
-    @property
-    def size(self) -> int:
-        return min(self._num_added, self._capacity)
-
-    @property
-    def capacity(self) -> int:
-        return self._capacity
+    num_added = property(lambda self: self._count, doc='items added since construction / reset')
+    size = property(lambda self: min(self._count, self._cap), doc='items currently held')
+    capacity = property(lambda self: self._cap, doc='ring size')
 
     def reset(self) -> None:
-        self._num_added = 0
+        self._count = 0
 
     def get_state(self) -> Mapping[Text, Any]:
-        return {'num_added': self._num_added, 'storage': None if self._store is None else {k: v.cpu() for k, v in self._store.items()},
-                'priorities': self._priorities}
+        ring = None if self._ring is None else {k: v.cpu() for k, v in self._ring.items()}
+        return {'num_added': self._count, 'storage': ring, 'priorities': self._prio}
 
     def set_state(self, state: Mapping[Text, Any]) -> None:
-        self._num_added = state['num_added']
-        self._store = None if state['storage'] is None else {k: v.to(self._device) for k, v in state['storage'].items()}
-        self._priorities = state['priorities']
+        self._count = state['num_added']
+        self._ring = None if state['storage'] is None else {k: v.to(self._dev) for k, v in state['storage'].items()}
+        self._prio = state['priorities']
