@@ -437,6 +437,78 @@ __global__ void k_avgpool(const float* in, float* out, int B, int C, int ih, int
     }
 }
 
+// The dynamics net's action planes, exactly, without the dense work.  network.py:440-444 builds the [A, h, w] block whose flat
+// element f = c*h*w + pixel is 1 iff f % A == action.  When gcd(h*w, A) == 1 (every board game: A = h*w + 1) exactly ONE
+// action channel is 1 at any pixel: c = (action - pixel) * (h*w)^-1 mod A.  So of the A * 9 action-plane terms of an output
+// only <= 9 are non-zero (one per in-image tap), each adding fma(1, w, acc) = acc + w; all the others are fma(0, w, acc) = acc.
+// The dense kernel therefore runs over the REAL channels only (they fill the leading 16-channel blocks: planes % 16 == 0) and
+// writes the pre-activation; this kernel adds the <= 9 weights in the chain's order -- (16-channel block, tap, channel) -- and
+// applies the ReLU: bit-identical to the dense evaluation (the sign of a zero accumulator is the only thing the skipped terms
+// could change, and the ReLU stores +0 for both).  C5: 23 channel blocks become 8.
+struct ActionSparseLaunch {
+    float* x;              // dense [B][cout][hw]: pre-activation in, ReLU(pre-activation + action terms) out
+    const int* action;     // [B]
+    const float* w;        // folded weights of the action channels [cout][A][9]
+    int B, cout, h, w_img, A;
+    int inv_hw;            // (h*w)^-1 mod A
+};
+
+__global__ __launch_bounds__(256) void k_action_sparse(const ActionSparseLaunch L) {
+    __shared__ int s_term[16][9];   // per pixel of the chunk: weight index c*9 + tap of its k-th term in chain order, -1 = none
+    const int hw = L.h * L.w_img, b = blockIdx.y, p0 = blockIdx.x * 16, tid = threadIdx.x;
+    if (tid < 16) {
+        const int p = p0 + tid;
+        int key[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            key[t] = 0x7fffffff;
+            const int y = p / L.w_img + t / 3 - 1, x = p % L.w_img + t % 3 - 1;
+            if (p < hw && y >= 0 && y < L.h && x >= 0 && x < L.w_img) {
+                const int nb = y * L.w_img + x;
+                int d = (L.action[b] - nb) % L.A;
+                d = d < 0 ? d + L.A : d;
+                const int c = (int)(((long long)d * L.inv_hw) % L.A);
+                key[t] = ((c >> 4) * 9 + t) * 16 + (c & 15);  // chain order: block, tap, channel in block
+            }
+        }
+#pragma unroll
+        for (int i = 1; i < 9; i++) {  // insertion sort, fully unrolled (registers)
+#pragma unroll
+            for (int k = i; k > 0; k--) {
+                const int a = key[k - 1], c2 = key[k];
+                key[k - 1] = a < c2 ? a : c2;
+                key[k] = a < c2 ? c2 : a;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int k = key[t];
+            s_term[tid][t] = k == 0x7fffffff ? -1 : (((k / 144) * 16 + (k & 15)) * 9 + (k % 144) / 16);
+        }
+    }
+    __syncthreads();
+    const int px = tid & 15, p = p0 + px;
+    if (p >= hw) return;
+    int term[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) term[t] = s_term[px][t];
+    for (int co = tid >> 4; co < L.cout; co += 16) {
+        float* o = L.x + ((size_t)b * L.cout + co) * hw + p;
+        const float* w = L.w + (size_t)co * L.A * 9;
+        float acc = *o;
+        float wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {  // branch-free: all nine loads in flight, absent terms add 0 (acc + 0 == acc up to the sign of
+            const int k = term[t];     // a zero, which the ReLU erases)
+            const float v = w[k < 0 ? 0 : k];
+            wv[t] = k < 0 ? 0.0f : v;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) acc = acc + wv[t];
+        *o = acc > 0.0f ? acc : 0.0f;
+    }
+}
+
 // normalize_hidden_state for conv states (util.py:31-36): min/max over the channels of each pixel (exact, so any reduction
 // order gives the reference's result).  in dense [B][C][hw]; written to every non-null destination: out_ptrs[b] (node store
 // rows), dense out_a, dense out_b.  Workgroup = one image x 32 pixels; thread (pixel, channel group of 8): its C/8 channels

@@ -44,6 +44,11 @@ struct ConvNetDev {
     // fused-tower copies (mz_tower.h): the packed weights / biases of a tower's 2 * blocks convs back to back
     const float *tw_rep = nullptr, *tb_rep = nullptr, *tw_dyn = nullptr, *tb_dyn = nullptr, *tw_pred = nullptr, *tb_pred = nullptr;
     ConvLayerDev dyn_conv;
+    // board games (gcd(h*w, A) == 1, planes % 16 == 0): the dynamics conv split into its real-channel part (dense MFMA kernel)
+    // and the action channels' folded weights [cout][A][9] for k_action_sparse; dyn_inv_hw == 0: not available
+    ConvLayerDev dyn_real;
+    float* dyn_act_w = nullptr;
+    int dyn_inv_hw = 0;
     HeadDev reward, policy, value;
     std::vector<void*> allocs;
     // work buffers (dense activations), sized by ensure_buffers
@@ -51,6 +56,11 @@ struct ConvNetDev {
     size_t buf_elems = 0;
     int hidden_size() const { return P * hh * hw; }
 };
+
+inline int env_int_early(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && v[0] ? atoi(v) : dflt;
+}
 
 inline hipError_t dev_upload(ConvNetDev& n, const std::vector<float>& h, float** d) {
     hipError_t e = hipMalloc(d, h.size() * sizeof(float));
@@ -63,7 +73,7 @@ inline hipError_t dev_upload(ConvNetDev& n, const std::vector<float>& h, float**
 // w' = w*alpha, b' = beta - mean*alpha (float32 operations in that order); weights packed into the MFMA A-fragment order
 // [co_tile][cb][tap][lane][4]:  W'[16t + (lane&15)][cb*16 + 4s + (lane>>4)][tap]
 inline int build_conv(ConvNetDev& n, const ParamMap& pm, const std::string& conv_w, const std::string& bn, int cin, int cin_real, int cout,
-                      int k, int stride, ConvLayerDev* out, std::string* err) {
+                      int k, int stride, ConvLayerDev* out, std::string* err, int pack_cin = -1, float** tail_w = nullptr) {
     auto wi = pm.find(conv_w);
     if (wi == pm.end()) { *err = "missing parameter " + conv_w; return -1; }
     const HostTensorRef& W = wi->second;
@@ -87,7 +97,22 @@ inline int build_conv(ConvNetDev& n, const ParamMap& pm, const std::string& conv
             bias[co] = t[1][co] - m;
         }
     }
-    const int taps = k * k, n_cb = (cin + 15) / 16, co_tiles = (cout + 15) / 16;
+    // pack_cin >= 0: pack only the first pack_cin input channels (and hand the folded weights of the rest to *tail_w as
+    // [cout][cin - pack_cin][taps])
+    const int pcin = pack_cin >= 0 ? pack_cin : cin;
+    const int taps = k * k, n_cb = (pcin + 15) / 16, co_tiles = (cout + 15) / 16;
+    if (tail_w) {
+        const int nt = cin - pcin;
+        std::vector<float> tw((size_t)cout * nt * taps);
+        for (int co = 0; co < cout; co++)
+            for (int c = 0; c < nt; c++)
+                for (int tap = 0; tap < taps; tap++) {
+                    float v = W.data[((size_t)co * cin + pcin + c) * taps + tap];
+                    if (!bn.empty()) v = v * alpha[co];
+                    tw[((size_t)co * nt + c) * taps + tap] = v;
+                }
+        if (dev_upload(n, tw, tail_w) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+    }
     std::vector<float> pw((size_t)co_tiles * n_cb * taps * 256, 0.0f);
     for (int t = 0; t < co_tiles; t++)
         for (int cb = 0; cb < n_cb; cb++)
@@ -95,13 +120,13 @@ inline int build_conv(ConvNetDev& n, const ParamMap& pm, const std::string& conv
                 for (int lane = 0; lane < 64; lane++)
                     for (int s = 0; s < 4; s++) {
                         const int co = 16 * t + (lane & 15), ci = cb * 16 + 4 * s + (lane >> 4);
-                        if (co < cout && ci < cin) {
+                        if (co < cout && ci < pcin) {
                             float v = W.data[((size_t)co * cin + ci) * taps + tap];
                             if (!bn.empty()) v = v * alpha[co];
                             pw[((((size_t)t * n_cb + cb) * taps + tap) * 64 + lane) * 4 + s] = v;
                         }
                     }
-    out->cin = cin; out->cin_real = cin_real; out->cout = cout; out->stride = stride;
+    out->cin = pcin; out->cin_real = pack_cin >= 0 ? pcin : cin_real; out->cout = cout; out->stride = stride;
     if (dev_upload(n, pw, &out->w) != hipSuccess || dev_upload(n, bias, &out->b) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
     return 0;
 }
@@ -173,6 +198,18 @@ inline int convnet_build(ConvNetDev& n, const ParamMap& pm, std::string* err) {
     }
     const int hw = n.hh * n.hw;
     if ((rc = build_conv(n, pm, "dynamics_net.conv_block.0.weight", "dynamics_net.conv_block.1", P + n.A, P, P, 3, 1, &n.dyn_conv, err))) return rc;
+    {
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        n.dyn_inv_hw = 0;
+        if ((P & 15) == 0 && gcd(hw, n.A) == 1 && env_int_early("MZ_ACTION_SPARSE", 1)) {
+            if ((rc = build_conv(n, pm, "dynamics_net.conv_block.0.weight", "dynamics_net.conv_block.1", P + n.A, P, P, 3, 1, &n.dyn_real, err, P,
+                                 &n.dyn_act_w)))
+                return rc;
+            for (int i = 1; i < n.A; i++)
+                if ((long long)i * (hw % n.A) % n.A == 1) n.dyn_inv_hw = i;
+            if (n.A == 1) n.dyn_inv_hw = 0;
+        }
+    }
     n.dyn_res.resize(R);
     n.pred_res.resize(R);
     for (int i = 0; i < R; i++) {
@@ -460,7 +497,14 @@ inline void convnet_recurrent(hipStream_t st, ConvNetDev& n, int B, const float*
                               float* const* dst_ptrs, float* dst_dense, float* reward, float* value, float* pi, const float* store_base = nullptr,
                               size_t store_floats = 0) {
     const int h = n.hh, w = n.hw, hw = h * w;
-    conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true, store_base, store_floats);
+    if (n.dyn_inv_hw > 0) {  // board games: dense part over the real channels, then the <= 9 non-zero action-plane terms per output
+        conv_run(st, n.dyn_real, B, src_dense, src_ptrs, nullptr, 0, h, w, nullptr, n.bufA, false, store_base, store_floats);
+        ActionSparseLaunch S{};
+        S.x = n.bufA; S.action = action; S.w = n.dyn_act_w; S.B = B; S.cout = n.P; S.h = h; S.w_img = w; S.A = n.A; S.inv_hw = n.dyn_inv_hw;
+        hipLaunchKernelGGL(k_action_sparse, dim3((hw + 15) / 16, B), dim3(256), 0, st, S);
+    } else {
+        conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true, store_base, store_floats);
+    }
     float* x = tower_run(st, n.dyn_res, 0, n.R, B, n.bufA, n.bufB, n.bufC, h, w, n.tw_dyn, n.tb_dyn);
     head_run(st, n.reward, B, x, nullptr, hw, 0, reward, nullptr);  // the reward head reads the un-normalised state (:447-448)
     convnet_tail(st, n, B, x, dst_ptrs, dst_dense, pi, value);
