@@ -315,7 +315,7 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes of HBM per launch', 'traffic_source': traffic_src,
                 'algorithmic_hbm_bytes_per_launch': B * (S * 2 * 64 * 4 + 20 * 4 + 64 * 4 + 2 * 8 + 16),
                 'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,

@@ -201,19 +201,20 @@ __global__ void k_env_reset(const EnvLaunch L) {
 }
 
 // before the search of a move: temperature for this move and the "obs / player before acting" half of the record
-__global__ void k_env_pre(const EnvLaunch L) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.B) return;
+__device__ inline void env_pre_one(const EnvLaunch& L, int e) {
     double T = L.temperature;
     if (T < 0.0) T = L.env.steps[e] < (L.env.kind == ENV_GOMOKU ? 30 : 6) ? 1.0 : 0.1;  // config.py:236-249
     L.temp_out[e] = T;  // (the observation half of the record is one device-to-device copy enqueued by the host)
     L.env.r_player[(size_t)L.slot * L.B + e] = L.cur[e];
 }
 
-// after the search: env.step(action), record, auto-reset (pipeline.py:106-113)
-__global__ void k_env_step(const EnvLaunch L) {
+__global__ void k_env_pre(const EnvLaunch L) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.B) return;
+    if (e < L.B) env_pre_one(L, e);
+}
+
+// after the search: env.step(action), record, auto-reset (pipeline.py:106-113)
+__device__ inline void env_step_one(const EnvLaunch& L, int e) {
     const int a = L.action[e], A = L.env.A;
     const size_t rec = (size_t)L.slot * L.B + e;
     float reward = 0.0f;
@@ -301,6 +302,11 @@ __global__ void k_env_step(const EnvLaunch L) {
         atomicAdd(&L.env.counters[0], (unsigned long long)L.B);
         atomicAdd(&L.env.counters[1], (unsigned long long)L.B * (unsigned long long)L.sims);
     }
+}
+
+__global__ void k_env_step(const EnvLaunch L) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < L.B) env_step_one(L, e);
 }
 
 }  // namespace mz

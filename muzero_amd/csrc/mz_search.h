@@ -9,6 +9,7 @@
 //     Python floats; hidden states go to an HBM node store hidden[env][node][H] (L2/MALL resident).
 // Environments are independent (mcts.py has no cross-env state), so no inter-workgroup communication exists.
 #pragma once
+#include "mz_env.h"
 #include "mz_mlp.h"
 
 namespace mz {
@@ -70,7 +71,21 @@ struct SearchParams {
     unsigned int move_counter;
     unsigned int env_offset;  // global id of env 0 (multi-GPU sharding: Philox streams are keyed by global env id)
     long long* stamps;        // diagnostic builds (-DMZ_STAMPS) only: per-phase cycle sums of block 0, else unused
+    // device self-play with the environment fused into the search kernel (one launch per lock-step move): the env's first lane
+    // runs env_pre_one before the search (temperature, record of player / observation) and env_step_one after it
+    int fuse_env;
+    EnvLaunch fenv;
 };
+
+// the pre-search half of a fused self-play move for env e (global id env_g); call with the env's 16 lanes
+__device__ __forceinline__ void fused_env_pre(const SearchParams& P, int a0, int env_g, bool env_ok) {
+    if (!P.fuse_env || !env_ok) return;
+    const int D = P.fenv.env.D;
+    float* ro = P.fenv.env.r_obs + ((size_t)P.fenv.slot * P.fenv.B + env_g) * D;
+    const float* o = P.fenv.obs + (size_t)env_g * D;
+    for (int i = a0; i < D; i += 16) ro[i] = o[i];
+    if (a0 == 0) env_pre_one(P.fenv, env_g);
+}
 
 // Phase stamps for the diagnostic build (python -m muzero_amd.build --stamps -> libmzplanner_hip_stamps.so): thread 0
 // of block 0 accumulates s_memtime deltas per phase.  Never compiled into the product library; read SHARES, not totals.
@@ -391,6 +406,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15;
     const int env_g = blockIdx.x * TILE_E + e;
     const bool env_ok = env_g < P.B;
+    if (!SCRIPTED) fused_env_pre(P, a0, env_g, env_ok);
     float* pi0 = reinterpret_cast<float*>(smem + P.t_pi0);
     const float** src = reinterpret_cast<const float**>(smem + P.t_ptr);
     float** dst = reinterpret_cast<float**>(smem + P.t_ptr) + 16;
@@ -475,6 +491,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     if (a0 == 0 && env_ok) {
         if (P.tree_mode == 2) tree2_finish(smem, P, e, env_g);
         else tree_finish(smem, P, e, env_g);
+        if (!SCRIPTED && P.fuse_env) env_step_one(P.fenv, env_g);
     }
 }
 

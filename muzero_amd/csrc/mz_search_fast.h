@@ -176,7 +176,8 @@ __device__ __forceinline__ f32x4 chain_layer_ring(float4 (&ring)[D], const WSrc&
 }
 
 // P = num_planes (256 or 512); XG = k-groups of the dynamics input (hidden 64 + one-hot A): 5 for A <= 16
-template <int P, bool SCRIPTED_UNUSED = false>
+// FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
+template <int P, bool FUSE = false>
 __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
     constexpr int NT = P / 64;   // wide-layer tiles per wave
     constexpr int KGP = P / 16;  // k-groups of the chain layers
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int env_g = blockIdx.x * TILE_E + e;
     const bool env_ok = env_g < Pm.B;
+    if constexpr (FUSE) fused_env_pre(Pm, a0, env_g, env_ok);
     const MlpNet& net = Pm.net;
     const MlpLds& o = Pm.o;
     float* pi0 = reinterpret_cast<float*>(smem + Pm.t_pi0);
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     if (a0 == 0 && env_ok) {
         if (Pm.tree_mode == 2) tree2_finish(smem, Pm, e, env_g);
         else tree_finish(smem, Pm, e, env_g);
+        if constexpr (FUSE) env_step_one(Pm.fenv, env_g);  // env.step + record + auto-reset with the action this lane just sampled
     }
     MZ_STAMP(10);  // play policy + action
     MZ_STAMP_FLUSH(Pm);

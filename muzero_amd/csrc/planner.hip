@@ -67,6 +67,7 @@ struct mz_planner {
     int fast_planes = 0;  // 0: generic kernel only; 256 / 512: k_search_fast<P>
     bool tree_old = false;       // MZ_TREE_OLD=1: evaluate every level on every descent (A/B measurements, tests)
     bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
+    bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
     float* d_stream[3] = {};
     FastWeights fw{};
 
@@ -245,6 +246,10 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     {
         const char* fg = getenv("MZ_FORCE_GENERIC");
         p->force_generic = fg && fg[0] == '1';
+        const char* fe = getenv("MZ_FUSE_ENV");
+        // default: fuse for short moves, where three extra launches are >= 4 % of a move (C3: 0.45 ms); for long moves the kernels
+        // stay separate (the env work would run single-lane at the search kernel's tail and gain nothing)
+        p->fuse_env = fe ? fe[0] != '0' : cfg->num_simulations <= 30;
         const char* to = getenv("MZ_TREE_OLD");
         p->tree_old = to && to[0] == '1';
     }
@@ -335,6 +340,8 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         p->fast_planes = c.num_planes;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
     *out = p;
     return MZ_OK;
@@ -539,7 +546,7 @@ static int next_kernel_events(mz_planner* p, hipEvent_t* a, hipEvent_t* b) {
 }
 
 // launches the fused search kernel over inputs that are already resident in the planner's device buffers
-static int launch_search(mz_planner* p, int batch, int deterministic, bool has_mask, bool injected_rng, bool scripted) {
+static int launch_search(mz_planner* p, int batch, int deterministic, bool has_mask, bool injected_rng, bool scripted, const EnvLaunch* fenv = nullptr) {
     const mz_config& c = p->cfg;
     const bool mode2 = p->tree2_ok && !p->tree_old;
     SearchParams s = mode2 ? p->sp2 : p->sp;
@@ -559,6 +566,8 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     s.out_action = p->d_action; s.out_pi = p->d_pi; s.out_root = p->d_root; s.out_visits = p->d_visits; s.err = p->d_err;
     s.s_pi0 = p->d_spi0; s.s_values = p->d_svalues; s.s_rewards = p->d_srewards; s.trace_parent = p->d_tparent; s.trace_action = p->d_taction;
     s.seed = c.seed; s.move_counter = p->move_counter++; s.env_offset = 0; s.stamps = p->d_stamps;
+    s.fuse_env = fenv ? 1 : 0;
+    if (fenv) s.fenv = *fenv;
     const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
     hipEvent_t ea = nullptr, eb = nullptr;
     if (p->profiling) {
@@ -606,8 +615,13 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         hipLaunchKernelGGL(k_gtree_finish, grid, block, 0, p->stream, G);
     } else
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
-    else if (p->fast_planes == 512 && !p->force_generic) hipLaunchKernelGGL(k_search_fast<512>, grid, block, s.lds_bytes, p->stream, s, p->fw);
-    else if (p->fast_planes == 256 && !p->force_generic) hipLaunchKernelGGL(k_search_fast<256>, grid, block, s.lds_bytes, p->stream, s, p->fw);
+    else if (p->fast_planes == 512 && !p->force_generic) {
+        if (fenv) hipLaunchKernelGGL((k_search_fast<512, true>), grid, block, s.lds_bytes, p->stream, s, p->fw);
+        else hipLaunchKernelGGL((k_search_fast<512, false>), grid, block, s.lds_bytes, p->stream, s, p->fw);
+    } else if (p->fast_planes == 256 && !p->force_generic) {
+        if (fenv) hipLaunchKernelGGL((k_search_fast<256, true>), grid, block, s.lds_bytes, p->stream, s, p->fw);
+        else hipLaunchKernelGGL((k_search_fast<256, false>), grid, block, s.lds_bytes, p->stream, s, p->fw);
+    }
     else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
     HIPCHK(hipGetLastError());
     if (p->profiling) HIPCHK(hipEventRecord(eb, p->stream));
@@ -747,6 +761,14 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
         L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.temperature = temperature; L.move_counter = p->move_counter;
         L.obs = p->d_obs; L.mask = p->d_mask; L.cur = p->d_cur; L.opp = p->d_opp; L.temp_out = p->d_temp;
         L.action = p->d_action; L.pi = p->d_pi; L.root = p->d_root; L.slot = p->ring_pos; L.sims = c.num_simulations;
+        if (!p->conv && p->fuse_env) {
+            // MLP nets: the whole move -- temperature / record, search, env.step, auto-reset -- is ONE kernel launch
+            int rc = launch_search(p, c.num_envs, 0, true, false, false, &L);
+            if (rc) return rc;
+            p->ring_pos = (p->ring_pos + 1) % p->ring_len;
+            if (p->ring_count < p->ring_len) p->ring_count++;
+            continue;
+        }
         // temperatures for this move, then the search, then env.step + record + auto-reset
         hipLaunchKernelGGL(k_env_pre, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
         HIPCHK(hipMemcpyAsync(p->env.r_obs + (size_t)p->ring_pos * c.num_envs * obs_dim(c), p->d_obs, (size_t)c.num_envs * obs_dim(c) * sizeof(float),
