@@ -502,8 +502,10 @@ struct InferParams {
     int t_ptr, t_pi, t_act, lds_bytes;
     int B;
     const float* in;     // obs [B][in_dim] or hidden [B][H]
+    const float* const* in_ptrs;  // or per-env input rows (gather from the node store); null = dense `in`
     const int* action;   // [B] (recurrent)
     float* hidden_out;   // [B][H]
+    float* const* out_ptrs;       // or per-env output rows (scatter into the node store); null = dense `hidden_out`
     float* reward;       // [B]
     float* value;        // [B]
     float* pi;           // [B][A]
@@ -522,8 +524,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_infer(const InferParams P) {
     int* act = reinterpret_cast<int*>(smem + P.t_act);
     stage_biases(P.net, lds, tid);
     if (a0 == 0) {
-        src[e] = env_ok ? P.in + (size_t)env_g * (INITIAL ? P.net.in_dim : P.net.H) : nullptr;
-        dst[e] = env_ok ? P.hidden_out + (size_t)env_g * P.net.H : nullptr;
+        src[e] = env_ok ? (P.in_ptrs ? P.in_ptrs[env_g] : P.in + (size_t)env_g * (INITIAL ? P.net.in_dim : P.net.H)) : nullptr;
+        dst[e] = env_ok ? (P.out_ptrs ? P.out_ptrs[env_g] : P.hidden_out + (size_t)env_g * P.net.H) : nullptr;
         act[e] = (!INITIAL && env_ok) ? P.action[env_g] : 0;
     }
     __syncthreads();

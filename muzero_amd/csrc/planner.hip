@@ -94,6 +94,11 @@ struct mz_planner {
 
     // conv nets (MZ_NET_BOARD / MZ_NET_ATARI): network, HBM tree regions and the per-simulation exchange buffers
     bool conv = false;
+    // MLP nets whose trees do not fit the LDS-resident kernels (many simulations, > 64 actions; MZ_HBM_TREE=1 forces it): the
+    // HBM tree kernels around k_infer launches, one (select, inference, backup) triple per simulation
+    bool hbm_tree = false;
+    SearchParams spg{};  // tree layout inside a per-workgroup HBM region (hbm_tree)
+    float* d_pi_scratch = nullptr;
     ConvNetDev cnet{};
     unsigned char* d_regions = nullptr;
     float *d_pi0 = nullptr, *d_sim_reward = nullptr, *d_sim_value = nullptr;
@@ -196,9 +201,9 @@ static void compute_layout(mz_planner* p) {
 }
 
 // conv nets: the tree part only, laid out from offset 0 of a per-workgroup HBM region (same structure as tree_mode 0 in LDS)
-static void compute_layout_conv(mz_planner* p) {
+static void compute_layout_conv(mz_planner* p, SearchParams* target = nullptr) {
     const mz_config& c = p->cfg;
-    SearchParams& s = p->sp;
+    SearchParams& s = target ? *target : p->sp;
     s.S = c.num_simulations; s.A = c.num_actions; s.NN = c.num_simulations + 1;
     int b = 0;
     auto take = [&](int bytes, int align) { b = (b + align - 1) / align * align; int r = b; b += bytes; return r; };
@@ -213,17 +218,17 @@ static void compute_layout_conv(mz_planner* p) {
     s.t_ftab = take((s.S + 1) * (s.S + 1) * 8, 16);
     s.lds_bytes = (b + 255) & ~255;
     s.tree_mode = 0;
-    p->lds_mode0 = s.lds_bytes;
-    p->tree2_ok = false;
+    if (!target) {
+        p->lds_mode0 = s.lds_bytes;
+        p->tree2_ok = false;
+    }
 }
 
 extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner** out) {
     if (!cfg || !out) return fail(MZ_E_INVALID, "null argument");
     const bool conv = cfg->net_kind == MZ_NET_BOARD || cfg->net_kind == MZ_NET_ATARI;
     if (cfg->net_kind != MZ_NET_MLP && !conv) return fail(MZ_E_INVALID, "unknown net_kind");
-    if (!conv && (cfg->num_actions < 1 || cfg->num_actions > 16 * MAX_CH))
-        return fail(MZ_E_INVALID, "num_actions must be in [1, 64] for the LDS-resident search kernel (MLP nets)");
-    if (conv && (cfg->num_actions < 1 || cfg->num_actions > 256)) return fail(MZ_E_INVALID, "num_actions must be in [1, 256] for conv nets");
+    if (cfg->num_actions < 1 || cfg->num_actions > 256) return fail(MZ_E_INVALID, "num_actions must be in [1, 256]");
     if (cfg->num_simulations < 1 || cfg->num_simulations > 4000) return fail(MZ_E_INVALID, "num_simulations out of range");
     if (conv) {
         if (cfg->obs_c < 1 || cfg->obs_h < 1 || cfg->obs_w < 1 || cfg->num_res_blocks < 0) return fail(MZ_E_INVALID, "bad conv network dimensions");
@@ -265,10 +270,17 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     } else {
         compute_layout(p);
     }
-    if (!conv && p->sp.lds_bytes > 160 * 1024 && !p->tree2_ok) {
-        int need = p->sp.lds_bytes;
-        delete p;
-        return fail(MZ_E_INVALID, "configuration needs " + std::to_string(need) + " bytes of LDS per workgroup (> 160 KiB): tree does not fit the LDS-resident kernel");
+    if (!conv) {
+        const char* ht = getenv("MZ_HBM_TREE");
+        p->hbm_tree = (ht && ht[0] == '1') || cfg->num_actions > 16 * MAX_CH || (p->sp.lds_bytes > 160 * 1024 && !p->tree2_ok);
+        if (p->hbm_tree) {
+            if (p->ip.lds_bytes > 160 * 1024) {
+                const int need = p->ip.lds_bytes;
+                delete p;
+                return fail(MZ_E_INVALID, "network needs " + std::to_string(need) + " bytes of LDS per workgroup (> 160 KiB)");
+            }
+            compute_layout_conv(p, &p->spg);
+        }
     }
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -312,9 +324,10 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     }
     HIPCHK(hipEventCreate(&p->ev_begin));
     HIPCHK(hipEventCreate(&p->ev_end));
-    if (conv) {
+    if (conv || p->hbm_tree) {
         const size_t blocks = (B + TILE_E - 1) / TILE_E, HS = (size_t)p->cfg.hidden_dim;
-        HIPCHK(hipMalloc(&p->d_regions, blocks * (size_t)p->sp.lds_bytes));
+        HIPCHK(hipMalloc(&p->d_regions, blocks * (size_t)(conv ? p->sp.lds_bytes : p->spg.lds_bytes)));
+        HIPCHK(hipMalloc(&p->d_pi_scratch, B * A * sizeof(float)));
         HIPCHK(hipMalloc(&p->d_pi0, B * A * sizeof(float)));
         HIPCHK(hipMalloc(&p->d_sim_reward, B * sizeof(float)));
         HIPCHK(hipMalloc(&p->d_sim_value, B * sizeof(float)));
@@ -325,11 +338,14 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         std::vector<float*> roots(B);
         for (size_t i = 0; i < B; i++) roots[i] = p->d_hidden + i * (S + 1) * HS;
         HIPCHK(hipMemcpy(p->d_rootptrs, roots.data(), B * sizeof(float*), hipMemcpyHostToDevice));
-        *out = p;
-        return MZ_OK;
+        if (conv) {
+            *out = p;
+            return MZ_OK;
+        }
     }
     int max_lds = p->tree2_ok ? p->lds_mode2 : 0;
     if (p->lds_mode0 <= 160 * 1024 && p->lds_mode0 > max_lds) max_lds = p->lds_mode0;
+    if (max_lds == 0) max_lds = p->ip.lds_bytes;  // hbm_tree: the LDS-resident search kernels are never launched
     if (p->lds_mode0 > 160 * 1024) p->tree_old = false;  // only the mode-2 layout fits
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -362,7 +378,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     }
     for (int i = 0; i < 3; i++)
         if (p->d_stream[i]) (void)hipFree(p->d_stream[i]);
-    void* cbufs[] = {p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
+    void* cbufs[] = {p->d_pi_scratch, p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
     for (void* b : cbufs)
         if (b) (void)hipFree(b);
     convnet_free(p->cnet);
@@ -504,7 +520,7 @@ static int run_infer(mz_planner* p, bool initial, int batch, const float* h_in, 
         HIPCHK(hipGetLastError());
     } else {
     InferParams ip = p->ip;
-    ip.B = batch; ip.in = p->d_inf_in; ip.action = p->d_inf_action; ip.hidden_out = p->d_inf_hidden; ip.reward = p->d_inf_reward;
+    ip.B = batch; ip.in = p->d_inf_in; ip.in_ptrs = nullptr; ip.out_ptrs = nullptr; ip.action = p->d_inf_action; ip.hidden_out = p->d_inf_hidden; ip.reward = p->d_inf_reward;
     ip.value = p->d_inf_value; ip.pi = p->d_inf_pi;
     const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
     if (initial) hipLaunchKernelGGL(k_infer<true>, grid, block, ip.lds_bytes, p->stream, ip);
@@ -575,9 +591,13 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         if (rc) return rc;
         HIPCHK(hipEventRecord(ea, p->stream));
     }
-    if (p->conv) {
-        // HBM-resident trees: root inference -> init -> S x {select, dynamics + prediction towers, expand + backup} -> play
-        s = p->sp;
+    if (p->conv || p->hbm_tree) {
+        // HBM-resident trees: root inference -> init -> S x {select, network evaluation, expand + backup} -> play
+        const bool mlp = !p->conv;
+        InferParams ip = p->ip;
+        ip.net = p->net; ip.B = batch; ip.in = nullptr; ip.in_ptrs = nullptr; ip.action = p->d_sim_action; ip.hidden_out = nullptr;
+        ip.out_ptrs = nullptr; ip.reward = p->d_sim_reward; ip.value = p->d_sim_value; ip.pi = p->d_pi_scratch;
+        s = mlp ? p->spg : p->sp;
         s.tree_mode = 0;
         s.discount = c.discount; s.board = c.is_board_game; s.has_bounds = c.has_known_bounds;
         s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
@@ -595,6 +615,11 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         G.actions = p->d_sim_action;
         if (scripted) {
             G.pi0 = p->d_spi0;
+        } else if (mlp) {
+            InferParams r = ip;
+            r.in = p->d_obs; r.out_ptrs = p->d_rootptrs; r.pi = p->d_pi0;
+            hipLaunchKernelGGL(k_infer<true>, grid, block, r.lds_bytes, p->stream, r);  // root value discarded (mcts.py:356-367)
+            G.pi0 = p->d_pi0;
         } else {
             convnet_initial(p->stream, p->cnet, batch, p->d_obs, p->d_rootptrs, nullptr, p->d_pi0, p->d_sim_value);  // root value discarded
             G.pi0 = p->d_pi0;
@@ -605,6 +630,11 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
             hipLaunchKernelGGL(k_gtree_select, grid, block, 0, p->stream, G);
             if (scripted) {
                 G.reward = p->d_srewards + sim; G.value = p->d_svalues + sim; G.rv_stride = c.num_simulations;
+            } else if (mlp) {
+                InferParams r = ip;
+                r.in_ptrs = p->d_srcptrs; r.out_ptrs = p->d_dstptrs;
+                hipLaunchKernelGGL(k_infer<false>, grid, block, r.lds_bytes, p->stream, r);
+                G.reward = p->d_sim_reward; G.value = p->d_sim_value; G.rv_stride = 1;
             } else {
                 convnet_recurrent(p->stream, p->cnet, batch, p->d_srcptrs, nullptr, p->d_sim_action, p->d_dstptrs, nullptr, p->d_sim_reward,
                                   p->d_sim_value, nullptr, p->d_hidden, (size_t)c.num_envs * (c.num_simulations + 1) * (size_t)c.hidden_dim);
@@ -761,7 +791,7 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
         L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.temperature = temperature; L.move_counter = p->move_counter;
         L.obs = p->d_obs; L.mask = p->d_mask; L.cur = p->d_cur; L.opp = p->d_opp; L.temp_out = p->d_temp;
         L.action = p->d_action; L.pi = p->d_pi; L.root = p->d_root; L.slot = p->ring_pos; L.sims = c.num_simulations;
-        if (!p->conv && p->fuse_env) {
+        if (!p->conv && !p->hbm_tree && p->fuse_env) {
             // MLP nets: the whole move -- temperature / record, search, env.step, auto-reset -- is ONE kernel launch
             int rc = launch_search(p, c.num_envs, 0, true, false, false, &L);
             if (rc) return rc;

@@ -54,12 +54,9 @@ def test_create_rejects_unsupported_configurations():
         pl.Planner(_cfg(net, num_envs=1, num_simulations=3, is_board_game=True, discount=0.9), 0)
     with pytest.raises(pl.PlannerError, match='device_id'):
         pl.Planner(_cfg(net, num_envs=1, num_simulations=3), 99)
-    wide = build_mlp(('w', (4,), 65, 16, 1, 1, 16, 1))
+    wide = build_mlp(('w', (4,), 257, 16, 1, 1, 16, 1))
     with pytest.raises(pl.PlannerError, match='num_actions'):
         pl.Planner(_cfg(wide, num_envs=1, num_simulations=3), 0)
-    big = build_mlp(mlp_case('cartpole'))
-    with pytest.raises(pl.PlannerError, match='LDS'):
-        pl.Planner(_cfg(big, num_envs=1, num_simulations=1200), 0)  # tree does not fit the LDS-resident kernel
     atari = build_conv(('a', 'atari', (4, 96, 96), 4, 1, 8, 5, 5, 1))
     c = _cfg(atari, num_envs=1, num_simulations=2)
     c.obs_h = 84
@@ -104,5 +101,41 @@ def test_edge_shapes_against_oracle(oracle, shape):
     r = p.search(obs, mask, 1, 1, 0.5, False, noise=noise, u_tie=u_tie, u_final=u_final)
     ocfg = oracle.make_config(A, S, 0.997)
     o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), 1, 1, 0.5, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    for k in ('visits', 'pi', 'action', 'root_value'):
+        np.testing.assert_array_equal(r[k], o[k])
+
+
+@pytest.mark.parametrize('shape', ['many_simulations', 'many_actions', 'forced'])
+def test_mlp_nets_beyond_the_lds_kernel_use_hbm_trees(oracle, shape, monkeypatch):
+    """MLP configurations whose trees do not fit a workgroup's LDS (CartPole net with 150 simulations; 100 actions) fall back
+    to HBM-resident trees around batched inference launches instead of being rejected -- same results, bit for bit."""
+    from muzero_amd import planner as pl
+    from test_oracle_nets import _oracle_net
+
+    if shape == 'many_simulations':
+        case, B, S = mlp_case('cartpole'), 21, 150
+    elif shape == 'many_actions':
+        case, B, S = ('wide', (6,), 100, 48, 5, 5, 24, 41), 19, 20
+    else:
+        monkeypatch.setenv('MZ_HBM_TREE', '1')
+        case, B, S = mlp_case('tictactoe'), 40, 25
+    net = build_mlp(case)
+    onet = _oracle_net(oracle, net, 'mlp')
+    A = case[2]
+    board = shape == 'forced'
+    kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+    p = pl.Planner(_cfg(net, num_envs=B, **kw), 0)
+    p.load_state_dict(net.state_dict())
+    rs = np.random.RandomState(3)
+    obs = rs.uniform(-1, 1, size=(B,) + tuple(case[1])).astype(np.float32)
+    mask = rs.rand(B, A) < 0.8
+    mask[np.arange(B), rs.randint(0, A, B)] = True
+    cur = rs.randint(1, 3, B).astype(np.int32) if board else np.ones(B, np.int32)
+    opp = (3 - cur).astype(np.int32) if board else np.ones(B, np.int32)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie, u_final = rs.rand(B, 4 * S + 8), rs.rand(B)
+    r = p.search(obs, mask, cur, opp, 1.0, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    ocfg = oracle.make_config(A, S, kw['discount'], board, kw['known_bounds'], 0.25, 0.25)
+    o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, np.ones(B), False, noise=noise, u_tie=u_tie, u_final=u_final)
     for k in ('visits', 'pi', 'action', 'root_value'):
         np.testing.assert_array_equal(r[k], o[k])
