@@ -55,7 +55,7 @@ def main():
     net.eval()
     p.load_state_dict(net.state_dict())
     p.selfplay_reset(pl.ENV_CARTPOLE)
-    asm = EpisodeAssembler(cfg, args.envs)
+    asm = EpisodeAssembler(cfg, args.envs, (4, 5))
 
     steps, t0, last = 0, time.time(), dict(episodes=0, episode_steps=0)
     log = []

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""End-to-end MuZero on TicTacToe (two-player path: player switching, sign-flipping backup, Monte-Carlo returns, bounds
-(-1, 1)) with the MI355X planner, same single-process loop as examples/train_cartpole.py.  Hyper-parameters: the reference's
-tictactoe config (config.py:106-136, tictactoe/run_training.py:34-59).  Evaluation: deterministic games against a uniformly
-random opponent, as black and as white; an agent that has learnt the game almost never loses.
+"""End-to-end MuZero on Gomoku 9x9 (five in a row) with a small conv (board) network: the conv-tower planner path -- MFMA conv
+kernels / fused residual tower, HBM-resident trees, sparse action planes, device Gomoku env -- driving the same single-process
+loop as examples/train_tictactoe.py.  The reference's gomoku hyper-parameters (config.py:139-167) with a smaller network
+(32 planes, 2 blocks) and 32 simulations so that a few minutes show learning.  Evaluation: deterministic games against a uniformly
+random opponent as black and as white (win = five in a row before the opponent; the random player never resigns).
 
-    python examples/train_tictactoe.py --train-steps 4000 --envs 256"""
+    python examples/train_gomoku.py --train-steps 2000 --envs 128"""
 import argparse
 import json
 import os
@@ -20,17 +21,17 @@ import torch  # noqa: E402
 
 def play_vs_random(net, dev, cfg, agent_player, games, rs):
     from muzero_amd import mcts
-    from muzero_amd.games import TicTacToeEnv
+    from muzero_amd.games import GomokuEnv
 
     res = dict(win=0, draw=0, loss=0)
     for _ in range(games):
-        env = TicTacToeEnv()
+        env = GomokuEnv(board_size=9)
         obs, done = env.reset(), False
         while not done:
             if env.current_player == agent_player:
                 action, *_ = mcts.uct_search(obs, net, dev, cfg, 0.0, env.actions_mask, env.current_player, env.opponent_player, deterministic=True)
             else:
-                legal = np.flatnonzero(env.actions_mask[:9])  # the random opponent never resigns
+                legal = np.flatnonzero(env.actions_mask[:81])  # the random opponent never resigns
                 action = int(rs.choice(legal))
             obs, _, done, _ = env.step(action)
         res['draw' if env.winner is None else ('win' if env.winner == agent_player else 'loss')] += 1
@@ -40,42 +41,42 @@ def play_vs_random(net, dev, cfg, agent_player, games, rs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--train-steps', type=int, default=4000)
-    ap.add_argument('--envs', type=int, default=256)
+    ap.add_argument('--envs', type=int, default=128)
     ap.add_argument('--moves-per-iter', type=int, default=8)
     ap.add_argument('--updates-per-iter', type=int, default=16)
     ap.add_argument('--report-every', type=int, default=500)
-    ap.add_argument('--eval-games', type=int, default=50)
+    ap.add_argument('--eval-games', type=int, default=10)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--out', default='')
     args = ap.parse_args()
 
     from muzero_amd import learner
     from muzero_amd import planner as pl
-    from muzero_amd.config import make_tictactoe_config
-    from muzero_amd.network import MuZeroMLPNet
+    from muzero_amd.config import make_gomoku_config
+    from muzero_amd.network import MuZeroBoardGameNet
     from muzero_amd.pipeline import EpisodeAssembler
     from muzero_amd.replay import PrioritizedReplay
 
     torch.manual_seed(args.seed)
     dev = torch.device('cuda', 0)
-    cfg = make_tictactoe_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
-    cfg.num_envs = args.envs
-    net = MuZeroMLPNet((9, 3, 3), 10, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+    cfg = make_gomoku_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
+    cfg.num_envs, cfg.num_simulations, cfg.num_planes, cfg.num_res_blocks = args.envs, 32, 32, 2
+    net = MuZeroBoardGameNet((9, 9, 9), 82, cfg.num_res_blocks, cfg.num_planes).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
     replay = PrioritizedReplay(20000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
     net.eval()
     p.load_state_dict(net.state_dict())
-    p.selfplay_reset(pl.ENV_TICTACTOE)
-    asm = EpisodeAssembler(cfg, args.envs, (9, 3, 3))
+    p.selfplay_reset(pl.ENV_GOMOKU)
+    asm = EpisodeAssembler(cfg, args.envs, (9, 9, 9))
     rs = np.random.RandomState(args.seed + 7)
 
     log = [dict(train_steps=0, black=play_vs_random(net, dev, cfg, 1, args.eval_games, rs), white=play_vs_random(net, dev, cfg, 2, args.eval_games, rs))]
     print(json.dumps(log[0]), flush=True)
     steps, t0 = 0, time.time()
     while steps < args.train_steps:
-        p.selfplay_step(-1.0, args.moves_per_iter)  # per-env temperature schedule of the game (config.py:236-241)
+        p.selfplay_step(-1.0, args.moves_per_iter)  # per-env temperature schedule of the game (config.py:244-249)
         for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
             replay.add(tr, prio)
         if replay.size < cfg.min_replay_size:

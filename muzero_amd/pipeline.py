@@ -135,16 +135,18 @@ class EpisodeAssembler:
     """Cuts the lock-step record stream [moves, envs, ...] into per-env episodes and turns finished episodes into
     (Transition, priority) items exactly like pipeline.py:144-165."""
 
-    def __init__(self, config, num_envs: int):
+    def __init__(self, config, num_envs: int, obs_shape=None):
         self.config = config
         self.open = [[] for _ in range(num_envs)]
+        self.obs_shape = None if obs_shape is None else tuple(obs_shape)  # the env's observation shape (records are flat rows)
 
     def feed(self, rec) -> Iterable:
         cfg = self.config
         n_moves, B = rec['action'].shape
         for m in range(n_moves):
             for b in range(B):
-                self.open[b].append((rec['obs'][m, b], int(rec['action'][m, b]), float(rec['reward'][m, b]), rec['pi'][m, b],
+                o = rec['obs'][m, b] if self.obs_shape is None else rec['obs'][m, b].reshape(self.obs_shape)
+                self.open[b].append((o, int(rec['action'][m, b]), float(rec['reward'][m, b]), rec['pi'][m, b],
                                      float(rec['root_value'][m, b]), int(rec['player'][m, b])))
                 if rec['done'][m, b]:
                     traj, self.open[b] = self.open[b], []
@@ -189,7 +191,7 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
     p = pl.Planner(pl.make_mz_config(network.planner_spec(), config, num_envs=num_envs, seed=int(getattr(config, 'planner_seed', 1)) + 7919 * rank), idx)
     p.load_state_dict(network.state_dict())
     p.selfplay_reset(kinds[name])
-    asm = EpisodeAssembler(config, num_envs)
+    asm = EpisodeAssembler(config, num_envs, getattr(network, 'input_shape', None))
     version = network._weights_version()
     played = 0
     while not stop_event.is_set() and (max_moves is None or played < max_moves):

@@ -94,7 +94,7 @@ def test_run_self_play_counterpart_emits_reference_shaped_items():
         items.append(q.get())
     assert len(items) > 32
     for tr, prio in items:
-        assert tr.state.shape == (81,) and tr.action.shape == (5,) and tr.action.dtype == np.int8
+        assert tr.state.shape == (9, 3, 3) and tr.action.shape == (5,) and tr.action.dtype == np.int8
         assert tr.pi_prob.shape == (5, 10) and tr.pi_prob.dtype == np.float32
         assert tr.value.dtype == np.float32 and tr.reward.dtype == np.float32
         assert set(np.unique(tr.value)).issubset({-1.0, 0.0, 1.0})  # Monte-Carlo returns of a board game
@@ -177,6 +177,6 @@ def test_run_self_play_gomoku_conv_net_emits_mc_return_items():
         items.append(q.get())
     assert len(items) > 16  # at least one finished game per env slot on average (81 points, random-ish play)
     for tr, prio in items:
-        assert tr.state.shape == (9 * 9 * 9,) and set(np.unique(tr.state)).issubset({0.0, 1.0})
+        assert tr.state.shape == (9, 9, 9) and set(np.unique(tr.state)).issubset({0.0, 1.0})
         assert tr.action.shape == (5,) and tr.pi_prob.shape == (5, 82) and tr.value.shape == (5,)
         assert set(np.unique(tr.value)).issubset({-1.0, 0.0, 1.0}) and np.isfinite(prio)
