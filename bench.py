@@ -143,10 +143,8 @@ def conv_cpu_baseline(name, case, net, kw, full_sims):
 
 def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev='cuda'):
     from helpers import build_conv, build_mlp, mlp_case
-    from muzero_amd import build as mz_build
     from muzero_amd import planner as pl
 
-    mz_build.build()
     if name == 'c3':  # BASELINE.json configs[2]: TicTacToe MLP 256/64, MSE heads, two-player backup, 25 sims, 4096 envs
         envs, sims, env_kind = 4096, 25, 'tictactoe'
         kw = dict(discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.25)
@@ -182,12 +180,13 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # C3: transition 35 328 + reward 16 640 + value 16 640 MAC per simulation; root 37 120 + 18 944 + 16 640
+    f_sim, f_root = (2 * 68608, 2 * 72704) if name == 'c3' else conv_flops(case)
+    flop_per_move = B * (S * f_sim + f_root)
+    sustained = None if args.no_sustained else sustained_leg(p, T, 1e3 * elapsed / args.steps, flop_per_move)
     if rank == 0:
-        # C3: transition 35 328 + reward 16 640 + value 16 640 MAC per simulation; root 37 120 + 18 944 + 16 640
-        f_sim, f_root = (2 * 68608, 2 * 72704) if name == 'c3' else conv_flops(case)
         sims_per_s = world * B * S * args.steps / elapsed
         ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
-        flop_per_move = B * (S * f_sim + f_root)
         achieved = flop_per_move / (ms * 1e-3) / 1e12
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -205,10 +204,59 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
                          'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                          'avg_move_ms': ms, 'flop_per_move': flop_per_move, 'flop_per_sim': f_sim,
                          'timed_with': 'hipEvent pairs on the planner stream around each move\'s kernel sequence'},
+            'sustained': sustained,
         }), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without torchrun: start N rank processes (one per GPU) and relay rank 0's JSON line.
+    Runs BEFORE anything touches HIP in this process (the parent never initialises a GPU and never exec()s); the
+    library is built once here so that the ranks only load it.  Mirrors the reference's topology of N actor processes
+    (classic/run_training.py:168-186)."""
+    import socket
+    import subprocess
+
+    from muzero_amd import build as mz_build
+
+    mz_build.build()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f'bench.py: rank exit codes {codes}\n')
+        return 1
+    return 0
+
+
+def sustained_leg(p, T, ms_per_move_hint, flop_per_launch, seconds=2.0):
+    """>= `seconds` of back-to-back lock-step moves after the timed region: the clock the chip HOLDS under this load, not
+    a 30 ms burst.  Own HIP-event timing; does not change steps / ms_per_step."""
+    n = max(20, int(seconds * 1e3 / max(ms_per_move_hint, 1e-3)) + 1)
+    p.synchronize()
+    p.profile_begin()
+    t0 = time.perf_counter()
+    p.selfplay_step(T, n)
+    p.synchronize()
+    wall = time.perf_counter() - t0
+    prof = p.profile_end()
+    k_ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
+    ach = flop_per_launch / (k_ms * 1e-3) / 1e12
+    return {'moves': n, 'seconds': wall, 'ms_per_move': 1e3 * wall / n, 'avg_launch_ms': k_ms, 'achieved': ach,
+            'frac': ach / PEAK_FP32_MFMA_TFLOPS}
 
 
 def main():
@@ -221,14 +269,21 @@ def main():
     ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
                     help='c2 (default, the headline line): CartPole MLP; c3: TicTacToe MLP; c4 / c5: the conv-tower configs of BASELINE.json (extra measurements)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the >= 2 s sustained leg')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong GPU count\n')
+        return 2
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     # MZ_BENCH_BACKEND=gloo: control-flow check of the N > 1 path on a box with fewer GPUs than ranks (ranks then share
     # devices and the barrier / MAX run on CPU tensors); the driver's multi-GPU runs use the default, RCCL.
     backend = os.environ.get('MZ_BENCH_BACKEND', 'nccl')
@@ -245,14 +300,19 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
+    from muzero_amd import build as mz_build
+
+    if rank == 0:
+        mz_build.build()  # locked + atomic rename (muzero_amd/build.py); the other ranks only load the finished file
+    if world > 1:
+        dist.barrier()
+
     if args.workload != 'c2':
         return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist, red_dev)
 
     from helpers import build_mlp, mlp_case
-    from muzero_amd import build as mz_build
     from muzero_amd import planner as pl
 
-    mz_build.build()
     net = build_mlp(mlp_case('cartpole'))  # 512/64/31, seeded random init
     B, S = args.envs or 4096, args.sims or 50
     cfg = pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=1000 + rank, num_simulations=S, discount=0.997,
@@ -280,12 +340,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     counters = p.selfplay_counters()
+    flop_per_launch = B * (S * FLOP_PER_SIM + FLOP_PER_ROOT)
+    sustained = None if args.no_sustained else sustained_leg(p, 1.0, 1e3 * elapsed / args.steps, flop_per_launch)
 
     if rank == 0:
         total_sims = world * B * S * args.steps
         sims_per_s = total_sims / elapsed
         k_ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
-        flop_per_launch = B * (S * FLOP_PER_SIM + FLOP_PER_ROOT)
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this very
         # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the profiled workload.
@@ -321,6 +382,7 @@ def main():
                 'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,
                 'flop_per_sim': FLOP_PER_SIM, 'timed_with': 'hipEvent pairs on the planner stream',
             },
+            'sustained': sustained,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, sample_envs=B)
@@ -331,4 +393,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -5,6 +5,8 @@
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerical contract: all fused multiply-adds in
 the kernels are explicit (see csrc/mz_device.h).
 """
+import fcntl
+import glob
 import os
 import subprocess
 import sys
@@ -14,17 +16,21 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmzplanner_hip.so')
 SOURCES = ['planner.hip']
-HEADERS = ['mz_device.h', 'mz_mlp.h', 'mz_search.h', 'mz_tree2.h', 'mz_search_fast.h', 'mz_env.h', os.path.join('..', '..', 'include', 'mzplanner.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-pass-failed']
+
+
+def _deps():
+    """Every file the library is compiled from: all of csrc/ (sources and headers), the public C header, this script."""
+    return sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.hip'))) + \
+        [os.path.join(HERE, '..', 'include', 'mzplanner.h'), os.path.abspath(__file__)]
 
 
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build_stamps(counters=False):
@@ -38,13 +44,29 @@ def build_stamps(counters=False):
 
 
 def build(force=False, verbose=False):
+    """Compile if any dependency is newer than the library.  Safe to call from several processes at once (ranks of a
+    multi-GPU job, pytest-xdist workers): one holds the lock and compiles into a temporary file that is renamed into
+    place, so nobody ever dlopen()s a partially written library."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', 'hipcc')
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + FLAGS + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
-        [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB_PATH]
-    subprocess.check_call(cmd)
+    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another process built it while we waited
+                return LIB_PATH
+            tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+            cmd = [hipcc] + FLAGS + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
+                [os.path.join(CSRC, s) for s in SOURCES] + ['-o', tmp]
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
