@@ -2,16 +2,24 @@
 //
 // Every Linear layer (network.py:145-149,172-182,212-222) is Y[n][e] = b[n] + sum_k W[n][k] * X[e][k] computed with
 // v_mfma_f32_16x16x4_f32: A operand = 16 output neurons x 4 k of the weight matrix, B operand = 4 k x 16 environments
-// of the activations, D = 16 neurons x 16 environments.  The MFMA accumulates k in order as one float32 fmaf chain
-// (exact f32, no wider internal sum), and the chain's initial value is the bias, so each output equals the oracle's
-// sequential fmaf chain bit for bit.  K is never split across waves or accumulators.
+// of the activations, D = 16 neurons x 16 environments.  The MFMA accumulates its 4 k in order as one float32 fmaf
+// chain (exact f32, no wider internal sum).
 //
-// Activations live in LDS in "fragment-packed" order so that ONE ds_read_b128 per lane feeds 4 consecutive k-steps:
-//     pk(k, e) = ((k >> 4) * 64 + (k & 3) * 16 + e) * 4 + ((k >> 2) & 3)          [float index]
-// i.e. lane (q = lane >> 4, e = lane & 15) reads float4 #(g*64 + lane) and gets X[e][16g + 4s + q], s = 0..3 --
-// exactly the B operand of k-steps 4g .. 4g+3.  Weights are pre-packed on the host into the mirror-image A-operand
-// order, so one global_load_dwordx4 per lane (1 KiB contiguous per wave) feeds the same 4 k-steps:
-//     Wp[((t * KG + g) * 64 + lane) * 4 + s] = W[16 t + (lane & 15)][16 g + 4 s + (lane >> 4)]
+// SUMMATION ORDER (the numerical contract; oracle/mz_oracle.c linear_mlp is the same order on the CPU):
+//   * inputs are taken in blocks of 16; k-step i (0..3) of block g multiplies k = 16g + 4q + i, q = 0..3 in that order.
+//     That is the order in which an MFMA consumes a D-layout accumulator as its B operand: lane (e, q) of D holds
+//     neurons 16t + 4q .. 4q+3 in registers 0..3, and register i of lane (e, q) is B[k = q][n = e] of k-step i.  A
+//     layer's output therefore feeds the next layer straight from registers (mz_search_fast.h) -- or from LDS, where
+//     the same order makes lane (e, q)'s four k-steps ONE aligned float4 of four consecutive k:
+//         pk(k, e) = ((k >> 4) * 64 + ((k >> 2) & 3) * 16 + e) * 4 + (k & 3)          [float index]
+//   * the one-hot action inputs of the dynamics net (network.py:191-193) form their own block(s) after the (padded)
+//     hidden blocks, in natural order: action a of a block sits at lane q = a & 3, k-step i = a >> 2 (pk_act).
+//   * the second layer of every two-layer net (K = num_planes) is K-SPLIT: its blocks are dealt to 4 contiguous
+//     quarters, one chain each (quarter 0 starts from the bias, the others from +0), result ((c0 + c1) + c2) + c3.
+//     In the tuned kernel quarter w is the part of the hidden layer that wave w computed and still holds in registers.
+// Weights are pre-packed on the host into the matching A-operand order, one global_load_dwordx4 per lane (1 KiB
+// contiguous per wave) per tile and block:
+//     Wp[((t * KG + g) * 64 + lane) * 4 + i] = W[16 t + (lane & 15)][kidx(g, q = lane >> 4, i)]
 // Weights are streamed L2 -> VGPR (each element is used once per 16-env tile, so LDS staging would add nothing).
 #pragma once
 #include "mz_device.h"
@@ -24,7 +32,11 @@ constexpr int TILE_E = 16;      // environments per workgroup tile
 constexpr int WG_THREADS = 256; // 4 waves
 constexpr int WG_WAVES = 4;
 
-__device__ __forceinline__ int pk(int k, int e) { return (((k >> 4) * 64 + (k & 3) * 16 + e) << 2) + ((k >> 2) & 3); }
+__device__ __forceinline__ int pk(int k, int e) { return (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + e) << 2) + (k & 3); }
+// one-hot action a of the dynamics input; hblocks = 16-blocks of the padded hidden part in front of the action block(s)
+__device__ __forceinline__ int pk_act(int a, int e, int hblocks) {
+    return (((hblocks + (a >> 4)) * 64 + (a & 3) * 16 + e) << 2) + ((a & 15) >> 2);
+}
 
 // Layer ids in the packed parameter table (state_dict order, network.py:236-267)
 enum { L_REP0 = 0, L_REP1, L_DYN0, L_DYN1, L_REW0, L_REW1, L_POL0, L_POL1, L_VAL0, L_VAL1, L_COUNT };
@@ -35,15 +47,17 @@ struct MlpLayer {
     int n;           // real output features
     int k;           // real input features
     int n_tiles;     // ceil(n/16)
-    int k_steps;     // ceil(k/4)
-    int kg;          // ceil(k/16)
+    int kg;          // 16-blocks of the (padded) input; the dynamics layer 0 counts its action block(s) too
+    int last_steps;  // k-steps of the LAST block (1..4); every other block runs all 4 (padding is exact zeros)
+    int split;       // K-split layer: 4 quarter chains of kq blocks each
+    int kq;          // ceil(kg / 4)
     int b_lds;       // float offset of the LDS copy of b (staged once per kernel by stage_biases)
 };
 
 struct MlpNet {
     MlpLayer L[L_COUNT];
     int in_dim, A, P, H, Sv, Sr;
-    int in_pad, x_pad, p_pad, h_pad;  // multiples of 16: obs, H+A, P, H
+    int in_pad, x_pad, p_pad, h_pad;  // multiples of 16: obs, pad16(H) + pad16(A), P, H
 };
 
 // LDS carve-out of the network part (float offsets from the dynamic-LDS base)
@@ -60,6 +74,25 @@ struct MlpLds {
     int PM;   // [2][4][16] : per-wave min / max partials of the hidden state (fused normalisation)
     int total_floats;
 };
+
+// 4 k-steps (or `steps` of them) of one block for NACC accumulators
+template <int NACC>
+__device__ __forceinline__ void mma_block(f32x4 (&acc)[NACC], const float4 (&w)[NACC], const float4 x, int steps) {
+#pragma unroll
+    for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, x.x, acc[j], 0, 0, 0);
+    if (steps > 1) {
+#pragma unroll
+        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, x.y, acc[j], 0, 0, 0);
+    }
+    if (steps > 2) {
+#pragma unroll
+        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, x.z, acc[j], 0, 0, 0);
+    }
+    if (steps > 3) {
+#pragma unroll
+        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, x.w, acc[j], 0, 0, 0);
+    }
+}
 
 // One Linear layer over this workgroup's tile.  Tiles of 16 output neurons are dealt to waves round-robin
 // (tile = wave_slot + i*WG_WAVES); up to NACC tiles are accumulated concurrently (independent MFMA chains hide the
@@ -78,47 +111,69 @@ __device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __res
         wp[j] = reinterpret_cast<const float4*>(L.w) + (size_t)t * L.kg * 64 + lane;
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
-    const int full = L.k_steps >> 2;
-    for (int g = 0; g < full; g++) {
+    for (int g = 0; g < L.kg; g++) {
         const float4 x = xp[g * 64];
         float4 w[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; j++) w[j] = wp[j][g * 64];
-#pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, x.x, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, x.y, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, x.z, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, x.w, acc[j], 0, 0, 0);
-    }
-    const int rem = L.k_steps & 3;
-    if (rem) {
-        const int g = full;
-        const float4 x = xp[g * 64];
-        float4 w[NACC];
-#pragma unroll
-        for (int j = 0; j < NACC; j++) w[j] = wp[j][g * 64];
-#pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, x.x, acc[j], 0, 0, 0);
-        if (rem > 1) {
-#pragma unroll
-            for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, x.y, acc[j], 0, 0, 0);
-        }
-        if (rem > 2) {
-#pragma unroll
-            for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, x.z, acc[j], 0, 0, 0);
-        }
+        mma_block<NACC>(acc, w, x, g + 1 < L.kg ? 4 : L.last_steps);
     }
 #pragma unroll
     for (int j = 0; j < NACC; j++) epi(t0 + j * WG_WAVES, acc[j]);
+}
+
+// K-split layer: NT2 tiles x 4 quarter chains concurrently; quarter c covers blocks [c*kq, min(kg, (c+1)*kq))
+template <int NT2, typename Epi>
+__device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs, int t0,
+                                                 int lane, Epi& epi) {
+    const int q = lane >> 4;
+    f32x4 acc[NT2][4];
+    const float4* wp[NT2];
+#pragma unroll
+    for (int j = 0; j < NT2; j++) {
+        const int t = t0 + j * WG_WAVES;
+        const float4 bv = *reinterpret_cast<const float4*>(lds + L.b_lds + t * 16 + q * 4);
+        acc[j][0] = f32x4{bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int c = 1; c < 4; c++) acc[j][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        wp[j] = reinterpret_cast<const float4*>(L.w) + (size_t)t * L.kg * 64 + lane;
+    }
+    const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
+    for (int gg = 0; gg < L.kq; gg++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int g = c * L.kq + gg;
+            if (g < L.kg) {
+                const float4 x = xp[g * 64];
+                float4 w[NT2];
+                f32x4 a[NT2];
+#pragma unroll
+                for (int j = 0; j < NT2; j++) { w[j] = wp[j][g * 64]; a[j] = acc[j][c]; }
+                mma_block<NT2>(a, w, x, g + 1 < L.kg ? 4 : L.last_steps);
+#pragma unroll
+                for (int j = 0; j < NT2; j++) acc[j][c] = a[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT2; j++) {
+        const f32x4 y = ((acc[j][0] + acc[j][1]) + acc[j][2]) + acc[j][3];
+        epi(t0 + j * WG_WAVES, y);
+    }
 }
 
 template <typename Epi>
 __device__ __forceinline__ void gemm_layer(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs, int wave_slot,
                                            int lane, Epi epi) {
     int t = wave_slot;
+    if (L.split) {
+        while (t + 1 * WG_WAVES < L.n_tiles) {
+            gemm_chunk_split<2>(L, lds, Xs, t, lane, epi);
+            t += 2 * WG_WAVES;
+        }
+        if (t < L.n_tiles) gemm_chunk_split<1>(L, lds, Xs, t, lane, epi);
+        return;
+    }
     while (t + 7 * WG_WAVES < L.n_tiles) {
         gemm_chunk<8>(L, lds, Xs, t, lane, epi);
         t += 8 * WG_WAVES;
@@ -139,15 +194,12 @@ struct EpiReluPacked {
     float* dst;
     int lane;
     __device__ __forceinline__ void operator()(int t, const f32x4& a) const {
-        const int q = lane >> 4, e = lane & 15;
-        // pk(16t + 4q + r, e) = ((t*64 + r*16 + e) << 2) + q
-        float* p = dst + ((t * 64 + e) << 2) + q;
+        // pk(16t + 4q + r, e), r = 0..3, is the float4 #(t*64 + lane): one ds_write_b128
         // ReLU as one v_med3_f32 (median of x, 0, +inf == max(x, 0) for every non-NaN x)
         const float inf = __uint_as_float(0x7f800000u);
-        p[0 * 64] = __builtin_amdgcn_fmed3f(a[0], 0.0f, inf);
-        p[1 * 64] = __builtin_amdgcn_fmed3f(a[1], 0.0f, inf);
-        p[2 * 64] = __builtin_amdgcn_fmed3f(a[2], 0.0f, inf);
-        p[3 * 64] = __builtin_amdgcn_fmed3f(a[3], 0.0f, inf);
+        reinterpret_cast<float4*>(dst)[t * 64 + lane] =
+            make_float4(__builtin_amdgcn_fmed3f(a[0], 0.0f, inf), __builtin_amdgcn_fmed3f(a[1], 0.0f, inf),
+                        __builtin_amdgcn_fmed3f(a[2], 0.0f, inf), __builtin_amdgcn_fmed3f(a[3], 0.0f, inf));
     }
 };
 
@@ -156,12 +208,7 @@ struct EpiRawPacked {
     float* dst;
     int lane;
     __device__ __forceinline__ void operator()(int t, const f32x4& a) const {
-        const int q = lane >> 4, e = lane & 15;
-        float* p = dst + ((t * 64 + e) << 2) + q;
-        p[0 * 64] = a[0];
-        p[1 * 64] = a[1];
-        p[2 * 64] = a[2];
-        p[3 * 64] = a[3];
+        reinterpret_cast<float4*>(dst)[t * 64 + lane] = make_float4(a[0], a[1], a[2], a[3]);
     }
 };
 
@@ -197,11 +244,11 @@ __device__ __forceinline__ void normalize_tile(const MlpNet& net, const float* H
     float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
     for (int c = c0; c < chunks; c += 16) {
         const int k = c << 2;
-        const float* p = HN + (((k >> 4) * 64 + e) << 2) + ((k >> 2) & 3);  // pk(k + j, e) = base + j*64
+        const float* p = HN + pk(k, e);  // pk(k + j, e) = base + j
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (k + j < net.H) {
-                const float v = p[j * 64];
+                const float v = p[j];
                 mn = v < mn ? v : mn;
                 mx = v > mx ? v : mx;
             }
@@ -217,13 +264,13 @@ __device__ __forceinline__ void normalize_tile(const MlpNet& net, const float* H
     float* g = grow ? grow[e] : nullptr;
     for (int c = c0; c < chunks; c += 16) {
         const int k = c << 2;
-        const int base = (((k >> 4) * 64 + e) << 2) + ((k >> 2) & 3);
+        const int base = pk(k, e);
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float v = (k + j < net.H) ? (HN[base + j * 64] - mn) / d : 0.0f;
+            const float v = (k + j < net.H) ? (HN[base + j] - mn) / d : 0.0f;
             o[j] = v;
-            HS[base + j * 64] = v;
+            HS[base + j] = v;
         }
         if (g) {
             if (k + 3 < net.H) {
@@ -318,12 +365,12 @@ __device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds
     __syncthreads();
 }
 
-// Fill X with [hidden row (H floats, global) | one-hot(action)] for the 16 envs (network.py:191-193).
-// src[e] may be null (env slot unused): zeros.  256 threads: 16 per env, float4 loads.
+// Fill X with [hidden row (H floats, global; zero padded to h_pad) | one-hot(action) block(s)] for the 16 envs
+// (network.py:191-193).  src[e] may be null (env slot unused): zeros.  256 threads: 16 per env, float4 loads.
 __device__ __forceinline__ void load_hidden_onehot(const MlpNet& net, float* X, const float* const* src, const int* action, int tid) {
     const int e = tid >> 4, c0 = tid & 15;
     const float* s = src[e];
-    const int chunks = net.x_pad >> 2;
+    const int chunks = net.h_pad >> 2;
     for (int c = c0; c < chunks; c += 16) {
         const int k = c << 2;
         float v[4];
@@ -332,18 +379,12 @@ __device__ __forceinline__ void load_hidden_onehot(const MlpNet& net, float* X, 
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int kk = k + j;
-                float t = 0.0f;
-                if (kk < net.H) t = s ? s[kk] : 0.0f;
-                else if (kk < net.H + net.A) t = (kk - net.H == action[e]) ? 1.0f : 0.0f;
-                v[j] = t;
-            }
+            for (int j = 0; j < 4; j++) v[j] = (k + j < net.H && s) ? s[k + j] : 0.0f;
         }
-        const int base = (((k >> 4) * 64 + e) << 2) + ((k >> 2) & 3);
-#pragma unroll
-        for (int j = 0; j < 4; j++) X[base + j * 64] = v[j];
+        *reinterpret_cast<float4*>(X + pk(k, e)) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    const int hblocks = net.h_pad >> 4, a_pad = net.x_pad - net.h_pad;
+    for (int a = c0; a < a_pad; a += 16) X[pk_act(a, e, hblocks)] = (a < net.A && a == action[e]) ? 1.0f : 0.0f;
 }
 
 // Fill X with flattened observations (float32 rows of in_dim).
@@ -353,11 +394,11 @@ __device__ __forceinline__ void load_obs(const MlpNet& net, float* X, const floa
     const int chunks = net.in_pad >> 2;
     for (int c = c0; c < chunks; c += 16) {
         const int k = c << 2;
-        const int base = (((k >> 4) * 64 + e) << 2) + ((k >> 2) & 3);
+        const int base = pk(k, e);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int kk = k + j;
-            X[base + j * 64] = (s && kk < net.in_dim) ? s[kk] : 0.0f;
+            X[base + j] = (s && kk < net.in_dim) ? s[kk] : 0.0f;
         }
     }
 }

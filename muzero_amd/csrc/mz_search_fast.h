@@ -1,17 +1,28 @@
 // mz_search_fast.h -- the tuned search kernel for the benchmark shapes (hidden_dim 64, num_planes 256 or 512,
 // value/reward support <= 32, <= 16 actions: CartPole, LunarLander, TicTacToe MLP nets).  Same algorithm, same LDS
-// tree, same numerics as k_search (mz_search.h); what changes is how the per-simulation network evaluation is fed:
+// tree, same numerics as k_search (mz_search.h); what changes is how the per-simulation network evaluation runs:
 //
-//   * "chain" layers (K = num_planes: dynamics layer 2, reward layer 2, value layer 2) have one 16-neuron tile per
-//     wave and a 4*P/16-deep dependent MFMA chain.  Their weight tile streams through an 8-group register ring that
-//     is primed one phase early (during the preceding wide layer) and refilled 8 groups (1280 chain cycles) ahead.
-//   * "wide" layers (N = num_planes: dynamics layer 1, reward layer 1, value layer 1) stream their weights from L2
-//     through a double-buffered register ring, in a per-wave contiguous "stream" layout, one group (8 tiles x 16 k)
-//     ahead of the MFMAs -- including across layer and simulation boundaries (the next layer's first group is
-//     requested before the current layer's epilogue / barriers / tree phase), so the loads are never waited for.
+//   * REGISTER-RESIDENT ACTIVATIONS.  Wave w computes the contiguous quarter [NT*w, NT*w + NT) of every num_planes-wide
+//     hidden layer (NT = P/64 tiles of 16 neurons) and keeps it in its accumulators: a D-layout accumulator IS the B
+//     operand of the next layer's MFMAs in the summation order of mz_mlp.h (k-step i of block g = register i of tile g).
+//     The following K = num_planes layer is K-split: each wave multiplies its own quarter and the four partial tiles
+//     meet in LDS -- ((c0 + c1) + c2) + c3, the order the oracle restates.  The 512 x 16 hidden layers never touch LDS
+//     (v1 of this kernel wrote and re-read 32 KiB per layer and barriered after every layer: 7 barriers per
+//     simulation; this one has 4).
+//   * ONE WEIGHT STREAM PER WAVE.  All six layers' A operands of a simulation are packed on the host in exactly the
+//     order wave w consumes them, in slots of NT float4[64] blocks (4 NT MFMAs each); the wave walks the stream
+//     cyclically through an RD-deep register ring, RD - 1 slots (~2 k cycles) ahead of the MFMAs -- across layer,
+//     barrier and simulation boundaries, so a load is never waited for.  buffer_load with an SGPR offset: no address
+//     VGPRs.
 //
-// Stream layout (host packs it, see pack_stream in planner.hip): for wave w, layer with NT tiles per wave
-// (tile t = w + 4 j) and KG k-groups, block (g, j) is the float4[64] at  ((w * KG + g) * NT + j) * 64 + lane.
+// Stream layout (host: pack_fast_stream in planner.hip): float4 index ((w * SL + slot) * NT + j) * 64 + lane, slots of
+// one simulation in order
+//     D1  dynamics layer 1, 5 slots: input block g (4 hidden blocks + the action block), j = tile NT w + j
+//     D2  dynamics layer 2 (K-split), 4 slots: j <-> (kb = (slot NT + j) / 4, t = (slot NT + j) % 4): out tile t, input block NT w + kb
+//     R1  reward layer 1, 4 slots (input block g of the un-normalised state, network.py:195-196)
+//     R2  reward layer 2 (K-split), TR slots: j <-> (kb, t) with TR out tiles
+//     V1  value layer 1, 4 slots (normalised state);  V2  value layer 2 (K-split), TV slots
+//     zero padding up to a multiple of RD slots.
 #pragma once
 #include <type_traits>
 
@@ -20,9 +31,8 @@
 namespace mz {
 
 struct FastWeights {
-    const float4* dyn0;  // stream, NT = P/64, KG = ceil((64+A)/16)
-    const float4* rew0;  // stream, NT = P/64, KG = 4
-    const float4* val0;  // stream, NT = P/64, KG = 4
+    const float4* stream;
+    unsigned bytes;  // whole stream (4 waves)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -47,141 +57,136 @@ __device__ __forceinline__ float4 bload(const WSrc& w, int voff, int block) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int NT>
-__device__ __forceinline__ void wload(float4 (&w)[NT], const WSrc& src, int voff, int block0) {
+__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// P = num_planes; TR / TV = 16-neuron tiles of the reward / value support; RD = ring depth
+template <int P, int TR, int TV, int RD>
+struct FastCfg {
+    static constexpr int NT = P / 64;
+    static constexpr int XG = 5;  // input blocks of the dynamics net: hidden 64 + one action block (A <= 16)
+    static constexpr int I_D1 = 0, I_D2 = I_D1 + XG, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
+    static constexpr int SL = (I_END + RD - 1) / RD * RD;  // slots per simulation incl. padding
+};
+
+// request slot I + RD - 1 (cyclic) into the ring entry that slot I - 1 has just vacated
+template <typename C, int RD, int I>
+__device__ __forceinline__ void prefetch_slot(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff) {
+    constexpr int T = (I + RD - 1) % C::SL;
 #pragma unroll
-    for (int j = 0; j < NT; j++) w[j] = bload(src, voff, block0 + j);
+    for (int j = 0; j < C::NT; j++) ring[T % RD][j] = bload(ws, voff, T * C::NT + j);
 }
 
-template <int NT>
-__device__ __forceinline__ void wmma4(f32x4 (&acc)[NT], const float4 (&w)[NT], const float4 x) {
+// issue order inside a slot: (the B-operand LDS read,) then one weight load per 4 MFMAs -- the loads' issue slots hide
+// under the 32-cycle MFMAs instead of preceding them
+template <int NT, bool LDS_READ>
+__device__ __forceinline__ void slot_schedule() {
+    if (LDS_READ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, x.x, acc[j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, x.y, acc[j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, x.z, acc[j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, x.w, acc[j], 0, 0, 0);
+    for (int i = 0; i < NT; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the ring RD - 1 slots deep: no hoisting of later slots' loads
 }
 
-template <int NT>
-__device__ __forceinline__ void wmma_rem(f32x4 (&acc)[NT], const float4 (&w)[NT], const float4 x, int rem) {
-#pragma unroll
-    for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, x.x, acc[j], 0, 0, 0);
-    if (rem > 1) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, x.y, acc[j], 0, 0, 0);
-    }
-    if (rem > 2) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, x.z, acc[j], 0, 0, 0);
-    }
-    if (rem > 3) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, x.w, acc[j], 0, 0, 0);
-    }
-}
-
-// One streamed wide layer for this wave.  On entry buf[PAR] holds group 0 of this layer (requested earlier); on exit
-// buf[(PAR + KG) & 1] holds group 0 of the NEXT layer (`next`), requested while the last group was being multiplied.
-// `last_steps` = k-steps in the last group (1..4).
-template <int NT, int KG, int PAR, typename Epi>
-__device__ __forceinline__ void stream_layer(float4 (&buf)[2][NT], const WSrc& cur, const WSrc& next, const float* __restrict__ bias,
-                                             const float* __restrict__ Xs, int last_steps, int wave, int lane, Epi epi) {
-    const int voff = lane * 16;
-    const int q = lane >> 4;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + (wave + 4 * j) * 16 + q * 4);
-        acc[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
-    }
-    const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
-#pragma unroll
-    for (int g = 0; g < KG; g++) {
-        if (g + 1 < KG) wload<NT>(buf[(PAR + g + 1) & 1], cur, voff, (g + 1) * NT);
-        else wload<NT>(buf[(PAR + g + 1) & 1], next, voff, 0);
-        const float4 x = xp[g * 64];
-        if (g + 1 < KG) wmma4<NT>(acc, buf[(PAR + g) & 1], x);
-        else wmma_rem<NT>(acc, buf[(PAR + g) & 1], x, last_steps);
-        // issue order inside the group: the B-operand read, then one weight load per 4 MFMAs (the loads' issue slots hide
-        // under the 32-cycle MFMAs instead of preceding them)
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-        for (int i = 0; i < NT; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+// The slot loops need the slot index as a compile-time constant for the ring entry; `#pragma unroll` loops over a
+// constexpr bound give that after unrolling, but the prefetch helper takes it as a template argument, so the loops are
+// written with an index_sequence-style recursion.
+template <typename C, int RD, int I0, int G, int KG, bool FROM_LDS>
+struct WideSlots {
+    // FROM_LDS: B operand = float4 read from the packed LDS buffer; else B operand = hin[G] (D-layout registers)
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const float4* xp, const f32x4 (&hin)[4],
+                                               int last_steps, f32x4 (&acc)[C::NT]) {
+        constexpr int NT = C::NT, I = I0 + G;
+        prefetch_slot<C, RD, I>(ring, ws, voff);
+        float b[4];
+        if (FROM_LDS) {
+            const float4 x = xp[G * 64];
+            b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = x.w;
+        } else {
+            b[0] = hin[G][0]; b[1] = hin[G][1]; b[2] = hin[G][2]; b[3] = hin[G][3];
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the ring 1 group deep: no hoisting of later groups' loads
+        const float4(&w)[NT] = ring[I % RD];
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, b[0], acc[j], 0, 0, 0);
+        if (G + 1 < KG || last_steps > 1) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, b[1], acc[j], 0, 0, 0);
+        }
+        if (G + 1 < KG || last_steps > 2) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, b[2], acc[j], 0, 0, 0);
+        }
+        if (G + 1 < KG || last_steps > 3) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, b[3], acc[j], 0, 0, 0);
+        }
+        slot_schedule<NT, FROM_LDS>();
+        if constexpr (G + 1 < KG) WideSlots<C, RD, I0, G + 1, KG, FROM_LDS>::run(ring, ws, voff, xp, hin, last_steps, acc);
     }
-#pragma unroll
-    for (int j = 0; j < NT; j++) epi(wave + 4 * j, acc[j]);
-}
+};
 
-// One chain layer tile with register-resident weights: 4*KGP dependent MFMAs, B operand from LDS.
-template <int KGP, typename Epi>
-__device__ __forceinline__ void chain_layer(const float4 (&wres)[KGP], const float* __restrict__ bias, int tile, const float* __restrict__ Xs,
-                                            int lane, Epi epi) {
-    const int q = lane >> 4;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + tile * 16 + q * 4);
-    f32x4 acc = f32x4{bv.x, bv.y, bv.z, bv.w};
-    const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
-    float4 x = xp[0], x1 = xp[64];
+// K-split layer, this wave's quarter: TO output tiles, input = the NT tiles this wave holds in registers (hin).
+// Slot D holds NT float4: entry jj <-> (kb = (D NT + jj) / TO, t = (D NT + jj) % TO).
+template <typename C, int RD, int I0, int D, int TO>
+struct SplitSlots {
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const f32x4 (&hin)[C::NT], f32x4 (&acc)[TO]) {
+        constexpr int NT = C::NT, I = I0 + D, KPS = NT / TO;
+        static_assert(NT % TO == 0, "tiles per slot");
+        prefetch_slot<C, RD, I>(ring, ws, voff);
+        const float4(&w)[NT] = ring[I % RD];
 #pragma unroll
-    for (int g = 0; g < KGP; g++) {
-        const float4 x2 = xp[(g + 2 < KGP ? g + 2 : g) * 64];  // B operand two groups ahead of the chain
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[g].x, x.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[g].y, x.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[g].z, x.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[g].w, x.w, acc, 0, 0, 0);
-        x = x1;
-        x1 = x2;
-        __builtin_amdgcn_sched_barrier(0);
+        for (int kk = 0; kk < KPS; kk++) {
+            const int kb = D * KPS + kk;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+#pragma unroll
+                for (int t = 0; t < TO; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(w[kk * TO + t], st), hin[kb][st], acc[t], 0, 0, 0);
+            }
+        }
+        slot_schedule<NT, false>();
+        if constexpr (D + 1 < TO) SplitSlots<C, RD, I0, D + 1, TO>::run(ring, ws, voff, hin, acc);
     }
-    epi(tile, acc);
-}
+};
 
-// Chain layer tile with its weights streamed through a D-deep register ring: on entry ring[d] holds group d
-// (requested by chain_prime well before); every consumed slot is immediately re-requested D groups ahead, so D * 4
-// dependent MFMAs (D * 160 cycles) of latency cover is always in flight.
-template <int KGP, int D>
-__device__ __forceinline__ void chain_prime(float4 (&ring)[D], const WSrc& wp, int lane) {
-#pragma unroll
-    for (int d = 0; d < D; d++) ring[d] = bload(wp, lane * 16, d);
-}
-
-template <int KGP, int D>
-__device__ __forceinline__ f32x4 chain_layer_ring(float4 (&ring)[D], const WSrc& wp, const float* __restrict__ bias, int tile,
-                                                  const float* __restrict__ Xs, int lane) {
-    const int q = lane >> 4;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + tile * 16 + q * 4);
-    f32x4 acc = f32x4{bv.x, bv.y, bv.z, bv.w};
-    const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
-    float4 x = xp[0], x1 = xp[64];
-#pragma unroll
-    for (int g = 0; g < KGP; g++) {
-        const float4 x2 = xp[(g + 2 < KGP ? g + 2 : g) * 64];
-        const float4 w = ring[g % D];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc, 0, 0, 0);
-        if (g + D < KGP) ring[g % D] = bload(wp, lane * 16, g + D);
-        x = x1;
-        x1 = x2;
-        __builtin_amdgcn_sched_barrier(0);
+// padding slots: nothing to multiply, but the ring must keep turning (their prefetches are the next simulation's first slots)
+template <typename C, int RD, int I>
+struct PadSlots {
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff) {
+        if constexpr (I < C::SL) {
+            prefetch_slot<C, RD, I>(ring, ws, voff);
+            __builtin_amdgcn_sched_barrier(0);
+            PadSlots<C, RD, I + 1>::run(ring, ws, voff);
+        }
     }
-    return acc;
+};
+
+template <int N>
+__device__ __forceinline__ void relu_tiles(f32x4 (&a)[N]) {
+    const float inf = __uint_as_float(0x7f800000u);
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) a[j][r] = __builtin_amdgcn_fmed3f(a[j][r], 0.0f, inf);
+    }
 }
 
-// P = num_planes (256 or 512); XG = k-groups of the dynamics input (hidden 64 + one-hot A): 5 for A <= 16
+// logit n of env e from the four waves' partial tiles of a K-split head: ((c0 + c1) + c2) + c3
+template <int TO>
+__device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
+    const int t = n >> 4, idx = ((t * 64 + ((n & 15) >> 2) * 16 + e) << 2) + (n & 3);
+    const float c0 = PB[idx], c1 = PB[idx + TO * 256], c2 = PB[idx + 2 * TO * 256], c3 = PB[idx + 3 * TO * 256];
+    return ((c0 + c1) + c2) + c3;
+}
+
+// P = num_planes (256 or 512); TR / TV: tiles of the reward / value support (1 or 2)
 // FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
-template <int P, bool FUSE = false>
+template <int P, int TR, int TV, bool FUSE = false>
 __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
-    constexpr int NT = P / 64;   // wide-layer tiles per wave
-    constexpr int KGP = P / 16;  // k-groups of the chain layers
-    constexpr int XG = 5;
+    constexpr int RD = 3;
+    using C = FastCfg<P, TR, TV, RD>;
+    constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lds = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15, lane = tid & 63;
@@ -231,22 +236,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     __syncthreads();
     if (a0 == 0 && env_ok) root_prior(smem, Pm, e, env_g);
 
-    // ---- chain-layer weight sources: dynamics layer 2 tile `wave`; reward layer 2 (waves 0,1) / value layer 2 (waves 2,3) ----
-    constexpr int HD = 8;  // chain ring depth (groups in flight): shared by the dynamics-2 chain and the head chain
-    float4 cring[HD];
-    const WSrc pd = make_wsrc(net.L[L_DYN1].w, (unsigned)net.L[L_DYN1].n_tiles * KGP * 1024u, wave * KGP * 1024);
-    const bool is_val_wave = wave >= 2;
-    const int head_tile = wave & 1;
-    const MlpLayer& HL = is_val_wave ? net.L[L_VAL1] : net.L[L_REW1];
-    const bool head_ok = head_tile < HL.n_tiles;
-    const WSrc ph = make_wsrc(HL.w, (unsigned)HL.n_tiles * KGP * 1024u, (head_ok ? head_tile : 0) * KGP * 1024);
-    // ---- streamed wide-layer weights: per-wave stream bases; ring primed with dynamics layer 1, group 0 ----
-    const WSrc s_dyn0 = make_wsrc(FW.dyn0, 4u * XG * NT * 1024u, wave * XG * NT * 1024);
-    const WSrc s_rew0 = make_wsrc(FW.rew0, 4u * 4 * NT * 1024u, wave * 4 * NT * 1024);
-    const WSrc s_val0 = make_wsrc(FW.val0, 4u * 4 * NT * 1024u, wave * 4 * NT * 1024);
-    float4 ring[2][NT];
-    wload<NT>(ring[0], s_dyn0, lane * 16, 0);
-    const int x_last = net.L[L_DYN0].k_steps - 4 * (XG - 1);  // k-steps in the last input group (1..4)
+    // ---- this wave's weight stream; ring primed with the first RD - 1 slots ----
+    const int voff = lane * 16;
+    const WSrc ws = make_wsrc(FW.stream, FW.bytes, wave * C::SL * NT * 1024);
+    float4 ring[RD][NT];
+#pragma unroll
+    for (int i = 0; i < RD - 1; i++) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) ring[i][j] = bload(ws, voff, i * NT + j);
+    }
+    const int x_last = net.L[L_DYN0].last_steps;  // k-steps of the action block (1..4)
     // MFMA-side env of this lane (D column) and its hidden-state rows in the HBM node store
     const int e2 = lane & 15, q = lane >> 4;
     const int env2 = blockIdx.x * TILE_E + e2;
@@ -254,105 +253,162 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     float* const hid_sel = Pm.hidden + (size_t)(env_ok ? env_g : 0) * Pm.NN * 64;   // select-side env (tid >> 4)
     float* const hid_mma = Pm.hidden + (size_t)(env2_ok ? env2 : 0) * Pm.NN * 64;  // MFMA-side env (lane & 15)
     const float* bias = lds;  // biases live in LDS (stage_biases)
+    // K-split partial tiles (LDS, aliased onto the H1 / V1 buffers that only the root inference uses):
+    // PB [4 waves][4 tiles] dynamics layer 2, PBr [4][TR] reward layer 2, PBv [4][TV] value layer 2, float4[64] each
+    float4* const PB = reinterpret_cast<float4*>(lds + o.H1);
+    float4* const PBr = reinterpret_cast<float4*>(lds + o.V1);
+    float4* const PBv = PBr + 4 * TR * 64;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     MZ_STAMP(0);  // root: tables + initial inference + prior
 
-    // Ring parity: a layer that starts with its group 0 in ring[PAR] and has KG groups leaves its successor's group 0
-    // in ring[(PAR + KG) & 1].  dyn0 has 5 groups, rew0 and val0 4 each, so the parity flips once per simulation:
-    // the body is instantiated for both parities and the simulation loop alternates them (no register copies).
-    auto sim = [&](auto par_tag, int s) {
-        constexpr int PAR = decltype(par_tag)::value;
+    for (int s = 0; s < Pm.S; s++) {
         int lp, la, mypath = 0;
         if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, mypath);
         else tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
-        // their descent and scatter it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
+        // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
         {
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (env_ok) hv = *reinterpret_cast<const float4*>(hid_sel + (size_t)lp * 64 + a0 * 4);
             float* X = lds + o.X;
-            const int base = ((((a0 >> 2) * 64) + e) << 2) + (a0 & 3);  // pk(4*a0 + j, e) = base + 64 j
-            X[base] = hv.x; X[base + 64] = hv.y; X[base + 128] = hv.z; X[base + 192] = hv.w;
-            X[(((4 * 64) + (a0 & 3) * 16 + e) << 2) + (a0 >> 2)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;  // pk(64 + a0, e)
+            reinterpret_cast<float4*>(X)[(a0 >> 2) * 64 + (a0 & 3) * 16 + e] = hv;  // pk(4 a0 .. 4 a0 + 3, e)
+            X[pk_act(a0, e, 4)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;
         }
-        chain_prime<KGP, HD>(cring, pd, lane);  // dynamics-2 chain weights: first HD groups land during dynamics layer 1
         __syncthreads();
         MZ_STAMP(1);  // select + gather
-        // dynamics layer 1 (wide, streamed): X -> H1
-        stream_layer<NT, XG, PAR>(ring, s_dyn0, s_rew0, bias + net.L[L_DYN0].b_lds, lds + o.X, x_last, wave, lane, EpiReluPacked{lds + o.H1, lane});
-        __syncthreads();
-        MZ_STAMP(3);  // dynamics layer 1
-        // dynamics layer 2 (chain): H1 -> h; normalisation (util.py:31-36) fused into the epilogue: per-wave min/max
-        // partials through LDS, then every lane normalises its own 4 neurons in registers
+        // ---- dynamics layer 1 (this wave's NT tiles; X from LDS) and layer 2 (K-split partial from registers) ----
+        f32x4 h1[NT], h[4];
         {
-            const f32x4 h = chain_layer_ring<KGP, HD>(cring, pd, bias + net.L[L_DYN1].b_lds, wave, lds + o.H1, lane);
-            float mn = h[0] < h[1] ? h[0] : h[1], mx = h[0] > h[1] ? h[0] : h[1];
-            mn = h[2] < mn ? h[2] : mn; mx = h[2] > mx ? h[2] : mx;
-            mn = h[3] < mn ? h[3] : mn; mx = h[3] > mx ? h[3] : mx;
-            float t;
-            t = __shfl_xor(mn, 16, 64); mn = t < mn ? t : mn;
-            t = __shfl_xor(mx, 16, 64); mx = t > mx ? t : mx;
-            t = __shfl_xor(mn, 32, 64); mn = t < mn ? t : mn;
-            t = __shfl_xor(mx, 32, 64); mx = t > mx ? t : mx;
-            float* pm = lds + o.PM;
-            if (q == 0) { pm[wave * 16 + e2] = mn; pm[64 + wave * 16 + e2] = mx; }
-            EpiRawPacked{lds + o.HN, lane}(wave, h);  // un-normalised state feeds the reward head (network.py:195-196)
-            chain_prime<KGP, HD>(cring, ph, lane);    // head-chain weights: land during the two wide layers below
-            __syncthreads();
-            MZ_STAMP(4);  // dynamics layer 2 (chain)
+            const float* b1 = bias + net.L[L_DYN0].b_lds + wave * NT * 16;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const float a = pm[w * 16 + e2], b = pm[64 + w * 16 + e2];
-                mn = a < mn ? a : mn;
-                mx = b > mx ? b : mx;
+            for (int j = 0; j < NT; j++) {
+                const float4 bv = *reinterpret_cast<const float4*>(b1 + j * 16 + q * 4);
+                h1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            const float d = (mx - mn) + 1e-8f;
-            const f32x4 hs = f32x4{(h[0] - mn) / d, (h[1] - mn) / d, (h[2] - mn) / d, (h[3] - mn) / d};
-            EpiRawPacked{lds + o.HS, lane}(wave, hs);
-            if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = make_float4(hs[0], hs[1], hs[2], hs[3]);
+            WideSlots<C, RD, C::I_D1, 0, C::XG, true>::run(ring, ws, voff, reinterpret_cast<const float4*>(lds + o.X) + lane, h, x_last, h1);
+            relu_tiles<NT>(h1);
+            MZ_STAMP(3);  // dynamics layer 1
+            f32x4 acc2[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float4 bv = wave == 0 ? *reinterpret_cast<const float4*>(bias + net.L[L_DYN1].b_lds + t * 16 + q * 4) : zero4;
+                acc2[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
+            }
+            SplitSlots<C, RD, C::I_D2, 0, 4>::run(ring, ws, voff, h1, acc2);
+#pragma unroll
+            for (int t = 0; t < 4; t++) PB[(wave * 4 + t) * 64 + lane] = make_float4(acc2[t][0], acc2[t][1], acc2[t][2], acc2[t][3]);
         }
         __syncthreads();
-        MZ_STAMP(5);  // normalise + hidden store
-        // reward layer 1 (HN -> H1) and value layer 1 (HS -> V1), wide, streamed; the last one requests the next
-        // simulation's dynamics group 0, which then lands during the chain / softmax / tree phases
-        stream_layer<NT, 4, PAR ^ 1>(ring, s_rew0, s_val0, bias + net.L[L_REW0].b_lds, lds + o.HN, 4, wave, lane, EpiReluPacked{lds + o.H1, lane});
-        stream_layer<NT, 4, PAR ^ 1>(ring, s_val0, s_dyn0, bias + net.L[L_VAL0].b_lds, lds + o.HS, 4, wave, lane, EpiReluPacked{lds + o.V1, lane});
-        __syncthreads();
-        MZ_STAMP(6);  // reward + value layer 1
-        // reward layer 2 (waves 0,1) / value layer 2 (waves 2,3): chain, weights through the ring
-        if (head_ok) {
-            if (is_val_wave) {
-                const f32x4 lg = chain_layer_ring<KGP, HD>(cring, ph, bias + net.L[L_VAL1].b_lds, head_tile, lds + o.V1, lane);
-                EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane}(head_tile, lg);
-            } else {
-                const f32x4 lg = chain_layer_ring<KGP, HD>(cring, ph, bias + net.L[L_REW1].b_lds, head_tile, lds + o.H1, lane);
-                EpiLogits{lds + o.LG, o.lg_stride, lane}(head_tile, lg);
-            }
-        }
-        __syncthreads();
-        MZ_STAMP(7);  // reward / value layer 2 (chain)
-        // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
-        // the results are segment-uniform, so the env's lane 0 goes straight on to expand + backup
+        MZ_STAMP(4);  // dynamics layer 2 (partials)
+        // ---- every wave rebuilds the whole un-normalised state h (64 x 16) from the partials; normalisation
+        // (util.py:31-36) of its own tile goes to LDS (value head input) and to the HBM node store ----
         {
-            const float* rr = lds + o.LG + e * o.lg_stride;
-            const float* rv = lds + o.LG + (16 + e) * o.lg_stride;
-            const bool r0 = a0 < net.Sr, r1 = a0 + 16 < net.Sr, v0 = a0 < net.Sv, v1 = a0 + 16 < net.Sv;
-            const float lr0 = rr[r0 ? a0 : 0], lr1 = rr[r1 ? a0 + 16 : 0], lv0 = rv[v0 ? a0 : 0], lv1 = rv[v1 ? a0 + 16 : 0];
-            const float rew = net.Sr == 1 ? rr[0] : row2_logits_to_scalar(lr0, lr1, r0, r1, net.Sr, a0);
-            const float val = net.Sv == 1 ? rv[0] : row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float4 c0 = PB[(0 * 4 + t) * 64 + lane], c1 = PB[(1 * 4 + t) * 64 + lane], c2 = PB[(2 * 4 + t) * 64 + lane],
+                             c3 = PB[(3 * 4 + t) * 64 + lane];
+                h[t] = f32x4{((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
+                             ((c0.w + c1.w) + c2.w) + c3.w};
+            }
+            float mn = h[0][0], mx = h[0][0];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    mn = h[t][r] < mn ? h[t][r] : mn;
+                    mx = h[t][r] > mx ? h[t][r] : mx;
+                }
+            }
+            float tt;
+            tt = __shfl_xor(mn, 16, 64); mn = tt < mn ? tt : mn;
+            tt = __shfl_xor(mx, 16, 64); mx = tt > mx ? tt : mx;
+            tt = __shfl_xor(mn, 32, 64); mn = tt < mn ? tt : mn;
+            tt = __shfl_xor(mx, 32, 64); mx = tt > mx ? tt : mx;
+            const float d = (mx - mn) + 1e-8f;
+            f32x4 hw = h[0];
+            if (wave == 1) hw = h[1];
+            if (wave == 2) hw = h[2];
+            if (wave == 3) hw = h[3];
+            const float4 hs = make_float4((hw[0] - mn) / d, (hw[1] - mn) / d, (hw[2] - mn) / d, (hw[3] - mn) / d);
+            reinterpret_cast<float4*>(lds + o.HS)[wave * 64 + lane] = hs;
+            if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = hs;
+        }
+        MZ_STAMP(5);  // reduce + normalise + hidden store
+        // ---- reward head on the UN-normalised state (network.py:195-196): layer 1 from registers, layer 2 K-split ----
+        {
+            f32x4 r1[NT];
+            const float* b1 = bias + net.L[L_REW0].b_lds + wave * NT * 16;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const float4 bv = *reinterpret_cast<const float4*>(b1 + j * 16 + q * 4);
+                r1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
+            }
+            WideSlots<C, RD, C::I_R1, 0, 4, false>::run(ring, ws, voff, nullptr, h, 4, r1);
+            relu_tiles<NT>(r1);
+            f32x4 accr[TR];
+#pragma unroll
+            for (int t = 0; t < TR; t++) {
+                const float4 bv = wave == 0 ? *reinterpret_cast<const float4*>(bias + net.L[L_REW1].b_lds + t * 16 + q * 4) : zero4;
+                accr[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
+            }
+            SplitSlots<C, RD, C::I_R2, 0, TR>::run(ring, ws, voff, r1, accr);
+#pragma unroll
+            for (int t = 0; t < TR; t++) PBr[(wave * TR + t) * 64 + lane] = make_float4(accr[t][0], accr[t][1], accr[t][2], accr[t][3]);
+        }
+        __syncthreads();
+        MZ_STAMP(6);  // reward head
+        // ---- value head on the normalised state (from LDS) ----
+        {
+            f32x4 v1[NT];
+            const float* b1 = bias + net.L[L_VAL0].b_lds + wave * NT * 16;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const float4 bv = *reinterpret_cast<const float4*>(b1 + j * 16 + q * 4);
+                v1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
+            }
+            WideSlots<C, RD, C::I_V1, 0, 4, true>::run(ring, ws, voff, reinterpret_cast<const float4*>(lds + o.HS) + lane, h, 4, v1);
+            relu_tiles<NT>(v1);
+            f32x4 accv[TV];
+#pragma unroll
+            for (int t = 0; t < TV; t++) {
+                const float4 bv = wave == 0 ? *reinterpret_cast<const float4*>(bias + net.L[L_VAL1].b_lds + t * 16 + q * 4) : zero4;
+                accv[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
+            }
+            SplitSlots<C, RD, C::I_V2, 0, TV>::run(ring, ws, voff, v1, accv);
+#pragma unroll
+            for (int t = 0; t < TV; t++) PBv[(wave * TV + t) * 64 + lane] = make_float4(accv[t][0], accv[t][1], accv[t][2], accv[t][3]);
+            PadSlots<C, RD, C::I_END>::run(ring, ws, voff);
+        }
+        __syncthreads();
+        MZ_STAMP(7);  // value head
+        // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
+        // the results are segment-uniform, so the env's lanes go straight on to expand + backup
+        {
+            const float* fr = reinterpret_cast<const float*>(PBr);
+            const float* fv = reinterpret_cast<const float*>(PBv);
+            float rew, val;
+            if (net.Sr == 1) {
+                rew = head_logit<TR>(fr, 0, e);
+            } else {
+                const bool r0 = a0 < net.Sr, r1 = a0 + 16 < net.Sr;
+                const float lr0 = head_logit<TR>(fr, r0 ? a0 : 0, e), lr1 = head_logit<TR>(fr, r1 ? a0 + 16 : 0, e);
+                rew = row2_logits_to_scalar(lr0, lr1, r0, r1, net.Sr, a0);
+            }
+            if (net.Sv == 1) {
+                val = head_logit<TV>(fv, 0, e);
+            } else {
+                const bool v0 = a0 < net.Sv, v1 = a0 + 16 < net.Sv;
+                const float lv0 = head_logit<TV>(fv, v0 ? a0 : 0, e), lv1 = head_logit<TV>(fv, v1 ? a0 + 16 : 0, e);
+                val = row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
+            }
             MZ_STAMP(8);  // softmax + expectation + transform
             if (Pm.tree_mode == 2) tree2_backup(smem, Pm, tid, env_ok, s, rew, val, mypath);
             else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
-        __syncthreads();
+        if (Pm.tree_mode != 2) __syncthreads();  // mode 2: backup and the next select of an env run on the same 16 lanes
         MZ_STAMP(9);  // expand + backup
-    };
-    int s = 0;
-    for (; s + 1 < Pm.S; s += 2) {
-        sim(std::integral_constant<int, 0>{}, s);
-        sim(std::integral_constant<int, 1>{}, s + 1);
     }
-    if (s < Pm.S) sim(std::integral_constant<int, 0>{}, s);
     if (a0 == 0 && env_ok) {
         if (Pm.tree_mode == 2) tree2_finish(smem, Pm, e, env_g);
         else tree_finish(smem, Pm, e, env_g);

@@ -68,7 +68,7 @@ struct mz_planner {
     bool tree_old = false;       // MZ_TREE_OLD=1: evaluate every level on every descent (A/B measurements, tests)
     bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
     bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
-    float* d_stream[3] = {};
+    float* d_stream[1] = {};
     FastWeights fw{};
 
     // per-env device buffers (capacity cfg.num_envs)
@@ -130,13 +130,24 @@ static void compute_layout(mz_planner* p) {
     MlpNet& n = p->net;
     n.in_dim = obs_dim(c); n.A = c.num_actions; n.P = c.num_planes; n.H = c.hidden_dim;
     n.Sv = c.value_support_size; n.Sr = c.reward_support_size;
-    n.in_pad = pad16(n.in_dim); n.x_pad = pad16(n.H + n.A); n.p_pad = pad16(n.P); n.h_pad = pad16(n.H);
+    n.in_pad = pad16(n.in_dim); n.h_pad = pad16(n.H); n.x_pad = n.h_pad + pad16(n.A); n.p_pad = pad16(n.P);
     const int dims[L_COUNT][2] = {{n.P, n.in_dim}, {n.H, n.P}, {n.P, n.H + n.A}, {n.H, n.P}, {n.P, n.H},
                                   {n.Sr, n.P},     {n.P, n.H}, {n.A, n.P},       {n.P, n.H}, {n.Sv, n.P}};
     for (int l = 0; l < L_COUNT; l++) {
         MlpLayer& L = n.L[l];
         L.n = dims[l][0]; L.k = dims[l][1];
-        L.n_tiles = (L.n + 15) / 16; L.k_steps = (L.k + 3) / 4; L.kg = (L.k + 15) / 16;
+        L.n_tiles = (L.n + 15) / 16;
+        if (l == L_DYN0) {  // [hidden padded to 16 | one-hot action block(s)], summation order: mz_mlp.h header
+            const int ab = (n.A + 15) / 16, a_last = n.A - 16 * (ab - 1);
+            L.kg = n.h_pad / 16 + ab;
+            L.last_steps = (a_last + 3) / 4;
+        } else {
+            L.kg = (L.k + 15) / 16;
+            const int rem = L.k - 16 * (L.kg - 1);
+            L.last_steps = rem < 4 ? rem : 4;
+        }
+        L.split = (l == L_REP1 || l == L_DYN1 || l == L_REW1 || l == L_POL1 || l == L_VAL1) ? 1 : 0;
+        L.kq = (L.kg + 3) / 4;
     }
     MlpLds& o = p->o;
     int off = 0;
@@ -352,12 +363,16 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     if (c.hidden_dim == 64 && (c.num_planes == 256 || c.num_planes == 512) && c.num_actions <= 16 && c.value_support_size <= 32 &&
-        c.reward_support_size <= 32) {
+        c.reward_support_size <= 32 && (c.value_support_size + 15) / 16 == (c.reward_support_size + 15) / 16) {
         p->fast_planes = c.num_planes;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
     *out = p;
     return MZ_OK;
@@ -376,8 +391,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
         if (p->d_w[l]) (void)hipFree(p->d_w[l]);
         if (p->d_b[l]) (void)hipFree(p->d_b[l]);
     }
-    for (int i = 0; i < 3; i++)
-        if (p->d_stream[i]) (void)hipFree(p->d_stream[i]);
+    if (p->d_stream[0]) (void)hipFree(p->d_stream[0]);
     void* cbufs[] = {p->d_pi_scratch, p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
     for (void* b : cbufs)
         if (b) (void)hipFree(b);
@@ -402,6 +416,23 @@ extern "C" int mz_planner_set_param(mz_planner* p, const char* name, const float
     p->params[name] = std::move(t);
     p->committed = false;
     return MZ_OK;
+}
+
+// column of layer l's weight matrix that lane group q supplies for k-step s of block g (-1: padding).  Hidden-type
+// blocks: 16g + 4q + s; the dynamics layer's action block(s): action 16(g - hblocks) + 4s + q (mz_mlp.h header).
+static int packed_k(const MlpNet& n, int l, int g, int q, int s) {
+    const MlpLayer& L = n.L[l];
+    if (l == L_DYN0) {
+        const int hb = n.h_pad / 16;
+        if (g >= hb) {
+            const int a = 16 * (g - hb) + 4 * s + q;
+            return a < n.A ? n.H + a : -1;
+        }
+        const int k = 16 * g + 4 * q + s;
+        return k < n.H ? k : -1;
+    }
+    const int k = 16 * g + 4 * q + s;
+    return k < L.k ? k : -1;
 }
 
 extern "C" int mz_planner_commit_params(mz_planner* p) {
@@ -434,14 +465,14 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
         const HostTensor &W = wi->second, &Bv = bi->second;
         if (W.shape.size() != 2 || W.shape[0] != L.n || W.shape[1] != L.k || Bv.data.size() != (size_t)L.n)
             return fail(MZ_E_INVALID, "shape mismatch for " + wn + ": expected [" + std::to_string(L.n) + ", " + std::to_string(L.k) + "]");
-        // A-operand fragment order of v_mfma_f32_16x16x4_f32 (see mz_mlp.h)
+        // A-operand fragment order of v_mfma_f32_16x16x4_f32 in the summation order of mz_mlp.h
         std::vector<float> pw((size_t)L.n_tiles * L.kg * 256, 0.0f), pb((size_t)L.n_tiles * 16, 0.0f);
         for (int t = 0; t < L.n_tiles; t++)
             for (int g = 0; g < L.kg; g++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int s = 0; s < 4; s++) {
-                        const int nn = 16 * t + (lane & 15), kk = 16 * g + 4 * s + (lane >> 4);
-                        if (nn < L.n && kk < L.k) pw[(((size_t)t * L.kg + g) * 64 + lane) * 4 + s] = W.data[(size_t)nn * L.k + kk];
+                        const int nn = 16 * t + (lane & 15), kk = packed_k(p->net, l, g, lane >> 4, s);
+                        if (nn < L.n && kk >= 0) pw[(((size_t)t * L.kg + g) * 64 + lane) * 4 + s] = W.data[(size_t)nn * L.k + kk];
                     }
         for (int i = 0; i < L.n; i++) pb[i] = Bv.data[i];
         if (!p->d_w[l]) HIPCHK(hipMalloc(&p->d_w[l], pw.size() * sizeof(float)));
@@ -454,28 +485,36 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
     p->sp.net = p->net;
     p->ip.net = p->net;
     if (p->fast_planes) {
-        // per-wave contiguous streams of the wide layers (layout: mz_search_fast.h)
-        const int lay[3] = {L_DYN0, L_REW0, L_VAL0};
-        for (int i = 0; i < 3; i++) {
-            const MlpLayer& L = p->net.L[lay[i]];
-            const int NT = L.n_tiles / WG_WAVES, KG = L.kg;
-            const std::string wn = std::string(kMlpNames[lay[i]]) + ".weight";
-            const HostTensor& W = p->params.find(wn)->second;
-            std::vector<float> st((size_t)WG_WAVES * KG * NT * 256, 0.0f);
-            for (int w = 0; w < WG_WAVES; w++)
-                for (int g = 0; g < KG; g++)
-                    for (int j = 0; j < NT; j++)
-                        for (int lane = 0; lane < 64; lane++)
-                            for (int q4 = 0; q4 < 4; q4++) {
-                                const int nn = 16 * (w + WG_WAVES * j) + (lane & 15), kk = 16 * g + 4 * q4 + (lane >> 4);
-                                if (nn < L.n && kk < L.k) st[((((size_t)w * KG + g) * NT + j) * 64 + lane) * 4 + q4] = W.data[(size_t)nn * L.k + kk];
-                            }
-            if (!p->d_stream[i]) HIPCHK(hipMalloc(&p->d_stream[i], st.size() * sizeof(float)));
-            HIPCHK(hipMemcpy(p->d_stream[i], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+        // ONE per-wave weight stream in consumption order (layout: mz_search_fast.h header)
+        const int NT = p->fast_planes / 64, TR = p->net.L[L_REW1].n_tiles, TV = p->net.L[L_VAL1].n_tiles, RD = 3;
+        const int I_D1 = 0, I_D2 = I_D1 + 5, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
+        const int SL = (I_END + RD - 1) / RD * RD;
+        std::vector<float> st((size_t)WG_WAVES * SL * NT * 256, 0.0f);
+        auto put = [&](int w, int slot, int j, int l, int row_tile, int g) {
+            const MlpLayer& L = p->net.L[l];
+            const HostTensor& W = p->params.find(std::string(kMlpNames[l]) + ".weight")->second;
+            float* d = &st[(((size_t)w * SL + slot) * NT + j) * 256];
+            for (int lane = 0; lane < 64; lane++)
+                for (int i = 0; i < 4; i++) {
+                    const int nn = 16 * row_tile + (lane & 15), kk = packed_k(p->net, l, g, lane >> 4, i);
+                    if (nn < L.n && kk >= 0) d[lane * 4 + i] = W.data[(size_t)nn * L.k + kk];
+                }
+        };
+        for (int w = 0; w < WG_WAVES; w++) {
+            for (int g = 0; g < 5; g++)
+                for (int j = 0; j < NT; j++) put(w, I_D1 + g, j, L_DYN0, NT * w + j, g);
+            for (int idx = 0; idx < 4 * NT; idx++) put(w, I_D2 + idx / NT, idx % NT, L_DYN1, idx % 4, NT * w + idx / 4);
+            for (int g = 0; g < 4; g++)
+                for (int j = 0; j < NT; j++) put(w, I_R1 + g, j, L_REW0, NT * w + j, g);
+            for (int idx = 0; idx < TR * NT; idx++) put(w, I_R2 + idx / NT, idx % NT, L_REW1, idx % TR, NT * w + idx / TR);
+            for (int g = 0; g < 4; g++)
+                for (int j = 0; j < NT; j++) put(w, I_V1 + g, j, L_VAL0, NT * w + j, g);
+            for (int idx = 0; idx < TV * NT; idx++) put(w, I_V2 + idx / NT, idx % NT, L_VAL1, idx % TV, NT * w + idx / TV);
         }
-        p->fw.dyn0 = reinterpret_cast<const float4*>(p->d_stream[0]);
-        p->fw.rew0 = reinterpret_cast<const float4*>(p->d_stream[1]);
-        p->fw.val0 = reinterpret_cast<const float4*>(p->d_stream[2]);
+        if (!p->d_stream[0]) HIPCHK(hipMalloc(&p->d_stream[0], st.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(p->d_stream[0], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+        p->fw.stream = reinterpret_cast<const float4*>(p->d_stream[0]);
+        p->fw.bytes = (unsigned)(st.size() * sizeof(float));
     }
     p->committed = true;
     return MZ_OK;
@@ -645,12 +684,13 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         hipLaunchKernelGGL(k_gtree_finish, grid, block, 0, p->stream, G);
     } else
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
-    else if (p->fast_planes == 512 && !p->force_generic) {
-        if (fenv) hipLaunchKernelGGL((k_search_fast<512, true>), grid, block, s.lds_bytes, p->stream, s, p->fw);
-        else hipLaunchKernelGGL((k_search_fast<512, false>), grid, block, s.lds_bytes, p->stream, s, p->fw);
-    } else if (p->fast_planes == 256 && !p->force_generic) {
-        if (fenv) hipLaunchKernelGGL((k_search_fast<256, true>), grid, block, s.lds_bytes, p->stream, s, p->fw);
-        else hipLaunchKernelGGL((k_search_fast<256, false>), grid, block, s.lds_bytes, p->stream, s, p->fw);
+    else if (p->fast_planes && !p->force_generic) {
+        const int two = p->net.L[L_VAL1].n_tiles == 2;
+#define MZ_FAST(PL, T) do { if (fenv) hipLaunchKernelGGL((k_search_fast<PL, T, T, true>), grid, block, s.lds_bytes, p->stream, s, p->fw); \
+                            else hipLaunchKernelGGL((k_search_fast<PL, T, T, false>), grid, block, s.lds_bytes, p->stream, s, p->fw); } while (0)
+        if (p->fast_planes == 512) { if (two) MZ_FAST(512, 2); else MZ_FAST(512, 1); }
+        else { if (two) MZ_FAST(256, 2); else MZ_FAST(256, 1); }
+#undef MZ_FAST
     }
     else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
     HIPCHK(hipGetLastError());

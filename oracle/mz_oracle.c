@@ -141,6 +141,37 @@ static void linear(const float* x, int K, const float* W, const float* b, int N,
     }
 }
 
+/* The MLP nets' Linear layers (network.py:145-149,172-182,212-222) in the summation order of the MFMA tile pipeline
+ * (muzero_amd/csrc/mz_mlp.h): inputs are taken in blocks of 16; inside a block the chain visits k = 16g + 4q + i in
+ * the order i = 0..3 (outer), q = 0..3 (inner) -- the order in which v_mfma_f32_16x16x4_f32 consumes a D-layout
+ * accumulator (lane (e, q) holds neurons 4q..4q+3) as the next layer's B operand.  The Ka one-hot action inputs of the
+ * dynamics net (network.py:191-193) follow the Kh hidden inputs in natural order.  `split` (the second layer of every
+ * two-layer net, K = num_planes): the blocks are dealt to 4 contiguous quarters, one chain each -- quarter 0 starts
+ * from the bias, the others from +0 -- and the result is ((c0 + c1) + c2) + c3: the four waves of a workgroup each own
+ * one quarter of the hidden layer in registers and never exchange it. */
+static void linear_mlp(const float* x, int Kh, int Ka, const float* W, const float* b, int N, float* y, int relu, int split) {
+    const int NB = (Kh + 15) / 16;
+    const int NBq = split ? (NB + 3) / 4 : NB;
+    const int chains = split ? 4 : 1;
+    for (int n = 0; n < N; n++) {
+        const float* w = W + (size_t)n * (Kh + Ka);
+        float total = 0.0f;
+        for (int c = 0; c < chains; c++) {
+            float acc = (c == 0) ? b[n] : 0.0f;
+            const int g1 = (c + 1) * NBq < NB ? (c + 1) * NBq : NB;
+            for (int g = c * NBq; g < g1; g++)
+                for (int i = 0; i < 4; i++)
+                    for (int q = 0; q < 4; q++) {
+                        const int k = 16 * g + 4 * q + i;
+                        if (k < Kh) acc = fmaf(x[k], w[k], acc);
+                    }
+            total = (c == 0) ? acc : total + acc;
+        }
+        for (int a = 0; a < Ka; a++) total = fmaf(x[Kh + a], w[Kh + a], total);
+        y[n] = (relu && !(total > 0.0f)) ? 0.0f : total;
+    }
+}
+
 /* ============================================================================================ */
 /* networks                                                                                     */
 /* ============================================================================================ */
@@ -391,12 +422,12 @@ static float scalar_from_logits(const float* logits, int S) { return S == 1 ? lo
 static void mlp_prediction(mzo_net* n, const float* hidden, float* pi_out, float* value_out) {
     float t[4096], lg[1024];
     if (pi_out) {
-        linear(hidden, n->H, n->mp[12], n->mp[13], n->P, t, 1);
-        linear(t, n->P, n->mp[14], n->mp[15], n->A, lg, 0);
+        linear_mlp(hidden, n->H, 0, n->mp[12], n->mp[13], n->P, t, 1, 0);
+        linear_mlp(t, n->P, 0, n->mp[14], n->mp[15], n->A, lg, 0, 1);
         softmax_f32(lg, n->A, pi_out);
     }
-    linear(hidden, n->H, n->mp[16], n->mp[17], n->P, t, 1);
-    linear(t, n->P, n->mp[18], n->mp[19], n->Sv, lg, 0);
+    linear_mlp(hidden, n->H, 0, n->mp[16], n->mp[17], n->P, t, 1, 0);
+    linear_mlp(t, n->P, 0, n->mp[18], n->mp[19], n->Sv, lg, 0, 1);
     *value_out = scalar_from_logits(lg, n->Sv);
 }
 
@@ -427,8 +458,8 @@ void mzo_initial_inference(mzo_net* n, const float* obs, float* hidden_out, floa
     }
     if (n->kind == NET_MLP) {
         float t[4096];
-        linear(obs, n->in_dim, n->mp[0], n->mp[1], n->P, t, 1); /* network.py:151-156 */
-        linear(t, n->P, n->mp[2], n->mp[3], n->H, hidden_out, 0);
+        linear_mlp(obs, n->in_dim, 0, n->mp[0], n->mp[1], n->P, t, 1, 0); /* network.py:151-156 */
+        linear_mlp(t, n->P, 0, n->mp[2], n->mp[3], n->H, hidden_out, 0, 1);
         mzo_normalize_hidden(hidden_out, n->H, 1);               /* network.py:256-259 */
         mlp_prediction(n, hidden_out, pi_out, value_out);
         return;
@@ -483,11 +514,11 @@ void mzo_recurrent_inference(mzo_net* n, const float* hidden_in, int32_t action,
         float x[4096], t[4096], lg[1024];
         memcpy(x, hidden_in, sizeof(float) * n->H);
         for (int a = 0; a < n->A; a++) x[n->H + a] = (a == action) ? 1.0f : 0.0f; /* network.py:191-193 */
-        linear(x, n->H + n->A, n->mp[4], n->mp[5], n->P, t, 1);
-        linear(t, n->P, n->mp[6], n->mp[7], n->H, hidden_out, 0);
+        linear_mlp(x, n->H, n->A, n->mp[4], n->mp[5], n->P, t, 1, 0);
+        linear_mlp(t, n->P, 0, n->mp[6], n->mp[7], n->H, hidden_out, 0, 1);
         /* reward head reads the UN-normalised hidden state (network.py:195-196); normalisation follows (:263) */
-        linear(hidden_out, n->H, n->mp[8], n->mp[9], n->P, t, 1);
-        linear(t, n->P, n->mp[10], n->mp[11], n->Sr, lg, 0);
+        linear_mlp(hidden_out, n->H, 0, n->mp[8], n->mp[9], n->P, t, 1, 0);
+        linear_mlp(t, n->P, 0, n->mp[10], n->mp[11], n->Sr, lg, 0, 1);
         *reward_out = scalar_from_logits(lg, n->Sr);
         mzo_normalize_hidden(hidden_out, n->H, 1);
         mlp_prediction(n, hidden_out, pi_out, value_out);
