@@ -37,8 +37,8 @@ def build_stamps(counters=False):
     """Diagnostic library with per-phase s_memtime stamps (never loaded by the product path); counters=True adds the
     atomic tree counters (hit rates, depths), which distort the timings."""
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    out = os.path.join(LIB_DIR, 'libmzplanner_hip_stamps.so')
-    extra = ['-DMZ_STAMPS'] + (['-DMZ_COUNTERS'] if counters else [])
+    out = os.environ.get('MZ_STAMPS_OUT', os.path.join(LIB_DIR, 'libmzplanner_hip_stamps.so'))
+    extra = ['-DMZ_STAMPS'] + (['-DMZ_COUNTERS'] if counters else []) + os.environ.get('MZ_EXTRA_FLAGS', '').split()
     subprocess.check_call([hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out])
     return out
 
@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
             if not force and not needs_build():  # another process built it while we waited
                 return LIB_PATH
             tmp = LIB_PATH + '.tmp.%d' % os.getpid()
-            cmd = [hipcc] + FLAGS + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
+            cmd = [hipcc] + FLAGS + os.environ.get('MZ_EXTRA_FLAGS', '').split() + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
                 [os.path.join(CSRC, s) for s in SOURCES] + ['-o', tmp]
             try:
                 subprocess.check_call(cmd)

@@ -13,9 +13,10 @@ __device__ __forceinline__ float bits2f(uint32_t u) { return __uint_as_float(u);
 // exp() used by every softmax on the path (policy network.py:72,100; value/reward util.py:88).
 // Cephes-style: n = rint(x*log2e), r = x - n*ln2 in two fmaf steps, degree-5 polynomial, scale by 2^n.
 // ~1 ulp; deterministic instruction sequence (no libm, no fast-math).
-__device__ __forceinline__ float expf_det(float x) {
-    if (x > 88.5f) return __uint_as_float(0x7f800000u);
-    if (x < -103.5f) return 0.0f;
+// Branch-free: out-of-range arguments are clamped for the polynomial and the result is selected at the end (the
+// same values as early returns; straight-line code can be scheduled into MFMA shadows, branches cannot).
+__device__ __forceinline__ float expf_det(float x0) {
+    const float x = __builtin_amdgcn_fmed3f(x0, -104.0f, 89.0f);  // == x0 wherever the polynomial's result is used
     float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -28,15 +29,14 @@ __device__ __forceinline__ float expf_det(float x) {
     float r2 = r * r;
     float y = fmaf(p, r2, r) + 1.0f;
     int ni = (int)n;
-    if (ni < -126) {
-        y = y * 5.42101086242752217e-20f;  // 2^-64
-        ni += 64;
-    }
-    if (ni > 127) {
-        y = y * 2.0f;
-        ni -= 1;
-    }
-    return y * bits2f((uint32_t)(ni + 127) << 23);
+    const bool lo = ni < -126, hi = ni > 127;
+    y = lo ? y * 5.42101086242752217e-20f : y;  // 2^-64
+    ni = lo ? ni + 64 : ni;
+    y = hi ? y * 2.0f : y;
+    ni = hi ? ni - 1 : ni;
+    float res = y * bits2f((uint32_t)(ni + 127) << 23);
+    asm volatile("" : "+v"(res));  // keeps the polynomial unconditional: hipcc would turn the selects below back into branches around it
+    return x0 > 88.5f ? __uint_as_float(0x7f800000u) : (x0 < -103.5f ? 0.0f : res);
 }
 
 // signed_parabolic, util.py:25-28 (eps = 1e-3), float32 in the op order of the torch expression.
@@ -96,20 +96,23 @@ __device__ __forceinline__ float butterfly16_min(float v) {
 // register-only version for rows of at most 32 values: lane j holds l0 = row[j], l1 = row[j + 16] (has1 says whether
 // the second one exists).  Same arithmetic as row_logits_to_scalar.
 __device__ __forceinline__ float row2_logits_to_scalar(float l0, float l1, bool has0, bool has1, int S, int j) {
+    // straight-line (selects, no branches): everything is computed for both slots and masked
     const float ninf = __uint_as_float(0xff800000u);
     float m = has0 ? l0 : ninf;
-    m = (has1 && l1 > m) ? l1 : m;
+    m = (has1 & (l1 > m)) ? l1 : m;
     m = butterfly16_max(m);
-    const float e0 = has0 ? expf_det(l0 - m) : 0.0f;
-    const float e1 = has1 ? expf_det(l1 - m) : 0.0f;
+    const float x0 = expf_det((has0 ? l0 : m) - m), x1 = expf_det((has1 ? l1 : m) - m);
+    const float e0 = has0 ? x0 : 0.0f, e1 = has1 ? x1 : 0.0f;
     float a = 0.0f;
-    if (has0) a = a + e0;
-    if (has1) a = a + e1;
+    a = has0 ? a + e0 : a;
+    a = has1 ? a + e1 : a;
     const float sum = butterfly16(a);
     const int half = (S - 1) / 2;
     float t = 0.0f;
-    if (has0) { const float p = e0 / sum; const float tt = p * (float)(j - half); t = t + tt; }
-    if (has1) { const float p = e1 / sum; const float tt = p * (float)(j + 16 - half); t = t + tt; }
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    const float t0 = p0 * (float)(j - half), t1 = p1 * (float)(j + 16 - half);
+    t = has0 ? t + t0 : t;
+    t = has1 ? t + t1 : t;
     return signed_parabolic(butterfly16(t));
 }
 

@@ -100,6 +100,9 @@ __device__ long long g_sub[8];  // sub-phase cycle sums written by thread 0 of b
 #define MZ_SUB_DECL long long _s0 = 0;
 #define MZ_SUB_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _s0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_SUB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _s1 = __builtin_readcyclecounter(); g_sub[i] += _s1 - _s0; _s0 = _s1; } } while (0)  // [0] levels visited, [1] cache hits, [2] descents, [3] version bumps, [4] max-depth sum per wave-descent
+#define MZ_SUBX_START() long long _x0 = 0; do { if (blockIdx.x == 0 && threadIdx.x == 0) _x0 = __builtin_readcyclecounter(); } while (0)
+#define MZ_SUBX(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _x1 = __builtin_readcyclecounter(); g_sub[i] += _x1 - _x0; _x0 = _x1; } } while (0)
+#define MZ_SUBX_COUNT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sub[i] += 1; } while (0)
 #define MZ_STAMP_DECL long long _t0 = 0; long long _acc[16] = {0};
 #define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); _acc[i] += _t1 - _t0; _t0 = _t1; } } while (0)
@@ -109,6 +112,9 @@ __device__ long long g_sub[8];  // sub-phase cycle sums written by thread 0 of b
 #define MZ_SUB_DECL
 #define MZ_SUB_START() do {} while (0)
 #define MZ_SUB(i) do {} while (0)
+#define MZ_SUBX_START() do {} while (0)
+#define MZ_SUBX(i) do {} while (0)
+#define MZ_SUBX_COUNT(i) do {} while (0)
 #define MZ_STAMP_DECL
 #define MZ_STAMP_START() do {} while (0)
 #define MZ_STAMP(i) do {} while (0)
@@ -455,9 +461,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     if (a0 == 0 && env_ok) root_prior(smem, P, e, env_g);
     __syncthreads();
 
+    int mypath = 0, resume = 0;
     for (int s = 0; s < P.S; s++) {
-        int lp_unused, la_unused, mypath = 0;
-        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused, mypath);
+        int lp_unused, la_unused;
+        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused, mypath, resume);
         else tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
         __syncthreads();
         const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
             r32 = lds[P.o.OUT + e * 4 + 0];
             v32 = lds[P.o.OUT + e * 4 + 1];
         }
-        if (P.tree_mode == 2) tree2_backup(smem, P, tid, env_ok, s, r32, v32, mypath);
+        if (P.tree_mode == 2) resume = tree2_backup(smem, P, tid, env_ok, s, r32, v32, mypath);
         else if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
         __syncthreads();
     }

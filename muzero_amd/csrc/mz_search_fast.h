@@ -30,6 +30,11 @@
 
 namespace mz {
 
+#ifndef MZ_FAST_RD
+#define MZ_FAST_RD 3
+#endif
+constexpr int kFastRD = MZ_FAST_RD;  // depth of the weight ring: the stream runs kFastRD - 1 slots ahead of the MFMAs
+
 struct FastWeights {
     const float4* stream;
     unsigned bytes;  // whole stream (4 waves)
@@ -72,36 +77,59 @@ struct FastCfg {
 template <typename C, int RD, int I>
 __device__ __forceinline__ void prefetch_slot(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff) {
     constexpr int T = (I + RD - 1) % C::SL;
+#ifdef MZ_EXP_NOLOAD
+    return;
+#endif
+    if constexpr (T < C::I_END) {  // padding slots hold nothing: only the ring position advances
 #pragma unroll
-    for (int j = 0; j < C::NT; j++) ring[T % RD][j] = bload(ws, voff, T * C::NT + j);
+        for (int j = 0; j < C::NT; j++) ring[T % RD][j] = bload(ws, voff, T * C::NT + j);
+    }
 }
 
 // issue order inside a slot: (the B-operand LDS read,) then one weight load per 4 MFMAs -- the loads' issue slots hide
 // under the 32-cycle MFMAs instead of preceding them
-template <int NT, bool LDS_READ>
+// NV > 0: NV VALU instructions of independent work (the reward row's softmax, computed while the value head multiplies)
+// ride in every MFMA's shadow: an MFMA holds the issue port for 8 of its 32 cycles, the rest is free for them
+template <int NT, bool LDS_READ, int NV = 0>
 __device__ __forceinline__ void slot_schedule() {
     if (LDS_READ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
     for (int i = 0; i < NT; i++) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (NV == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            }
+        }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the ring RD - 1 slots deep: no hoisting of later slots' loads
+    if (NV == 0) __builtin_amdgcn_sched_barrier(0);  // keep the ring RD - 1 slots deep: no hoisting of later slots' loads
+    else __builtin_amdgcn_sched_barrier(0);
 }
 
 // The slot loops need the slot index as a compile-time constant for the ring entry; `#pragma unroll` loops over a
 // constexpr bound give that after unrolling, but the prefetch helper takes it as a template argument, so the loops are
 // written with an index_sequence-style recursion.
-template <typename C, int RD, int I0, int G, int KG, bool FROM_LDS>
+// side work placed one stage per slot (between two scheduling fences, so it can only ride in that slot's MFMA shadows)
+struct NoHook {
+    template <int K>
+    __device__ __forceinline__ void stage() {}
+};
+
+template <typename C, int RD, int I0, int G, int KG, bool FROM_LDS, int NV = 0, typename Hook = NoHook, int HK0 = 0>
 struct WideSlots {
     // FROM_LDS: B operand = float4 read from the packed LDS buffer; else B operand = hin[G] (D-layout registers)
-    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const float4* xp, const f32x4 (&hin)[4],
-                                               int last_steps, f32x4 (&acc)[C::NT]) {
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const float4 (&xs)[5], const f32x4 (&hin)[4],
+                                               int last_steps, f32x4 (&acc)[C::NT], Hook& hook) {
         constexpr int NT = C::NT, I = I0 + G;
         prefetch_slot<C, RD, I>(ring, ws, voff);
+        hook.template stage<HK0 + G>();
         float b[4];
-        if (FROM_LDS) {
-            const float4 x = xp[G * 64];
+        if (FROM_LDS) {  // all of the layer's B operands were read from LDS before its first MFMA (xs)
+            const float4 x = xs[G];
             b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = x.w;
         } else {
             b[0] = hin[G][0]; b[1] = hin[G][1]; b[2] = hin[G][2]; b[3] = hin[G][3];
@@ -121,19 +149,21 @@ struct WideSlots {
 #pragma unroll
             for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, b[3], acc[j], 0, 0, 0);
         }
-        slot_schedule<NT, FROM_LDS>();
-        if constexpr (G + 1 < KG) WideSlots<C, RD, I0, G + 1, KG, FROM_LDS>::run(ring, ws, voff, xp, hin, last_steps, acc);
+        slot_schedule<NT, false, NV>();
+        if constexpr (G + 1 < KG) WideSlots<C, RD, I0, G + 1, KG, FROM_LDS, NV, Hook, HK0>::run(ring, ws, voff, xs, hin, last_steps, acc, hook);
     }
 };
 
 // K-split layer, this wave's quarter: TO output tiles, input = the NT tiles this wave holds in registers (hin).
 // Slot D holds NT float4: entry jj <-> (kb = (D NT + jj) / TO, t = (D NT + jj) % TO).
-template <typename C, int RD, int I0, int D, int TO>
+template <typename C, int RD, int I0, int D, int TO, int NV = 0, typename Hook = NoHook, int HK0 = 0>
 struct SplitSlots {
-    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const f32x4 (&hin)[C::NT], f32x4 (&acc)[TO]) {
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const f32x4 (&hin)[C::NT], f32x4 (&acc)[TO],
+                                               Hook& hook) {
         constexpr int NT = C::NT, I = I0 + D, KPS = NT / TO;
         static_assert(NT % TO == 0, "tiles per slot");
         prefetch_slot<C, RD, I>(ring, ws, voff);
+        hook.template stage<HK0 + D>();
         const float4(&w)[NT] = ring[I % RD];
 #pragma unroll
         for (int kk = 0; kk < KPS; kk++) {
@@ -145,8 +175,8 @@ struct SplitSlots {
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(w[kk * TO + t], st), hin[kb][st], acc[t], 0, 0, 0);
             }
         }
-        slot_schedule<NT, false>();
-        if constexpr (D + 1 < TO) SplitSlots<C, RD, I0, D + 1, TO>::run(ring, ws, voff, hin, acc);
+        slot_schedule<NT, false, NV>();
+        if constexpr (D + 1 < TO) SplitSlots<C, RD, I0, D + 1, TO, NV, Hook, HK0>::run(ring, ws, voff, hin, acc, hook);
     }
 };
 
@@ -161,6 +191,25 @@ struct PadSlots {
         }
     }
 };
+
+// min / max of two non-NaN floats as ONE v_med3_f32 (fminf / fmaxf add a canonicalising v_max x, x per operand)
+__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __uint_as_float(0xff800000u)); }
+__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __uint_as_float(0x7f800000u)); }
+// all-lane min / max over the four 16-lane rows of a wave (same lane & 15): v_permlane16_swap / v_permlane32_swap
+// exchange whole rows between two registers, so min(r[0], r[1]) is the xor-16 (xor-32) butterfly step in every lane
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_min(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmin2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmin2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 template <int N>
 __device__ __forceinline__ void relu_tiles(f32x4 (&a)[N]) {
@@ -184,7 +233,7 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
 // FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
 template <int P, int TR, int TV, bool FUSE = false>
 __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
-    constexpr int RD = 3;
+    constexpr int RD = kFastRD;
     using C = FastCfg<P, TR, TV, RD>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -259,12 +308,22 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     float4* const PBr = reinterpret_cast<float4*>(lds + o.V1);
     float4* const PBv = PBr + 4 * TR * 64;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 xs0[5] = {zero4, zero4, zero4, zero4, zero4};
+    NoHook nohook;
+    // quarter chains 1..3 of a K-split layer start from +0, quarter 0 from the bias: one pointer select per layer instead
+    // of a branch per component (the PM block is free in this kernel: 128 zeros)
+    float* const zeros = lds + o.PM;
+    if (tid < 128) zeros[tid] = 0.0f;
+    const float* const b_d2 = wave == 0 ? bias + net.L[L_DYN1].b_lds : zeros;
+    const float* const b_r2 = wave == 0 ? bias + net.L[L_REW1].b_lds : zeros;
+    const float* const b_v2 = wave == 0 ? bias + net.L[L_VAL1].b_lds : zeros;
     __syncthreads();
     MZ_STAMP(0);  // root: tables + initial inference + prior
 
+    int mypath = 0, resume = 0;
     for (int s = 0; s < Pm.S; s++) {
-        int lp, la, mypath = 0;
-        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, mypath);
+        int lp, la;
+        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, mypath, resume);
         else tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
@@ -286,16 +345,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 const float4 bv = *reinterpret_cast<const float4*>(b1 + j * 16 + q * 4);
                 h1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            WideSlots<C, RD, C::I_D1, 0, C::XG, true>::run(ring, ws, voff, reinterpret_cast<const float4*>(lds + o.X) + lane, h, x_last, h1);
+            float4 xs[5];
+#pragma unroll
+            for (int g = 0; g < C::XG; g++) xs[g] = reinterpret_cast<const float4*>(lds + o.X)[g * 64 + lane];
+            WideSlots<C, RD, C::I_D1, 0, C::XG, true>::run(ring, ws, voff, xs, h, x_last, h1, nohook);
             relu_tiles<NT>(h1);
             MZ_STAMP(3);  // dynamics layer 1
             f32x4 acc2[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const float4 bv = wave == 0 ? *reinterpret_cast<const float4*>(bias + net.L[L_DYN1].b_lds + t * 16 + q * 4) : zero4;
+                const float4 bv = *reinterpret_cast<const float4*>(b_d2 + t * 16 + q * 4);
                 acc2[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            SplitSlots<C, RD, C::I_D2, 0, 4>::run(ring, ws, voff, h1, acc2);
+            SplitSlots<C, RD, C::I_D2, 0, 4>::run(ring, ws, voff, h1, acc2, nohook);
 #pragma unroll
             for (int t = 0; t < 4; t++) PB[(wave * 4 + t) * 64 + lane] = make_float4(acc2[t][0], acc2[t][1], acc2[t][2], acc2[t][3]);
         }
@@ -311,20 +373,18 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 h[t] = f32x4{((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
                              ((c0.w + c1.w) + c2.w) + c3.w};
             }
+            // min / max over the 64 features: 16 in this lane, the rest in the lanes of the other three rows (same env)
             float mn = h[0][0], mx = h[0][0];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    mn = h[t][r] < mn ? h[t][r] : mn;
-                    mx = h[t][r] > mx ? h[t][r] : mx;
+                    mn = fmin2(h[t][r], mn);
+                    mx = fmax2(h[t][r], mx);
                 }
             }
-            float tt;
-            tt = __shfl_xor(mn, 16, 64); mn = tt < mn ? tt : mn;
-            tt = __shfl_xor(mx, 16, 64); mx = tt > mx ? tt : mx;
-            tt = __shfl_xor(mn, 32, 64); mn = tt < mn ? tt : mn;
-            tt = __shfl_xor(mx, 32, 64); mx = tt > mx ? tt : mx;
+            mn = rows_min(mn);
+            mx = rows_max(mx);
             const float d = (mx - mn) + 1e-8f;
             f32x4 hw = h[0];
             if (wave == 1) hw = h[1];
@@ -344,15 +404,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 const float4 bv = *reinterpret_cast<const float4*>(b1 + j * 16 + q * 4);
                 r1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            WideSlots<C, RD, C::I_R1, 0, 4, false>::run(ring, ws, voff, nullptr, h, 4, r1);
+            WideSlots<C, RD, C::I_R1, 0, 4, false>::run(ring, ws, voff, xs0, h, 4, r1, nohook);
             relu_tiles<NT>(r1);
             f32x4 accr[TR];
 #pragma unroll
             for (int t = 0; t < TR; t++) {
-                const float4 bv = wave == 0 ? *reinterpret_cast<const float4*>(bias + net.L[L_REW1].b_lds + t * 16 + q * 4) : zero4;
+                const float4 bv = *reinterpret_cast<const float4*>(b_r2 + t * 16 + q * 4);
                 accr[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            SplitSlots<C, RD, C::I_R2, 0, TR>::run(ring, ws, voff, r1, accr);
+            SplitSlots<C, RD, C::I_R2, 0, TR>::run(ring, ws, voff, r1, accr, nohook);
 #pragma unroll
             for (int t = 0; t < TR; t++) PBr[(wave * TR + t) * 64 + lane] = make_float4(accr[t][0], accr[t][1], accr[t][2], accr[t][3]);
         }
@@ -367,15 +427,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 const float4 bv = *reinterpret_cast<const float4*>(b1 + j * 16 + q * 4);
                 v1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            WideSlots<C, RD, C::I_V1, 0, 4, true>::run(ring, ws, voff, reinterpret_cast<const float4*>(lds + o.HS) + lane, h, 4, v1);
+            float4 xs[5];
+#pragma unroll
+            for (int g = 0; g < 4; g++) xs[g] = reinterpret_cast<const float4*>(lds + o.HS)[g * 64 + lane];
+            xs[4] = zero4;
+            WideSlots<C, RD, C::I_V1, 0, 4, true>::run(ring, ws, voff, xs, h, 4, v1, nohook);
             relu_tiles<NT>(v1);
             f32x4 accv[TV];
 #pragma unroll
             for (int t = 0; t < TV; t++) {
-                const float4 bv = wave == 0 ? *reinterpret_cast<const float4*>(bias + net.L[L_VAL1].b_lds + t * 16 + q * 4) : zero4;
+                const float4 bv = *reinterpret_cast<const float4*>(b_v2 + t * 16 + q * 4);
                 accv[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
             }
-            SplitSlots<C, RD, C::I_V2, 0, TV>::run(ring, ws, voff, v1, accv);
+            SplitSlots<C, RD, C::I_V2, 0, TV>::run(ring, ws, voff, v1, accv, nohook);
 #pragma unroll
             for (int t = 0; t < TV; t++) PBv[(wave * TV + t) * 64 + lane] = make_float4(accv[t][0], accv[t][1], accv[t][2], accv[t][3]);
             PadSlots<C, RD, C::I_END>::run(ring, ws, voff);
@@ -385,6 +449,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
         // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
         // the results are segment-uniform, so the env's lanes go straight on to expand + backup
         {
+            // (tried: the reward row's softmax staged into the value head's MFMA slots -- VALU between the dependent MFMAs of a
+            // lone wave slowed the MFMA stream by more than the softmax costs here: 7.9 k -> 10.0 k cycles for 1.8 k saved)
             const float* fr = reinterpret_cast<const float*>(PBr);
             const float* fv = reinterpret_cast<const float*>(PBv);
             float rew, val;
@@ -403,7 +469,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 val = row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            if (Pm.tree_mode == 2) tree2_backup(smem, Pm, tid, env_ok, s, rew, val, mypath);
+            if (Pm.tree_mode == 2) resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val, mypath);
             else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
         if (Pm.tree_mode != 2) __syncthreads();  // mode 2: backup and the next select of an env run on the same 16 lanes

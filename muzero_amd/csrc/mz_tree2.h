@@ -2,8 +2,15 @@
 // out and scheduled for the 16-lanes-per-env segments of the search kernels.  Included from mz_search.h (inside
 // namespace mz, after SearchParams and the select helpers).
 //
-//   * child ENTRY table: entry[node][action] = {vq, N, child node} of that child, kept up to date by backup.  One
-//     16-byte LDS read per action lane gives everything child_Q / child_U need about a child (mcts.py:159-200).
+//   * child ENTRY table: entry[node][action] = {vq, child_U, N, child node} of that child, kept up to date by backup.
+//     One 16-byte LDS read per action lane gives everything best_child needs about a child (mcts.py:159-200): the
+//     child_U term prior * f(N_parent, N_child) (mcts.py:189-200) changes only when a backup passes through the parent,
+//     which recomputes it for all of the parent's actions, so selection reads no factor table and no node.
+//   * NORMALISATION WITHOUT DIVIDING (MinMaxStats.normalize, mcts.py:44-48): the reference rounds
+//     q64 = (v - min) / (max - min) to float32 (mcts.py:176).  Here y = (v - min) * RN(1 / (max - min)) -- the reciprocal
+//     is computed once per min-max change -- differs from q64 by at most 2.5 ulp64, so float32(y) == float32(q64)
+//     unless y lies within 4 ulp64 of a float32 rounding midpoint (probability ~2e-8); only then is the division
+//     done.  The result is the reference's float32 bit for bit (norm_q).
 //   * selection CACHE: every node caches its current best child together with the MARGIN by which it beat the
 //     runner-up.  A node's pUCT ranking depends on its own N, its children's (N, vq), the root prior -- all of which
 //     change only when a backup passes through the node (which refreshes the cache) -- and on the env's min-max pair,
@@ -15,6 +22,10 @@
 //     shortcut: it never changes a result.
 //   * a DESCENT is therefore mostly a chain of single 16-byte cache reads; the visited nodes are kept in registers
 //     (lane d of the env's segment holds the node at depth d).
+//   * RESUMED DESCENTS: a backup refreshes the cache of every node on its path, so it knows how far the NEXT descent
+//     will retrace that path: down to the first node whose refreshed choice is not "unique, valid, and the next path
+//     node".  The next select starts there (the nodes above are already in the lanes' path registers) instead of at
+//     the root -- in the deep, narrow trees of single-player searches most descents start at or next to the leaf.
 //   * BACKUP (mcts.py:129-157) runs on the env's 16 lanes: lane i owns the i-th path node from the leaf; the value
 //     recurrence is a DPP shift chain in registers; W/N/Q/vq updates, the min-max reduction and the best-child refresh
 //     of every path node (each lane loops over its node's actions) are lane-parallel.
@@ -30,19 +41,38 @@ struct __attribute__((aligned(8))) Node2 {  // 24 bytes
 };
 struct __attribute__((aligned(16))) Entry2 {  // 16 bytes
     double vq;  // child's reward + discount * (+/-)Q  (the min-max update value == un-normalised child_Q term)
-    int cn;     // child's visit count (0: never expanded)
-    int c;      // child's node index, -1 if unexpanded
+    float U;    // child_U of this action for the parent's and child's current visit counts (float32, mcts.py:189-200)
+    short cn;   // child's visit count (0: never expanded)
+    short c;    // child's node index, -1 if unexpanded
 };
 struct __attribute__((aligned(8))) SelCache {  // 8 bytes
     int packed;  // bits 0-7 best action (0xff: evaluate at visit time), bits 8-15 env epoch when computed (mod 256,
                  // bumped when normalisation switches on), bits 16-31 best child node (signed, -1 unexpanded)
     float t;     // margin + 2 * drift at compute time, rounded down: valid while 2 * drift_now + slack < t
 };
-struct EnvCacheState {  // per env, 16 bytes
+struct EnvCacheState {  // per env, 32 bytes
     double drift;  // sum of D_k
+    double rinv;   // RN(1 / (max - min)) of the env's current min-max pair (valid while max > min)
     int epoch;
-    int pad;
+    int pad[3];
 };
+
+// float32(MinMaxStats.normalize(v)) exactly as the reference computes it, usually without the division (see header)
+__device__ __forceinline__ float norm_q(double v, double mn, double mx, double rinv) {
+    const double d = v - mn;
+    double y = d * rinv;
+    const long long b = __double_as_longlong(y);
+    const int lo = (int)(b & 0x1fffffffLL) - 0x10000000;
+    const int ex = (int)((b >> 52) & 0x7ff);
+    if ((lo >= -4 && lo <= 4) || (ex < 1023 - 120 && d != 0.0)) y = d / (mx - mn);  // ambiguous rounding / float32 subnormal range
+    return (float)y;
+}
+
+// child_U of one action (mcts.py:189-200): float64 product rounded once in self-play; float32 * float32 when the root
+// prior stayed float32 (deterministic search under numpy 2)
+__device__ __forceinline__ float child_u(double prior_a, double f, bool prior_f32) {
+    return prior_f32 ? ((float)prior_a * (float)f) : (float)(prior_a * f);
+}
 constexpr float kCacheSlack = 4e-5f;  // float32 rounding of child_Q / child_U / their sum, for |ucb| < 64
 
 template <int CTRL>
@@ -82,12 +112,15 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     double* ft = reinterpret_cast<double*>(smem + P.t2_ftab);
     for (int i = tid; i < ((P.S + 1) * (P.S + 2)) / 2; i += WG_THREADS) ft[i] = P.ftab_tri[i];
     Entry2* en = reinterpret_cast<Entry2*>(smem + P.t2_entries);
-    for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].cn = 0; en[i].c = -1; }
+    // U = prior * f(0, 0) = 0 for the root before its first visit (sqrt(0), mcts.py:193-195); every other node's row is
+    // written by the backup that creates it
+    for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].U = 0.0f; en[i].cn = 0; en[i].c = -1; }
     SelCache* c = reinterpret_cast<SelCache*>(smem + P.t_cache);
     for (int i = tid; i < TILE_E * P.NN; i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); }  // t = -inf: never a hit
     if (tid < TILE_E) {
         EnvCacheState* st = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + tid;
-        st->drift = 0.0; st->epoch = 0; st->pad = 0;
+        st->drift = 0.0; st->epoch = 0;
+        st->rinv = P.has_bounds ? 1.0 / (P.kb_max - P.kb_min) : 0.0;
     }
     if ((tid & 15) == 0) {
         const int e = tid >> 4;
@@ -96,16 +129,11 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     }
 }
 
-// pUCT value of one action of a node from its entry (child_Q + child_U, mcts.py:159-200)
-__device__ __forceinline__ float puct_entry(const Entry2& en, double f, double prior_a, double mn, double mx, bool norm, bool prior_f32) {
+// pUCT value of one action of a node from its entry (child_Q + child_U, mcts.py:159-200), exact
+__device__ __forceinline__ float puct_entry(const Entry2& en, double mn, double mx, double rinv, bool norm) {
     float qa = 0.0f;
-    if (en.cn > 0) {
-        double v = en.vq;
-        if (norm) v = (v - mn) / (mx - mn);
-        qa = (float)v;
-    }
-    const float ua = prior_f32 ? ((float)prior_a * (float)f) : (float)(prior_a * f);
-    return qa + ua;
+    if (en.cn > 0) qa = norm ? norm_q(en.vq, mn, mx, rinv) : (float)en.vq;
+    return qa + en.U;
 }
 
 // One descent (mcts.py:372-379).  Results segment-uniform.  All 64 lanes of every wave must call it.
@@ -113,84 +141,98 @@ __device__ __forceinline__ float puct_entry(const Entry2& en, double f, double p
 // Two alternating phases: (A) a tight pointer chase along valid cache entries -- one 8-byte LDS read, two compares and a
 // few selects per level; (B) when no segment of the wave can advance by its cache, one full evaluation of the current
 // level for the segments that are not done (best_child, mcts.py:104-127).
+// `resume` (from the previous tree2_backup; 0 for the first descent): node to start at | its depth << 16; `mypath` must
+// then still hold the previous descent's path registers.
 __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
-                                             int& leaf_action, int& mypath) {
+                                             int& leaf_action, int& mypath, int resume = 0) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
     const double* mm = reinterpret_cast<const double*>(smem + P.t_mm) + e * 2;
     int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
     short* path = path_row(smem, P, e);
     const SelCache* cb = cache_at(smem, P, e, 0);
-    const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
     const EnvCacheState st = reinterpret_cast<const EnvCacheState*>(smem + P.t_ver)[e];
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
     const int ep = st.epoch & 0xff;
     const double mn = mm[0], mx = mm[1];
-    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0), lane_ok = a0 < P.A;
-    const double prior_a = lane_ok ? (reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A)[a0] : 0.0;
-    const int cp0 = env_ok ? P.cur[env_g] : 0, op0 = env_ok ? P.opp[env_g] : 0;
-    int n = 0, ties = sel[3];
+    const bool norm = mx > mn, lane_ok = a0 < P.A;
+    int n = resume & 0xffff, ties = sel[3];
     bool done = !env_ok;
-    int lp = 0, la = 0, k = 0;  // k: levels descended so far
-    mypath = 0;
+    int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
     MZ_SUB_DECL
     MZ_SUB_START();
+    // The loop bodies are written as selects, not branches: a wave that runs alone on its SIMD pays for every scalar
+    // branch on a lane predicate (s_and_saveexec / s_cbranch_execz) far more than for the few VALU selects.
     while (__any(!done)) {
         // ---- phase A: chase cached best children ----
+        MZ_SUBX_START();
         for (;;) {
+            MZ_SUBX_COUNT(5);
             const SelCache cc = cb[n];
-            const bool adv = !done && (((cc.packed >> 8) & 0xff) == ep) && (thr < cc.t);
+            const bool adv = !done & (((cc.packed >> 8) & 0xff) == ep) & (thr < cc.t);
             if (a0 == 0 && !done) { MZ_COUNT(0, 1); MZ_COUNT(1, adv ? 1 : 0); }
             if (!__any(adv)) break;
-            if (adv) {
-                if (k < 16) { if (a0 == k) mypath = n; }
-                else if (a0 == 0) path[k] = (short)n;
-                k++;
-                const int c = cc.packed >> 16;
-                if (c < 0 || k > P.NN) { done = true; lp = n; la = cc.packed & 0xff; }
-                else n = c;
+            if (__any(adv & (k >= 16))) {  // deep paths (rare): positions past the 16 path registers go to the LDS path row
+                if (adv && k >= 16 && a0 == 0) path[k] = (short)n;
             }
+            mypath = (adv & (a0 == k)) ? n : mypath;
+            const int c = cc.packed >> 16, k1 = k + 1;
+            const bool stop = adv & ((c < 0) | (k1 > P.NN));
+            lp = stop ? n : lp;
+            la = stop ? (cc.packed & 0xff) : la;
+            n = (adv & !stop) ? c : n;
+            k = adv ? k1 : k;
+            done |= stop;
         }
+        MZ_SUBX(4);
         if (!__any(!done)) break;
+        MZ_SUBX_COUNT(7);
         // ---- phase B: every segment that is not done sits on a level its cache cannot decide: evaluate it ----
         {
-            const int Np = node2_at(smem, P, e, n)->N;
             const Entry2 en = entry2_row(smem, P, e, n)[lane_ok ? a0 : 0];
-            const double f = ftab[tri(Np) + en.cn];
-            const float u = lane_ok ? puct_entry(en, f, prior_a, mn, mx, norm, prior_f32) : __uint_as_float(0xff800000u);
+            const float u = lane_ok ? puct_entry(en, mn, mx, st.rinv, norm) : __uint_as_float(0xff800000u);
             const float best = butterfly16_max(u);
-            const bool eq = lane_ok && (u == best);
+            const bool eq = lane_ok & (u == best);
             const unsigned long long bal = __ballot(eq);
             const unsigned msk = (unsigned)(bal >> (16 * seg)) & 0xffffu;  // tie set in ascending action order
             const int total = __popc(msk);
             int pick = 0;
-            if (!done && total > 1) {  // np.random.choice consumes randomness only for a real tie
-                double uu;
-                if (P.rng_mode == 0) {
-                    if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
-                    else { uu = 0.5; if (a0 == 0) atomicExch(P.err, 4); }
-                } else {
-                    Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
-                    uu = g.uniform();
+            if (__any(!done & (total > 1))) {
+                if (!done && total > 1) {  // np.random.choice consumes randomness only for a real tie
+                    double uu;
+                    if (P.rng_mode == 0) {
+                        if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
+                        else { uu = 0.5; if (a0 == 0) atomicExch(P.err, 4); }
+                    } else {
+                        Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
+                        uu = g.uniform();
+                    }
+                    ties++;
+                    pick = (int)floor(uu * (double)total);
+                    pick = pick >= total ? total - 1 : pick;
                 }
-                ties++;
-                pick = (int)floor(uu * (double)total);
-                pick = pick >= total ? total - 1 : pick;
             }
             const int as = nth_set_bit(msk, pick);
-            const int cs = row_max_i((a0 == as) ? en.c : -2);  // broadcast the chosen lane's child index
-            if (!done) {
-                if (k < 16) { if (a0 == k) mypath = n; }
-                else if (a0 == 0) path[k] = (short)n;
-                k++;
-                if (cs < 0 || k > P.NN) { done = true; lp = n; la = as; }
-                else n = cs;
+            const int cs = row_max_i((a0 == as) ? (int)en.c : -2);  // broadcast the chosen lane's child index
+            const bool adv = !done;
+            if (__any(adv & (k >= 16))) {
+                if (adv && k >= 16 && a0 == 0) path[k] = (short)n;
             }
+            mypath = (adv & (a0 == k)) ? n : mypath;
+            const int k1 = k + 1;
+            const bool stop = adv & ((cs < 0) | (k1 > P.NN));
+            lp = stop ? n : lp;
+            la = stop ? as : la;
+            n = (adv & !stop) ? cs : n;
+            k = adv ? k1 : k;
+            done |= stop;
         }
+        MZ_SUBX(6);
     }
     MZ_SUB(3);  // descent loop
     if (a0 == 0 && env_ok) MZ_COUNT(2, 1);
     if (a0 == 0) {
         // players swap at every level (mcts.py:379): the leaf's player follows from the parity of the depth
+        const int cp0 = env_ok ? P.cur[env_g] : 0, op0 = env_ok ? P.opp[env_g] : 0;
         sel[0] = lp; sel[1] = la; sel[2] = (k & 1) ? op0 : cp0; sel[3] = ties;
         reinterpret_cast<int*>(smem + P.t_sel)[80 + e] = k;  // expanded nodes on the path (root .. leaf parent)
     }
@@ -200,8 +242,9 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
 
 // expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
 // mypath as produced by tree2_select of the same simulation
-__device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
-                                             int mypath) {
+// returns the resume point of the next descent (see header)
+__device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
+                                            int mypath) {
     const int e = tid >> 4, a0 = tid & 15;
     const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
     double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
@@ -256,7 +299,7 @@ __device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchPa
             x->W = W; x->N = N;
             if (par >= 0) {
                 Entry2* en = entry2_row(smem, P, e, par) + mv;
-                en->vq = v; en->cn = N; en->c = p;
+                en->vq = v; en->cn = (short)N; en->c = (short)p;
             }
             mx = v > mx ? v : mx;
             mn = v < mn ? v : mn;
@@ -276,9 +319,10 @@ __device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchPa
     // cache-validity bookkeeping for the min-max change of this backup (see header)
     EnvCacheState st = *stp;
     if (mn != mn0 || mx != mx0) {
+        st.rinv = mx > mn ? 1.0 / (mx - mn) : 0.0;  // the one division per min-max change (norm_q)
         if (mx0 > mn0) {
-            const double w = mx - mn;
-            const double d_lo = (mn0 - mn) / w, d_hi = (mx - mx0) / w;
+            // D_k is only an upper bound: the products are within 2 ulp of the quotients, the 1.000001 factor covers that
+            const double d_lo = (mn0 - mn) * st.rinv, d_hi = (mx - mx0) * st.rinv;
             st.drift += (d_lo > d_hi ? d_lo : d_hi) * 1.000001 + 1e-12;
         } else {
             st.epoch++;  // normalisation may switch on: nothing cached before survives
@@ -287,35 +331,75 @@ __device__ __forceinline__ void tree2_backup(unsigned char* smem, const SearchPa
     }
     if (a0 == 0 && env_ok) { mm[0] = mn; mm[1] = mx; *stp = st; }
     MZ_SUB(1);  // statistics update + min-max reduction
-    // pass 2: best child of every path node with the final statistics (same lane ownership; LDS ops are in order, so the
-    // entry writes of pass 1 -- all from this wave -- are visible)
+    // pass 2: child_U and best child of every path node with the final statistics (same lane ownership; LDS ops are in
+    // order, so the entry writes of pass 1 -- all from this wave -- are visible)
     const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0);
+    const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;  // what the next select will compare the margins with
+    int resume = 0;
     for (int base = 0; __any(base < L); base += 16) {
         const int idx = L - 1 - (base + a0);
         const bool valid = idx >= 0;
         const int from_reg = __shfl(mypath, (tid & 48) | (idx & 15), 64);
         int p = 0;
         if (valid) p = (idx == L - 1) ? nw : (idx < 16 ? from_reg : (int)path[idx]);
+        bool decided = false;  // the refreshed cache entry will let the next descent pass through p without evaluating it
+        int bestc = -1;
         if (valid) {
             const int Np = node2_at(smem, P, e, p)->N;
             const double* frow = ftab + tri(Np);
-            const Entry2* er = entry2_row(smem, P, e, p);
+            Entry2* er = entry2_row(smem, P, e, p);
             float best = __uint_as_float(0xff800000u), second = __uint_as_float(0xff800000u);
-            int besta = 0, bestc = -1, cnt = 0;
-            for (int a = 0; a < P.A; a++) {
-                const Entry2 en = er[a];
-                const float u = puct_entry(en, frow[en.cn], prior[a], mn, mx, norm, prior_f32);
-                if (u > best) { second = best; best = u; besta = a; bestc = en.c; cnt = 1; }
-                else if (u == best) { cnt++; }
-                else if (u > second) { second = u; }
+            int besta = 0, cnt = 0;
+            for (int a4 = 0; a4 < P.A; a4 += 4) {  // 4 actions per round: their LDS reads overlap
+                Entry2 en[4];
+                double f[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) en[j] = er[a4 + j < P.A ? a4 + j : P.A - 1];
+#pragma unroll
+                for (int j = 0; j < 4; j++) f[j] = frow[en[j].cn];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int a = a4 + j;
+                    if (a < P.A) {
+                        const float ua = child_u(prior[a], f[j], prior_f32);  // this node's N (and one child's) just changed
+                        er[a].U = ua;
+                        // the cached ranking may use the un-checked product: its error (1 ulp of float32) is far inside the
+                        // cache's slack, and a choice that is not decided by more than the slack is re-evaluated exactly
+                        // at visit time anyway
+                        float qa = 0.0f;
+                        if (en[j].cn > 0) qa = norm ? (float)((en[j].vq - mn) * st.rinv) : (float)en[j].vq;
+                        const float u = qa + ua;
+                        // first maximum, number of actions tied with it, runner-up -- as selects (branches on lane
+                        // predicates cost a wave that runs alone on its SIMD far more than the selects do)
+                        const bool gt = u > best, eq = u == best;
+                        second = gt ? best : ((!eq && u > second) ? u : second);
+                        cnt = gt ? 1 : (eq ? cnt + 1 : cnt);
+                        besta = gt ? a : besta;
+                        bestc = gt ? (int)en[j].c : bestc;
+                        best = gt ? u : best;
+                    }
+                }
             }
             SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
             cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
             cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : __uint_as_float(0xff800000u);
             *cache_at(smem, P, e, p) = cc;
+            decided = thr < cc.t;
+        }
+        if (L <= 16) {
+            // lane a0 owns path position L-1-a0 (lane 0: the new leaf, lane L-1: the root); the next descent retraces the
+            // path while every node from the root down is decided AND its choice is the next path node (lane a0 - 1)
+            const int pnext = dpp_i<DPP_SHR1>(p);
+            const bool ok = decided && a0 >= 1 && bestc == pnext;
+            const unsigned okm = (unsigned)(__ballot(ok) >> (tid & 48)) & 0xffffu;
+            const unsigned stop = (~okm & ((1u << L) - 1u)) | 1u;  // lanes at which the retrace stops; the leaf lane always does
+            const int r = 31 - __clz((int)stop);                  // the one nearest to the root
+            const int pr = __shfl(p, (tid & 48) | r, 64);
+            resume = env_ok ? (pr | ((L - 1 - r) << 16)) : 0;
         }
     }
     MZ_SUB(2);  // best-child refresh
+    return resume;
 }
 
 __device__ __forceinline__ void tree2_finish(unsigned char* smem, const SearchParams& P, int e, int env_g) {

@@ -190,7 +190,7 @@ static void compute_layout(mz_planner* p) {
         const int n2 = take(16 * s.NN * 24, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
                   p0 = take(16 * s.A * 4, 16), mmo = take(16 * 2 * 8, 16), se = take(128 * 4, 16), pt = take(32 * 8, 16),
                   ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * s.NN * 8, 16), pa = take(16 * (s.NN + 3) * 2, 16),
-                  ve = take(16 * 16, 16);
+                  ve = take(16 * 32, 16);
         const int total = (b + 15) & ~15;
         if (total <= 160 * 1024) {
             p->tree2_ok = true;
@@ -486,7 +486,7 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
     p->ip.net = p->net;
     if (p->fast_planes) {
         // ONE per-wave weight stream in consumption order (layout: mz_search_fast.h header)
-        const int NT = p->fast_planes / 64, TR = p->net.L[L_REW1].n_tiles, TV = p->net.L[L_VAL1].n_tiles, RD = 3;
+        const int NT = p->fast_planes / 64, TR = p->net.L[L_REW1].n_tiles, TV = p->net.L[L_VAL1].n_tiles, RD = kFastRD;
         const int I_D1 = 0, I_D2 = I_D1 + 5, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
         const int SL = (I_END + RD - 1) / RD * RD;
         std::vector<float> st((size_t)WG_WAVES * SL * NT * 256, 0.0f);
@@ -915,6 +915,11 @@ extern "C" int mz_debug_read_counters(mz_planner* p, long long out[8]) {
     unsigned long long dbg[8];
     HIPCHK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(mz::g_dbg), sizeof(dbg)));
     for (int i = 0; i < 8; i++) out[i] = (long long)dbg[i];
+    long long sub[8];
+    HIPCHK(hipMemcpyFromSymbol(sub, HIP_SYMBOL(mz::g_sub), sizeof(sub)));
+#ifndef MZ_COUNTERS
+    for (int i = 4; i < 8; i++) out[i] = sub[i];  // select sub-phases of block 0 / wave 0: [4] phase-A cycles, [5] phase-A iterations, [6] phase-B cycles, [7] rounds
+#endif
 #endif
     return MZ_OK;
 }

@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 
 from muzero_amd import planner as pl  # noqa: E402
 
-pl.LIB_PATH = os.path.join(REPO, 'muzero_amd', 'lib', 'libmzplanner_hip_stamps.so')
+pl.LIB_PATH = os.environ.get('MZ_STAMPS_LIB', os.path.join(REPO, 'muzero_amd', 'lib', 'libmzplanner_hip_stamps.so'))
 from helpers import build_mlp, mlp_case  # noqa: E402
 
 NAMES = ['root', 'select', 'gather', 'dyn1(wide)', 'dyn2(chain)', 'normalise', 'rew1+val1(wide)', 'heads2(chain)', 'softmax', 'backup', 'finish']
@@ -48,6 +48,10 @@ def main():
     cn = (C.c_longlong * 8)()
     p.lib.mz_debug_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     p.lib.mz_debug_read_counters(p.h, cn)
+    if not cn[0] and cn[5]:
+        d = (n + 5) * S
+        print(f'select, wave 0 of block 0, per descent: phase A {cn[4] / d:.0f} cycles in {cn[5] / d:.2f} iterations ({cn[4] / max(cn[5], 1):.0f} each); '
+              f'phase B {cn[6] / d:.0f} cycles in {cn[7] / d:.2f} rounds ({cn[6] / max(cn[7], 1):.0f} each)')
     if cn[0]:
         print(f'tree counters (counters build; timings below are distorted): levels {cn[0]}, cache hits {cn[1]} ({100 * cn[1] / cn[0]:.1f}%), '
               f'descents {cn[2]}, mean depth {cn[0] / max(cn[2], 1):.2f}, min-max changes per descent {cn[3] / max(cn[2], 1):.3f}')
