@@ -58,6 +58,8 @@ struct MlpNet {
     MlpLayer L[L_COUNT];
     int in_dim, A, P, H, Sv, Sr;
     int in_pad, x_pad, p_pad, h_pad;  // multiples of 16: obs, pad16(H) + pad16(A), P, H
+    const float* b_all;  // every layer's padded bias vector, concatenated in the order of the LDS copies (b_lds)
+    int b_base, b_count; // first float of the LDS copy, number of floats
 };
 
 // LDS carve-out of the network part (float offsets from the dynamic-LDS base)
@@ -111,12 +113,18 @@ __device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __res
         wp[j] = reinterpret_cast<const float4*>(L.w) + (size_t)t * L.kg * 64 + lane;
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
+    // weights one block ahead of the MFMAs (an L2 round trip is ~2 k cycles; un-prefetched, every block would wait for it)
+    float4 w[NACC], wn[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; j++) w[j] = wp[j][0];
     for (int g = 0; g < L.kg; g++) {
         const float4 x = xp[g * 64];
-        float4 w[NACC];
+        const int gn = g + 1 < L.kg ? g + 1 : g;
 #pragma unroll
-        for (int j = 0; j < NACC; j++) w[j] = wp[j][g * 64];
+        for (int j = 0; j < NACC; j++) wn[j] = wp[j][gn * 64];
         mma_block<NACC>(acc, w, x, g + 1 < L.kg ? 4 : L.last_steps);
+#pragma unroll
+        for (int j = 0; j < NACC; j++) w[j] = wn[j];
     }
 #pragma unroll
     for (int j = 0; j < NACC; j++) epi(t0 + j * WG_WAVES, acc[j]);
@@ -139,20 +147,39 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
         wp[j] = reinterpret_cast<const float4*>(L.w) + (size_t)t * L.kg * 64 + lane;
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
+    // the four quarters' blocks of round gg are loaded while round gg - 1 multiplies (see gemm_chunk)
+    float4 w[4][NT2], wn[4][NT2];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int g = c * L.kq < L.kg ? c * L.kq : 0;
+#pragma unroll
+        for (int j = 0; j < NT2; j++) w[c][j] = wp[j][g * 64];
+    }
     for (int gg = 0; gg < L.kq; gg++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int g = c * L.kq + gg + 1;
+            const int gl = (gg + 1 < L.kq && g < L.kg) ? g : 0;
+#pragma unroll
+            for (int j = 0; j < NT2; j++) wn[c][j] = wp[j][gl * 64];
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int g = c * L.kq + gg;
             if (g < L.kg) {
                 const float4 x = xp[g * 64];
-                float4 w[NT2];
                 f32x4 a[NT2];
 #pragma unroll
-                for (int j = 0; j < NT2; j++) { w[j] = wp[j][g * 64]; a[j] = acc[j][c]; }
-                mma_block<NT2>(a, w, x, g + 1 < L.kg ? 4 : L.last_steps);
+                for (int j = 0; j < NT2; j++) a[j] = acc[j][c];
+                mma_block<NT2>(a, w[c], x, g + 1 < L.kg ? 4 : L.last_steps);
 #pragma unroll
                 for (int j = 0; j < NT2; j++) acc[j][c] = a[j];
             }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int j = 0; j < NT2; j++) w[c][j] = wn[c][j];
         }
     }
 #pragma unroll
@@ -229,10 +256,9 @@ struct EpiLogits {
 // copy every layer's padded bias vector into LDS (once per kernel): bias reads then cost an LDS access, not an
 // exposed L2 round trip at the head of each layer
 __device__ __forceinline__ void stage_biases(const MlpNet& net, float* lds, int tid) {
-    for (int l = 0; l < L_COUNT; l++) {
-        const MlpLayer& L = net.L[l];
-        for (int i = tid; i < L.n_tiles * 16; i += WG_THREADS) lds[L.b_lds + i] = L.b[i];
-    }
+    // one flat copy (the loads of a thread are independent: they overlap instead of paying an L2 round trip per layer)
+    for (int i = tid * 4; i < net.b_count; i += WG_THREADS * 4)
+        *reinterpret_cast<float4*>(lds + net.b_base + i) = *reinterpret_cast<const float4*>(net.b_all + i);
 }
 
 // normalize_hidden_state (util.py:31-36) for the MLP nets: min/max over the H features of each env, then

@@ -278,9 +278,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
         }
     }
     __syncthreads();
+    MZ_STAMP(2);  // root: bias staging + tree tables
     root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
     load_obs(net, lds + o.X, src, tid);
     __syncthreads();
+    MZ_STAMP(15);  // root: Dirichlet draws + observation load
     mlp_initial_tile(net, o, lds, dst, pi0, tid);
     __syncthreads();
     if (a0 == 0 && env_ok) root_prior(smem, Pm, e, env_g);

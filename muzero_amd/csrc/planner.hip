@@ -69,6 +69,7 @@ struct mz_planner {
     bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
     bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
     float* d_stream[1] = {};
+    float* d_bias_all = nullptr;
     FastWeights fw{};
 
     // per-env device buffers (capacity cfg.num_envs)
@@ -392,6 +393,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
         if (p->d_b[l]) (void)hipFree(p->d_b[l]);
     }
     if (p->d_stream[0]) (void)hipFree(p->d_stream[0]);
+    if (p->d_bias_all) (void)hipFree(p->d_bias_all);
     void* cbufs[] = {p->d_pi_scratch, p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
     for (void* b : cbufs)
         if (b) (void)hipFree(b);
@@ -481,6 +483,18 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
         HIPCHK(hipMemcpy(p->d_b[l], pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
         p->net.L[l].w = p->d_w[l];
         p->net.L[l].b = p->d_b[l];
+    }
+    {
+        // all padded bias vectors in one buffer, laid out like their LDS copies (stage_biases)
+        const int base = p->o.BIAS, count = p->o.PM - p->o.BIAS;
+        std::vector<float> all((size_t)count, 0.0f);
+        for (int l = 0; l < L_COUNT; l++) {
+            const HostTensor& Bv = p->params.find(std::string(kMlpNames[l]) + ".bias")->second;
+            for (int i = 0; i < p->net.L[l].n; i++) all[p->net.L[l].b_lds - base + i] = Bv.data[i];
+        }
+        if (!p->d_bias_all) HIPCHK(hipMalloc(&p->d_bias_all, all.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(p->d_bias_all, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+        p->net.b_all = p->d_bias_all; p->net.b_base = base; p->net.b_count = count;
     }
     p->sp.net = p->net;
     p->ip.net = p->net;

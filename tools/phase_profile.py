@@ -16,7 +16,7 @@ from muzero_amd import planner as pl  # noqa: E402
 pl.LIB_PATH = os.environ.get('MZ_STAMPS_LIB', os.path.join(REPO, 'muzero_amd', 'lib', 'libmzplanner_hip_stamps.so'))
 from helpers import build_mlp, mlp_case  # noqa: E402
 
-NAMES = ['root', 'select', 'gather', 'dyn1(wide)', 'dyn2(chain)', 'normalise', 'rew1+val1(wide)', 'heads2(chain)', 'softmax', 'backup', 'finish']
+NAMES = ['root: inference + prior', 'select + gather', 'root: tables', 'dyn1(wide)', 'dyn2(chain)', 'normalise', 'rew1+val1(wide)', 'heads2(chain)', 'softmax', 'backup', 'finish']
 
 
 def main():
@@ -41,8 +41,9 @@ def main():
         tot += np.array(st[:], dtype=np.float64)
     tot /= n
     sub = np.array(st[11:15], dtype=np.float64) / ((n + 5) * S)  # cumulative over all launches of this process
+    root_noise = tot[15]
     tot[11:] = 0
-    total = tot.sum()
+    total = tot.sum() + root_noise
     print(f'sub-phases per sim (cycles): backup loads+chain {sub[0]:.0f}, update+minmax {sub[1]:.0f}, best-child refresh {sub[2]:.0f}; '
           f'select descent loop {sub[3]:.0f}')
     cn = (C.c_longlong * 8)()
@@ -56,6 +57,7 @@ def main():
         print(f'tree counters (counters build; timings below are distorted): levels {cn[0]}, cache hits {cn[1]} ({100 * cn[1] / cn[0]:.1f}%), '
               f'descents {cn[2]}, mean depth {cn[0] / max(cn[2], 1):.2f}, min-max changes per descent {cn[3] / max(cn[2], 1):.3f}')
     print(f'{g}: total stamped ticks per move (block 0): {total:.0f}  (s_memtime ticks, 100 MHz on gfx950)')
+    print(f'  {"root: noise + obs":18s} {root_noise:10.0f}  {100 * root_noise / total:5.1f}%')
     for i, name in enumerate(NAMES):
         per_sim = tot[i] / (S if 1 <= i <= 9 else 1)
         print(f'  {name:18s} {tot[i]:10.0f}  {100 * tot[i] / total:5.1f}%   per-sim {per_sim:8.1f}')
