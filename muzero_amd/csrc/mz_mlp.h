@@ -5,7 +5,7 @@
 // of the activations, D = 16 neurons x 16 environments.  The MFMA accumulates its 4 k in order as one float32 fmaf
 // chain (exact f32, no wider internal sum).
 //
-// SUMMATION ORDER (the numerical contract; oracle/mz_oracle.c linear_mlp is the same order on the CPU):
+// SUMMATION ORDER (the numerical contract; the CPU checker restates the same order):
 //   * inputs are taken in blocks of 16; k-step i (0..3) of block g multiplies k = 16g + 4q + i, q = 0..3 in that order.
 //     That is the order in which an MFMA consumes a D-layout accumulator as its B operand: lane (e, q) of D holds
 //     neurons 16t + 4q .. 4q+3 in registers 0..3, and register i of lane (e, q) is B[k = q][n = e] of k-step i.  A

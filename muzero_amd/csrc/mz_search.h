@@ -70,6 +70,11 @@ struct SearchParams {
     unsigned long long seed;
     unsigned int move_counter;
     unsigned int env_offset;  // global id of env 0 (multi-GPU sharding: Philox streams are keyed by global env id)
+    // test hook (mz_debug_capture_rng): when set, production-mode (Philox) searches store the draws they consume in the layout
+    // of the injected-randomness inputs, so that a test can replay the very same search in parity mode
+    double* dbg_noise;        // [B][A] normalised Dirichlet noise
+    double* dbg_utie;         // [B][max_ties]
+    double* dbg_ufinal;       // [B]
     long long* stamps;        // diagnostic builds (-DMZ_STAMPS) only: per-phase cycle sums of block 0, else unused
     // device self-play with the environment fused into the search kernel (one launch per lock-step move): the env's first lane
     // runs env_pre_one before the search (temperature, record of player / observation) and env_step_one after it
@@ -196,6 +201,7 @@ __device__ __forceinline__ int select_level(unsigned char* smem, const SearchPar
         } else {
             Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
             uu = g.uniform();
+            if (P.dbg_utie && a0 == 0 && ties < P.max_ties) P.dbg_utie[(size_t)env_g * P.max_ties + ties] = uu;
         }
         ties++;
         pick = (int)floor(uu * (double)total);
@@ -302,6 +308,8 @@ __device__ __forceinline__ void root_prior(unsigned char* smem, const SearchPara
             double s = 0.0;
             for (int a = 0; a < A; a++) s += tmp[a];
             for (int a = 0; a < A; a++) tmp[a] = s > 0.0 ? tmp[a] / s : 1.0 / (double)A;
+            if (P.dbg_noise)
+                for (int a = 0; a < A; a++) P.dbg_noise[(size_t)env_g * A + a] = tmp[a];
         }
         const float om = (float)(1.0 - P.eps);
         for (int a = 0; a < A; a++) {
@@ -378,6 +386,7 @@ __device__ __forceinline__ void play_from_visits(unsigned char* smem, const Sear
         else {
             Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x30000000u);
             uu = g.uniform();
+            if (P.dbg_ufinal) P.dbg_ufinal[env_g] = uu;
         }
         // np.random.choice(p=pi): cdf = cumsum(pi); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
         double c = 0.0;

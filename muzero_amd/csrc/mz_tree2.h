@@ -205,6 +205,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                     } else {
                         Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
                         uu = g.uniform();
+                        if (P.dbg_utie && a0 == 0 && ties < P.max_ties) P.dbg_utie[(size_t)env_g * P.max_ties + ties] = uu;
                     }
                     ties++;
                     pick = (int)floor(uu * (double)total);

@@ -70,6 +70,7 @@ struct mz_planner {
     bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
     float* d_stream[1] = {};
     float* d_bias_all = nullptr;
+    double *d_dbg_noise = nullptr, *d_dbg_utie = nullptr, *d_dbg_ufinal = nullptr;  // mz_debug_capture_rng
     FastWeights fw{};
 
     // per-env device buffers (capacity cfg.num_envs)
@@ -394,6 +395,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     }
     if (p->d_stream[0]) (void)hipFree(p->d_stream[0]);
     if (p->d_bias_all) (void)hipFree(p->d_bias_all);
+    if (p->d_dbg_noise) { (void)hipFree(p->d_dbg_noise); (void)hipFree(p->d_dbg_utie); (void)hipFree(p->d_dbg_ufinal); }
     void* cbufs[] = {p->d_pi_scratch, p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
     for (void* b : cbufs)
         if (b) (void)hipFree(b);
@@ -635,6 +637,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     s.out_action = p->d_action; s.out_pi = p->d_pi; s.out_root = p->d_root; s.out_visits = p->d_visits; s.err = p->d_err;
     s.s_pi0 = p->d_spi0; s.s_values = p->d_svalues; s.s_rewards = p->d_srewards; s.trace_parent = p->d_tparent; s.trace_action = p->d_taction;
     s.seed = c.seed; s.move_counter = p->move_counter++; s.env_offset = 0; s.stamps = p->d_stamps;
+    s.dbg_noise = p->d_dbg_noise; s.dbg_utie = p->d_dbg_utie; s.dbg_ufinal = p->d_dbg_ufinal;
     s.fuse_env = fenv ? 1 : 0;
     if (fenv) s.fenv = *fenv;
     const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
@@ -663,6 +666,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         s.out_action = p->d_action; s.out_pi = p->d_pi; s.out_root = p->d_root; s.out_visits = p->d_visits; s.err = p->d_err;
         s.trace_parent = scripted ? p->d_tparent : nullptr; s.trace_action = scripted ? p->d_taction : nullptr;
         s.seed = c.seed; s.move_counter = p->move_counter - 1; s.env_offset = 0; s.stamps = nullptr;
+        s.dbg_noise = p->d_dbg_noise; s.dbg_utie = p->d_dbg_utie; s.dbg_ufinal = p->d_dbg_ufinal;
         GTreeLaunch G{};
         G.P = s; G.regions = p->d_regions; G.hidden_size = c.hidden_dim; G.src_ptrs = p->d_srcptrs; G.dst_ptrs = p->d_dstptrs;
         G.actions = p->d_sim_action;
@@ -916,6 +920,53 @@ extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
     for (int i = 0; i < 4; i++) out[11 + i] = sub[i];
     (void)dbg;
 #endif
+    return MZ_OK;
+}
+
+// test hooks, not part of the ABI header: capture the randomness a production-mode (on-device Philox) search consumes --
+// normalised root Dirichlet noise, tie-break uniforms in the order they were drawn, the final action-sampling uniform -- in
+// the layout of mz_rng_inputs, so a test can check their distributions and replay the same search in parity mode.
+extern "C" int mz_debug_capture_rng(mz_planner* p, int32_t enable) {
+    if (!p) return fail(MZ_E_INVALID, "null planner");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    const size_t B = (size_t)p->cfg.num_envs, A = (size_t)p->cfg.num_actions, T = (size_t)p->cfg.max_ties;
+    if (enable && !p->d_dbg_noise) {
+        HIPCHK(hipMalloc(&p->d_dbg_noise, B * A * sizeof(double)));
+        HIPCHK(hipMalloc(&p->d_dbg_utie, B * T * sizeof(double)));
+        HIPCHK(hipMalloc(&p->d_dbg_ufinal, B * sizeof(double)));
+    }
+    if (!enable) {
+        if (p->d_dbg_noise) { (void)hipFree(p->d_dbg_noise); (void)hipFree(p->d_dbg_utie); (void)hipFree(p->d_dbg_ufinal); }
+        p->d_dbg_noise = p->d_dbg_utie = p->d_dbg_ufinal = nullptr;
+    } else {  // 0.5 where a search draws nothing: what the parity-mode tests inject for unused slots
+        std::vector<double> half(B * (T > A ? T : A), 0.5);
+        HIPCHK(hipMemcpy(p->d_dbg_utie, half.data(), B * T * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->d_dbg_ufinal, half.data(), B * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(p->d_dbg_noise, 0, B * A * sizeof(double)));
+    }
+    return MZ_OK;
+}
+
+extern "C" int mz_debug_read_rng(mz_planner* p, double* h_noise, double* h_utie, double* h_ufinal) {
+    if (!p || !p->d_dbg_noise) return fail(MZ_E_STATE, "mz_debug_capture_rng(p, 1) first");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    const size_t B = (size_t)p->cfg.num_envs, A = (size_t)p->cfg.num_actions, T = (size_t)p->cfg.max_ties;
+    if (h_noise) HIPCHK(hipMemcpy(h_noise, p->d_dbg_noise, B * A * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_utie) HIPCHK(hipMemcpy(h_utie, p->d_dbg_utie, B * T * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_ufinal) HIPCHK(hipMemcpy(h_ufinal, p->d_dbg_ufinal, B * sizeof(double), hipMemcpyDeviceToHost));
+    return MZ_OK;
+}
+
+// test hook, not part of the ABI header: overwrite the per-env step counters of the running episodes (lets a test reach the
+// TimeLimit-500 truncation of CartPole without a policy that balances the pole for 500 steps)
+extern "C" int mz_debug_set_env_steps(mz_planner* p, const int32_t* h_steps) {
+    if (!p || !h_steps) return fail(MZ_E_INVALID, "null argument");
+    if (p->env_kind == MZ_ENV_NONE) return fail(MZ_E_STATE, "call mz_selfplay_reset first");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpy(p->env.steps, h_steps, (size_t)p->cfg.num_envs * sizeof(int), hipMemcpyHostToDevice));
     return MZ_OK;
 }
 

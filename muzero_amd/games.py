@@ -141,31 +141,81 @@ class GomokuEnv(BoardGameEnv):
         super().__init__(board_size=board_size, stack_history=stack_history, num_to_win=num_to_win, name='Gomoku')
 
 
-class CartPoleEnv:
-    """Host-side CartPole-v1 as the reference's `create_classic_environment('CartPole-v1', stack_history=4)` presents it
-    (`gym_env.py:271-365,436-459`): gym 0.23.1's published equations (an un-vendored dependency of the reference), float64
-    state, float32 observation rows [obs, (action + 1) / A] stacked newest first (reset fills every row with the first
-    observation and action 0), reward 1 per step, TimeLimit 500, players 1 / 1, all actions legal.  Same rules as the device
-    environment in `csrc/mz_env.h`; for evaluators and tools."""
+class StackFrameAndAction:
+    """`gym_env.py:271-353`: stacks the last `stack_history` observations, newest first, each with the action that led to it
+    as a bias value (action + 1) / num_actions (reset fills every slot with the first observation and action 0).  Vector
+    observations [D] become [stack, D + 1]; channel-first images [C, H, W] become [stack * (C + 1), H, W] with the action
+    broadcast to a plane.  `env` needs reset() -> obs, step(a) -> (obs, reward, done, info), `observation_shape` and
+    `num_actions`."""
+
+    def __init__(self, env, stack_history: int, is_obs_image: bool = False) -> None:
+        self.env, self.stack_history, self.is_obs_image = env, stack_history, is_obs_image
+        self.num_actions = env.num_actions
+        shp = tuple(env.observation_shape)
+        self.old_obs_shape = shp[1:] if is_obs_image else shp
+        self.observation_shape = (stack_history * (shp[0] + 1),) + shp[1:] if is_obs_image else (stack_history, shp[0] + 1)
+        self._obs, self._act = [], []
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def _plane(self, action) -> np.ndarray:
+        scaled = (action + 1) / self.num_actions
+        return scaled * np.ones(self.old_obs_shape if self.is_obs_image else (1,)).astype(np.float32)
+
+    def observation(self) -> np.ndarray:
+        obs = np.stack(self._obs, axis=0).astype(np.float32)
+        act = np.stack(self._act, axis=0).astype(np.float32)
+        if self.is_obs_image:
+            return np.concatenate([obs.reshape((-1,) + obs.shape[2:]), act], axis=0)
+        return np.concatenate([obs, act], axis=1)
+
+    def reset(self, **kwargs) -> np.ndarray:
+        first = self.env.reset(**kwargs)
+        self._obs = [first] * self.stack_history
+        self._act = [self._plane(0)] * self.stack_history
+        return self.observation()
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        self._obs = [obs] + self._obs[:-1]
+        self._act = [self._plane(action)] + self._act[:-1]
+        return self.observation(), reward, done, info
+
+
+class PlayerIdAndActionMaskWrapper:
+    """`gym_env.py:356-365`: single-player environments present player ids 1 / 1 and an all-legal action mask."""
+
+    def __init__(self, env) -> None:
+        self.env = env
+        self.current_player = self.opponent_player = 1
+        self.actions_mask = np.ones(env.num_actions, dtype=np.bool_).flatten()
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def step(self, action):
+        return self.env.step(action)
+
+
+class _CartPolePhysics:
+    """gym 0.23.1 CartPole-v1 (an un-vendored dependency of the reference; its published equations): float64 state, float32
+    observation, reward 1 per step, failure beyond |x| 2.4 or |theta| 12 degrees, TimeLimit 500."""
 
     num_actions = 2
+    observation_shape = (4,)
 
-    def __init__(self, stack_history: int = 4, seed: int = 1) -> None:
-        self.stack_history = stack_history
+    def __init__(self, seed: int = 1) -> None:
         self._rs = np.random.RandomState(seed)
-        self.current_player = self.opponent_player = 1
-        self.actions_mask = np.ones(self.num_actions, dtype=np.bool_)
-        self.observation_shape = (stack_history, 5)
-        self.reset()
-
-    def _row(self, action: int) -> np.ndarray:
-        return np.concatenate([self.state.astype(np.float32), np.array([(action + 1) / self.num_actions], np.float32)])
+        self.state, self.steps, self.done = np.zeros(4), 0, True
 
     def reset(self, state=None) -> np.ndarray:
         self.state = np.asarray(state, np.float64).copy() if state is not None else self._rs.uniform(-0.05, 0.05, size=4)
         self.steps, self.done = 0, False
-        self._rows = [self._row(0) for _ in range(self.stack_history)]
-        return np.stack(self._rows, axis=0)
+        return self.state.astype(np.float32)
 
     def step(self, action: int):
         if self.done:
@@ -186,5 +236,18 @@ class CartPoleEnv:
         self.steps += 1
         failed = x < -2.4 or x > 2.4 or theta < -12 * 2 * np.pi / 360 or theta > 12 * 2 * np.pi / 360
         self.done = bool(failed or self.steps >= 500)
-        self._rows = [self._row(int(action))] + self._rows[:-1]
-        return np.stack(self._rows, axis=0), 1.0, self.done, {}
+        return self.state.astype(np.float32), 1.0, self.done, {}
+
+
+class CartPoleEnv(PlayerIdAndActionMaskWrapper):
+    """Host-side CartPole-v1 as the reference's `create_classic_environment('CartPole-v1', stack_history=4)` presents it
+    (`gym_env.py:436-459`): the physics above inside StackFrameAndAction(stack_history, is_obs_image=False) inside
+    PlayerIdAndActionMaskWrapper.  Same rules as the device environment in `csrc/mz_env.h`; for evaluators and tools."""
+
+    def __init__(self, stack_history: int = 4, seed: int = 1) -> None:
+        super().__init__(StackFrameAndAction(_CartPolePhysics(seed), stack_history, False))
+        self.stack_history = stack_history
+        self.reset()
+
+    def reset(self, state=None) -> np.ndarray:
+        return self.env.reset(state=state)

@@ -148,11 +148,13 @@ class EpisodeAssembler:
                 o = rec['obs'][m, b] if self.obs_shape is None else rec['obs'][m, b].reshape(self.obs_shape)
                 self.open[b].append((o, int(rec['action'][m, b]), float(rec['reward'][m, b]), rec['pi'][m, b],
                                      float(rec['root_value'][m, b]), int(rec['player'][m, b])))
+                # same order as the reference's loop body: the mid-episode flush check first (pipeline.py:118-142), then the
+                # end of the episode (:144-165) -- when both fall on one step the prefix is flushed and the rest finishes
+                if (not cfg.is_board_game) and len(self.open[b]) == cfg.acc_seq_length + cfg.unroll_steps + cfg.td_steps:
+                    yield from self._flush_prefix(b)
                 if rec['done'][m, b]:
                     traj, self.open[b] = self.open[b], []
                     yield from self._finish(traj)
-                elif (not cfg.is_board_game) and len(self.open[b]) == cfg.acc_seq_length + cfg.unroll_steps + cfg.td_steps:
-                    yield from self._flush_prefix(b)  # pipeline.py:118-142
 
     def _finish(self, traj):
         cfg = self.config

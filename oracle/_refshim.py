@@ -57,11 +57,30 @@ def install():
             return None
 
     class Wrapper(Env):
+        # gym.Wrapper (gym 0.23.1 core.py): attribute access and reset / step / close are forwarded to the wrapped env
         def __init__(self, env):
             self.env = env
 
         def __getattr__(self, name):
             return getattr(self.env, name)
+
+        def reset(self, **kwargs):
+            return self.env.reset(**kwargs)
+
+        def step(self, action):
+            return self.env.step(action)
+
+        def close(self):
+            return self.env.close()
+
+    class ObservationWrapper(Wrapper):
+        # gym.ObservationWrapper: reset / step outputs pass through self.observation()
+        def reset(self, **kwargs):
+            return self.observation(self.env.reset(**kwargs))
+
+        def step(self, action):
+            observation, reward, done, info = self.env.step(action)
+            return self.observation(observation), reward, done, info
 
     class Box:
         def __init__(self, low, high, shape=None, dtype=np.float32):
@@ -76,7 +95,7 @@ def install():
         'gym',
         Env=Env,
         Wrapper=Wrapper,
-        ObservationWrapper=Wrapper,
+        ObservationWrapper=ObservationWrapper,
         RewardWrapper=Wrapper,
         spaces=spaces,
         wrappers=types.SimpleNamespace(),

@@ -18,6 +18,9 @@ Groups:
   env    G5  TicTacToe / Gomoku scripted games (incl. the reference tests' win lines)
   learn  L   PrioritizedReplay sampling, calc_loss (loss, priorities, gradients), 3 optimizer steps, 2-hot projection
   play   G6  one full reference run_self_play episode on TicTacToe
+  classic G7 the classic-control observation path: StackFrameAndAction + PlayerIdAndActionMaskWrapper
+             (gym_env.py:271-365) over a scripted base env, and reference run_self_play episodes on it with a small
+             acc_seq_length, i.e. through the mid-episode flush branch (pipeline.py:118-142)
 """
 import os
 import sys
@@ -882,7 +885,142 @@ def gen_learn():
     print('learn: done,', len(out), 'arrays')
 
 
-GROUPS = dict(tree=gen_tree, nets=gen_nets, search=gen_search, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
+# --------------------------------------------------------------------------------------------
+# G7: classic-control observation path and the n-step / mid-episode-flush branch of run_self_play
+# --------------------------------------------------------------------------------------------
+def gen_classic():
+    import gym  # the placeholder module of _refshim: Env / Wrapper / spaces only
+    import muzero.gym_env as ref_gym_env
+
+    class ScriptedEnv(gym.Env):
+        """Stands in for gym's CartPole (absent from this image): a fixed table of float32 observations, rewards and
+        episode lengths.  The wrappers under test only see reset() / step() / the two spaces."""
+
+        def __init__(self, obs, rewards):
+            self.obs, self.rewards = obs, rewards  # lists per episode: [T+1, D] float32, [T] float64
+            self.observation_space = gym.spaces.Box(low=np.full(obs[0].shape[1], -4.0, np.float32), high=np.full(obs[0].shape[1], 4.0, np.float32),
+                                                    shape=(obs[0].shape[1],), dtype=np.float32)
+            self.action_space = gym.spaces.Discrete(2)
+            self.ep, self.t = -1, 0
+            self.actions = []
+
+        def reset(self, **kwargs):
+            self.ep += 1
+            self.t = 0
+            return self.obs[self.ep % len(self.obs)][0]
+
+        def step(self, action):
+            e = self.ep % len(self.obs)
+            self.actions.append(int(action))
+            self.t += 1
+            done = self.t == len(self.rewards[e])
+            return self.obs[e][self.t], float(self.rewards[e][self.t - 1]), done, {}
+
+    out = {}
+    rng = np.random.RandomState(777)
+
+    def table(lengths, D=4):
+        return ([rng.uniform(-2.0, 2.0, size=(T + 1, D)).astype(np.float32) for T in lengths],
+                [np.round(rng.uniform(0.0, 2.0, size=T), 3) for T in lengths])
+
+    # ---- (a) StackFrameAndAction(stack, is_obs_image=False) + PlayerIdAndActionMaskWrapper: reset / step stacks ----
+    for j, (stack, lengths) in enumerate([(4, (6, 3, 5)), (1, (2, 2)), (3, (9,))]):
+        obs, rew = table(lengths)
+        base = ScriptedEnv(obs, rew)
+        env = ref_gym_env.PlayerIdAndActionMaskWrapper(ref_gym_env.StackFrameAndAction(base, stack, False))  # __init__ consumes one reset()
+        pre = f'stack_{j}'
+        out[f'{pre}_cfg'] = np.array([stack, len(lengths)], np.int32)
+        out[f'{pre}_obs_space_shape'] = np.array(env.observation_space.shape, np.int32)
+        out[f'{pre}_mask'] = np.asarray(env.actions_mask).astype(np.uint8)
+        out[f'{pre}_players'] = np.array([env.current_player, env.opponent_player], np.int32)
+        stacks, acts, rws, dns, eps = [], [], [], [], []
+        for e in range(len(lengths)):
+            # episode e of the wrapped env plays table row (e + 1) % n: the constructor used up row 0's reset
+            o = env.reset()
+            stacks.append(np.asarray(o, np.float32).copy()); acts.append(-1); rws.append(0.0); dns.append(0); eps.append(base.ep % len(obs))
+            done = False
+            while not done:
+                a = int(rng.randint(0, 2))
+                o, r, done, _ = env.step(a)
+                stacks.append(np.asarray(o, np.float32).copy()); acts.append(a); rws.append(r); dns.append(int(done)); eps.append(base.ep % len(obs))
+        out[f'{pre}_stacks'] = np.stack(stacks)
+        out[f'{pre}_actions'] = np.array(acts, np.int32)   # -1: the row is a reset() output
+        out[f'{pre}_rewards'] = np.array(rws, np.float64)
+        out[f'{pre}_dones'] = np.array(dns, np.uint8)
+        out[f'{pre}_table_row'] = np.array(eps, np.int32)
+        for e in range(len(lengths)):
+            out[f'{pre}_base_obs_{e}'] = obs[e]
+            out[f'{pre}_base_rew_{e}'] = rew[e]
+    out['stack_n'] = np.int32(3)
+
+    # ---- (b) reference run_self_play on the wrapped scripted env: n-step targets + mid-episode flush (pipeline.py:118-142) ----
+    for j, (acc, td, lengths, seed) in enumerate([(4, 3, (30, 12, 7), 5150), (6, 10, (17, 23), 5151), (3, 2, (10, 10, 10), 5152)]):
+        net = ref_network.MuZeroMLPNet((4, 5), 2, 32, 7, 7, 16)
+        net.load_state_dict(seeded_state_dict(net, 31 + j))
+        net.eval()
+        cfg = ref_config.MuZeroConfig(discount=0.997, dirichlet_alpha=0.25, num_simulations=6, batch_size=8, td_steps=td, lr_init=0.01,
+                                      lr_milestones=[10], visit_softmax_temperature_fn=lambda a, b: 1.0, value_support_size=7,
+                                      reward_support_size=7, acc_seq_length=acc, use_tensorboard=False, is_board_game=False)
+        obs, rew = table(lengths)
+        base = ScriptedEnv(obs, rew)
+        env = ref_gym_env.PlayerIdAndActionMaskWrapper(ref_gym_env.StackFrameAndAction(base, 4, False))
+        n_episodes = len(lengths)
+        records, steps = [], []
+
+        class Stop:
+            def is_set(self):
+                # stop once `n_episodes` episodes have been played AND flushed (the check runs at the top of both loops)
+                return base.ep >= n_episodes and base.t == len(rew[base.ep % len(obs)])
+
+        class Q:
+            def put(self, item):
+                records.append((item, len(steps)))
+
+        counter = types.SimpleNamespace(value=0)
+        orig_search = ref_pipeline.uct_search
+
+        def logged_search(**kw):
+            res = orig_search(**kw)
+            steps.append(dict(obs=np.asarray(kw['state'], np.float32).copy(), action=np.int32(res[0]), pi=np.asarray(res[1], np.float64),
+                              root=np.float64(res[2]), player=np.int32(kw['current_player'])))
+            return res
+
+        ref_pipeline.uct_search = logged_search
+        ref_pipeline.handle_exit_signal = lambda: None
+        np.random.seed(seed)
+        try:
+            ref_pipeline.run_self_play(cfg, 0, net, torch.device('cpu'), env, Q(), counter, Stop(), None)
+        finally:
+            ref_pipeline.uct_search = orig_search
+        pre = f'sp_{j}'
+        n = len(steps)
+        # per-step env outputs in play order: the scripted table replayed with the recorded actions
+        rws, dns = [], []
+        e, t = 1 % len(obs), 0  # constructor consumed row 0's reset; the first played episode is table row 1 % n
+        for k in range(n):
+            rws.append(rew[e][t]); t += 1
+            d = t == len(rew[e]); dns.append(int(d))
+            if d:
+                e, t = (e + 1) % len(obs), 0
+        out[f'{pre}_cfg'] = np.array([acc, td, cfg.unroll_steps, n], np.int32)
+        out[f'{pre}_discount'] = np.float64(cfg.discount)
+        for k in steps[0].keys():
+            out[f'{pre}_step_{k}'] = np.stack([np.asarray(s_[k]) for s_ in steps])
+        out[f'{pre}_step_reward'] = np.array(rws, np.float64)
+        out[f'{pre}_step_done'] = np.array(dns, np.uint8)
+        out[f'{pre}_tr_state'] = np.stack([t_.state for (t_, _), _ in records])
+        out[f'{pre}_tr_action'] = np.stack([t_.action for (t_, _), _ in records])
+        out[f'{pre}_tr_reward'] = np.stack([t_.reward for (t_, _), _ in records])
+        out[f'{pre}_tr_value'] = np.stack([t_.value for (t_, _), _ in records])
+        out[f'{pre}_tr_pi'] = np.stack([t_.pi_prob for (t_, _), _ in records])
+        out[f'{pre}_tr_priority'] = np.array([p_ for (_, p_), _ in records], np.float64)
+        out[f'{pre}_tr_emitted_after_step'] = np.array([k for _, k in records], np.int32)  # env steps played when the item was put
+    out['sp_n'] = np.int32(3)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'classic_cases.npz'), **out)
+    print('classic: done,', len(out), 'arrays')
+
+
+GROUPS = dict(classic=gen_classic, tree=gen_tree, nets=gen_nets, search=gen_search, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
 
 if __name__ == '__main__':
     os.makedirs(GOLDEN_DIR, exist_ok=True)

@@ -92,3 +92,22 @@ def build_conv(case, network_module=None):
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+# ---- Philox4x32-10 exactly as muzero_amd/csrc/mz_device.h keys it (production-mode randomness of the device envs / search) ----
+def philox_uniforms(seed, c1, c2, c3, n):
+    """The first `n` doubles of the device stream Philox(seed, c1, c2, c3): block i has counter (i, c1, c2, c3), key
+    (seed low, seed high); uniform = ((r0 >> 5) * 2^26 + (r1 >> 6)) / 2^53."""
+    M = 0xFFFFFFFF
+    out = []
+    for i in range(n):
+        c = [i & M, c1 & M, c2 & M, c3 & M]
+        k0, k1 = seed & M, (seed >> 32) & M
+        for _ in range(10):
+            p0 = 0xD2511F53 * c[0]
+            p1 = 0xCD9E8D57 * c[2]
+            c = [((p1 >> 32) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> 32) ^ c[3] ^ k1) & M, p0 & M]
+            k0 = (k0 + 0x9E3779B9) & M
+            k1 = (k1 + 0xBB67AE85) & M
+        out.append(((c[0] >> 5) * 67108864.0 + (c[1] >> 6)) / 9007199254740992.0)
+    return np.array(out)

@@ -51,29 +51,66 @@ def test_tictactoe_device_env_matches_oracle_env(oracle):
 
 
 def test_cartpole_device_env_matches_oracle_env(oracle):
-    """float64 physics + float32 stacked observations vs the oracle CartPole from injected initial states (one ulp of the
-    device sin/cos is allowed for: 1e-6 relative on float32 observations) until each env's first reset."""
+    """float64 physics + float32 stacked observations vs the oracle CartPole (one ulp of the device sin/cos is allowed for:
+    1e-6 relative on float32 observations), ACROSS auto-resets: episode 0 starts from injected states, every later episode
+    from the device's Philox reset stream U(-0.05, 0.05)^4 keyed by (seed, env, episode), which the test regenerates."""
+    from helpers import philox_uniforms
     from muzero_amd import planner as pl
 
     net = build_mlp(mlp_case('cartpole'))
-    B, M = 64, 24
+    B, M, seed = 48, 120, 3
     rs = np.random.RandomState(4)
     init = rs.uniform(-0.05, 0.05, size=(B, 4))
-    p = _planner(net, B, num_simulations=50, discount=0.997)
+    p = _planner(net, B, seed=seed, num_simulations=50, discount=0.997)
     p.selfplay_reset(pl.ENV_CARTPOLE, init)
-    p.selfplay_step(1.0, M)
-    rec = p.selfplay_read(M)
+    rec = {}
+    for lo in range(0, M, 40):  # the record ring keeps 64 moves
+        p.selfplay_step(1.0, 40)
+        part = p.selfplay_read(40)
+        for k, v in part.items():
+            rec[k] = v if k not in rec else np.concatenate([rec[k], v])
     assert (rec['reward'] == 1.0).all() and (rec['player'] == 1).all()
     np.testing.assert_array_equal(rec['pi'], np.round(rec['pi'] * 50) / 50)  # T = 1: visit counts / 50
+    episodes = 0
     for b in range(B):
         env = oracle.CartPoleEnv(4)
         obs = env.reset(init[b])
+        ep = 0
         for m in range(M):
             np.testing.assert_allclose(rec['obs'][m, b].reshape(4, 5), obs, rtol=1e-6, atol=1e-7)
             obs, r, done = env.step(int(rec['action'][m, b]))
-            assert done == bool(rec['done'][m, b])
+            assert done == bool(rec['done'][m, b]), (b, m)
             if done:
-                break
+                ep += 1
+                obs = env.reset(-0.05 + 0.1 * philox_uniforms(seed, b, ep, 0x40000000, 4))  # mz_env.h cartpole_fresh
+        episodes += ep
+    assert episodes > 2 * B  # random-weight policies drop the pole within a few dozen steps
+
+
+def test_cartpole_time_limit_truncation(oracle):
+    """TimeLimit 500 (gym registration of CartPole-v1; gym_env.py:452): with the step counters moved to 497 the third step
+    from there ends every surviving episode with done = 1 and the env resets to its Philox state."""
+    import ctypes as C
+    from helpers import philox_uniforms
+    from muzero_amd import planner as pl
+
+    net = build_mlp(mlp_case('cartpole'))
+    B, seed = 32, 9
+    init = np.zeros((B, 4))  # upright and centred: no env fails within the few steps played
+    p = _planner(net, B, seed=seed, num_simulations=50, discount=0.997)
+    p.selfplay_reset(pl.ENV_CARTPOLE, init)
+    p.selfplay_step(1.0, 2)
+    p.lib.mz_debug_set_env_steps.argtypes = [C.c_void_p, C.c_void_p]
+    steps = np.full(B, 497, np.int32)
+    assert p.lib.mz_debug_set_env_steps(p.h, steps.ctypes.data_as(C.c_void_p)) == 0
+    p.selfplay_step(1.0, 4)
+    rec = p.selfplay_read(6)
+    np.testing.assert_array_equal(rec['done'][:, :].astype(int), np.array([0, 0, 0, 0, 1, 0])[:, None] * np.ones((1, B), int))
+    for b in range(B):
+        fresh = (-0.05 + 0.1 * philox_uniforms(seed, b, 1, 0x40000000, 4)).astype(np.float32)
+        o = rec['obs'][5, b].reshape(4, 5)
+        np.testing.assert_array_equal(o[:, :4], np.tile(fresh, (4, 1)))
+        np.testing.assert_array_equal(o[:, 4], np.full(4, np.float32(0.5)))
 
 
 def test_run_self_play_counterpart_emits_reference_shaped_items():
