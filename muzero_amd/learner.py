@@ -28,34 +28,55 @@ from muzero_amd.replay import PrioritizedReplay, Transition
 # targets
 # ---------------------------------------------------------------------------------------------------------------
 def transform_to_2hot(scalar: torch.Tensor, min_value: float, max_value: float, num_bins: int) -> torch.Tensor:
-    """util.py:48-59: scalar -> two adjacent support bins holding its linear interpolation weights."""
-    scalar = torch.clamp(scalar, min_value, max_value)
-    scalar_bin = (scalar - min_value) / (max_value - min_value) * (num_bins - 1)
-    lower, upper = torch.floor(scalar_bin), torch.ceil(scalar_bin)
-    lower_value = (lower / (num_bins - 1.0)) * (max_value - min_value) + min_value
-    upper_value = (upper / (num_bins - 1.0)) * (max_value - min_value) + min_value
-    p_lower = (upper_value - scalar) / (upper_value - lower_value + 1e-5)
-    p_upper = 1 - p_lower
-    lower_one_hot = F.one_hot(lower.long(), num_bins) * torch.unsqueeze(p_lower, -1)
-    upper_one_hot = F.one_hot(upper.long(), num_bins) * torch.unsqueeze(p_upper, -1)
-    return lower_one_hot + upper_one_hot
+    """Scalar -> categorical over `num_bins` equally spaced support points in [min_value, max_value]: the two bins that
+    bracket the (clamped) scalar share the mass (semantics of util.py:48-59, including its 1e-5 in the interpolation
+    denominator, which the recorded reference projections pin).  Written as two scatter-adds into a zero tensor."""
+    span = max_value - min_value
+    z = scalar.clamp(min_value, max_value)
+    pos = (z - min_value) / span * (num_bins - 1)
+    below, above = pos.floor(), pos.ceil()
+
+    def support(i):
+        return i / (num_bins - 1.0) * span + min_value
+
+    w_below = (support(above) - z) / (support(above) - support(below) + 1e-5)
+    out = torch.zeros(*z.shape, num_bins, dtype=z.dtype, device=z.device)
+    out.scatter_add_(-1, below.long().unsqueeze(-1), w_below.unsqueeze(-1))
+    out.scatter_add_(-1, above.long().unsqueeze(-1), (1 - w_below).unsqueeze(-1))
+    return out
 
 
 def scalar_to_categorical_probabilities(x: torch.Tensor, support_size: int) -> torch.Tensor:
     """util.py:96-116: signed_hyperbolic, then projection onto the integer support [-(S-1)/2, (S-1)/2]."""
-    x = signed_hyperbolic(x)
-    max_value = (support_size - 1) // 2
-    return transform_to_2hot(x, -max_value, max_value, support_size)
+    half = (support_size - 1) // 2
+    return transform_to_2hot(signed_hyperbolic(x), -half, half, support_size)
 
 
 def loss_func(prediction: torch.Tensor, target: torch.Tensor, mse: bool = False) -> torch.Tensor:
-    """pipeline.py:615-629: per-sample MSE (scalar heads) or soft-target cross entropy (categorical heads, policy)."""
-    assert prediction.shape == target.shape
-    if not mse:
-        assert len(prediction.shape) == 2
+    """Per-sample loss of one head (pipeline.py:615-629): squared error for scalar heads, cross entropy against a SOFT
+    target distribution for categorical heads and the policy.  Works on [B, ...] and on stacked [B, K, ...] inputs."""
+    if prediction.shape != target.shape:
+        raise ValueError(f'prediction {tuple(prediction.shape)} and target {tuple(target.shape)} differ in shape')
     if mse:
-        return F.mse_loss(prediction, target, reduction='none')
-    return F.cross_entropy(prediction, target, reduction='none')
+        return (prediction - target) ** 2
+    return -(target * F.log_softmax(prediction, dim=-1)).sum(dim=-1)
+
+
+class _ScaleGradient(torch.autograd.Function):
+    """Identity in the forward pass; multiplies the incoming gradient by a constant in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        ctx.factor = factor
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad * ctx.factor, None
+
+
+def scale_gradient(x: torch.Tensor, factor: float) -> torch.Tensor:
+    return _ScaleGradient.apply(x, factor)
 
 
 def _as_tensor(x, device, dtype):
@@ -63,46 +84,54 @@ def _as_tensor(x, device, dtype):
     return t.to(device=device, dtype=dtype, non_blocking=True)
 
 
+def unroll(network: MuZeroNet, state: torch.Tensor, action: torch.Tensor):
+    """K-step unroll of the learned model from the root observation (pipeline.py:575-592): returns the stacked head
+    outputs policy logits [B, K, A], value [B, K, Sv], reward [B, K, Sr].  The gradient flowing back into each unrolled
+    hidden state is halved (pipeline.py:584)."""
+    pis, values, rewards = [], [], []
+    hidden = network.represent(state)
+    for k in range(action.shape[1]):
+        pi_logits, value = network.prediction(hidden)
+        hidden, reward = network.dynamics(hidden, action[:, k:k + 1])
+        hidden = scale_gradient(hidden, 0.5)
+        pis.append(pi_logits)
+        values.append(value)
+        rewards.append(reward)
+    return torch.stack(pis, dim=1), torch.stack(values, dim=1), torch.stack(rewards, dim=1)
+
+
 def calc_loss(network: MuZeroNet, device: torch.device, transitions: Transition, weights: torch.Tensor) -> Tuple[torch.Tensor, np.ndarray]:
-    """pipeline.py:541-612.  `transitions` fields may be numpy arrays (reference form) or tensors already on `device`
-    (`PrioritizedReplay.sample_tensors`)."""
-    state = _as_tensor(transitions.state, device, torch.float32)                   # [B, *state_shape]
-    action = _as_tensor(transitions.action, device, torch.long)                    # [B, T]
-    target_value_scalar = _as_tensor(transitions.value, device, torch.float32)     # [B, T]
-    target_reward_scalar = _as_tensor(transitions.reward, device, torch.float32)   # [B, T]
-    target_pi_prob = _as_tensor(transitions.pi_prob, device, torch.float32)        # [B, T, A]
+    """The MuZero loss of one batch and the new replay priorities (pipeline.py:541-612).  `transitions` fields may be numpy
+    arrays (reference form) or tensors already on `device` (`PrioritizedReplay.sample_tensors`).
 
-    target_value = target_value_scalar if network.mse_loss_for_value else scalar_to_categorical_probabilities(
-        target_value_scalar, network.value_support_size)
-    target_reward = target_reward_scalar if network.mse_loss_for_reward else scalar_to_categorical_probabilities(
-        target_reward_scalar, network.reward_support_size)
+    Structure: the scalar targets of all K unroll steps are projected onto their supports at once ([B, K, S]); the network
+    is unrolled once into stacked head outputs; each head's per-sample loss is summed over K.  The reported loss is the
+    importance-weighted batch mean of (reward + value + policy) -- summed, not averaged, over the K steps -- while its
+    GRADIENT is scaled by 1/K (pipeline.py:600).  Priorities are the step-0 value errors in scalar space (:609)."""
+    state = _as_tensor(transitions.state, device, torch.float32)           # [B, *state_shape]
+    action = _as_tensor(transitions.action, device, torch.long)            # [B, K]
+    value_scalar = _as_tensor(transitions.value, device, torch.float32)    # [B, K]
+    reward_scalar = _as_tensor(transitions.reward, device, torch.float32)  # [B, K]
+    pi_target = _as_tensor(transitions.pi_prob, device, torch.float32)     # [B, K, A]
+    K = action.shape[1]
+    mse_v, mse_r = network.mse_loss_for_value, network.mse_loss_for_reward
 
-    B, T = action.shape
-    reward_loss, value_loss, policy_loss = (0, 0, 0)
-    loss_scale = 1.0 / T
-    pred_values = []
-
-    hidden_state = network.represent(state)
-    for t in range(T):  # unroll K steps
-        pred_pi_logits, pred_value = network.prediction(hidden_state)
-        hidden_state, pred_reward = network.dynamics(hidden_state, action[:, t].unsqueeze(1))
-        hidden_state.register_hook(lambda grad: grad * 0.5)
-        value_loss += loss_func(pred_value.squeeze(), target_value[:, t], network.mse_loss_for_value)
-        reward_loss += loss_func(pred_reward.squeeze(), target_reward[:, t], network.mse_loss_for_reward)
-        policy_loss += loss_func(pred_pi_logits, target_pi_prob[:, t])
-        pred_values.append(pred_value.detach())
-
-    loss = reward_loss + value_loss + policy_loss
-    loss = torch.mean(loss * weights.detach())
-    loss.register_hook(lambda grad: grad * loss_scale)
+    pi_logits, value_out, reward_out = unroll(network, state, action)
+    value_target = value_scalar.unsqueeze(-1) if mse_v else scalar_to_categorical_probabilities(value_scalar, network.value_support_size)
+    reward_target = reward_scalar.unsqueeze(-1) if mse_r else scalar_to_categorical_probabilities(reward_scalar, network.reward_support_size)
+    v_loss = loss_func(value_out, value_target, mse_v)
+    r_loss = loss_func(reward_out, reward_target, mse_r)
+    if mse_v:
+        v_loss = v_loss.squeeze(-1)
+    if mse_r:
+        r_loss = r_loss.squeeze(-1)
+    per_sample = (r_loss + v_loss + loss_func(pi_logits, pi_target)).sum(dim=1)  # [B]
+    loss = scale_gradient((per_sample * weights.detach()).mean(), 1.0 / K)
 
     with torch.no_grad():
-        pred_values = torch.stack(pred_values, dim=1)
-        if network.mse_loss_for_value:
-            pred_values_scalar = pred_values.squeeze(-1)
-        else:
-            pred_values_scalar = logits_to_transformed_expected_value(pred_values, network.value_support_size).squeeze(-1)
-        priorities = (pred_values_scalar[:, 0] - target_value_scalar[:, 0]).abs().cpu().numpy()
+        v0 = value_out[:, 0]
+        v0_scalar = v0.squeeze(-1) if mse_v else logits_to_transformed_expected_value(v0, network.value_support_size).squeeze(-1)
+        priorities = (v0_scalar - value_scalar[:, 0]).abs().cpu().numpy()
     return loss, priorities
 
 
@@ -159,29 +188,70 @@ def train_step(config, network, optimizer, lr_scheduler, device, transitions, we
     return float(loss.detach()), priorities
 
 
+def _all_ranks(flag_any: bool, device) -> bool:
+    """True if `flag_any` is set on ANY learner rank (a tiny MAX all-reduce); the local value without a process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flag_any
+    dev = device if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([1.0 if flag_any else 0.0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def run_training(config, network, optimizer, lr_scheduler, device, actor_network, replay: PrioritizedReplay, data_queue, train_steps_counter,
                  checkpoint_dir: str, checkpoint_files: List, stop_event, tag: Optional[str] = None, stop_grace_seconds: float = 10.0) -> None:
-    """pipeline.py:170-286: the learner loop that paces the pipeline.  Same arguments; trackers/tensorboard are out of
-    scope.  With an initialised `torch.distributed` group every rank runs this loop on its own replay shard and the
-    gradients are averaged each step, so all ranks hold identical weights."""
+    """pipeline.py:170-286: the learner loop that paces the pipeline.  Same arguments; the reference's tensorboard trackers are
+    the JSON-lines metrics of `muzero_amd.metrics` (same tag names).
+
+    Data-parallel learners (an initialised `torch.distributed` group, one rank per GPU, each with its own replay shard):
+    the decisions that gate the gradient all-reduce are COLLECTIVE -- a step is taken only when every rank's replay is
+    warm, and all ranks stop together as soon as any rank sees `stop_event` or reaches `num_training_steps` -- so no rank
+    is left waiting in an all-reduce; rank 0 alone writes checkpoints (all ranks hold identical weights) and the other
+    ranks pass a barrier before anyone consumes the file."""
+    import torch.distributed as dist
+
     ckpt_prefix = 'train_steps' if not tag else f'{tag}_train_steps'
     network = network.to(device=device)
     network.train()
+    rank = _rank()
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     ckpt_dir = Path(checkpoint_dir) if checkpoint_dir else None
-    if ckpt_dir is not None and not ckpt_dir.exists():
+    if ckpt_dir is not None and rank == 0:
         ckpt_dir.mkdir(parents=True, exist_ok=True)
+    from muzero_amd import metrics as mzm
 
-    def get_state_to_save():
+    metrics = mzm.LearnerMetrics(mzm.run_file(config, 'learner', tag) if rank == 0 else None)
+
+    def snapshot():
         return {'network': network.state_dict(), 'optimizer': optimizer.state_dict(), 'lr_scheduler': lr_scheduler.state_dict(),
                 'train_steps': train_steps_counter.value}
 
+    def save(name):
+        if ckpt_dir is None:
+            return None
+        path = ckpt_dir / name
+        if rank == 0:
+            create_checkpoint(snapshot(), path)
+        if multi:
+            dist.barrier()  # nobody loads a checkpoint that rank 0 is still writing
+        return path
+
     while True:
-        if replay.size < config.min_replay_size or replay.size < config.batch_size:
+        cold = replay.size < config.min_replay_size or replay.size < config.batch_size
+        if _all_ranks(stop_event.is_set() and cold, device):
+            return  # stopped before training could start (pipeline.py:232-236), on every rank at once
+        if _all_ranks(cold, device):
             time.sleep(0.001)
-            if stop_event.is_set():
-                return
             continue
-        if train_steps_counter.value >= config.num_training_steps:
+        if _all_ranks(train_steps_counter.value >= config.num_training_steps, device):
             break
         transitions, indices, weights = replay.sample_tensors(config.batch_size)
         loss, priorities = train_step(config, network, optimizer, lr_scheduler, device, transitions, weights)
@@ -190,13 +260,15 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
                 raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {priorities.shape}')
             replay.update_priorities(indices, priorities)
         train_steps_counter.value += 1
+        metrics.step(loss, lr_scheduler.get_last_lr()[0], train_steps_counter.value)
         del transitions, indices, weights
         if train_steps_counter.value > 1 and train_steps_counter.value % config.checkpoint_interval == 0:
-            if ckpt_dir is not None:
-                ckpt_file = ckpt_dir / f'{ckpt_prefix}_{train_steps_counter.value}'
-                create_checkpoint(get_state_to_save(), ckpt_file)
-                checkpoint_files.append(ckpt_file)
-            actor_network.load_state_dict(network.state_dict())  # the planner reloads on the parameter-version bump
+            path = save(f'{ckpt_prefix}_{train_steps_counter.value}')
+            if path is not None:
+                checkpoint_files.append(path)
+            # actors in this process see the new tensors' versions; actors in other processes (shared-memory parameters)
+            # see train_steps_counter cross a checkpoint_interval boundary -- pipeline.run_self_play reloads on either
+            actor_network.load_state_dict(network.state_dict())
             actor_network.eval()
         if config.train_delay is not None and config.train_delay > 0 and train_steps_counter.value > 1:
             time.sleep(config.train_delay)
@@ -204,27 +276,24 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
     stop_event.set()
     time.sleep(stop_grace_seconds)
     data_queue.put('STOP')
-    if ckpt_dir is not None:
-        create_checkpoint(get_state_to_save(), ckpt_dir / f'{ckpt_prefix}_{train_steps_counter.value}_final')
+    save(f'{ckpt_prefix}_{train_steps_counter.value}_final')
+    metrics.close()
 
 
 def run_data_collector(data_queue, replay: PrioritizedReplay, save_frequency: int = 0, save_dir: Optional[str] = None, tag: Optional[str] = None) -> None:
-    """pipeline.py:491-538: moves `(Transition, priority)` items from the actors' queue into the replay until 'STOP'."""
-    prefix = 'replay' if not tag else f'{tag}_replay'
-    save_path = Path(save_dir) if save_dir else None
-    if save_path is not None and not save_path.exists():
+    """Drains the actors' queue into the replay until the 'STOP' sentinel arrives (the job of pipeline.py:491-538);
+    optionally snapshots the replay state every `save_frequency` additions."""
+    save_path = Path(save_dir) if save_dir and save_frequency > 0 else None
+    if save_path is not None:
         save_path.mkdir(parents=True, exist_ok=True)
-    should_save = save_path is not None and save_frequency > 0
+    stem = f'{tag}_replay' if tag else 'replay'
     while True:
         try:
             item = data_queue.get()
-            if isinstance(item, str) and item == 'STOP':
-                break
-            transition, priority = item
-            replay.add(transition, priority)
-            if should_save and replay.num_added > 1 and replay.num_added % save_frequency == 0:
-                torch.save(replay.get_state(), save_path / f'{prefix}_{replay.size}_{int(time.time())}')
-        except queue.Empty:
-            pass
-        except EOFError:
-            pass
+        except (queue.Empty, EOFError):
+            continue
+        if isinstance(item, str) and item == 'STOP':
+            return
+        replay.add(*item)
+        if save_path is not None and replay.num_added > 1 and replay.num_added % save_frequency == 0:
+            torch.save(replay.get_state(), save_path / f'{stem}_{replay.size}_{int(time.time())}')

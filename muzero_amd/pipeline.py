@@ -128,6 +128,15 @@ def aggregate_throughput(local_units: float, local_seconds: float):
     return float(units.item() / secs.item()), float(units.item()), float(secs.item())
 
 
+def weights_key(network, train_steps_counter, config):
+    """What an actor watches to know that the learner refreshed `network` (pipeline.py:261-267: every checkpoint_interval
+    train steps).  In one process the tensors' version counters change; in another process (the reference's layout:
+    shared-memory parameters, mp.Process actors) only the storage changes, so the shared train-step counter crossing a
+    checkpoint_interval boundary is the signal that travels."""
+    every = max(1, int(getattr(config, 'checkpoint_interval', 1) or 1))
+    return network._weights_version(), int(train_steps_counter.value) // every
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # self-play actor over the device-resident planner
 # ------------------------------------------------------------------------------------------------------------------
@@ -194,19 +203,26 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
     p.load_state_dict(network.state_dict())
     p.selfplay_reset(kinds[name])
     asm = EpisodeAssembler(config, num_envs, getattr(network, 'input_shape', None))
-    version = network._weights_version()
+    from muzero_amd import metrics as mzm
+
+    tracker = mzm.ActorMetrics(mzm.run_file(config, f'actor{rank}', tag), num_envs)  # trackers.py:74-80 tag names
+
+    version = weights_key(network, train_steps_counter, config)
     played = 0
     while not stop_event.is_set() and (max_moves is None or played < max_moves):
-        if network._weights_version() != version:  # learner pushed new weights (pipeline.py:266)
+        if weights_key(network, train_steps_counter, config) != version:  # learner pushed new weights (pipeline.py:266)
             p.load_state_dict(network.state_dict())
-            version = network._weights_version()
+            version = weights_key(network, train_steps_counter, config)
         n = moves_per_drain if max_moves is None else min(moves_per_drain, max_moves - played)
         # classic/atari schedules depend on train steps only; board games on the env's own step count (config.py:236-267)
         T = -1.0 if config.is_board_game else float(config.visit_softmax_temperature_fn(0, train_steps_counter.value))
         p.selfplay_step(T, n)
-        for item in asm.feed(p.selfplay_read(n)):
+        rec = p.selfplay_read(n)
+        tracker.moves(rec['reward'], rec['done'])
+        for item in asm.feed(rec):
             data_queue.put(item)
         played += n
+    tracker.close()
     return played * num_envs
 
 
@@ -225,6 +241,9 @@ def run_board_game_evaluator(config, old_checkpoint_network, new_ckpt_network, d
         for p in net.parameters():
             p.requires_grad = False
     black_elo = white_elo = initial_elo
+    from muzero_amd import metrics as mzm
+
+    tracker = mzm.EvaluatorMetrics(mzm.run_file(config, 'evaluator', tag))  # trackers.py:173-189 tag names
     while True:
         if stop_event.is_set() and len(checkpoint_files) == 0:
             break
@@ -249,9 +268,11 @@ def run_board_game_evaluator(config, old_checkpoint_network, new_ckpt_network, d
         elif env.winner == env.white_player_id:
             black_elo, _ = compute_elo_rating(1, black_elo, white_elo)
         white_elo = black_elo
+        tracker.board_game_step(black_elo, env.steps, train_steps)
         if on_result is not None:
             on_result(black_elo, env.steps, train_steps)
         old_checkpoint_network.load_state_dict(new_ckpt_network.state_dict())
+    tracker.close()
     return black_elo
 
 
@@ -265,6 +286,9 @@ def run_evaluator(config, new_ckpt_network, device, env, temperature, checkpoint
 
     for p in new_ckpt_network.parameters():
         p.requires_grad = False
+    from muzero_amd import metrics as mzm
+
+    tracker = mzm.EvaluatorMetrics(mzm.run_file(config, 'evaluator', tag))  # trackers.py:165-170 tag names
     results = []
     while True:
         if stop_event.is_set() and len(checkpoint_files) == 0:
@@ -290,8 +314,10 @@ def run_evaluator(config, new_ckpt_network, device, env, temperature, checkpoint
             eval_returns.append(returns)
             eval_steps.append(steps)
         results.append((eval_returns, eval_steps, train_steps))
+        tracker.step(eval_returns, eval_steps, train_steps)
         if on_result is not None:
             on_result(eval_returns, eval_steps, train_steps)
+    tracker.close()
     return results
 
 

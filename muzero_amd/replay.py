@@ -4,12 +4,20 @@ get_state / set_state`) over a structure-of-arrays ring buffer instead of a Pyth
 
 Storage is one preallocated tensor per `Transition` field (`state [cap, *shape]`, `action int8 [cap, K]`,
 `pi_prob f32 [cap, K, A]`, `value f32 [cap, K]`, `reward f32 [cap, K]`) on a torch device: with `device='cuda'` the
-ring lives in HBM and `sample_tensors` hands the learner device tensors without a host round trip (a 288 GB MI355X
-holds the reference's largest replay, 10^6 Atari transitions of 8x96x96 uint8-equivalent frames, many times over);
-with the default `device='cpu'` it is a drop-in for the reference class.  Sampling semantics are the reference's,
+ring lives in HBM, `sample_tensors` hands the learner device tensors without a host round trip, and the planner's
+device epilogue (`Planner.attach_replay`) writes finished transitions straight into it.  States are stored in the dtype
+of the first item unless `state_dtype` says otherwise: float32 Atari-sized states (8x96x96) cost 295 KB each, so 10^6 of
+them do NOT fit even 288 GB -- pass `state_dtype=torch.float16` / `torch.uint8` for image states (converted back to
+float32 in `sample_tensors`); the constructor-time size check refuses a ring that exceeds the free memory of its device
+instead of letting the process die.  With the default `device='cpu'` it is a drop-in for the reference class.
+
+Thread safety: the collector thread adds while the learner thread samples (pipeline.py:491-538 vs :238-255).  The
+reference swaps one tuple per slot atomically; here the five field writes of an add and the gather of a sample hold one
+lock, so a batch never contains a torn transition.  Sampling semantics are the reference's,
 draw for draw: uniform replay draws `random_state.uniform(0, size, batch).astype(int64)` (`replay.py:87-89`),
 prioritized replay draws from the process-global `np.random.choice` (`replay.py:90-98`; an upstream quirk kept on
 purpose) with importance weights `((1/size) / p_i)^beta / max`."""
+import threading
 from typing import Any, List, Mapping, NamedTuple, Optional, Sequence, Text, Tuple
 
 import numpy as np
@@ -35,7 +43,7 @@ class PrioritizedReplay:
     FIELDS = Transition._fields
 
     def __init__(self, capacity: int, priority_exponent: float, importance_sampling_exponent: float, random_state: np.random.RandomState,
-                 device='cpu'):
+                 device='cpu', state_dtype: Optional[torch.dtype] = None):
         if capacity <= 0:
             raise ValueError(f'Expect capacity to be a positive integer, got {capacity}')
         self.structure = TransitionStructure
@@ -44,7 +52,10 @@ class PrioritizedReplay:
         self._alpha, self._beta = priority_exponent, importance_sampling_exponent
         self._prio = np.zeros(self._cap, dtype=np.float32)
         self._dev = torch.device(device)
+        self._state_dtype = state_dtype
         self._ring = None  # field -> tensor [capacity, ...]; allocated on the first add, when the shapes are known
+        self._lock = threading.Lock()
+        self._attached = None  # device-side (priority, num_added) tensors while a planner epilogue writes into the ring
 
     # ---- storage ----
     @staticmethod
@@ -53,40 +64,98 @@ class PrioritizedReplay:
         if not np.isfinite(pr).all() or (pr < 0.0).any():
             raise ValueError('Priority must be finite and positive.')
 
+    def allocate(self, shapes: Mapping[Text, Tuple[int, ...]], dtypes: Optional[Mapping[Text, torch.dtype]] = None) -> None:
+        """Allocate the ring for per-item field shapes (done implicitly by the first add; explicitly before a planner
+        epilogue is attached).  Raises MemoryError if `capacity` items do not fit the free memory of the device."""
+        defaults = dict(state=torch.float32, action=torch.int8, pi_prob=torch.float32, value=torch.float32, reward=torch.float32)
+        defaults.update(dtypes or {})
+        if self._state_dtype is not None:
+            defaults['state'] = self._state_dtype
+        need = sum(int(np.prod(shapes[f], dtype=np.int64)) * torch.empty(0, dtype=defaults[f]).element_size() for f in self.FIELDS) * self._cap
+        if self._dev.type == 'cuda':
+            free = torch.cuda.mem_get_info(self._dev)[0]
+        else:
+            import psutil
+
+            free = psutil.virtual_memory().available
+        if need > 0.9 * free:
+            raise MemoryError(f'replay of {self._cap} items needs {need / 2**30:.1f} GiB on {self._dev} but only {free / 2**30:.1f} GiB are free: '
+                              f'lower the capacity or store states in a narrower dtype (state_dtype=torch.float16 / torch.uint8)')
+        self._ring = {f: torch.zeros((self._cap,) + tuple(shapes[f]), dtype=defaults[f], device=self._dev) for f in self.FIELDS}
+
     def _allocate(self, item: Transition) -> None:
-        self._ring = {}
-        for name, x in zip(self.FIELDS, item):
-            a = np.asarray(x)
-            self._ring[name] = torch.zeros((self._cap,) + a.shape, dtype=torch.from_numpy(np.zeros(1, a.dtype)).dtype, device=self._dev)
+        arrs = [np.asarray(x) for x in item]
+        self.allocate({f: a.shape for f, a in zip(self.FIELDS, arrs)},
+                      {f: torch.from_numpy(np.zeros(1, a.dtype)).dtype for f, a in zip(self.FIELDS, arrs)})
+
+    def _check_shapes(self, item_shapes) -> None:
+        for f, shp in zip(self.FIELDS, item_shapes):
+            if tuple(shp) != tuple(self._ring[f].shape[1:]):
+                raise ValueError(f'Transition.{f} has shape {tuple(shp)}, the replay holds {tuple(self._ring[f].shape[1:])}')
 
     def add(self, item: Transition, priority: float) -> None:
         """One item into the ring slot `num_added % capacity` (replay.py:67-75)."""
         self._check_priorities(priority)
-        if self._ring is None:
-            self._allocate(item)
-        slot = self._count % self._cap
-        for name, x in zip(self.FIELDS, item):
-            self._ring[name][slot] = torch.from_numpy(np.ascontiguousarray(x))
-        self._prio[slot] = priority
-        self._count += 1
+        with self._lock:
+            self._sync_attached()
+            if self._ring is None:
+                self._allocate(item)
+            arrs = [np.ascontiguousarray(x) for x in item]
+            self._check_shapes([a.shape for a in arrs])
+            slot = self._count % self._cap
+            for name, a in zip(self.FIELDS, arrs):
+                self._ring[name][slot] = torch.from_numpy(a).to(self._ring[name].dtype)
+            self._prio[slot] = priority
+            self._count += 1
+            self._push_attached()
 
     def add_batch(self, items: Transition, priorities: Sequence[float]) -> None:
         """n items at once (fields stacked on axis 0): the form the device-resident actor produces."""
         self._check_priorities(priorities)
         n = len(priorities)
-        if self._ring is None:
-            self._allocate(Transition(*[np.asarray(x)[0] for x in items]))
-        slots = (self._count + np.arange(n)) % self._cap
-        tslots = torch.from_numpy(slots).to(self._dev)
-        for name, x in zip(self.FIELDS, items):
-            x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
-            self._ring[name][tslots] = x.to(self._dev, dtype=self._ring[name].dtype)
-        self._prio[slots] = np.asarray(priorities, np.float32)
-        self._count += n
+        with self._lock:
+            self._sync_attached()
+            if self._ring is None:
+                self._allocate(Transition(*[np.asarray(x)[0] for x in items]))
+            self._check_shapes([tuple(x.shape[1:]) for x in items])
+            slots = (self._count + np.arange(n)) % self._cap
+            tslots = torch.from_numpy(slots).to(self._dev)
+            for name, x in zip(self.FIELDS, items):
+                x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
+                self._ring[name][tslots] = x.to(self._dev, dtype=self._ring[name].dtype)
+            self._prio[slots] = np.asarray(priorities, np.float32)
+            self._count += n
+            self._push_attached()
 
     def get(self, indices: Sequence[int]) -> List[Transition]:
         """Items by index (replay.py:77-79)."""
-        return [Transition(*[self._ring[f][int(i)].cpu().numpy() for f in self.FIELDS]) for i in indices]
+        with self._lock:
+            self._sync_attached()
+            return [Transition(*[self._ring[f][int(i)].cpu().numpy() for f in self.FIELDS]) for i in indices]
+
+    # ---- device epilogue (Planner.attach_replay): the planner writes items and priorities, this class only counts ----
+    def attach_device_writer(self):
+        """Tensors a device-side writer needs besides the ring: float32 priorities [capacity] and the uint64 `num_added`
+        counter, both on the replay's device.  Host-side bookkeeping is refreshed from them before every use."""
+        if self._ring is None:
+            raise RuntimeError('allocate() the ring before attaching a device writer')
+        if self._attached is None:
+            prio = torch.from_numpy(self._prio.copy()).to(self._dev)
+            count = torch.tensor([self._count], dtype=torch.int64, device=self._dev)
+            self._attached = (prio, count)
+        return self._attached
+
+    def _sync_attached(self) -> None:
+        if self._attached is not None:
+            prio, count = self._attached
+            self._count = int(count.item())
+            self._prio = prio.cpu().numpy()
+
+    def _push_attached(self) -> None:
+        if self._attached is not None:
+            prio, count = self._attached
+            prio.copy_(torch.from_numpy(self._prio))
+            count.fill_(self._count)
 
     # ---- sampling ----
     def _draw(self, batch_size: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -105,10 +174,19 @@ class PrioritizedReplay:
         return picks, is_w
 
     def sample_tensors(self, batch_size: int) -> Tuple[Transition, np.ndarray, np.ndarray]:
-        """Like `sample`, but the batch stays on the replay's device as torch tensors (no host copy)."""
-        picks, is_w = self._draw(batch_size)
-        tpicks = torch.from_numpy(picks).to(self._dev)
-        return Transition(*[self._ring[f].index_select(0, tpicks) for f in self.FIELDS]), picks, is_w
+        """Like `sample`, but the batch stays on the replay's device as torch tensors (no host copy).  States stored in a
+        narrow dtype come back as float32."""
+        with self._lock:
+            if self._attached is not None:
+                self._count = int(self._attached[1].item())
+                if self._alpha != 0:
+                    self._prio = self._attached[0].cpu().numpy()
+            picks, is_w = self._draw(batch_size)
+            tpicks = torch.from_numpy(picks).to(self._dev)
+            batch = [self._ring[f].index_select(0, tpicks) for f in self.FIELDS]
+        if batch[0].dtype != torch.float32 and self._state_dtype is not None:
+            batch[0] = batch[0].to(torch.float32)
+        return Transition(*batch), picks, is_w
 
     def sample(self, batch_size: int) -> Tuple[Transition, np.ndarray, np.ndarray]:
         """A batch with replacement (replay.py:81-104): numpy arrays stacked on axis 0, the indices, the IS weights."""
@@ -120,18 +198,29 @@ class PrioritizedReplay:
         pr = np.asarray(priorities)
         if not np.isfinite(pr).all() or (pr < 0.0).any():
             raise ValueError('Priorities must be finite and positive.')
-        for i, v in zip(indices, pr):
-            self._prio[i] = v
+        with self._lock:
+            self._sync_attached()
+            for i, v in zip(indices, pr):
+                self._prio[i] = v
+            self._push_attached()
 
     # ---- bookkeeping (replay.py:115-142) ----
-    num_added = property(lambda self: self._count, doc='items added since construction / reset')
-    size = property(lambda self: min(self._count, self._cap), doc='items currently held')
+    def _live_count(self) -> int:
+        if self._attached is not None:
+            self._count = int(self._attached[1].item())
+        return self._count
+
+    num_added = property(lambda self: self._live_count(), doc='items added since construction / reset')
+    size = property(lambda self: min(self._live_count(), self._cap), doc='items currently held')
     capacity = property(lambda self: self._cap, doc='ring size')
 
     def reset(self) -> None:
-        self._count = 0
+        with self._lock:
+            self._count = 0
+            self._push_attached()
 
     def get_state(self) -> Mapping[Text, Any]:
+        self._sync_attached()
         ring = None if self._ring is None else {k: v.cpu() for k, v in self._ring.items()}
         return {'num_added': self._count, 'storage': ring, 'priorities': self._prio}
 

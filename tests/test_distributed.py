@@ -124,3 +124,126 @@ def test_learner_gradient_allreduce_world2():
         assert p.exitcode == 0
     res = out.get()
     assert res['differ_local'] and res['ok_mean'] and res['same']
+
+
+def _actor_side(actor, counter, ready, go, out):
+    """Runs in a SPAWNED process, like the reference's actors (classic/run_training.py:168-186): watches the shared network."""
+    sys.path.insert(0, REPO)
+    import types
+
+    from muzero_amd import pipeline
+
+    cfg = types.SimpleNamespace(checkpoint_interval=5)
+    k0 = pipeline.weights_key(actor, counter, cfg)
+    w0 = float(next(actor.parameters()).flatten()[0])
+    ready.set()
+    go.wait(60)
+    k1 = pipeline.weights_key(actor, counter, cfg)
+    w1 = float(next(actor.parameters()).flatten()[0])
+    out.put((k0 != k1, w0, w1))
+
+
+def test_weight_refresh_signal_crosses_processes():
+    """tensor._version does not cross processes.  An actor in another process must still notice that the learner
+    loaded new weights into the shared-memory actor network: the train-step counter crossing a checkpoint_interval
+    boundary is part of the key run_self_play watches, and the shared storage then holds the new values."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch
+
+    from helpers import build_mlp, mlp_case
+
+    ctx = mp.get_context('spawn')
+    actor = build_mlp(mlp_case('tiny'))
+    actor.share_memory()
+    counter = ctx.Value('i', 3)
+    ready, go, out = ctx.Event(), ctx.Event(), ctx.SimpleQueue()
+    proc = ctx.Process(target=_actor_side, args=(actor, counter, ready, go, out))
+    proc.start()
+    assert ready.wait(120)
+    new = {k: v + 1.0 if v.dtype.is_floating_point else v for k, v in actor.state_dict().items()}
+    actor.load_state_dict(new)  # what run_training does at a checkpoint (in place: the shared storage changes)
+    counter.value = 5
+    go.set()
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    changed, w0, w1 = out.get()
+    assert changed and abs((w1 - w0) - 1.0) < 1e-6
+
+
+def _train_worker(rank, world, port, out, tmp):
+    """run_training on two learner ranks whose replay shards warm up at different times and of which only one sees the stop
+    event: all decisions around the gradient all-reduce are collective, nobody hangs, rank 0 alone writes checkpoints."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import queue
+    import threading
+    import time
+    import types
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import learner
+    from muzero_amd.config import make_tictactoe_config
+    from muzero_amd.replay import PrioritizedReplay, Transition
+
+    torch.set_num_threads(1)
+    net, actor = build_mlp(mlp_case('tiny_mse')), build_mlp(mlp_case('tiny_mse'))
+    net.train()
+    cfg = make_tictactoe_config(num_training_steps=1000, batch_size=4, min_replay_size=8, use_tensorboard=False)
+    cfg.checkpoint_interval, cfg.train_delay = 3, 0.0
+    rs = np.random.RandomState(rank)
+    rp = PrioritizedReplay(64, 0.0, 0.0, np.random.RandomState(1 + rank))
+
+    def fill():
+        if rank == 1:
+            time.sleep(1.0)  # this shard warms up later: rank 0 must wait for it instead of entering the all-reduce alone
+        for _ in range(12):
+            rp.add(Transition(rs.uniform(-1, 1, (2, 2, 2)).astype(np.float32), rs.randint(0, 5, 5).astype(np.int8),
+                              rs.dirichlet(np.ones(5), 5).astype(np.float32), rs.uniform(-1, 1, 5).astype(np.float32),
+                              rs.uniform(-1, 1, 5).astype(np.float32)), 1.0)
+
+    threading.Thread(target=fill).start()
+    stop = threading.Event()
+    counter = types.SimpleNamespace(value=0)
+
+    class StopAfter:  # only rank 1 ever raises the stop flag, after 7 of its own steps
+        def is_set(self):
+            return stop.is_set() or (rank == 1 and counter.value >= 7)
+
+        def set(self):
+            stop.set()
+
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.1)
+    files = []
+    # a stop raised mid-run ends the loop only through num_training_steps in the reference; here rank 1 lowers its own limit
+    if rank == 1:
+        cfg.num_training_steps = 7
+    learner.run_training(cfg, net, opt, sched, torch.device('cpu'), actor, rp, queue.Queue(), counter, tmp, files, StopAfter(), stop_grace_seconds=0.0)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    both = [None] * world
+    dist.all_gather_object(both, (flat, counter.value, sorted(os.listdir(tmp))))
+    if rank == 0:
+        out.put(dict(same=bool(np.array_equal(both[0][0], both[1][0])), steps=(both[0][1], both[1][1]), files=both[0][2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_training_world2_is_collective(tmp_path):
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, out, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    res = out.get()
+    assert res['same'] and res['steps'] == (7, 7)  # both ranks stopped together when rank 1 reached its limit
+    assert res['files'] == ['train_steps_3', 'train_steps_6', 'train_steps_7_final']  # written once, by rank 0
