@@ -259,6 +259,33 @@ def sustained_leg(p, T, ms_per_move_hint, flop_per_launch, seconds=2.0):
             'frac': ach / PEAK_FP32_MFMA_TFLOPS}
 
 
+def e2e_leg(p, pl, env_kind, T, obs_shape, classic_cfg, moves=300):
+    """Env steps that END UP IN THE REPLAY as (Transition, priority) items: the planner with the device epilogue attached
+    (n-step / MC targets, priorities, K-step unroll windows written into an HBM replay ring on the GPU, pipeline.py:118-165 +
+    replay.py:67-75), this GPU only.  Warm-up runs past the first mid-episode flush (acc_seq_length + unroll + td moves)."""
+    import torch
+    from muzero_amd.replay import PrioritizedReplay
+
+    rp = PrioritizedReplay(1 << 20, 0.0, 0.0, np.random.RandomState(0), device='cuda')
+    p.attach_replay(rp, classic_cfg, obs_shape=obs_shape)
+    p.selfplay_reset(env_kind)
+    warm = 0 if classic_cfg.is_board_game else classic_cfg.acc_seq_length + classic_cfg.unroll_steps + classic_cfg.td_steps + 5
+    p.selfplay_step(T, max(warm, 20))
+    p.synchronize()
+    n0 = rp.num_added
+    t0 = time.perf_counter()
+    p.selfplay_step(T, moves)
+    p.synchronize()
+    dt = time.perf_counter() - t0
+    n1 = rp.num_added
+    p.detach_replay()
+    del rp
+    torch.cuda.empty_cache()
+    return {'moves': moves, 'seconds': dt, 'env_steps_per_sec': p.B * moves / dt, 'items_into_replay_per_sec': (n1 - n0) / dt,
+            'items_added': int(n1 - n0), 'what': 'device epilogue attached: targets, priorities and unroll windows built on the GPU and written '
+                                                 'into an HBM replay ring; the host only reads the counter'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -270,6 +297,7 @@ def main():
                     help='c2 (default, the headline line): CartPole MLP; c3: TicTacToe MLP; c4 / c5: the conv-tower configs of BASELINE.json (extra measurements)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 2 s sustained leg')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the env-steps-into-replay leg')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -342,6 +370,14 @@ def main():
     counters = p.selfplay_counters()
     flop_per_launch = B * (S * FLOP_PER_SIM + FLOP_PER_ROOT)
     sustained = None if args.no_sustained else sustained_leg(p, 1.0, 1e3 * elapsed / args.steps, flop_per_launch)
+    e2e = None
+    if not args.no_e2e:
+        import types
+
+        # the reference's classic-control settings (config.py:170-201): acc_seq_length 200, unroll 5, td_steps 10
+        e2e = e2e_leg(p, pl, pl.ENV_CARTPOLE, 1.0, (4, 5),
+                      types.SimpleNamespace(is_board_game=False, acc_seq_length=200, unroll_steps=5, td_steps=10, discount=0.997))
+        e2e['fraction_of_planner_rate'] = e2e['env_steps_per_sec'] / (B * args.steps / elapsed)
 
     if rank == 0:
         total_sims = world * B * S * args.steps
@@ -383,6 +419,7 @@ def main():
                 'flop_per_sim': FLOP_PER_SIM, 'timed_with': 'hipEvent pairs on the planner stream',
             },
             'sustained': sustained,
+            'e2e': e2e,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, sample_envs=B)

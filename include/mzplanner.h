@@ -129,6 +129,28 @@ int mz_selfplay_read(mz_planner* p, int32_t n_moves, float* h_obs, int32_t* h_ac
 /* counters since reset: [0] env steps, [1] simulations, [2] finished episodes, [3] sum of finished episode lengths */
 int mz_selfplay_counters(mz_planner* p, int64_t out[4]);
 
+/* Device epilogue of run_self_play: what the reference does per episode on the host -- compute_n_step_target /
+ * compute_mc_return_target (pipeline.py:632-707), priorities (:129,156), make_unroll_sequence (:710-767), including the
+ * mid-episode flush every acc_seq_length steps (:118-142), then data_queue.put -> PrioritizedReplay.add (replay.py:67-75)
+ * -- done on the GPU after every lock-step move, written straight into a caller-owned replay ring in device memory.
+ * All pointers are DEVICE pointers (e.g. the storages of muzero_amd.replay.PrioritizedReplay(device='cuda')); the caller
+ * keeps them alive while attached.  Items of one environment appear in step order; environments interleave (the
+ * reference's actors are independent processes).  Call BEFORE mz_selfplay_reset (the record ring is sized to hold an open
+ * trajectory); ring == NULL detaches.  mz_selfplay_read then returns at most the moves the record ring holds. */
+typedef struct {
+    int64_t capacity;     /* ring slots; slot of the i-th item ever added = i % capacity */
+    float* state;         /* [capacity, obs_c*obs_h*obs_w] */
+    int8_t* action;       /* [capacity, unroll_steps] (num_actions <= 128) */
+    float* pi_prob;       /* [capacity, unroll_steps, num_actions] */
+    float* value;         /* [capacity, unroll_steps] */
+    float* reward;        /* [capacity, unroll_steps] */
+    float* priority;      /* [capacity] */
+    int64_t* num_added;   /* one counter, incremented atomically by the device */
+    int32_t* origin;      /* optional [capacity]: index of the environment that produced the item, or NULL */
+    int32_t acc_seq_length, unroll_steps, td_steps;  /* MuZeroConfig fields (config.py:58-94) */
+} mz_replay_ring;
+int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ring);
+
 /* Measurement hooks (bench.py): HIP-event timing on the planner's own stream.
  * mz_profile_begin/end bracket a region; mz_profile_end returns elapsed milliseconds and the number of
  * search-kernel launches inside it (the dominant kernel of the path). */

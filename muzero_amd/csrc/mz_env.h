@@ -40,6 +40,7 @@ struct EnvState {
     int* r_player;         // [ring][B]
     unsigned char* r_done; // [ring][B]
     unsigned long long* counters;  // env steps, simulations, finished episodes, sum of finished episode lengths
+    long long* ep_start;   // [B] absolute move index of the first step of the env's open trajectory (device epilogue)
 };
 
 struct EnvLaunch {
@@ -62,7 +63,7 @@ struct EnvLaunch {
 
 inline void env_free(EnvState& e) {
     void* bufs[] = {e.cp_state, e.steps, e.episode, e.init_state, e.board, e.planes, e.player, e.r_obs, e.r_action,
-                    e.r_reward, e.r_pi, e.r_root, e.r_player, e.r_done, e.counters};
+                    e.r_reward, e.r_pi, e.r_root, e.r_player, e.r_done, e.counters, e.ep_start};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     e = EnvState{};
@@ -91,6 +92,7 @@ inline hipError_t env_alloc(EnvState& e, int kind, int B, int A, int D, int ring
     MZ_ALLOC(e.r_player, (size_t)ring_len * B * sizeof(int));
     MZ_ALLOC(e.r_done, (size_t)ring_len * B);
     MZ_ALLOC(e.counters, 4 * sizeof(unsigned long long));
+    MZ_ALLOC(e.ep_start, (size_t)B * sizeof(long long));
 #undef MZ_ALLOC
     return hipSuccess;
 }
@@ -307,6 +309,110 @@ __device__ inline void env_step_one(const EnvLaunch& L, int e) {
 __global__ void k_env_step(const EnvLaunch L) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < L.B) env_step_one(L, e);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device epilogue of run_self_play (pipeline.py:118-165): the record ring is each env's open trajectory; after every
+// lock-step move one wave per env checks the two conditions of the reference's loop body, in its order --
+//   (1) not a board game and the open trajectory holds acc_seq_length + unroll_steps + td_steps steps: its first
+//       acc_seq_length steps become items, with n-step targets computed over the whole open trajectory (:118-142);
+//   (2) the episode ended: every remaining step becomes an item (:144-165), Monte-Carlo returns for board games (:676-707)
+// -- and writes the items (state, K-step action / reward / value / policy windows with the absorbing padding of
+// make_unroll_sequence :710-767, priority |root value - target| :129,156) straight into the HBM replay ring
+// (replay.py:67-75: slot = num_added % capacity).  The host only reads the counter.  Arithmetic is the reference's:
+// float64 left-to-right sums with host-computed discount ** i, rounded to float32 where the reference's np.array(...,
+// dtype=np.float32) does.
+// ---------------------------------------------------------------------------------------------------------
+struct ReplayRing {
+    long long capacity;
+    float* state;         // [capacity][D]
+    signed char* action;  // [capacity][K]
+    float* pi_prob;       // [capacity][K][A]
+    float* value;         // [capacity][K]
+    float* reward;        // [capacity][K]
+    float* priority;      // [capacity]
+    long long* num_added; // device counter
+    int* origin;          // optional [capacity]: env that produced the item (tests), or null
+    int acc, K, td, board;
+    double pw[34];        // discount ** i, i = 0..td (host libm pow == Python float pow)
+};
+
+struct EpiLaunch {
+    EnvState env;
+    ReplayRing ring;
+    int B;
+    long long move_abs;   // absolute index (since mz_selfplay_reset) of the move that has just been recorded
+};
+
+// z[t], t in [0, T): target value of every step of the open trajectory (compute_n_step_target :632-673 /
+// compute_mc_return_target :676-707); rec(i) = record index of trajectory position i
+__device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int T, int n, double* z, int lane) {
+    const EnvState& V = E.env;
+    const ReplayRing& R = E.ring;
+    const int B = E.B, A = V.A, D = V.D, K = R.K;
+    auto rec = [&](int i) { return (size_t)((start + i) % V.ring_len) * B + e; };
+    if (R.board) {
+        const double fr = (double)V.r_reward[rec(T - 1)];
+        const int fp = V.r_player[rec(T - 1)];
+        for (int t = lane; t < T; t += 64) z[t] = fr != 0.0 ? (V.r_player[rec(t)] == fp ? fr : -fr) : 0.0;
+    } else {
+        for (int t = lane; t < T; t += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < R.td; i++) acc = acc + R.pw[i] * (t + i < T ? (double)V.r_reward[rec(t + i)] : 0.0);
+            z[t] = acc + R.pw[R.td] * (t + R.td < T ? V.r_root[rec(t + R.td)] : 0.0);
+        }
+    }
+    __syncthreads();
+    __shared__ long long base_s;
+    if (lane == 0) base_s = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(R.num_added), (unsigned long long)n);
+    __syncthreads();
+    const long long base = base_s;
+    // the n items are written with the wave's lanes spread over (item, element) pairs: a flush emits acc_seq_length items at once
+    for (int j = lane; j < n * D; j += 64) {
+        const int t = j / D, i = j - t * D;
+        R.state[(size_t)((base + t) % R.capacity) * D + i] = V.r_obs[rec(t) * D + i];
+    }
+    for (int j = lane; j < n * K; j += 64) {
+        const int t = j / K, k = j - t * K, idx = t + k;
+        const size_t o = (size_t)((base + t) % R.capacity) * K + k;
+        const bool real = idx < T;  // past the end: absorbing step (action 0, reward 0, value 0, uniform policy)
+        R.action[o] = real ? (signed char)V.r_action[rec(idx)] : (signed char)0;
+        R.reward[o] = real ? V.r_reward[rec(idx)] : 0.0f;
+        R.value[o] = real ? (float)z[idx] : 0.0f;
+    }
+    for (int j = lane; j < n * K * A; j += 64) {
+        const int t = j / (K * A), r = j - t * K * A, k = r / A, a = r - k * A, idx = t + k;
+        R.pi_prob[((size_t)((base + t) % R.capacity) * K + k) * A + a] = idx < T ? (float)V.r_pi[rec(idx) * A + a] : (float)(1.0 / (double)A);
+    }
+    for (int t = lane; t < n; t += 64) {
+        const size_t slot = (size_t)((base + t) % R.capacity);
+        const double d = V.r_root[rec(t)] - z[t];
+        R.priority[slot] = (float)(d < 0.0 ? -d : d);
+        if (R.origin) R.origin[slot] = e;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_epilogue(const EpiLaunch E) {
+    extern __shared__ double z[];  // [ring_len]
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const EnvState& V = E.env;
+    const ReplayRing& R = E.ring;
+    long long start = V.ep_start[e];
+    int len = (int)(E.move_abs + 1 - start);
+    const bool done = V.r_done[(size_t)(E.move_abs % V.ring_len) * E.B + e] != 0;
+    const bool flush = !R.board && len == R.acc + R.K + R.td;
+    if (!flush && !done) return;
+    if (flush) {
+        epi_emit(E, e, start, len, R.acc, z, lane);
+        start += R.acc;
+        len -= R.acc;
+    }
+    if (done) {
+        epi_emit(E, e, start, len, len, z, lane);
+        start = E.move_abs + 1;
+    }
+    if (lane == 0) V.ep_start[e] = start;
 }
 
 }  // namespace mz

@@ -113,6 +113,9 @@ struct mz_planner {
     int env_kind = MZ_ENV_NONE;
     unsigned int move_counter = 0;
     int ring_len = 0, ring_pos = 0, ring_count = 0;
+    bool has_replay = false;
+    ReplayRing replay{};
+    long long selfplay_moves = 0;  // moves since mz_selfplay_reset
 
     // profiling
     bool profiling = false;
@@ -822,6 +825,12 @@ extern "C" int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* 
     }
     p->env_kind = env_kind;
     p->ring_len = (size_t)c.num_envs * obs_dim(c) * sizeof(float) * 64 > ((size_t)4 << 30) ? 16 : 64;  // record ring: at most a few GB
+    if (p->has_replay) {
+        // the record ring is every env's open trajectory: a whole board game, or the acc + unroll + td window (pipeline.py:118-121)
+        const int need = c.is_board_game ? c.num_actions + 1 : p->replay.acc + p->replay.K + p->replay.td;
+        if (need > p->ring_len) p->ring_len = (need + 7) & ~7;
+    }
+    p->selfplay_moves = 0;
     p->ring_pos = 0;
     p->ring_count = 0;
     hipError_t e = env_alloc(p->env, env_kind, c.num_envs, c.num_actions, obs_dim(c), p->ring_len, board_n, num_to_win);
@@ -844,6 +853,14 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
     if (!p->committed) return fail(MZ_E_STATE, "weights not committed");
     HIPCHK(hipSetDevice(p->device));
     const mz_config& c = p->cfg;
+    auto epilogue = [&]() {
+        if (p->has_replay) {
+            EpiLaunch E{};
+            E.env = p->env; E.ring = p->replay; E.B = c.num_envs; E.move_abs = p->selfplay_moves;
+            hipLaunchKernelGGL(k_epilogue, dim3(c.num_envs), dim3(64), (size_t)p->ring_len * sizeof(double), p->stream, E);
+        }
+        p->selfplay_moves++;
+    };
     for (int m = 0; m < n_moves; m++) {
         EnvLaunch L{};
         L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.temperature = temperature; L.move_counter = p->move_counter;
@@ -853,6 +870,7 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
             // MLP nets: the whole move -- temperature / record, search, env.step, auto-reset -- is ONE kernel launch
             int rc = launch_search(p, c.num_envs, 0, true, false, false, &L);
             if (rc) return rc;
+            epilogue();
             p->ring_pos = (p->ring_pos + 1) % p->ring_len;
             if (p->ring_count < p->ring_len) p->ring_count++;
             continue;
@@ -866,10 +884,33 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
         hipLaunchKernelGGL(k_env_step, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
         if (p->env_kind == MZ_ENV_SYNTHETIC)
             hipLaunchKernelGGL(k_env_synth_obs, dim3(((size_t)c.num_envs * ((obs_dim(c) + 3) / 4) + 255) / 256), dim3(256), 0, p->stream, L);
+        epilogue();
         HIPCHK(hipGetLastError());
         p->ring_pos = (p->ring_pos + 1) % p->ring_len;
         if (p->ring_count < p->ring_len) p->ring_count++;
     }
+    return MZ_OK;
+}
+
+extern "C" int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ring) {
+    if (!p) return fail(MZ_E_INVALID, "null planner");
+    if (!ring) {
+        p->has_replay = false;
+        return MZ_OK;
+    }
+    const mz_config& c = p->cfg;
+    if (ring->capacity < 1 || !ring->state || !ring->action || !ring->pi_prob || !ring->value || !ring->reward || !ring->priority || !ring->num_added)
+        return fail(MZ_E_INVALID, "mz_replay_ring: capacity and every array but `origin` are required");
+    if (ring->unroll_steps < 1 || ring->td_steps < 0 || ring->td_steps > 32 || ring->acc_seq_length < 1)
+        return fail(MZ_E_INVALID, "mz_replay_ring: unroll_steps >= 1, 0 <= td_steps <= 32, acc_seq_length >= 1");
+    if (c.num_actions > 128) return fail(MZ_E_INVALID, "device epilogue stores int8 actions: num_actions <= 128");
+    ReplayRing& R = p->replay;
+    R.capacity = ring->capacity; R.state = ring->state; R.action = reinterpret_cast<signed char*>(ring->action); R.pi_prob = ring->pi_prob;
+    R.value = ring->value; R.reward = ring->reward; R.priority = ring->priority; R.num_added = reinterpret_cast<long long*>(ring->num_added);
+    R.origin = ring->origin; R.acc = ring->acc_seq_length; R.K = ring->unroll_steps; R.td = ring->td_steps; R.board = c.is_board_game;
+    for (int i = 0; i <= R.td; i++) R.pw[i] = std::pow(c.discount, (double)i);  // Python's discount ** i (pipeline.py:663-666)
+    p->has_replay = true;
+    p->env_kind = MZ_ENV_NONE;  // the record ring must be re-sized: mz_selfplay_reset next
     return MZ_OK;
 }
 

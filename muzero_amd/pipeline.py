@@ -189,8 +189,12 @@ class EpisodeAssembler:
 def run_self_play(config, rank, network, device, env, data_queue, train_steps_counter, stop_event, tag: str = None,
                   moves_per_drain: int = 16, max_moves: Optional[int] = None) -> int:
     """Self-play until `stop_event` is set (pipeline.py:41-167).  `env` names a device environment ('CartPole-v1',
-    'TicTacToe', 'Gomoku', or 'Synthetic-Atari': random frames standing in for the absent emulator); `config.num_envs` of them advance in lock-step on GPU `device`.  Items put on `data_queue` are the
-    reference's `(Transition, priority)` tuples.  Returns the number of env steps played."""
+    'TicTacToe', 'Gomoku', or 'Synthetic-Atari': random frames standing in for the absent emulator); `config.num_envs` of
+    them advance in lock-step on GPU `device`.  `data_queue` is either a queue -- items put on it are the reference's
+    `(Transition, priority)` tuples, assembled on the host from the device records -- or a
+    `muzero_amd.replay.PrioritizedReplay(device='cuda')`: then the planner's DEVICE EPILOGUE builds the items on the GPU and
+    writes them straight into that replay (no host assembly, no queue, no data collector thread); only rewards and done
+    flags are read back for the episode statistics.  Returns the number of env steps played."""
     from muzero_amd import planner as pl
 
     kinds = {'CartPole-v1': pl.ENV_CARTPOLE, 'TicTacToe': pl.ENV_TICTACTOE, 'Gomoku': pl.ENV_GOMOKU, 'Synthetic-Atari': pl.ENV_SYNTHETIC}
@@ -201,6 +205,11 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
     idx = device.index if getattr(device, 'index', None) is not None else 0
     p = pl.Planner(pl.make_mz_config(network.planner_spec(), config, num_envs=num_envs, seed=int(getattr(config, 'planner_seed', 1)) + 7919 * rank), idx)
     p.load_state_dict(network.state_dict())
+    from muzero_amd.replay import PrioritizedReplay
+
+    on_device = isinstance(data_queue, PrioritizedReplay)
+    if on_device:
+        p.attach_replay(data_queue, config, obs_shape=getattr(network, 'input_shape', None))
     p.selfplay_reset(kinds[name])
     asm = EpisodeAssembler(config, num_envs, getattr(network, 'input_shape', None))
     from muzero_amd import metrics as mzm
@@ -217,10 +226,14 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
         # classic/atari schedules depend on train steps only; board games on the env's own step count (config.py:236-267)
         T = -1.0 if config.is_board_game else float(config.visit_softmax_temperature_fn(0, train_steps_counter.value))
         p.selfplay_step(T, n)
-        rec = p.selfplay_read(n)
-        tracker.moves(rec['reward'], rec['done'])
-        for item in asm.feed(rec):
-            data_queue.put(item)
+        if on_device:
+            rec = p.selfplay_read(n, fields=('reward', 'done'))
+            tracker.moves(rec['reward'], rec['done'])
+        else:
+            rec = p.selfplay_read(n)
+            tracker.moves(rec['reward'], rec['done'])
+            for item in asm.feed(rec):
+                data_queue.put(item)
         played += n
     tracker.close()
     return played * num_envs

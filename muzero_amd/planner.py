@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     'mz_last_error', 'mz_version', 'mz_planner_create', 'mz_planner_destroy', 'mz_planner_set_param', 'mz_planner_commit_params',
     'mz_planner_initial_inference', 'mz_planner_recurrent_inference', 'mz_planner_hidden_size', 'mz_planner_search',
     'mz_planner_search_scripted', 'mz_selfplay_reset', 'mz_selfplay_step', 'mz_selfplay_read', 'mz_selfplay_counters',
+    'mz_selfplay_attach_replay',
     'mz_profile_begin', 'mz_profile_end', 'mz_planner_synchronize',
 ]
 
@@ -41,6 +42,12 @@ class MzConfig(C.Structure):
 
 class MzRngInputs(C.Structure):
     _fields_ = [('h_noise', C.c_void_p), ('h_u_tie', C.c_void_p), ('h_u_final', C.c_void_p)]
+
+
+class MzReplayRing(C.Structure):
+    _fields_ = [('capacity', C.c_int64), ('state', C.c_void_p), ('action', C.c_void_p), ('pi_prob', C.c_void_p), ('value', C.c_void_p),
+                ('reward', C.c_void_p), ('priority', C.c_void_p), ('num_added', C.c_void_p), ('origin', C.c_void_p),
+                ('acc_seq_length', C.c_int32), ('unroll_steps', C.c_int32), ('td_steps', C.c_int32)]
 
 
 _lib = None
@@ -74,6 +81,7 @@ def load_library():
     L.mz_selfplay_step.argtypes = [vp, C.c_double, i32]
     L.mz_selfplay_read.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.mz_selfplay_counters.argtypes = [vp, i64p]
+    L.mz_selfplay_attach_replay.argtypes = [vp, C.POINTER(MzReplayRing)]
     L.mz_profile_begin.argtypes = [vp]
     L.mz_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.mz_planner_synchronize.argtypes = [vp]
@@ -237,16 +245,50 @@ class Planner:
     def selfplay_step(self, temperature=1.0, n_moves=1):
         _chk(self.lib.mz_selfplay_step(self.h, float(temperature), int(n_moves)))
 
-    def selfplay_read(self, n_moves):
+    def selfplay_read(self, n_moves, fields=None):
+        """Records of the last `n_moves` moves, arrays [n_moves, B, ...].  `fields`: subset of ('obs', 'action', 'reward', 'pi',
+        'root_value', 'player', 'done') to copy out (default all): with the device epilogue attached a host loop only needs
+        rewards and done flags for its episode statistics."""
         B, A, D = self.B, self.A, self.obs_dim
-        out = dict(
-            obs=np.empty((n_moves, B, D), np.float32), action=np.empty((n_moves, B), np.int32), reward=np.empty((n_moves, B), np.float32),
-            pi=np.empty((n_moves, B, A), np.float64), root_value=np.empty((n_moves, B), np.float64), player=np.empty((n_moves, B), np.int32),
-            done=np.empty((n_moves, B), np.uint8),
-        )
-        _chk(self.lib.mz_selfplay_read(self.h, n_moves, _p(out['obs']), _p(out['action']), _p(out['reward']), _p(out['pi']),
-                                       _p(out['root_value']), _p(out['player']), _p(out['done'])))
+        spec = dict(obs=((n_moves, B, D), np.float32), action=((n_moves, B), np.int32), reward=((n_moves, B), np.float32),
+                    pi=((n_moves, B, A), np.float64), root_value=((n_moves, B), np.float64), player=((n_moves, B), np.int32),
+                    done=((n_moves, B), np.uint8))
+        want = set(spec) if fields is None else set(fields)
+        out = {k: np.empty(shp, dt) for k, (shp, dt) in spec.items() if k in want}
+        ptr = [(_p(out[k]) if k in out else None) for k in ('obs', 'action', 'reward', 'pi', 'root_value', 'player', 'done')]
+        _chk(self.lib.mz_selfplay_read(self.h, n_moves, *ptr))
         return out
+
+    def attach_replay(self, replay, config, obs_shape=None, with_origin=False):
+        """Device epilogue (mz_selfplay_attach_replay): finished trajectories become (Transition, priority) items in `replay`
+        -- a `muzero_amd.replay.PrioritizedReplay(device='cuda')` -- on the GPU, with the reference's target / unroll-window
+        arithmetic (pipeline.py:118-165, 632-767); the host only reads `replay.num_added`.  `config` supplies acc_seq_length,
+        unroll_steps, td_steps.  Call before `selfplay_reset`.  `with_origin`: also record which env produced each item
+        (returned tensor; tests)."""
+        import torch
+
+        K, A = int(config.unroll_steps), self.A
+        shp = tuple(obs_shape) if obs_shape is not None else (self.obs_dim,)
+        if replay._ring is None:
+            replay.allocate(dict(state=shp, action=(K,), pi_prob=(K, A), value=(K,), reward=(K,)))
+        ring = replay._ring
+        if ring['state'].device.type != 'cuda' or ring['state'].dtype != torch.float32 or ring['action'].dtype != torch.int8:
+            raise PlannerError('attach_replay needs a replay on the GPU with float32 states and int8 actions')
+        if int(np.prod(ring['state'].shape[1:])) != self.obs_dim or tuple(ring['pi_prob'].shape[1:]) != (K, A):
+            raise PlannerError('replay item shapes do not match the planner (observation size, unroll_steps, num_actions)')
+        prio, count = replay.attach_device_writer()
+        origin = torch.full((replay.capacity,), -1, dtype=torch.int32, device=ring['state'].device) if with_origin else None
+        r = MzReplayRing(replay.capacity, ring['state'].data_ptr(), ring['action'].data_ptr(), ring['pi_prob'].data_ptr(), ring['value'].data_ptr(),
+                         ring['reward'].data_ptr(), prio.data_ptr(), count.data_ptr(), origin.data_ptr() if with_origin else None,
+                         int(config.acc_seq_length), K, int(config.td_steps))
+        torch.cuda.synchronize()
+        _chk(self.lib.mz_selfplay_attach_replay(self.h, C.byref(r)))
+        self._replay_keepalive = (replay, prio, count, origin)
+        return origin
+
+    def detach_replay(self):
+        _chk(self.lib.mz_selfplay_attach_replay(self.h, None))
+        self._replay_keepalive = None
 
     def selfplay_counters(self):
         c = (C.c_int64 * 4)()

@@ -1,0 +1,116 @@
+"""Device epilogue (mz_selfplay_attach_replay): the items the GPU writes into the HBM replay ring vs the host
+EpisodeAssembler (itself pinned to the reference's run_self_play by selfplay_cases.npz / classic_cases.npz) fed with the
+very same records.  Exact: states, K-step windows, float32 targets, priorities -- Monte-Carlo returns (board game), n-step
+returns with the mid-episode flush (classic control), and a replay ring that wraps."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_mlp, mlp_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(game, B, moves, chunk, cfg, capacity, seed=5):
+    from muzero_amd import planner as pl
+    from muzero_amd.pipeline import EpisodeAssembler
+    from muzero_amd.replay import PrioritizedReplay
+
+    board = game == 'tictactoe'
+    net = build_mlp(mlp_case(game))
+    kw = dict(num_simulations=8, discount=cfg.discount, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=seed, **kw), 0)
+    p.load_state_dict(net.state_dict())
+    rp = PrioritizedReplay(capacity, 0.0, 0.0, np.random.RandomState(0), device='cuda')
+    origin = p.attach_replay(rp, cfg, obs_shape=mlp_case(game)[1], with_origin=True)
+    p.selfplay_reset(pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE)
+    asm = [EpisodeAssembler(cfg, 1, mlp_case(game)[1]) for _ in range(B)]
+    host = [[] for _ in range(B)]
+    for lo in range(0, moves, chunk):
+        p.selfplay_step(-1.0 if board else 1.0, chunk)
+        rec = p.selfplay_read(chunk)
+        for b in range(B):
+            host[b].extend(asm[b].feed({k: v[:, b:b + 1] for k, v in rec.items()}))
+    n = rp.num_added
+    assert n == sum(len(h) for h in host) and n > 0
+    return p, rp, origin.cpu().numpy(), host, n
+
+
+def _compare(rp, origin, host, n):
+    cap = rp.capacity
+    ring = {k: v.cpu().numpy() for k, v in rp._ring.items()}
+    prio = rp._attached[0].cpu().numpy()
+    # the last `cap` items are still in the ring; walk them in insertion order and match each env's tail
+    first = max(0, n - cap)
+    seen = {b: 0 for b in range(len(host))}
+    # items of env b before `first` were overwritten: count them by replaying the global order is impossible on the host, so
+    # match from the END: the k-th last item of env b in the ring is the k-th last item of host[b]
+    per_env = {}
+    for i in range(first, n):
+        per_env.setdefault(int(origin[i % cap]), []).append(i % cap)
+    checked = 0
+    for b, slots in per_env.items():
+        items = host[b][len(host[b]) - len(slots):] if n > cap else host[b]
+        assert len(items) == len(slots)
+        for s, (tr, pr) in zip(slots, items):
+            np.testing.assert_array_equal(ring['state'][s], np.asarray(tr.state, np.float32))
+            np.testing.assert_array_equal(ring['action'][s], tr.action)
+            np.testing.assert_array_equal(ring['reward'][s], tr.reward)
+            np.testing.assert_array_equal(ring['value'][s], tr.value)
+            np.testing.assert_array_equal(ring['pi_prob'][s], tr.pi_prob)
+            assert prio[s] == np.float32(pr)
+            checked += 1
+    return checked
+
+
+def test_board_game_items_match_host_assembler():
+    cfg = types.SimpleNamespace(is_board_game=True, acc_seq_length=200, unroll_steps=5, td_steps=0, discount=1.0)
+    p, rp, origin, host, n = _run('tictactoe', 64, 40, 8, cfg, capacity=8192)
+    assert _compare(rp, origin, host, n) == n
+    vals = rp._ring['value'].cpu().numpy()[:n]
+    assert set(np.unique(vals)).issubset({-1.0, 0.0, 1.0})  # Monte-Carlo returns (pipeline.py:676-707)
+    p.close()
+
+
+def test_classic_items_with_mid_episode_flush_match_host_assembler():
+    cfg = types.SimpleNamespace(is_board_game=False, acc_seq_length=6, unroll_steps=5, td_steps=3, discount=0.997)
+    p, rp, origin, host, n = _run('cartpole', 48, 96, 16, cfg, capacity=8192)
+    assert _compare(rp, origin, host, n) == n
+    p.close()
+
+
+def test_replay_ring_wraps_and_learner_can_sample():
+    """capacity < items: slot = num_added % capacity (replay.py:67-75); sampling the attached replay works while it fills."""
+    cfg = types.SimpleNamespace(is_board_game=False, acc_seq_length=10, unroll_steps=5, td_steps=10, discount=0.997)
+    p, rp, origin, host, n = _run('cartpole', 32, 120, 24, cfg, capacity=512)
+    assert n > 512 and rp.size == 512
+    assert _compare(rp, origin, host, n) == 512
+    batch, idx, w = rp.sample_tensors(64)
+    assert batch.state.shape == (64, 4, 5) and batch.state.is_cuda and batch.pi_prob.shape == (64, 5, 2)
+    np.testing.assert_allclose(batch.pi_prob.sum(-1).cpu().numpy(), 1.0, atol=1e-6)
+    p.close()
+
+
+def test_run_self_play_writes_into_a_device_replay():
+    """pipeline.run_self_play with a PrioritizedReplay(device='cuda') in place of the queue: items arrive through the device
+    epilogue, the host assembles nothing."""
+    import queue
+
+    from muzero_amd import pipeline
+    from muzero_amd.config import make_tictactoe_config
+    from muzero_amd.replay import PrioritizedReplay
+
+    net = build_mlp(mlp_case('tictactoe'))
+    cfg = make_tictactoe_config(use_tensorboard=False)
+    cfg.num_envs = 64
+    rp = PrioritizedReplay(4096, 0.0, 0.0, np.random.RandomState(0), device='cuda')
+    stop = types.SimpleNamespace(is_set=lambda: False)
+    steps = pipeline.run_self_play(cfg, 0, net, torch.device('cuda', 0), 'TicTacToe', rp, types.SimpleNamespace(value=0), stop, max_moves=32)
+    assert steps == 32 * 64
+    n = rp.num_added
+    assert 64 * 20 < n <= steps  # every finished episode's steps, nothing from the games still open
+    batch, _, _ = rp.sample_tensors(32)
+    assert batch.state.shape == (32, 9, 3, 3) and batch.action.dtype == torch.int8 and batch.pi_prob.shape == (32, 5, 10)
+    assert set(np.unique(batch.value.cpu().numpy())).issubset({-1.0, 0.0, 1.0})
