@@ -187,6 +187,8 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
     if rank == 0:
         sims_per_s = world * B * S * args.steps / elapsed
         ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
+        dom_kernel = {'c3': 'mz::k_search_fast<256, 1, 1, true>', 'c4': 'mz::k_res_tower<5>', 'c5': 'mz::k_conv3x3<15, 1, true>'}[name]
+        traffic, traffic_src = profiled_traffic(name, dom_kernel.replace('mz::', '')) if (B == envs and S == sims) else (None, None)
         achieved = flop_per_move / (ms * 1e-3) / 1e12
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -200,8 +202,9 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
                                    f'{B} envs per MI355X, {env_kind} device env, ' + ('LDS-resident trees' if name == 'c3' else 'HBM-resident trees'),
                        'envs_per_gpu': B, 'sims_per_move': S, 'parallelism': f'env-sharded x{world}', 'weights': 'seeded random init'},
             'env_steps_per_sec': sims_per_s / S,
-            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<256>' if name == 'c3' else 'mz::k_conv3x3<NPT,NCT,WHOLE> (conv towers; whole per-move kernel sequence timed)', 'achieved': achieved,
-                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+            'roofline': {'bound': 'mfma', 'kernel': dom_kernel + ('' if name == 'c3' else ' (dominant kernel; the whole per-move kernel sequence is timed)'), 'achieved': achieved,
+                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'bytes of HBM per launch of the dominant kernel', 'traffic_source': traffic_src,
                          'avg_move_ms': ms, 'flop_per_move': flop_per_move, 'flop_per_sim': f_sim,
                          'timed_with': 'hipEvent pairs on the planner stream around each move\'s kernel sequence'},
             'sustained': sustained,
@@ -209,6 +212,22 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def profiled_traffic(workload, kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this very command
+    (profiles/round2/<workload>/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the run, so this is the profiled
+    figure for the default workload sizes, or None."""
+    path = os.path.join(REPO, 'profiles', 'round2', workload, 'pmc_summary.json')
+    try:
+        pm = json.load(open(path))['pmc']
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for name, e in pm.items():
+        if kernel_substr in name and '_hbm_bytes_per_launch' in e:
+            return e['_hbm_bytes_per_launch']['total'], f'profiles/round2/{workload}/pmc_summary.json ({name}; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)'
+    return None, None
 
 
 def launch_ranks(args, argv):
@@ -386,11 +405,7 @@ def main():
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this very
         # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the profiled workload.
-        traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, 'profiles', 'round1', 'pmc_counters.json')
-        if os.path.exists(pmc) and B == 4096 and S == 50:
-            traffic = json.load(open(pmc))['_hbm_bytes_per_launch']['total']
-            traffic_src = 'profiles/round1/pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)'
+        traffic, traffic_src = (profiled_traffic('c2', 'k_search_fast<512') if (B == 4096 and S == 50) else (None, None))
         out = {
             'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)',
             'value': sims_per_s,
@@ -412,7 +427,7 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,2,2,false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes of HBM per launch', 'traffic_source': traffic_src,
                 'algorithmic_hbm_bytes_per_launch': B * (S * 2 * 64 * 4 + 20 * 4 + 64 * 4 + 2 * 8 + 16),
                 'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,

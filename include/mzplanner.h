@@ -123,7 +123,10 @@ int mz_planner_search_scripted(mz_planner* p, int32_t batch, const float* h_pi0,
  * temperature < 0: the board game's own per-env schedule by episode step (config.py:236-249). */
 int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* h_init_state);
 int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_moves);
-/* Copy out the records of the last `n_moves` moves (newest last): arrays [n_moves, B, ...]; any pointer may be NULL. */
+/* Copy out the records of the last `n_moves` moves (newest last): arrays [n_moves, B, ...]; any pointer may be NULL.
+ * The records live in a ring of R moves (R = 64; 16 when one move of observations exceeds 64 MiB; at least an open
+ * trajectory when a replay is attached): mz_selfplay_step may play more than R moves between reads -- older records are
+ * overwritten -- and mz_selfplay_read returns MZ_E_INVALID when asked for more moves than the ring holds. */
 int mz_selfplay_read(mz_planner* p, int32_t n_moves, float* h_obs, int32_t* h_action, float* h_reward, double* h_pi,
                      double* h_root_value, int32_t* h_player, uint8_t* h_done);
 /* counters since reset: [0] env steps, [1] simulations, [2] finished episodes, [3] sum of finished episode lengths */

@@ -240,6 +240,9 @@ static void compute_layout_conv(mz_planner* p, SearchParams* target = nullptr) {
     }
 }
 
+static int planner_init(mz_planner* p, bool conv);
+extern "C" int mz_planner_destroy(mz_planner* p);
+
 extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner** out) {
     if (!cfg || !out) return fail(MZ_E_INVALID, "null argument");
     const bool conv = cfg->net_kind == MZ_NET_BOARD || cfg->net_kind == MZ_NET_ATARI;
@@ -264,6 +267,18 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
     mz_planner* p = new mz_planner();
     p->cfg = *cfg;
     p->device = device_id;
+    const int rc = planner_init(p, conv);  // every failure past this point releases what was allocated so far
+    if (rc) {
+        (void)mz_planner_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return MZ_OK;
+}
+
+static int planner_init(mz_planner* p, bool conv) {
+    const mz_config* cfg = &p->cfg;
+    const int device_id = p->device;
     {
         const char* fg = getenv("MZ_FORCE_GENERIC");
         p->force_generic = fg && fg[0] == '1';
@@ -292,7 +307,6 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         if (p->hbm_tree) {
             if (p->ip.lds_bytes > 160 * 1024) {
                 const int need = p->ip.lds_bytes;
-                delete p;
                 return fail(MZ_E_INVALID, "network needs " + std::to_string(need) + " bytes of LDS per workgroup (> 160 KiB)");
             }
             compute_layout_conv(p, &p->spg);
@@ -355,7 +369,6 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         for (size_t i = 0; i < B; i++) roots[i] = p->d_hidden + i * (S + 1) * HS;
         HIPCHK(hipMemcpy(p->d_rootptrs, roots.data(), B * sizeof(float*), hipMemcpyHostToDevice));
         if (conv) {
-            *out = p;
             return MZ_OK;
         }
     }
@@ -379,7 +392,6 @@ extern "C" int mz_planner_create(const mz_config* cfg, int device_id, mz_planner
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
-    *out = p;
     return MZ_OK;
 }
 

@@ -3,6 +3,8 @@ conv kernels + HBM-resident tree kernels, called through the C ABI, against
   (1) the CPU oracle on the same seeded inputs -- bit-exact (every conv output is one float32 fmaf chain in the order
       16-channel block -> tap -> channel on both sides), and
   (2) the golden fixtures recorded from the reference implementation (tolerances of tests/test_oracle_nets.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -232,11 +234,17 @@ def test_full_size_conv_search_properties(name):
     assert len({tuple(x) for x in v[:B // 2]}) > 1  # different roots search differently
 
 
-@pytest.mark.parametrize('name,S,envs', [('c4', 50, (1, 4)), ('c5', 16, (3,))])
+_SPOT = [('c4', 50, (1, 4)), ('c5', 64, (3,))]
+if os.environ.get('MZ_SLOW_TESTS') == '1':  # the whole 200-simulation Gomoku move of C5 (several minutes of one host core)
+    _SPOT.append(('c5', 200, (3,)))
+
+
+@pytest.mark.parametrize('name,S,envs', _SPOT)
 def test_full_size_spot_check_vs_oracle(oracle, name, S, envs):
     """Envs of the full-size nets (C4: Atari net, 128 planes, 8 blocks, 96x96 frames, all 50 simulations; C5: Gomoku 15x15
-    net, A = 226, the first 16 of its 200 simulations -- the scalar oracle needs ~1 s per simulation there) inside a ragged
-    batch, bit-exact against the oracle: the deepest towers and widest trees the path has."""
+    net, A = 226, the first 64 of its 200 simulations by default -- the scalar oracle needs ~1 s per simulation there -- and
+    all 200 with MZ_SLOW_TESTS=1) inside a ragged batch, bit-exact against the oracle: the deepest towers and widest trees
+    the path has."""
     case, _, _, kw = FULL[name]
     net = build_conv(case)
     onet = _oracle_net(oracle, net, 'conv')

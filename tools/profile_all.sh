@@ -5,6 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
+python3 -m muzero_amd.build > /dev/null  # never inside the profiled process (the .so normally travels with the snapshot)
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, trace args, pmc args
   local W=$1 TARGS=$2 PARGS=$3
@@ -22,9 +23,10 @@ run() {  # name, trace args, pmc args
 }
 for W in "$@"; do
   case $W in
-    c2) run c2 "--steps 10 --warmup 2 --no-cpu-baseline" "--steps 4 --warmup 1 --no-cpu-baseline" ;;
-    c4) run c4 "--workload c4 --steps 1 --warmup 0" "--workload c4 --steps 1 --warmup 0 --sims 3" ;;
-    c5) run c5 "--workload c5 --steps 1 --warmup 0" "--workload c5 --steps 1 --warmup 0 --sims 2" ;;
+    c2) run c2 "--steps 10 --warmup 2 --no-cpu-baseline --no-sustained --no-e2e" "--steps 4 --warmup 1 --no-cpu-baseline --no-sustained --no-e2e" ;;
+    c3) run c3 "--workload c3 --steps 10 --warmup 2 --no-cpu-baseline --no-sustained" "--workload c3 --steps 4 --warmup 1 --no-cpu-baseline --no-sustained" ;;
+    c4) run c4 "--workload c4 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c4 --steps 1 --warmup 0 --sims 3 --no-cpu-baseline --no-sustained" ;;
+    c5) run c5 "--workload c5 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c5 --steps 1 --warmup 0 --sims 2 --no-cpu-baseline --no-sustained" ;;
   esac
 done
 ls -R $OUT | head -50
