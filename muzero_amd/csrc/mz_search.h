@@ -105,9 +105,22 @@ __device__ long long g_sub[8];  // sub-phase cycle sums written by thread 0 of b
 #define MZ_SUB_DECL long long _s0 = 0;
 #define MZ_SUB_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _s0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_SUB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _s1 = __builtin_readcyclecounter(); g_sub[i] += _s1 - _s0; _s0 = _s1; } } while (0)  // [0] levels visited, [1] cache hits, [2] descents, [3] version bumps, [4] max-depth sum per wave-descent
-#define MZ_SUBX_START() long long _x0 = 0; do { if (blockIdx.x == 0 && threadIdx.x == 0) _x0 = __builtin_readcyclecounter(); } while (0)
-#define MZ_SUBX(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _x1 = __builtin_readcyclecounter(); g_sub[i] += _x1 - _x0; _x0 = _x1; } } while (0)
-#define MZ_SUBX_COUNT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sub[i] += 1; } while (0)
+// fine-grained segment stamps of the tree functions (block 0, wave 0): cycles and event counts accumulate in REGISTERS
+// and reach memory once per call (a global read-modify-write per event costs more than the segments it would time)
+__device__ long long g_ts[32];
+__device__ __forceinline__ long long ts_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return (long long)t;
+}
+#define MZ_TS_DECL long long _ts0 = 0; long long _tsa[12] = {0}; const bool _tson = blockIdx.x == 0 && threadIdx.x < 64;
+#define MZ_TS_START() do { if (_tson) _ts0 = ts_now(); } while (0)
+#define MZ_TS(i) do { if (_tson) { const long long _n = ts_now(); _tsa[i] += _n - _ts0; _ts0 = _n; } } while (0)
+#define MZ_TS_COUNT(i) do { if (_tson) _tsa[i] += 1; } while (0)
+#define MZ_TS_FLUSH(base) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int _i = 0; _i < 12; _i++) g_ts[(base) + _i] += _tsa[_i]; } while (0)
+#define MZ_SUBX_START() do {} while (0)
+#define MZ_SUBX(i) do {} while (0)
+#define MZ_SUBX_COUNT(i) do {} while (0)
 #define MZ_STAMP_DECL long long _t0 = 0; long long _acc[16] = {0};
 #define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); _acc[i] += _t1 - _t0; _t0 = _t1; } } while (0)
@@ -120,6 +133,11 @@ __device__ long long g_sub[8];  // sub-phase cycle sums written by thread 0 of b
 #define MZ_SUBX_START() do {} while (0)
 #define MZ_SUBX(i) do {} while (0)
 #define MZ_SUBX_COUNT(i) do {} while (0)
+#define MZ_TS_DECL
+#define MZ_TS_START() do {} while (0)
+#define MZ_TS(i) do {} while (0)
+#define MZ_TS_COUNT(i) do {} while (0)
+#define MZ_TS_FLUSH(base) do {} while (0)
 #define MZ_STAMP_DECL
 #define MZ_STAMP_START() do {} while (0)
 #define MZ_STAMP(i) do {} while (0)
@@ -470,10 +488,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     if (a0 == 0 && env_ok) root_prior(smem, P, e, env_g);
     __syncthreads();
 
-    int mypath = 0, resume = 0;
+    int resume = 0;
+    const int cp0 = env_ok ? P.cur[env_g] : 0, op0 = env_ok ? P.opp[env_g] : 0;  // the root's players: read once per move, not per descent
     for (int s = 0; s < P.S; s++) {
         int lp_unused, la_unused;
-        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused, mypath, resume);
+        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused, cp0, op0, resume);
         else tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
         __syncthreads();
         const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
@@ -500,7 +519,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
             r32 = lds[P.o.OUT + e * 4 + 0];
             v32 = lds[P.o.OUT + e * 4 + 1];
         }
-        if (P.tree_mode == 2) resume = tree2_backup(smem, P, tid, env_ok, s, r32, v32, mypath);
+        if (P.tree_mode == 2) resume = tree2_backup(smem, P, tid, env_ok, s, r32, v32);
         else if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
         __syncthreads();
     }

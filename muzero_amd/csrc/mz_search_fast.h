@@ -322,10 +322,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     __syncthreads();
     MZ_STAMP(0);  // root: tables + initial inference + prior
 
-    int mypath = 0, resume = 0;
+    int resume = 0;
+    const int cp0 = env_ok ? Pm.cur[env_g] : 0, op0 = env_ok ? Pm.opp[env_g] : 0;  // the root's players: read once per move, not per descent
     for (int s = 0; s < Pm.S; s++) {
         int lp, la;
-        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, mypath, resume);
+        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, cp0, op0, resume);
         else tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 val = row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            if (Pm.tree_mode == 2) resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val, mypath);
+            if (Pm.tree_mode == 2) resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val);
             else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
         if (Pm.tree_mode != 2) __syncthreads();  // mode 2: backup and the next select of an env run on the same 16 lanes

@@ -20,8 +20,14 @@
 //     < margin.  Otherwise (or if the cached evaluation saw a real tie, whose np.random.choice draw must be consumed at
 //     visit time, mcts.py:124) the level is evaluated at visit time exactly as the reference does.  The cache is a pure
 //     shortcut: it never changes a result.
-//   * a DESCENT is therefore mostly a chain of single 16-byte cache reads; the visited nodes are kept in registers
-//     (lane d of the env's segment holds the node at depth d).
+//   * a DESCENT is therefore mostly a chain of single 8-byte cache reads, software-pipelined: the next level's entry is
+//     requested before the loop's exit test resolves (measured on gfx950 with one wave per SIMD, tools/micro/chase.hip:
+//     a bare dependent ds_read_b64 chain costs 69 cycles per level, the first version of this loop -- lane predicates
+//     bouncing between VALU compares and SALU mask logic, two branches -- 305, this form 180).  A segment that has
+//     found its leaf parks on a SENTINEL node (index NN, margin -inf) instead of carrying a `done` predicate; the path
+//     (node per depth) is written to the env's LDS path row unconditionally -- re-writing a slot with the same node
+//     is harmless -- so no lane bookkeeping depends on predicates.  A normalisation switch-on (the only event that
+//     invalidates every cached choice at once) resets all margins of the env to -inf: no epoch test per level.
 //   * RESUMED DESCENTS: a backup refreshes the cache of every node on its path, so it knows how far the NEXT descent
 //     will retrace that path: down to the first node whose refreshed choice is not "unique, valid, and the next path
 //     node".  The next select starts there (the nodes above are already in the lanes' path registers) instead of at
@@ -101,7 +107,7 @@ __device__ __forceinline__ Entry2* entry2_row(unsigned char* smem, const SearchP
     return reinterpret_cast<Entry2*>(smem + P.t2_entries) + (size_t)(e * P.NN + i) * P.A;
 }
 __device__ __forceinline__ SelCache* cache_at(unsigned char* smem, const SearchParams& P, int e, int i) {
-    return reinterpret_cast<SelCache*>(smem + P.t_cache) + (e * P.NN + i);
+    return reinterpret_cast<SelCache*>(smem + P.t_cache) + (e * (P.NN + 1) + i);  // slot NN of every env: the sentinel
 }
 __device__ __forceinline__ short* path_row(unsigned char* smem, const SearchParams& P, int e) {
     return reinterpret_cast<short*>(smem + P.t_path) + e * (P.NN + 3);
@@ -116,7 +122,7 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     // written by the backup that creates it
     for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].U = 0.0f; en[i].cn = 0; en[i].c = -1; }
     SelCache* c = reinterpret_cast<SelCache*>(smem + P.t_cache);
-    for (int i = tid; i < TILE_E * P.NN; i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); }  // t = -inf: never a hit
+    for (int i = tid; i < TILE_E * (P.NN + 1); i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); }  // t = -inf: never a hit
     if (tid < TILE_E) {
         EnvCacheState* st = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + tid;
         st->drift = 0.0; st->epoch = 0;
@@ -137,14 +143,14 @@ __device__ __forceinline__ float puct_entry(const Entry2& en, double mn, double 
 }
 
 // One descent (mcts.py:372-379).  Results segment-uniform.  All 64 lanes of every wave must call it.
-// `mypath`: lane d of the segment receives the node visited at depth d (d < 16; deeper levels go to the LDS path row).
-// Two alternating phases: (A) a tight pointer chase along valid cache entries -- one 8-byte LDS read, two compares and a
-// few selects per level; (B) when no segment of the wave can advance by its cache, one full evaluation of the current
-// level for the segments that are not done (best_child, mcts.py:104-127).
-// `resume` (from the previous tree2_backup; 0 for the first descent): node to start at | its depth << 16; `mypath` must
-// then still hold the previous descent's path registers.
+// The nodes visited at depths 0 .. k-1 end up in the env's LDS path row (path[d] = node at depth d).
+// Two alternating phases: (A) the pointer chase along decided cache entries; (B) when no segment of the wave can
+// advance by its cache, one full evaluation of the current level for the segments that have not found their leaf
+// (best_child, mcts.py:104-127).
+// `resume` (from the previous tree2_backup; 0 for the first descent): node to start at | its depth << 16 -- the path row
+// still holds the nodes above it.  `cp0` / `op0`: the env's current / opponent player at the root.
 __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
-                                             int& leaf_action, int& mypath, int resume = 0) {
+                                             int& leaf_action, int cp0, int op0, int resume = 0) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
     const double* mm = reinterpret_cast<const double*>(smem + P.t_mm) + e * 2;
     int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
@@ -152,52 +158,51 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     const SelCache* cb = cache_at(smem, P, e, 0);
     const EnvCacheState st = reinterpret_cast<const EnvCacheState*>(smem + P.t_ver)[e];
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
-    const int ep = st.epoch & 0xff;
     const double mn = mm[0], mx = mm[1];
     const bool norm = mx > mn, lane_ok = a0 < P.A;
-    int n = resume & 0xffff, ties = sel[3];
-    bool done = !env_ok;
+    const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
+    int n = env_ok ? (resume & 0xffff) : SENT, ties = sel[3];
     int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
     MZ_SUB_DECL
     MZ_SUB_START();
-    // The loop bodies are written as selects, not branches: a wave that runs alone on its SIMD pays for every scalar
-    // branch on a lane predicate (s_and_saveexec / s_cbranch_execz) far more than for the few VALU selects.
-    while (__any(!done)) {
-        // ---- phase A: chase cached best children ----
-        MZ_SUBX_START();
+    MZ_TS_DECL
+    MZ_TS_START();
+    for (;;) {
+        // ---- phase A: chase cached best children (software-pipelined: see the header) ----
+        MZ_TS(0);  // [0] prelude / between phases
+        SelCache cc = cb[n];
         for (;;) {
-            MZ_SUBX_COUNT(5);
-            const SelCache cc = cb[n];
-            const bool adv = !done & (((cc.packed >> 8) & 0xff) == ep) & (thr < cc.t);
-            if (a0 == 0 && !done) { MZ_COUNT(0, 1); MZ_COUNT(1, adv ? 1 : 0); }
-            if (!__any(adv)) break;
-            if (__any(adv & (k >= 16))) {  // deep paths (rare): positions past the 16 path registers go to the LDS path row
-                if (adv && k >= 16 && a0 == 0) path[k] = (short)n;
-            }
-            mypath = (adv & (a0 == k)) ? n : mypath;
-            const int c = cc.packed >> 16, k1 = k + 1;
-            const bool stop = adv & ((c < 0) | (k1 > P.NN));
+            MZ_TS_COUNT(1);  // [1] phase-A iterations
+            const bool adv = thr < cc.t;
+            const int c = cc.packed >> 16;
+            const bool stop = adv & (c < 0);
+            const int nxt = adv ? (c < 0 ? SENT : c) : n;
+            const SelCache nc = cb[nxt];
+            if (a0 == 0) path[k] = (short)n;  // node at depth k (parked segments re-write their spare slot)
             lp = stop ? n : lp;
             la = stop ? (cc.packed & 0xff) : la;
-            n = (adv & !stop) ? c : n;
-            k = adv ? k1 : k;
-            done |= stop;
+            k += adv ? 1 : 0;
+            if (__builtin_amdgcn_ballot_w64(adv) == 0) break;
+            n = nxt;
+            cc = nc;
         }
-        MZ_SUBX(4);
-        if (!__any(!done)) break;
-        MZ_SUBX_COUNT(7);
-        // ---- phase B: every segment that is not done sits on a level its cache cannot decide: evaluate it ----
+        MZ_TS(2);  // [2] phase-A cycles
+        if (__builtin_amdgcn_ballot_w64(n != SENT) == 0) break;
+        MZ_TS_COUNT(3);  // [3] phase-B rounds
+        // ---- phase B: every segment that is not parked sits on a level its cache cannot decide: evaluate it ----
         {
-            const Entry2 en = entry2_row(smem, P, e, n)[lane_ok ? a0 : 0];
+            const bool live = n != SENT;
+            const Entry2 en = entry2_row(smem, P, e, live ? n : 0)[lane_ok ? a0 : 0];
             const float u = lane_ok ? puct_entry(en, mn, mx, st.rinv, norm) : __uint_as_float(0xff800000u);
+            MZ_TS(4);  // [4] phase B: entry read + pUCT value
             const float best = butterfly16_max(u);
             const bool eq = lane_ok & (u == best);
             const unsigned long long bal = __ballot(eq);
             const unsigned msk = (unsigned)(bal >> (16 * seg)) & 0xffffu;  // tie set in ascending action order
             const int total = __popc(msk);
             int pick = 0;
-            if (__any(!done & (total > 1))) {
-                if (!done && total > 1) {  // np.random.choice consumes randomness only for a real tie
+            if (__any(live & (total > 1))) {
+                if (live && total > 1) {  // np.random.choice consumes randomness only for a real tie
                     double uu;
                     if (P.rng_mode == 0) {
                         if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
@@ -212,40 +217,37 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                     pick = pick >= total ? total - 1 : pick;
                 }
             }
+            MZ_TS(5);  // [5] phase B: max, tie set, (rare) draw
             const int as = nth_set_bit(msk, pick);
             const int cs = row_max_i((a0 == as) ? (int)en.c : -2);  // broadcast the chosen lane's child index
-            const bool adv = !done;
-            if (__any(adv & (k >= 16))) {
-                if (adv && k >= 16 && a0 == 0) path[k] = (short)n;
-            }
-            mypath = (adv & (a0 == k)) ? n : mypath;
-            const int k1 = k + 1;
-            const bool stop = adv & ((cs < 0) | (k1 > P.NN));
+            MZ_TS(6);  // [6] phase B: pick + child broadcast
+            if (live && a0 == 0) path[k] = (short)n;
+            const bool stop = live & (cs < 0);
             lp = stop ? n : lp;
             la = stop ? as : la;
-            n = (adv & !stop) ? cs : n;
-            k = adv ? k1 : k;
-            done |= stop;
+            k += live ? 1 : 0;
+            n = live ? (cs < 0 ? SENT : cs) : n;
         }
-        MZ_SUBX(6);
+        MZ_TS(7);  // [7] phase B: bookkeeping
     }
     MZ_SUB(3);  // descent loop
     if (a0 == 0 && env_ok) MZ_COUNT(2, 1);
     if (a0 == 0) {
         // players swap at every level (mcts.py:379): the leaf's player follows from the parity of the depth
-        const int cp0 = env_ok ? P.cur[env_g] : 0, op0 = env_ok ? P.opp[env_g] : 0;
         sel[0] = lp; sel[1] = la; sel[2] = (k & 1) ? op0 : cp0; sel[3] = ties;
         reinterpret_cast<int*>(smem + P.t_sel)[80 + e] = k;  // expanded nodes on the path (root .. leaf parent)
     }
+    MZ_TS(8);  // [8] epilogue (sel[] writes)
+    MZ_TS_COUNT(9);  // [9] calls
+    MZ_TS_FLUSH(0);
     leaf_parent = lp;
     leaf_action = la;
 }
 
 // expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
-// mypath as produced by tree2_select of the same simulation
+// the path row as written by tree2_select of the same simulation
 // returns the resume point of the next descent (see header)
-__device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
-                                            int mypath) {
+__device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32) {
     const int e = tid >> 4, a0 = tid & 15;
     const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
     double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
@@ -260,6 +262,8 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     const bool board = P.board != 0;
     MZ_SUB_DECL
     MZ_SUB_START();
+    MZ_TS_DECL
+    MZ_TS_START();
     if (a0 == 0 && env_ok) {  // expand (mcts.py:386); LDS operations of one wave execute in order: later reads see this
         Node2* nd = node2_at(smem, P, e, nw);
         nd->W = 0.0; nd->N = 0; nd->reward = r32; nd->parent = (short)lp; nd->move = (short)la; nd->player = cp;
@@ -271,16 +275,19 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     for (int base = 0; __any(base < L); base += 16) {
         const int idx = L - 1 - (base + a0);
         const bool valid = idx >= 0;
-        // node at path position idx: the new node, a register of lane idx, or (deep paths) the LDS path row
-        const int from_reg = __shfl(mypath, (tid & 48) | (idx & 15), 64);
-        int p = 0;
-        if (valid) p = (idx == L - 1) ? nw : (idx < 16 ? from_reg : (int)path[idx]);
+        // node at path position idx: the new node, or the LDS path row (unconditional loads, selects afterwards: a load
+        // under a lane predicate becomes a branch with its own LDS round trip)
+        const int from_row = (int)path[idx >= 0 ? idx : 0];
+        const int p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
         Node2* x = node2_at(smem, P, e, p);
-        const double rw = valid ? (double)x->reward : 0.0;
-        const bool same = valid && (x->player == cp);
+        const float rwf = x->reward;
+        const int pl = x->player;
         const double W0 = x->W;
         const int N0 = x->N;
         const int par = x->parent, mv = x->move;
+        const double rw = valid ? (double)rwf : 0.0;
+        const bool same = valid & (pl == cp);
+        MZ_TS(0);  // [0] backup: expand + path node loads
         // value recurrence (mcts.py:152-155) as a shift chain: lane t receives lane t-1's value
         double val = val_in;
         const double prw = dpp_d<DPP_SHR1>(rw);
@@ -292,6 +299,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             if (a0 == t) val = cand;
         }
         MZ_SUB(0);  // loads + value chain
+        MZ_TS(1);  // [1] backup: value chain
         if (valid) {
             const double W = W0 + (same ? val : -val);
             const int N = N0 + 1;
@@ -305,6 +313,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             mx = v > mx ? v : mx;
             mn = v < mn ? v : mn;
         }
+        MZ_TS(2);  // [2] backup: W / N / Q update, entry write
         // carry into the next chunk of 16 path nodes (deep paths only)
         const double nxt = (board && same) ? (-rw + g * val) : (rw + g * val);
         val_in = __shfl(nxt, (tid & 48) | 15, 64);
@@ -317,10 +326,13 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         o = row_ror<2>(mn); mn = o < mn ? o : mn;  o = row_ror<2>(mx); mx = o > mx ? o : mx;
         o = row_ror<1>(mn); mn = o < mn ? o : mn;  o = row_ror<1>(mx); mx = o > mx ? o : mx;
     }
+    MZ_TS(3);  // [3] backup: min-max reduction
     // cache-validity bookkeeping for the min-max change of this backup (see header)
     EnvCacheState st = *stp;
+    bool switched_on = false;
     if (mn != mn0 || mx != mx0) {
         st.rinv = mx > mn ? 1.0 / (mx - mn) : 0.0;  // the one division per min-max change (norm_q)
+        switched_on = !(mx0 > mn0);
         if (mx0 > mn0) {
             // D_k is only an upper bound: the products are within 2 ulp of the quotients, the 1.000001 factor covers that
             const double d_lo = (mn0 - mn) * st.rinv, d_hi = (mx - mx0) * st.rinv;
@@ -331,7 +343,16 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         if (a0 == 0 && env_ok) MZ_COUNT(3, 1);
     }
     if (a0 == 0 && env_ok) { mm[0] = mn; mm[1] = mx; *stp = st; }
+    if (__any(switched_on)) {
+        // normalisation may have switched on: no cached choice of this env survives (rare: once per search); the path
+        // nodes get fresh entries in pass 2 below
+        if (switched_on) {
+            SelCache* cbase = cache_at(smem, P, e, 0);
+            for (int i = a0; i < P.NN; i += 16) cbase[i].t = __uint_as_float(0xff800000u);
+        }
+    }
     MZ_SUB(1);  // statistics update + min-max reduction
+    MZ_TS(4);  // [4] backup: drift / rinv bookkeeping + stores
     // pass 2: child_U and best child of every path node with the final statistics (same lane ownership; LDS ops are in
     // order, so the entry writes of pass 1 -- all from this wave -- are visible)
     const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0);
@@ -340,9 +361,8 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     for (int base = 0; __any(base < L); base += 16) {
         const int idx = L - 1 - (base + a0);
         const bool valid = idx >= 0;
-        const int from_reg = __shfl(mypath, (tid & 48) | (idx & 15), 64);
-        int p = 0;
-        if (valid) p = (idx == L - 1) ? nw : (idx < 16 ? from_reg : (int)path[idx]);
+        const int from_row = (int)path[idx >= 0 ? idx : 0];
+        const int p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
         bool decided = false;  // the refreshed cache entry will let the next descent pass through p without evaluating it
         int bestc = -1;
         if (valid) {
@@ -381,6 +401,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                     }
                 }
             }
+            MZ_TS(5);  // [5] backup pass 2: per-action loop
             SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
             cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
             cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : __uint_as_float(0xff800000u);
@@ -400,6 +421,9 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         }
     }
     MZ_SUB(2);  // best-child refresh
+    MZ_TS(6);  // [6] backup pass 2: cache write + resume point
+    MZ_TS_COUNT(9);
+    MZ_TS_FLUSH(12);
     return resume;
 }
 

@@ -194,7 +194,7 @@ static void compute_layout(mz_planner* p) {
         b = o.total_floats * 4;
         const int n2 = take(16 * s.NN * 24, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
                   p0 = take(16 * s.A * 4, 16), mmo = take(16 * 2 * 8, 16), se = take(128 * 4, 16), pt = take(32 * 8, 16),
-                  ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * s.NN * 8, 16), pa = take(16 * (s.NN + 3) * 2, 16),
+                  ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * (s.NN + 1) * 8, 16), pa = take(16 * (s.NN + 3) * 2, 16),
                   ve = take(16 * 32, 16);
         const int total = (b + 15) & ~15;
         if (total <= 160 * 1024) {
@@ -976,6 +976,18 @@ extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
     return MZ_OK;
 }
 
+// diagnostic builds only (-DMZ_STAMPS): register-accumulated segment stamps of tree2_select [0..11] and tree2_backup [12..23]
+extern "C" int mz_debug_read_tree_stamps(mz_planner* p, long long out[32]) {
+    if (!p || !out) return fail(MZ_E_INVALID, "null argument");
+    for (int i = 0; i < 32; i++) out[i] = 0;
+#ifdef MZ_STAMPS
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(mz::g_ts), 32 * sizeof(long long)));
+#endif
+    return MZ_OK;
+}
+
 // test hooks, not part of the ABI header: capture the randomness a production-mode (on-device Philox) search consumes --
 // normalised root Dirichlet noise, tie-break uniforms in the order they were drawn, the final action-sampling uniform -- in
 // the layout of mz_rng_inputs, so a test can check their distributions and replay the same search in parity mode.
@@ -1035,9 +1047,7 @@ extern "C" int mz_debug_read_counters(mz_planner* p, long long out[8]) {
     for (int i = 0; i < 8; i++) out[i] = (long long)dbg[i];
     long long sub[8];
     HIPCHK(hipMemcpyFromSymbol(sub, HIP_SYMBOL(mz::g_sub), sizeof(sub)));
-#ifndef MZ_COUNTERS
-    for (int i = 4; i < 8; i++) out[i] = sub[i];  // select sub-phases of block 0 / wave 0: [4] phase-A cycles, [5] phase-A iterations, [6] phase-B cycles, [7] rounds
-#endif
+    (void)sub;
 #endif
     return MZ_OK;
 }

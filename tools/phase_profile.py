@@ -49,10 +49,18 @@ def main():
     cn = (C.c_longlong * 8)()
     p.lib.mz_debug_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     p.lib.mz_debug_read_counters(p.h, cn)
-    if not cn[0] and cn[5]:
-        d = (n + 5) * S
-        print(f'select, wave 0 of block 0, per descent: phase A {cn[4] / d:.0f} cycles in {cn[5] / d:.2f} iterations ({cn[4] / max(cn[5], 1):.0f} each); '
-              f'phase B {cn[6] / d:.0f} cycles in {cn[7] / d:.2f} rounds ({cn[6] / max(cn[7], 1):.0f} each)')
+    ts = (C.c_longlong * 32)()
+    p.lib.mz_debug_read_tree_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    p.lib.mz_debug_read_tree_stamps(p.h, ts)
+    if ts[9]:
+        d = float(ts[9])
+        print(f'tree2_select (wave 0 of block 0, per call; each stamp itself ~40 cycles): prelude {ts[0] / d:.0f}; phase A {ts[2] / d:.0f} cycles in {ts[1] / d:.2f} '
+              f'iterations ({ts[2] / max(ts[1], 1):.0f} each); phase B {ts[3] / d:.2f} rounds: entry+pUCT {ts[4] / max(ts[3], 1):.0f}, max+ties {ts[5] / max(ts[3], 1):.0f}, '
+              f'pick+child {ts[6] / max(ts[3], 1):.0f}, bookkeeping {ts[7] / max(ts[3], 1):.0f} each; epilogue {ts[8] / d:.0f}')
+    if ts[21]:
+        d = float(ts[21])
+        print(f'tree2_backup (per call): expand+loads {ts[12] / d:.0f}, value chain {ts[13] / d:.0f}, update {ts[14] / d:.0f}, min-max reduce {ts[15] / d:.0f}, '
+              f'bookkeeping {ts[16] / d:.0f}, pass-2 action loop {ts[17] / d:.0f}, cache+resume {ts[18] / d:.0f}')
     if cn[0]:
         print(f'tree counters (counters build; timings below are distorted): levels {cn[0]}, cache hits {cn[1]} ({100 * cn[1] / cn[0]:.1f}%), '
               f'descents {cn[2]}, mean depth {cn[0] / max(cn[2], 1):.2f}, min-max changes per descent {cn[3] / max(cn[2], 1):.3f}')
