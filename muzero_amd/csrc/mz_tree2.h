@@ -293,10 +293,16 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         const double prw = dpp_d<DPP_SHR1>(rw);
         const int psame = dpp_i<DPP_SHR1>(same ? 1 : 0);
         const int steps = L - base - 1;  // lanes 1..steps of this chunk hold nodes
-        for (int t = 1; t < 16 && __any(t <= steps); t++) {
-            const double pv = dpp_d<DPP_SHR1>(val);
-            const double cand = (board && psame) ? (-prw + g * pv) : (prw + g * pv);
-            if (a0 == t) val = cand;
+        // (the term a lane adds is fixed: fold the sign choice once; exit test every 4 levels only -- a wave-level branch per
+        // level costs as much as the level's arithmetic)
+        const double sprw = (board && psame) ? -prw : prw;
+        for (int t0 = 1; t0 < 16 && __any(t0 <= steps); t0 += 4) {
+#pragma unroll
+            for (int t = t0; t < t0 + 4; t++) {
+                const double pv = dpp_d<DPP_SHR1>(val);
+                const double cand = sprw + g * pv;
+                val = (a0 == t) ? cand : val;
+            }
         }
         MZ_SUB(0);  // loads + value chain
         MZ_TS(1);  // [1] backup: value chain
