@@ -253,7 +253,10 @@ def launch_ranks(args, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's stdout may carry backend chatter (gloo prints its connection banner there): relay the JSON line only
+    for line in out.decode().splitlines():
+        if line.startswith('{') and '"metric"' in line:
+            sys.stdout.write(line + '\n')
     sys.stdout.flush()
     if any(codes):
         sys.stderr.write(f'bench.py: rank exit codes {codes}\n')

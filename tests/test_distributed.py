@@ -247,3 +247,23 @@ def test_run_training_world2_is_collective(tmp_path):
     res = out.get()
     assert res['same'] and res['steps'] == (7, 7)  # both ranks stopped together when rank 1 reached its limit
     assert res['files'] == ['train_steps_3', 'train_steps_6', 'train_steps_7_final']  # written once, by rank 0
+
+
+def test_bench_gpus_flag_never_reports_a_single_gpu_line():
+    """`python bench.py --gpus N` without torchrun must start N ranks itself, and a launch whose WORLD_SIZE
+    disagrees with --gpus must refuse to print a line.  Without a GPU the ranks fail (no CPU fallback) -- the point here is
+    that no run asked for 2 GPUs can ever print `"n_gpus": 1`."""
+    import subprocess
+
+    env = dict(os.environ, MZ_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+                        '--no-sustained', '--no-e2e'], capture_output=True, text=True, timeout=600, env=env)
+    assert '"n_gpus": 1' not in r.stdout
+    import torch
+
+    if not torch.cuda.is_available():
+        assert r.returncode != 0  # the ranks cannot create a planner without a GPU, and the launcher says so
+    r2 = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True,
+                        text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert r2.returncode == 2 and 'refusing' in r2.stderr and r2.stdout.strip() == ''
