@@ -48,12 +48,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct WSrc {
     __amdgpu_buffer_rsrc_t r;
     int base;  // wave-uniform byte offset of this wave's first block
+    int cur;   // running byte offset of the next slot to request (one SGPR, advanced by one s_add per slot)
 };
 
 __device__ __forceinline__ WSrc make_wsrc(const void* p, unsigned bytes, int base) {
     WSrc w;
     w.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
     w.base = base;
+    w.cur = base;
     return w;
 }
 
@@ -75,14 +77,23 @@ struct FastCfg {
 
 // request slot I + RD - 1 (cyclic) into the ring entry that slot I - 1 has just vacated
 template <typename C, int RD, int I>
-__device__ __forceinline__ void prefetch_slot(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff) {
+__device__ __forceinline__ void prefetch_slot(float4 (&ring)[RD][C::NT], WSrc& ws, int voff) {
     constexpr int T = (I + RD - 1) % C::SL;
 #ifdef MZ_EXP_NOLOAD
     return;
 #endif
     if constexpr (T < C::I_END) {  // padding slots hold nothing: only the ring position advances
+        // The slot's byte offset is made opaque here: left to itself hipcc treats the 168 (slot, tile) offsets of a simulation
+        // as loop invariants, runs out of SGPRs, parks them in VGPR lanes and then pays v_readlane + 5 wait states in front of
+        // EVERY load -- 5 cycles per MFMA over the whole network.  One s_add per slot and the 12-bit immediate field instead.
+        int so = ws.cur;  // == ws.base + T * NT * 1024
+        asm volatile("" : "+s"(so));
+        ws.cur = so + (T + 1 == C::I_END ? -(C::I_END - 1) : 1) * C::NT * 1024;  // the next real slot (the stream is cyclic)
 #pragma unroll
-        for (int j = 0; j < C::NT; j++) ring[T % RD][j] = bload(ws, voff, T * C::NT + j);
+        for (int j = 0; j < C::NT; j++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.r, voff + (j & 3) * 1024, so + (j >> 2) * 4096, 0);
+            ring[T % RD][j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
     }
 }
 
@@ -122,7 +133,7 @@ struct NoHook {
 template <typename C, int RD, int I0, int G, int KG, bool FROM_LDS, int NV = 0, typename Hook = NoHook, int HK0 = 0>
 struct WideSlots {
     // FROM_LDS: B operand = float4 read from the packed LDS buffer; else B operand = hin[G] (D-layout registers)
-    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const float4 (&xs)[5], const f32x4 (&hin)[4],
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], WSrc& ws, int voff, const float4 (&xs)[5], const f32x4 (&hin)[4],
                                                int last_steps, f32x4 (&acc)[C::NT], Hook& hook) {
         constexpr int NT = C::NT, I = I0 + G;
         prefetch_slot<C, RD, I>(ring, ws, voff);
@@ -158,7 +169,7 @@ struct WideSlots {
 // Slot D holds NT float4: entry jj <-> (kb = (D NT + jj) / TO, t = (D NT + jj) % TO).
 template <typename C, int RD, int I0, int D, int TO, int NV = 0, typename Hook = NoHook, int HK0 = 0>
 struct SplitSlots {
-    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff, const f32x4 (&hin)[C::NT], f32x4 (&acc)[TO],
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], WSrc& ws, int voff, const f32x4 (&hin)[C::NT], f32x4 (&acc)[TO],
                                                Hook& hook) {
         constexpr int NT = C::NT, I = I0 + D, KPS = NT / TO;
         static_assert(NT % TO == 0, "tiles per slot");
@@ -183,7 +194,7 @@ struct SplitSlots {
 // padding slots: nothing to multiply, but the ring must keep turning (their prefetches are the next simulation's first slots)
 template <typename C, int RD, int I>
 struct PadSlots {
-    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], const WSrc& ws, int voff) {
+    static __device__ __forceinline__ void run(float4 (&ring)[RD][C::NT], WSrc& ws, int voff) {
         if constexpr (I < C::SL) {
             prefetch_slot<C, RD, I>(ring, ws, voff);
             __builtin_amdgcn_sched_barrier(0);
@@ -289,7 +300,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
 
     // ---- this wave's weight stream; ring primed with the first RD - 1 slots ----
     const int voff = lane * 16;
-    const WSrc ws = make_wsrc(FW.stream, FW.bytes, wave * C::SL * NT * 1024);
+    WSrc ws = make_wsrc(FW.stream, FW.bytes, wave * C::SL * NT * 1024);
+    ws.cur = ws.base + (RD - 1) * NT * 1024;  // the ring is primed with slots 0 .. RD-2
     float4 ring[RD][NT];
 #pragma unroll
     for (int i = 0; i < RD - 1; i++) {
