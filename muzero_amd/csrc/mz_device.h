@@ -76,12 +76,15 @@ __device__ __forceinline__ float butterfly16(float part) {
     part = part + row_ror<1>(part);
     return part;
 }
+// max over the 16 lanes of a row, every lane gets it.  One v_max_f32 with a DPP-rotated operand per step (hipcc's own
+// rendering of `o = row_ror(v); v = o > v ? o : v` is mov + dpp mov + compare + select with wait states: 6 instructions a
+// step on the critical path of every selection and softmax).  Inputs are never NaN here; -inf is fine.
 __device__ __forceinline__ float butterfly16_max(float v) {
-    float o;
-    o = row_ror<8>(v); v = o > v ? o : v;
-    o = row_ror<4>(v); v = o > v ? o : v;
-    o = row_ror<2>(v); v = o > v ? o : v;
-    o = row_ror<1>(v); v = o > v ? o : v;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float butterfly16_min(float v) {

@@ -63,14 +63,19 @@ struct EnvCacheState {  // per env, 32 bytes
     int pad[3];
 };
 
-// float32(MinMaxStats.normalize(v)) exactly as the reference computes it, usually without the division (see header)
+// float32(MinMaxStats.normalize(v)) exactly as the reference computes it, usually without the division (see header).
+// Straight-line: the division sits behind a wave-level test that is almost never true.
 __device__ __forceinline__ float norm_q(double v, double mn, double mx, double rinv) {
     const double d = v - mn;
     double y = d * rinv;
     const long long b = __double_as_longlong(y);
     const int lo = (int)(b & 0x1fffffffLL) - 0x10000000;
     const int ex = (int)((b >> 52) & 0x7ff);
-    if ((lo >= -4 && lo <= 4) || (ex < 1023 - 120 && d != 0.0)) y = d / (mx - mn);  // ambiguous rounding / float32 subnormal range
+    const bool amb = ((lo >= -4) & (lo <= 4)) | ((ex < 1023 - 120) & (d != 0.0));  // ambiguous rounding / float32 subnormal range
+    if (__builtin_amdgcn_ballot_w64(amb) != 0) {
+        const double exact = d / (mx - mn);
+        y = amb ? exact : y;
+    }
     return (float)y;
 }
 
@@ -91,12 +96,12 @@ __device__ __forceinline__ double dpp_d(double v) {
 }
 constexpr int DPP_SHR1 = 0x111;
 
-__device__ __forceinline__ int row_max_i(int v) {
-    int o;
-    o = dpp_i<0x128>(v); v = o > v ? o : v;
-    o = dpp_i<0x124>(v); v = o > v ? o : v;
-    o = dpp_i<0x122>(v); v = o > v ? o : v;
-    o = dpp_i<0x121>(v); v = o > v ? o : v;
+__device__ __forceinline__ int row_max_i(int v) {  // signed max over the 16 lanes of a row (see butterfly16_max)
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
     return v;
 }
 
@@ -137,8 +142,9 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
 
 // pUCT value of one action of a node from its entry (child_Q + child_U, mcts.py:159-200), exact
 __device__ __forceinline__ float puct_entry(const Entry2& en, double mn, double mx, double rinv, bool norm) {
-    float qa = 0.0f;
-    if (en.cn > 0) qa = norm ? norm_q(en.vq, mn, mx, rinv) : (float)en.vq;
+    // straight-line: lanes whose child is unvisited compute a value too and drop it (a branch on `cn > 0` costs more)
+    const float qn = norm_q(en.vq, mn, mx, rinv), qr = (float)en.vq;
+    const float qa = en.cn > 0 ? (norm ? qn : qr) : 0.0f;
     return qa + en.U;
 }
 
