@@ -169,8 +169,6 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
     int n = env_ok ? (resume & 0xffff) : SENT, ties = sel[3];
     int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
-    MZ_SUB_DECL
-    MZ_SUB_START();
     MZ_TS_DECL
     MZ_TS_START();
     for (;;) {
@@ -236,7 +234,6 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
         }
         MZ_TS(7);  // [7] phase B: bookkeeping
     }
-    MZ_SUB(3);  // descent loop
     if (a0 == 0 && env_ok) MZ_COUNT(2, 1);
     if (a0 == 0) {
         // players swap at every level (mcts.py:379): the leaf's player follows from the parity of the depth
@@ -266,8 +263,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     const int L = env_ok ? depth + 1 : 0;  // path nodes including the new one
     const double g = P.discount;
     const bool board = P.board != 0;
-    MZ_SUB_DECL
-    MZ_SUB_START();
     MZ_TS_DECL
     MZ_TS_START();
     if (a0 == 0 && env_ok) {  // expand (mcts.py:386); LDS operations of one wave execute in order: later reads see this
@@ -310,7 +305,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 val = (a0 == t) ? cand : val;
             }
         }
-        MZ_SUB(0);  // loads + value chain
         MZ_TS(1);  // [1] backup: value chain
         if (valid) {
             const double W = W0 + (same ? val : -val);
@@ -363,7 +357,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             for (int i = a0; i < P.NN; i += 16) cbase[i].t = __uint_as_float(0xff800000u);
         }
     }
-    MZ_SUB(1);  // statistics update + min-max reduction
     MZ_TS(4);  // [4] backup: drift / rinv bookkeeping + stores
     // pass 2: child_U and best child of every path node with the final statistics (same lane ownership; LDS ops are in
     // order, so the entry writes of pass 1 -- all from this wave -- are visible)
@@ -383,36 +376,41 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             Entry2* er = entry2_row(smem, P, e, p);
             float best = __uint_as_float(0xff800000u), second = __uint_as_float(0xff800000u);
             int besta = 0, cnt = 0;
-            for (int a4 = 0; a4 < P.A; a4 += 4) {  // 4 actions per round: their LDS reads overlap
-                Entry2 en[4];
-                double f[4];
+            // CH actions per round (their LDS reads overlap); 2 when there are only 2 actions: padding a round costs real work
+            auto rank_actions = [&](auto ch_tag) {
+                constexpr int CH = decltype(ch_tag)::value;
+                for (int a4 = 0; a4 < P.A; a4 += CH) {
+                    Entry2 en[CH];
+                    double f[CH], pr[CH];
 #pragma unroll
-                for (int j = 0; j < 4; j++) en[j] = er[a4 + j < P.A ? a4 + j : P.A - 1];
+                    for (int j = 0; j < CH; j++) en[j] = er[a4 + j < P.A ? a4 + j : P.A - 1];
 #pragma unroll
-                for (int j = 0; j < 4; j++) f[j] = frow[en[j].cn];
+                    for (int j = 0; j < CH; j++) { f[j] = frow[en[j].cn]; pr[j] = prior[a4 + j < P.A ? a4 + j : P.A - 1]; }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int a = a4 + j;
-                    if (a < P.A) {
-                        const float ua = child_u(prior[a], f[j], prior_f32);  // this node's N (and one child's) just changed
-                        er[a].U = ua;
-                        // the cached ranking may use the un-checked product: its error (1 ulp of float32) is far inside the
-                        // cache's slack, and a choice that is not decided by more than the slack is re-evaluated exactly
-                        // at visit time anyway
-                        float qa = 0.0f;
-                        if (en[j].cn > 0) qa = norm ? (float)((en[j].vq - mn) * st.rinv) : (float)en[j].vq;
-                        const float u = qa + ua;
-                        // first maximum, number of actions tied with it, runner-up -- as selects (branches on lane
-                        // predicates cost a wave that runs alone on its SIMD far more than the selects do)
-                        const bool gt = u > best, eq = u == best;
-                        second = gt ? best : ((!eq && u > second) ? u : second);
-                        cnt = gt ? 1 : (eq ? cnt + 1 : cnt);
-                        besta = gt ? a : besta;
-                        bestc = gt ? (int)en[j].c : bestc;
-                        best = gt ? u : best;
+                    for (int j = 0; j < CH; j++) {
+                        const int a = a4 + j;
+                        if (a < P.A) {  // wave-uniform
+                            const float ua = child_u(pr[j], f[j], prior_f32);  // this node's N (and one child's) just changed
+                            er[a].U = ua;
+                            // the cached ranking may use the un-checked product: its error (1 ulp of float32) is far inside
+                            // the cache's slack, and a choice that is not decided by more than the slack is re-evaluated
+                            // exactly at visit time anyway
+                            const float qn = norm ? (float)((en[j].vq - mn) * st.rinv) : (float)en[j].vq;
+                            const float u = (en[j].cn > 0 ? qn : 0.0f) + ua;
+                            // first maximum, number of actions tied with it, runner-up -- as selects (branches on lane
+                            // predicates cost a wave that runs alone on its SIMD far more than the selects do)
+                            const bool gt = u > best, eq = u == best;
+                            second = gt ? best : ((!eq & (u > second)) ? u : second);
+                            cnt = gt ? 1 : (eq ? cnt + 1 : cnt);
+                            besta = gt ? a : besta;
+                            bestc = gt ? (int)en[j].c : bestc;
+                            best = gt ? u : best;
+                        }
                     }
                 }
-            }
+            };
+            if (P.A <= 2) rank_actions(std::integral_constant<int, 2>{});
+            else rank_actions(std::integral_constant<int, 4>{});
             MZ_TS(5);  // [5] backup pass 2: per-action loop
             SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
             cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
@@ -432,7 +430,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             resume = env_ok ? (pr | ((L - 1 - r) << 16)) : 0;
         }
     }
-    MZ_SUB(2);  // best-child refresh
     MZ_TS(6);  // [6] backup pass 2: cache write + resume point
     MZ_TS_COUNT(9);
     MZ_TS_FLUSH(12);

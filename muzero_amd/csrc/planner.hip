@@ -203,7 +203,8 @@ static void compute_layout(mz_planner* p) {
             p->sp2 = s;
             SearchParams& q = p->sp2;
             q.t2_nodes = n2; q.t2_entries = e2; q.t_prior = pr; q.t_tmp = tm; q.t_pi0 = p0; q.t_mm = mmo; q.t_sel = se; q.t_ptr = pt;
-            q.t2_ftab = ft; q.t_cache = ca; q.t_path = pa; q.t_ver = ve; q.lds_bytes = total; q.tree_mode = 2;
+            q.t2_ftab = ft; q.t_cache = ca; q.t_path = pa; q.t_ver = ve;
+            q.lds_bytes = total; q.tree_mode = 2;
         }
     }
 

@@ -44,8 +44,6 @@ def main():
     root_noise = tot[15]
     tot[11:] = 0
     total = tot.sum() + root_noise
-    print(f'sub-phases per sim (cycles): backup loads+chain {sub[0]:.0f}, update+minmax {sub[1]:.0f}, best-child refresh {sub[2]:.0f}; '
-          f'select descent loop {sub[3]:.0f}')
     cn = (C.c_longlong * 8)()
     p.lib.mz_debug_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     p.lib.mz_debug_read_counters(p.h, cn)
