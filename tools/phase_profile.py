@@ -16,7 +16,7 @@ from muzero_amd import planner as pl  # noqa: E402
 pl.LIB_PATH = os.environ.get('MZ_STAMPS_LIB', os.path.join(REPO, 'muzero_amd', 'lib', 'libmzplanner_hip_stamps.so'))
 from helpers import build_mlp, mlp_case  # noqa: E402
 
-NAMES = ['root: inference + prior', 'select + gather', 'root: tables', 'dyn1(wide)', 'dyn2(chain)', 'normalise', 'rew1+val1(wide)', 'heads2(chain)', 'softmax', 'backup', 'finish']
+NAMES = ['root: inference + prior', 'select + gather', 'root: tables', 'D1 dyn layer 1', 'D2 dyn layer 2 + barrier', 'reduce + normalise', 'reward head + barrier', 'value head + barrier', 'softmax (2 rows)', 'backup', 'finish']
 
 
 def main():
@@ -66,7 +66,7 @@ def main():
     print(f'  {"root: noise + obs":18s} {root_noise:10.0f}  {100 * root_noise / total:5.1f}%')
     for i, name in enumerate(NAMES):
         per_sim = tot[i] / (S if 1 <= i <= 9 else 1)
-        print(f'  {name:18s} {tot[i]:10.0f}  {100 * tot[i] / total:5.1f}%   per-sim {per_sim:8.1f}')
+        print(f'  {name:26s} {tot[i]:10.0f}  {100 * tot[i] / total:5.1f}%   per-sim {per_sim:8.1f}')
 
 
 if __name__ == '__main__':
