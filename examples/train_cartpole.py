@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end MuZero on CartPole-v1 with the MI355X planner: device-resident self-play (search + env + records in HBM) ->
-host episode assembly (the reference's n-step targets / unroll sequences) -> HBM-resident replay -> learner step (the
-reference's calc_loss, Adam, MultiStepLR) -> weights back into the planner.  One process, one GPU, no actor processes:
+device epilogue (the reference's n-step targets / priorities / unroll sequences built on the GPU, written straight into the
+HBM-resident replay; `--host-assembly` uses the host EpisodeAssembler instead) -> learner step (the reference's loss, Adam,
+MultiStepLR) -> weights back into the planner.  One process, one GPU, no actor processes:
 the roles of classic/run_training.py's six actors, data collector thread and learner thread are interleaved in one loop.
 
     python examples/train_cartpole.py --train-steps 3000 --envs 128
@@ -33,6 +34,7 @@ def main():
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--eval-episodes', type=int, default=3)
     ap.add_argument('--out', default='')
+    ap.add_argument('--host-assembly', action='store_true', help='assemble (Transition, priority) items on the host instead of the device epilogue')
     args = ap.parse_args()
 
     from muzero_amd import learner
@@ -54,6 +56,8 @@ def main():
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
     net.eval()
     p.load_state_dict(net.state_dict())
+    if not args.host_assembly:
+        p.attach_replay(replay, cfg, obs_shape=(4, 5))
     p.selfplay_reset(pl.ENV_CARTPOLE)
     asm = EpisodeAssembler(cfg, args.envs, (4, 5))
 
@@ -62,8 +66,9 @@ def main():
     while steps < args.train_steps:
         T = float(cfg.visit_softmax_temperature_fn(0, steps))
         p.selfplay_step(T, args.moves_per_iter)
-        for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
-            replay.add(tr, prio)
+        if args.host_assembly:
+            for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
+                replay.add(tr, prio)
         if replay.size < cfg.min_replay_size:
             continue
         net.train()
