@@ -196,6 +196,40 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
         // ---- phase B: every segment that is not parked sits on a level its cache cannot decide: evaluate it ----
         {
             const bool live = n != SENT;
+            int as, cs;
+            if (P.A == 2) {
+                // TWO actions: every lane evaluates action (lane & 1) and takes the other one's value and child from its
+                // neighbour (one quad permute each) -- no segment reduction, no ballot, no child broadcast
+                const Entry2 en = entry2_row(smem, P, e, live ? n : 0)[a0 & 1];
+                const float u = puct_entry(en, mn, mx, st.rinv, norm);
+                MZ_TS(4);  // [4] phase B: entry read + pUCT value
+                const float uo = __int_as_float(dpp_i<0xb1>(__float_as_int(u)));  // quad_perm [1,0,3,2]
+                const int co = dpp_i<0xb1>((int)en.c);
+                const bool odd = (a0 & 1) != 0;
+                const float u0 = odd ? uo : u, u1 = odd ? u : uo;
+                const int c0 = odd ? co : (int)en.c, c1 = odd ? (int)en.c : co;
+                as = u1 > u0 ? 1 : 0;  // np.where(ucb == max)[0]: the first maximum unless they tie
+                const bool tie = live & (u0 == u1);
+                if (__any(tie)) {
+                    if (tie) {  // np.random.choice consumes randomness only for a real tie
+                        double uu;
+                        if (P.rng_mode == 0) {
+                            if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
+                            else { uu = 0.5; if (a0 == 0) atomicExch(P.err, 4); }
+                        } else {
+                            Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
+                            uu = g.uniform();
+                            if (P.dbg_utie && a0 == 0 && ties < P.max_ties) P.dbg_utie[(size_t)env_g * P.max_ties + ties] = uu;
+                        }
+                        ties++;
+                        const int pick = (int)floor(uu * 2.0);
+                        as = pick >= 2 ? 1 : pick;
+                    }
+                }
+                MZ_TS(5);  // [5] phase B: max, tie set, (rare) draw
+                cs = as ? c1 : c0;
+                MZ_TS(6);  // [6] phase B: pick + child broadcast
+            } else {
             const Entry2 en = entry2_row(smem, P, e, live ? n : 0)[lane_ok ? a0 : 0];
             const float u = lane_ok ? puct_entry(en, mn, mx, st.rinv, norm) : __uint_as_float(0xff800000u);
             MZ_TS(4);  // [4] phase B: entry read + pUCT value
@@ -222,9 +256,10 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                 }
             }
             MZ_TS(5);  // [5] phase B: max, tie set, (rare) draw
-            const int as = nth_set_bit(msk, pick);
-            const int cs = row_max_i((a0 == as) ? (int)en.c : -2);  // broadcast the chosen lane's child index
+            as = nth_set_bit(msk, pick);
+            cs = row_max_i((a0 == as) ? (int)en.c : -2);  // broadcast the chosen lane's child index
             MZ_TS(6);  // [6] phase B: pick + child broadcast
+            }
             if (live && a0 == 0) path[k] = (short)n;
             const bool stop = live & (cs < 0);
             lp = stop ? n : lp;
