@@ -933,16 +933,22 @@ extern "C" int mz_selfplay_read(mz_planner* p, int32_t n_moves, float* h_obs, in
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
     const size_t B = (size_t)p->cfg.num_envs, A = (size_t)p->cfg.num_actions, D = (size_t)obs_dim(p->cfg);
-    for (int i = 0; i < n_moves; i++) {
-        const int slot = ((p->ring_pos - n_moves + i) % p->ring_len + p->ring_len) % p->ring_len;
-        if (h_obs) HIPCHK(hipMemcpy(h_obs + (size_t)i * B * D, p->env.r_obs + (size_t)slot * B * D, B * D * sizeof(float), hipMemcpyDeviceToHost));
-        if (h_action) HIPCHK(hipMemcpy(h_action + (size_t)i * B, p->env.r_action + (size_t)slot * B, B * sizeof(int), hipMemcpyDeviceToHost));
-        if (h_reward) HIPCHK(hipMemcpy(h_reward + (size_t)i * B, p->env.r_reward + (size_t)slot * B, B * sizeof(float), hipMemcpyDeviceToHost));
-        if (h_pi) HIPCHK(hipMemcpy(h_pi + (size_t)i * B * A, p->env.r_pi + (size_t)slot * B * A, B * A * sizeof(double), hipMemcpyDeviceToHost));
-        if (h_root) HIPCHK(hipMemcpy(h_root + (size_t)i * B, p->env.r_root + (size_t)slot * B, B * sizeof(double), hipMemcpyDeviceToHost));
-        if (h_player) HIPCHK(hipMemcpy(h_player + (size_t)i * B, p->env.r_player + (size_t)slot * B, B * sizeof(int), hipMemcpyDeviceToHost));
-        if (h_done) HIPCHK(hipMemcpy(h_done + (size_t)i * B, p->env.r_done + (size_t)slot * B, B, hipMemcpyDeviceToHost));
+    // the ring is slot-major, so the last n_moves records are at most two contiguous slot ranges per field: 7 (or 14)
+    // copies per call, not 7 per move
+    const int first = ((p->ring_pos - n_moves) % p->ring_len + p->ring_len) % p->ring_len;
+    const int n1 = n_moves < p->ring_len - first ? n_moves : p->ring_len - first;  // moves before the ring wraps
+    for (int part = 0; part < 2; part++) {
+        const size_t slot = part == 0 ? (size_t)first : 0, cnt = part == 0 ? (size_t)n1 : (size_t)(n_moves - n1), done_moves = part == 0 ? 0 : (size_t)n1;
+        if (cnt == 0) continue;
+        if (h_obs) HIPCHK(hipMemcpyAsync(h_obs + done_moves * B * D, p->env.r_obs + slot * B * D, cnt * B * D * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        if (h_action) HIPCHK(hipMemcpyAsync(h_action + done_moves * B, p->env.r_action + slot * B, cnt * B * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        if (h_reward) HIPCHK(hipMemcpyAsync(h_reward + done_moves * B, p->env.r_reward + slot * B, cnt * B * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        if (h_pi) HIPCHK(hipMemcpyAsync(h_pi + done_moves * B * A, p->env.r_pi + slot * B * A, cnt * B * A * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        if (h_root) HIPCHK(hipMemcpyAsync(h_root + done_moves * B, p->env.r_root + slot * B, cnt * B * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        if (h_player) HIPCHK(hipMemcpyAsync(h_player + done_moves * B, p->env.r_player + slot * B, cnt * B * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        if (h_done) HIPCHK(hipMemcpyAsync(h_done + done_moves * B, p->env.r_done + slot * B, cnt * B, hipMemcpyDeviceToHost, p->stream));
     }
+    HIPCHK(hipStreamSynchronize(p->stream));
     return MZ_OK;
 }
 
