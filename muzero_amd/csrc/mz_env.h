@@ -215,10 +215,109 @@ __global__ void k_env_pre(const EnvLaunch L) {
     if (e < L.B) env_pre_one(L, e);
 }
 
-// after the search: env.step(action), record, auto-reset (pipeline.py:106-113)
-__device__ inline void env_step_one(const EnvLaunch& L, int e) {
-    const int a = L.action[e], A = L.env.A;
+// one move's record (pipeline.py:106-113) -- written by the lane that ran the search's finish step, so that it reads
+// back its own pi / root stores; loads are batched ahead of the stores (they may alias as far as the compiler knows)
+__device__ inline void env_record(const EnvLaunch& L, int e, int a, float reward, bool done) {
+    const int A = L.env.A;
     const size_t rec = (size_t)L.slot * L.B + e;
+    L.env.r_action[rec] = a;
+    L.env.r_reward[rec] = reward;
+    L.env.r_root[rec] = L.root[e];
+    L.env.r_done[rec] = done ? 1 : 0;
+    for (int i0 = 0; i0 < A; i0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = i0 + k < A ? L.pi[(size_t)e * A + i0 + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (i0 + k < A) L.env.r_pi[rec * A + i0 + k] = t[k];
+    }
+    if (e == 0) {
+        atomicAdd(&L.env.counters[0], (unsigned long long)L.B);
+        atomicAdd(&L.env.counters[1], (unsigned long long)L.B * (unsigned long long)L.sims);
+    }
+}
+
+__device__ inline int group_or16(int v) {
+    v |= __shfl_xor(v, 1, 16); v |= __shfl_xor(v, 2, 16); v |= __shfl_xor(v, 4, 16); v |= __shfl_xor(v, 8, 16);
+    return v;
+}
+
+// BoardGameEnv.step (games/env.py:117-154) by the 16 lanes of an env's group (16 consecutive lanes of one wave).  Every
+// lane reads the pre-move state; the bulk moves (history shift, next observation, reset) are strided over the group.
+// Lanes of a wave run in lock-step and vector memory operations of a wave are served in issue order, so a location is
+// only ever read by instructions issued BEFORE the one that overwrites it (the history shift walks downwards for that).
+__device__ inline void board_step_group(const EnvLaunch& L, int e, int lane, int a, float& reward, bool& done) {
+    const int n = L.env.bn, nn = L.env.nn;
+    signed char* b = L.env.board + (size_t)e * nn;
+    signed char* pl = L.env.planes + (size_t)e * 8 * nn;
+    const int me = L.env.player[e], opp = 3 - me, st = L.env.steps[e];
+    signed char* mine = pl + (me - 1) * 4 * nn;
+    const signed char* theirs = pl + (opp - 1) * 4 * nn;
+    int winner = 0;
+    reward = 0.0f;
+    if (a == nn) {  // resign (games/env.py:134-136)
+        reward = -1.0f;
+        winner = opp;
+    } else if (st >= (L.env.win - 1) * 2) {  // games/tictactoe.py:37-38, games/gomoku.py:76-77 with the pre-increment step count
+        // lanes 0..7 walk one ray each from the new stone (which the rays do not include)
+        const int r = a / n, c = a % n, d = lane & 3, sg = (lane & 4) ? -1 : 1;
+        const int dr = sg * (d == 0 ? 0 : d == 3 ? -1 : 1), dc = sg * (d == 1 ? 0 : 1);  // (0,1) (1,0) (1,1) (-1,1)
+        const int k = lane < 8 ? board_line(b, n, r, c, dr, dc, me) : 0;
+        const int k2 = __shfl_xor(k, 4, 16);
+        if (group_or16(lane < 4 && 1 + k + k2 >= L.env.win)) { winner = me; reward = 1.0f; }
+    }
+    int open = 0;  // an empty point other than the one just played
+    for (int i = lane; i < nn; i += 16) open |= (b[i] == 0 && i != a) ? 1 : 0;
+    done = winner != 0 || !group_or16(open);
+    float* o = L.obs + (size_t)e * 9 * nn;
+    if (!done) {
+        // observation of the next side to move (games/env.py:242-271): its own history (unchanged by this move), the
+        // mover's history as it will be after the shift below, and the colour plane
+        for (int idx = lane; idx < 4 * nn; idx += 16) {
+            const int t = idx / nn, i = idx - t * nn;
+            const signed char x = theirs[idx];
+            const signed char y = t > 0 ? mine[idx - nn] : (signed char)((b[i] == me || i == a) ? 1 : 0);
+            o[(2 * t) * nn + i] = (float)x;
+            o[(2 * t + 1) * nn + i] = (float)y;
+        }
+        for (int i = lane; i < nn; i += 16) o[8 * nn + i] = opp == 1 ? 1.0f : 0.0f;
+        for (int j = (4 * nn + 15) / 16 - 1; j >= 0; j--) {  // mine[t] <- mine[t - 1], mine[0] <- the mover's stones
+            const int idx = j * 16 + lane;
+            if (idx < 4 * nn) {
+                const int t = idx / nn, i = idx - t * nn;
+                const signed char v = t > 0 ? mine[idx - nn] : (signed char)((b[i] == me || i == a) ? 1 : 0);
+                mine[idx] = v;
+            }
+        }
+        if (lane == 0) {
+            L.mask[(size_t)e * (nn + 1) + a] = 0;
+            b[a] = (signed char)me;
+            L.env.player[e] = opp;
+            L.env.steps[e] = st + 1;
+            L.cur[e] = opp;
+            L.opp[e] = me;
+        }
+    } else {  // auto-reset (pipeline.py:111-113): board_fresh, strided
+        for (int i = lane; i < nn; i += 16) b[i] = 0;
+        for (int i = lane; i < 8 * nn; i += 16) { pl[i] = 0; o[i] = 0.0f; }
+        for (int i = lane; i < nn; i += 16) o[8 * nn + i] = 1.0f;
+        for (int i = lane; i <= nn; i += 16) L.mask[(size_t)e * (nn + 1) + i] = 1;
+        if (lane == 0) {
+            atomicAdd(&L.env.counters[2], 1ULL);
+            atomicAdd(&L.env.counters[3], (unsigned long long)(st + 1));
+            L.env.steps[e] = 0;
+            L.env.episode[e] += 1;
+            L.env.player[e] = 1;
+            L.cur[e] = 1;
+            L.opp[e] = 2;
+        }
+    }
+}
+
+// after the search: env.step(action), record, auto-reset (pipeline.py:106-113)
+__device__ inline void env_step_one(const EnvLaunch& L, int e) {  // CartPole / synthetic: one lane per env
+    const int a = L.action[e];
     float reward = 0.0f;
     bool done = false;
     if (L.env.kind == ENV_CARTPOLE) {
@@ -254,61 +353,25 @@ __device__ inline void env_step_one(const EnvLaunch& L, int e) {
             L.env.episode[e] += 1;
         }
         L.env.steps[e] = done ? 0 : st;  // the next observation is drawn by k_env_synth_obs
-    } else {
-        const int n = L.env.bn, nn = L.env.nn;
-        signed char* b = L.env.board + (size_t)e * nn;
-        signed char* pl = L.env.planes + (size_t)e * 8 * nn;
-        const int me = L.env.player[e], opp = 3 - me;
-        const int st = L.env.steps[e];
-        int winner = 0;
-        L.mask[(size_t)e * (nn + 1) + a] = 0;
-        if (a == nn) {  // resign (games/env.py:134-136)
-            reward = -1.0f;
-            winner = opp;
-        } else {
-            b[a] = (signed char)me;
-            signed char* mine = pl + (me - 1) * 4 * nn;
-            for (int k = 3; k > 0; k--)
-                for (int i = 0; i < nn; i++) mine[k * nn + i] = mine[(k - 1) * nn + i];
-            for (int i = 0; i < nn; i++) mine[i] = b[i] == me;
-            if (st >= (L.env.win - 1) * 2) {  // games/tictactoe.py:37-38, games/gomoku.py:76-77 with the pre-increment step count
-                const int r = a / n, c = a % n;
-                const int dirs[4][2] = {{0, 1}, {1, 0}, {1, 1}, {-1, 1}};
-                for (int d = 0; d < 4; d++)
-                    if (1 + board_line(b, n, r, c, dirs[d][0], dirs[d][1], me) + board_line(b, n, r, c, -dirs[d][0], -dirs[d][1], me) >= L.env.win)
-                        winner = me;
-            }
-            if (winner) reward = 1.0f;
-        }
-        bool full = true;
-        for (int i = 0; i < nn; i++) full = full && b[i] != 0;
-        done = winner != 0 || full;
-        if (!done) {
-            L.env.player[e] = opp;
-            L.env.steps[e] = st + 1;
-            board_write_obs(L, e);
-        } else {
-            atomicAdd(&L.env.counters[2], 1ULL);
-            atomicAdd(&L.env.counters[3], (unsigned long long)(st + 1));
-            L.env.steps[e] = 0;
-            L.env.episode[e] += 1;
-            board_fresh(L, e);
-        }
     }
-    L.env.r_action[rec] = a;
-    L.env.r_reward[rec] = reward;
-    L.env.r_root[rec] = L.root[e];
-    L.env.r_done[rec] = done ? 1 : 0;
-    for (int i = 0; i < A; i++) L.env.r_pi[rec * A + i] = L.pi[(size_t)e * A + i];
-    if (e == 0) {
-        atomicAdd(&L.env.counters[0], (unsigned long long)L.B);
-        atomicAdd(&L.env.counters[1], (unsigned long long)L.B * (unsigned long long)L.sims);
+    env_record(L, e, a, reward, done);
+}
+// env.step of one env by its 16-lane group (`lane` 0..15; all 16 lanes call this)
+__device__ inline void env_step_group(const EnvLaunch& L, int e, int lane) {
+    if (L.env.kind != ENV_TICTACTOE && L.env.kind != ENV_GOMOKU) {
+        if (lane == 0) env_step_one(L, e);
+        return;
     }
+    const int a = __shfl(lane == 0 ? L.action[e] : 0, 0, 16);  // lane 0 may have stored it a moment ago (fused search)
+    float reward;
+    bool done;
+    board_step_group(L, e, lane, a, reward, done);
+    if (lane == 0) env_record(L, e, a, reward, done);
 }
 
-__global__ void k_env_step(const EnvLaunch L) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < L.B) env_step_one(L, e);
+__global__ void k_env_step(const EnvLaunch L) {  // 16 threads per env
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((g >> 4) < L.B) env_step_group(L, g >> 4, g & 15);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -77,7 +77,7 @@ struct SearchParams {
     double* dbg_ufinal;       // [B]
     long long* stamps;        // diagnostic builds (-DMZ_STAMPS) only: per-phase cycle sums of block 0, else unused
     // device self-play with the environment fused into the search kernel (one launch per lock-step move): the env's first lane
-    // runs env_pre_one before the search (temperature, record of player / observation) and env_step_one after it
+    // runs env_pre_one before the search (temperature, record of player / observation) and env_step_group after it
     int fuse_env;
     EnvLaunch fenv;
 };
@@ -526,8 +526,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     if (a0 == 0 && env_ok) {
         if (P.tree_mode == 2) tree2_finish(smem, P, e, env_g);
         else tree_finish(smem, P, e, env_g);
-        if (!SCRIPTED && P.fuse_env) env_step_one(P.fenv, env_g);
     }
+    if (!SCRIPTED && P.fuse_env && env_ok) env_step_group(P.fenv, env_g, a0);
 }
 
 // ---- stand-alone batched inference (network.py:62-111) on the same tile pipeline ----

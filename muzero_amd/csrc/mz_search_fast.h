@@ -493,8 +493,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     if (a0 == 0 && env_ok) {
         if (Pm.tree_mode == 2) tree2_finish(smem, Pm, e, env_g);
         else tree_finish(smem, Pm, e, env_g);
-        if constexpr (FUSE) env_step_one(Pm.fenv, env_g);  // env.step + record + auto-reset with the action this lane just sampled
     }
+    if constexpr (FUSE)
+        if (env_ok) env_step_group(Pm.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
     MZ_STAMP(10);  // play policy + action
     MZ_STAMP_FLUSH(Pm);
 }

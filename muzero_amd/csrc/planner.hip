@@ -894,7 +894,7 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
                               hipMemcpyDeviceToDevice, p->stream));
         int rc = launch_search(p, c.num_envs, 0, true, false, false);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_env_step, dim3((c.num_envs + 255) / 256), dim3(256), 0, p->stream, L);
+        hipLaunchKernelGGL(k_env_step, dim3((c.num_envs + 15) / 16), dim3(256), 0, p->stream, L);
         if (p->env_kind == MZ_ENV_SYNTHETIC)
             hipLaunchKernelGGL(k_env_synth_obs, dim3(((size_t)c.num_envs * ((obs_dim(c) + 3) / 4) + 255) / 256), dim3(256), 0, p->stream, L);
         epilogue();
