@@ -26,6 +26,16 @@
 
 namespace mz {
 
+#ifdef MZ_STAMPS
+// diagnostic build only: cycle sums of the root inference's segments (thread 0 of block 0), read by tools/phase_profile.py
+__device__ long long g_root_ts[8];
+#define MZ_ROOT_TS_START() long long _rt0 = (blockIdx.x == 0 && threadIdx.x == 0) ? (long long)__builtin_readcyclecounter() : 0
+#define MZ_ROOT_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _n = __builtin_readcyclecounter(); g_root_ts[i] += _n - _rt0; _rt0 = _n; } } while (0)
+#else
+#define MZ_ROOT_TS_START() do {} while (0)
+#define MZ_ROOT_TS(i) do {} while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_E = 16;      // environments per workgroup tile
@@ -96,6 +106,19 @@ __device__ __forceinline__ void mma_block(f32x4 (&acc)[NACC], const float4 (&w)[
     }
 }
 
+// all 4 k-steps of a block: no step-count branches between the MFMAs (every block but a layer's last one is full)
+template <int NACC>
+__device__ __forceinline__ void mma_block_full(f32x4 (&acc)[NACC], const float4 (&w)[NACC], const float4 x) {
+#pragma unroll
+    for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].x, x.x, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].y, x.y, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].z, x.z, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NACC; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].w, x.w, acc[j], 0, 0, 0);
+}
+
 // One Linear layer over this workgroup's tile.  Tiles of 16 output neurons are dealt to waves round-robin
 // (tile = wave_slot + i*WG_WAVES); up to NACC tiles are accumulated concurrently (independent MFMA chains hide the
 // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32).  epi(tile, acc) receives D: acc[r] = Y[16*tile + 4q + r][e].
@@ -114,17 +137,30 @@ __device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __res
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
     // weights one block ahead of the MFMAs (an L2 round trip is ~2 k cycles; un-prefetched, every block would wait for it)
-    float4 w[NACC], wn[NACC];
+    // two blocks of weights in flight, in two statically named register sets (a ring rotated by register moves would
+    // make every iteration wait for the load it has just issued); every block but the layer's last one is full
+    float4 w0[NACC], w1[NACC];
+    const int g1 = L.kg > 1 ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < NACC; j++) w[j] = wp[j][0];
-    for (int g = 0; g < L.kg; g++) {
-        const float4 x = xp[g * 64];
-        const int gn = g + 1 < L.kg ? g + 1 : g;
+    for (int j = 0; j < NACC; j++) w0[j] = wp[j][0];
 #pragma unroll
-        for (int j = 0; j < NACC; j++) wn[j] = wp[j][gn * 64];
-        mma_block<NACC>(acc, w, x, g + 1 < L.kg ? 4 : L.last_steps);
+    for (int j = 0; j < NACC; j++) w1[j] = wp[j][g1 * 64];
+    int g = 0;
+    for (; g + 2 < L.kg; g += 2) {
+        const float4 x0 = xp[g * 64], x1 = xp[(g + 1) * 64];
+        const int gn = g + 3 < L.kg ? g + 3 : L.kg - 1;
+        mma_block_full<NACC>(acc, w0, x0);
 #pragma unroll
-        for (int j = 0; j < NACC; j++) w[j] = wn[j];
+        for (int j = 0; j < NACC; j++) w0[j] = wp[j][(g + 2) * 64];
+        mma_block_full<NACC>(acc, w1, x1);
+#pragma unroll
+        for (int j = 0; j < NACC; j++) w1[j] = wp[j][gn * 64];
+    }
+    if (L.kg - g == 2) {
+        mma_block_full<NACC>(acc, w0, xp[g * 64]);
+        mma_block<NACC>(acc, w1, xp[(g + 1) * 64], L.last_steps);
+    } else {
+        mma_block<NACC>(acc, w0, xp[g * 64], L.last_steps);
     }
 #pragma unroll
     for (int j = 0; j < NACC; j++) epi(t0 + j * WG_WAVES, acc[j]);
@@ -147,39 +183,77 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
         wp[j] = reinterpret_cast<const float4*>(L.w) + (size_t)t * L.kg * 64 + lane;
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
-    // the four quarters' blocks of round gg are loaded while round gg - 1 multiplies (see gemm_chunk)
-    float4 w[4][NT2], wn[4][NT2];
+    constexpr int PD = NT2 == 1 ? 4 : 2;
+    if (L.kg == 4 * L.kq && L.last_steps == 4 && L.kq % PD == 0) {
+        // K a multiple of 64 * PD (every shipped configuration): four equal quarters of full blocks; PD rounds of weights in
+        // flight in statically named register sets (see gemm_chunk), straight-line body
+        float4 wr[PD][4][NT2];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int g = c * L.kq < L.kg ? c * L.kq : 0;
+        for (int d = 0; d < PD; d++) {
 #pragma unroll
-        for (int j = 0; j < NT2; j++) w[c][j] = wp[j][g * 64];
-    }
-    for (int gg = 0; gg < L.kq; gg++) {
+            for (int c = 0; c < 4; c++) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int g = c * L.kq + gg + 1;
-            const int gl = (gg + 1 < L.kq && g < L.kg) ? g : 0;
-#pragma unroll
-            for (int j = 0; j < NT2; j++) wn[c][j] = wp[j][gl * 64];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int g = c * L.kq + gg;
-            if (g < L.kg) {
-                const float4 x = xp[g * 64];
-                f32x4 a[NT2];
-#pragma unroll
-                for (int j = 0; j < NT2; j++) a[j] = acc[j][c];
-                mma_block<NT2>(a, w[c], x, g + 1 < L.kg ? 4 : L.last_steps);
-#pragma unroll
-                for (int j = 0; j < NT2; j++) acc[j][c] = a[j];
+                for (int j = 0; j < NT2; j++) wr[d][c][j] = wp[j][(c * L.kq + d) * 64];
             }
         }
+        for (int gg0 = 0; gg0 < L.kq; gg0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; d++) {
+                const int gg = gg0 + d, gw = gg + PD < L.kq ? gg + PD : L.kq - 1;  // the tail re-loads the last round
+                float4 x[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) x[c] = xp[(c * L.kq + gg) * 64];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    f32x4 a[NT2];
+#pragma unroll
+                    for (int j = 0; j < NT2; j++) a[j] = acc[j][c];
+                    mma_block_full<NT2>(a, wr[d][c], x[c]);
+#pragma unroll
+                    for (int j = 0; j < NT2; j++) acc[j][c] = a[j];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+#pragma unroll
+                    for (int j = 0; j < NT2; j++) wr[d][c][j] = wp[j][(c * L.kq + gw) * 64];
+                }
+            }
+        }
+    } else {
+        // any other shape: the four quarters' blocks of round gg + 1 are loaded while round gg multiplies
+        float4 w[4][NT2], wn[4][NT2];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
+            const int g = c * L.kq < L.kg ? c * L.kq : 0;
 #pragma unroll
-            for (int j = 0; j < NT2; j++) w[c][j] = wn[c][j];
+            for (int j = 0; j < NT2; j++) w[c][j] = wp[j][g * 64];
+        }
+        for (int gg = 0; gg < L.kq; gg++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int g = c * L.kq + gg + 1;
+                const int gl = (gg + 1 < L.kq && g < L.kg) ? g : 0;
+#pragma unroll
+                for (int j = 0; j < NT2; j++) wn[c][j] = wp[j][gl * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int g = c * L.kq + gg;
+                if (g < L.kg) {
+                    const float4 x = xp[g * 64];
+                    f32x4 a[NT2];
+#pragma unroll
+                    for (int j = 0; j < NT2; j++) a[j] = acc[j][c];
+                    mma_block<NT2>(a, w[c], x, g + 1 < L.kg ? 4 : L.last_steps);
+#pragma unroll
+                    for (int j = 0; j < NT2; j++) acc[j][c] = a[j];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int j = 0; j < NT2; j++) w[c][j] = wn[c][j];
+            }
         }
     }
 #pragma unroll
@@ -363,32 +437,59 @@ __device__ __forceinline__ void mlp_recurrent_tile(const MlpNet& net, const MlpL
 
 // representation + prediction (network.py:62-84).  Expects X (packed obs) in LDS, barrier passed.
 //   out: HS = normalised hidden (and grow rows), pi_out LDS [16][A] (softmax), OUT[e][1] = value.
+// The root's layers are read once per move, by every workgroup at the same moment, and have long left the L2 by then
+// (a move streams ~100 MB of hidden states through it): un-prefetched, each dependent block of the root GEMMs waits a
+// full HBM round trip.  Each workgroup touches its share of the lines of `layers` at kernel start -- workgroups are
+// dealt round-robin to the 8 XCDs, so the workgroups of one XCD (blockIdx / 8) split that XCD's copy -- and the GEMMs,
+// ~25 k cycles later, find them in L2.  Returns a value the caller must keep alive (store it under a condition that is
+// never true) so that the loads are not dropped.
+__device__ __forceinline__ float prefetch_root_weights(const MlpNet& net, const int* layers, int n_layers, int tid) {
+    const int peers = (int)(gridDim.x + 7) >> 3;
+    const int parts = peers < 32 ? peers : 32, part = (int)(blockIdx.x >> 3) % parts;
+    float acc = 0.0f;
+    for (int li = 0; li < n_layers; li++) {
+        const MlpLayer& L = net.L[layers[li]];
+        const int lines = L.n_tiles * L.kg * 8;  // 1 KiB per (tile, block) = 8 lines of 128 B
+        for (int i = part * WG_THREADS + tid; i < lines; i += parts * WG_THREADS) acc += __builtin_nontemporal_load(L.w + (size_t)i * 32);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds& o, float* lds, float* const* grow, float* pi_out, int tid,
-                                                 bool active = true) {
+                                                 bool active = true, bool want_value = true) {
+    // `want_value == false`: the search discards the root's value (mcts.py:356-367 expands the root with the prior only), so
+    // its value head is not evaluated
     // `active == false`: a wave that only keeps the workgroup barriers uniform (512-thread kernels run this 4-wave
     // pipeline on waves 0-3)
     const int lane = tid & 63, wave = tid >> 6;
+    MZ_ROOT_TS_START();
     if (active) gemm_layer(net.L[L_REP0], lds, lds + o.X, wave, lane, EpiReluPacked{lds + o.H1, lane});
     __syncthreads();
+    MZ_ROOT_TS(0);
     if (active) gemm_layer(net.L[L_REP1], lds, lds + o.H1, wave, lane, EpiRawPacked{lds + o.HN, lane});
     __syncthreads();
+    MZ_ROOT_TS(1);
     if (active) normalize_tile(net, lds + o.HN, lds + o.HS, grow, tid);
     __syncthreads();
+    MZ_ROOT_TS(2);
     if (active) {
         gemm_layer(net.L[L_POL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.H1, lane});
-        gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
+        if (want_value) gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
     }
     __syncthreads();
+    MZ_ROOT_TS(3);
     if (active) {
         gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-        gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+        if (want_value) gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
     }
     __syncthreads();
+    MZ_ROOT_TS(4);
     if (active) {
         row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi_out + (tid >> 4) * net.A, net.A, tid & 15);
-        heads_to_scalars(net, o, lds, tid, false);
+        if (want_value) heads_to_scalars(net, o, lds, tid, false);
     }
     __syncthreads();
+    MZ_ROOT_TS(5);
 }
 
 // Fill X with [hidden row (H floats, global; zero padded to h_pad) | one-hot(action) block(s)] for the 16 envs

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
     } else {
         load_obs(P.net, lds + P.o.X, src, tid);
         __syncthreads();
-        mlp_initial_tile(P.net, P.o, lds, dst, pi0, tid);  // root value is discarded (mcts.py:356-367)
+        mlp_initial_tile(P.net, P.o, lds, dst, pi0, tid, true, false);  // root value is discarded (mcts.py:356-367)
     }
     root_noise_lanes(smem, P, e, a0, env_g, env_ok);
     __syncthreads();

@@ -255,6 +255,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     const bool env_ok = env_g < Pm.B;
     if constexpr (FUSE) fused_env_pre(Pm, a0, env_g, env_ok);
     const MlpNet& net = Pm.net;
+    const int root_layers[4] = {L_REP0, L_REP1, L_POL0, L_POL1};
+    const float warm = prefetch_root_weights(net, root_layers, 4, tid);
     const MlpLds& o = Pm.o;
     float* pi0 = reinterpret_cast<float*>(smem + Pm.t_pi0);
     const float** src = reinterpret_cast<const float**>(smem + Pm.t_ptr);
@@ -294,9 +296,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     load_obs(net, lds + o.X, src, tid);
     __syncthreads();
     MZ_STAMP(15);  // root: Dirichlet draws + observation load
-    mlp_initial_tile(net, o, lds, dst, pi0, tid);
+    mlp_initial_tile(net, o, lds, dst, pi0, tid, true, false);  // the root's value is discarded (mcts.py:356-367)
+    if (Pm.S < 0) Pm.hidden[0] = warm;  // never true: keeps the prefetch loads alive
     __syncthreads();
-    if (a0 == 0 && env_ok) root_prior(smem, Pm, e, env_g);
+    {
+        MZ_ROOT_TS_START();
+        if (a0 == 0 && env_ok) root_prior(smem, Pm, e, env_g);
+        MZ_ROOT_TS(6);
+    }
 
     // ---- this wave's weight stream; ring primed with the first RD - 1 slots ----
     const int voff = lane * 16;

@@ -990,7 +990,8 @@ extern "C" int mz_debug_read_tree_stamps(mz_planner* p, long long out[32]) {
 #ifdef MZ_STAMPS
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(mz::g_ts), 32 * sizeof(long long)));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(mz::g_ts), 24 * sizeof(long long)));
+    HIPCHK(hipMemcpyFromSymbol(out + 24, HIP_SYMBOL(mz::g_root_ts), 8 * sizeof(long long)));  // root inference segments (mz_mlp.h)
 #endif
     return MZ_OK;
 }
