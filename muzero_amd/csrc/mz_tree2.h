@@ -20,6 +20,15 @@
 //     < margin.  Otherwise (or if the cached evaluation saw a real tie, whose np.random.choice draw must be consumed at
 //     visit time, mcts.py:124) the level is evaluated at visit time exactly as the reference does.  The cache is a pure
 //     shortcut: it never changes a result.
+//   * TWO ACTIONS (classic control): with one rival the validity of a cached choice can be tested exactly instead of through
+//     the drift bound, at the cost of two FMAs per level: the best action's lead over the other one is
+//         D = (Qn_best - Qn_other) + (U_best - U_other),   Qn = (vq - min) * rinv for a visited child, 0 for an unvisited one,
+//     and only min and rinv change between the backups that pass through the node.  The cache keeps ud = U_best - U_other and
+//     the Q part relative to a per-env reference point qref in [min, max]: both visited: a = vq_best - vq_other, k = 0; one
+//     visited (sign s = +1 if it is the best one): a = s * (vq - qref), k = s; so D = (a + k * (qref - min)) * rinv + ud in
+//     float32, within 3e-6 of what the evaluation would compute (every term is bounded by the range, so float32 rounding of
+//     the parts stays relative to normalised units).  D > slack proves the evaluation would pick the same action without
+//     a tie; 91 % of the level evaluations that the drift bound forced at 4096 CartPole envs re-confirmed the cached choice.
 //   * a DESCENT is therefore mostly a chain of single 8-byte cache reads, software-pipelined: the next level's entry is
 //     requested before the loop's exit test resolves (measured on gfx950 with one wave per SIMD, tools/micro/chase.hip:
 //     a bare dependent ds_read_b64 chain costs 69 cycles per level, the first version of this loop -- lane predicates
@@ -37,30 +46,34 @@
 //     of every path node (each lane loops over its node's actions) are lane-parallel.
 #pragma once
 
-struct __attribute__((aligned(8))) Node2 {  // 24 bytes
+struct __attribute__((aligned(16))) Node2 {  // 16 bytes: one ds_read_b128
     double W;
-    int N;
     float reward;
-    short parent;
-    short move;
-    int player;
+    short N;
+    unsigned short link;  // bits 0-7 parent node + 1 (0: the root), bits 8-11 the move that led here, bits 12-15 player to move
 };
+__device__ __forceinline__ unsigned short node_link(int parent, int move, int player) {
+    return (unsigned short)((parent + 1) | (move << 8) | (player << 12));
+}
 struct __attribute__((aligned(16))) Entry2 {  // 16 bytes
     double vq;  // child's reward + discount * (+/-)Q  (the min-max update value == un-normalised child_Q term)
     float U;    // child_U of this action for the parent's and child's current visit counts (float32, mcts.py:189-200)
     short cn;   // child's visit count (0: never expanded)
     short c;    // child's node index, -1 if unexpanded
 };
-struct __attribute__((aligned(8))) SelCache {  // 8 bytes
+struct __attribute__((aligned(16))) SelCache {  // 16 bytes: one ds_read_b128
     int packed;  // bits 0-7 best action (0xff: evaluate at visit time), bits 8-15 env epoch when computed (mod 256,
                  // bumped when normalisation switches on), bits 16-31 best child node (signed, -1 unexpanded)
-    float t;     // margin + 2 * drift at compute time, rounded down: valid while 2 * drift_now + slack < t
+    float t;     // A > 2: margin + 2 * drift at compute time, rounded down: valid while 2 * drift_now + slack < t
+                 // A == 2: ud = child_U(best) - child_U(other)
+    float a, k;  // A == 2 (see "TWO ACTIONS" in the header): the best action's lead is (a + k * (qref - min)) * rinv + ud
 };
 struct EnvCacheState {  // per env, 32 bytes
     double drift;  // sum of D_k
     double rinv;   // RN(1 / (max - min)) of the env's current min-max pair (valid while max > min)
+    double qref;   // A == 2: the env's minimum when normalisation switched on (any fixed point of [min, max] would do)
     int epoch;
-    int pad[3];
+    int pad;
 };
 
 // float32(MinMaxStats.normalize(v)) exactly as the reference computes it, usually without the division (see header).
@@ -127,16 +140,17 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     // written by the backup that creates it
     for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].U = 0.0f; en[i].cn = 0; en[i].c = -1; }
     SelCache* c = reinterpret_cast<SelCache*>(smem + P.t_cache);
-    for (int i = tid; i < TILE_E * (P.NN + 1); i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); }  // t = -inf: never a hit
+    for (int i = tid; i < TILE_E * (P.NN + 1); i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); c[i].a = __uint_as_float(0xff800000u); c[i].k = 0.0f; }  // -inf: never a hit
     if (tid < TILE_E) {
         EnvCacheState* st = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + tid;
         st->drift = 0.0; st->epoch = 0;
         st->rinv = P.has_bounds ? 1.0 / (P.kb_max - P.kb_min) : 0.0;
+        st->qref = P.has_bounds ? P.kb_min : 0.0;
     }
     if ((tid & 15) == 0) {
         const int e = tid >> 4;
         Node2* r = node2_at(smem, P, e, 0);
-        r->W = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1; r->player = env_ok ? P.cur[env_g] : 0;
+        r->W = 0.0; r->N = 0; r->reward = 0.0f; r->link = node_link(-1, 0, env_ok ? P.cur[env_g] : 0);
     }
 }
 
@@ -165,7 +179,8 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     const EnvCacheState st = reinterpret_cast<const EnvCacheState*>(smem + P.t_ver)[e];
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
     const double mn = mm[0], mx = mm[1];
-    const bool norm = mx > mn, lane_ok = a0 < P.A;
+    const bool norm = mx > mn, lane_ok = a0 < P.A, two = P.A == 2;
+    const float dmp = (float)(st.qref - mn), r32 = norm ? (float)st.rinv : 0.0f;  // two actions: exact lead test (header)
     const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
     int n = env_ok ? (resume & 0xffff) : SENT, ties = sel[3];
     int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
@@ -174,22 +189,28 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     for (;;) {
         // ---- phase A: chase cached best children (software-pipelined: see the header) ----
         MZ_TS(0);  // [0] prelude / between phases
-        SelCache cc = cb[n];
-        for (;;) {
-            MZ_TS_COUNT(1);  // [1] phase-A iterations
-            const bool adv = thr < cc.t;
-            const int c = cc.packed >> 16;
-            const bool stop = adv & (c < 0);
-            const int nxt = adv ? (c < 0 ? SENT : c) : n;
-            const SelCache nc = cb[nxt];
-            if (a0 == 0) path[k] = (short)n;  // node at depth k (parked segments re-write their spare slot)
-            lp = stop ? n : lp;
-            la = stop ? (cc.packed & 0xff) : la;
-            k += adv ? 1 : 0;
-            if (__builtin_amdgcn_ballot_w64(adv) == 0) break;
-            n = nxt;
-            cc = nc;
-        }
+        auto chase = [&](auto two_tag) {  // two copies of the loop: the exact two-action test costs the margin scheme's levels two FMAs
+            constexpr bool TWO = decltype(two_tag)::value;
+            SelCache cc = cb[n];
+            for (;;) {
+                MZ_TS_COUNT(1);  // [1] phase-A iterations
+                // (an entry stored before normalisation switched on has a = -inf: -inf * 0 is NaN, the test fails)
+                const bool adv = TWO ? (fmaf(fmaf(cc.k, dmp, cc.a), r32, cc.t) > kCacheSlack) : (thr < cc.t);
+                const int c = cc.packed >> 16;
+                const bool stop = adv & (c < 0);
+                const int nxt = adv ? (c < 0 ? SENT : c) : n;
+                const SelCache nc = cb[nxt];
+                if (a0 == 0) path[k] = (short)n;  // node at depth k (parked segments re-write their spare slot)
+                lp = stop ? n : lp;
+                la = stop ? (cc.packed & 0xff) : la;
+                k += adv ? 1 : 0;
+                if (__builtin_amdgcn_ballot_w64(adv) == 0) break;
+                n = nxt;
+                cc = nc;
+            }
+        };
+        if (two) chase(std::true_type{});
+        else chase(std::false_type{});
         MZ_TS(2);  // [2] phase-A cycles
         if (__builtin_amdgcn_ballot_w64(n != SENT) == 0) break;
         MZ_TS_COUNT(3);  // [3] phase-B rounds
@@ -227,6 +248,18 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                     }
                 }
                 MZ_TS(5);  // [5] phase B: max, tie set, (rare) draw
+#ifdef MZ_COUNTERS
+                const int ocn = dpp_i<0xb1>((int)en.cn);
+                if (live && a0 == 0) {  // why was this level evaluated?  [4] evaluations, [5] both children visited, [6] of those: the cached choice still stands, [7] one child unvisited and the cached choice still stands
+                    const SelCache pc = cb[n];
+                    const int ca = pc.packed & 0xff;
+                    const bool both = (en.cn > 0) && (ocn > 0);
+                    MZ_COUNT(4, 1);
+                    if (both) MZ_COUNT(5, 1);
+                    if (both && ca != 0xff && ca == as && !tie) MZ_COUNT(6, 1);
+                    if (!both && ca != 0xff && ca == as && !tie) MZ_COUNT(7, 1);
+                }
+#endif
                 cs = as ? c1 : c0;
                 MZ_TS(6);  // [6] phase B: pick + child broadcast
             } else {
@@ -302,7 +335,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     MZ_TS_START();
     if (a0 == 0 && env_ok) {  // expand (mcts.py:386); LDS operations of one wave execute in order: later reads see this
         Node2* nd = node2_at(smem, P, e, nw);
-        nd->W = 0.0; nd->N = 0; nd->reward = r32; nd->parent = (short)lp; nd->move = (short)la; nd->player = cp;
+        nd->W = 0.0; nd->N = 0; nd->reward = r32; nd->link = node_link(lp, la, cp);
     }
     double mn = mm[0], mx = mm[1];
     const double mn0 = mn, mx0 = mx;
@@ -316,11 +349,11 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         const int from_row = (int)path[idx >= 0 ? idx : 0];
         const int p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
         Node2* x = node2_at(smem, P, e, p);
-        const float rwf = x->reward;
-        const int pl = x->player;
-        const double W0 = x->W;
-        const int N0 = x->N;
-        const int par = x->parent, mv = x->move;
+        const Node2 xn = *x;
+        const float rwf = xn.reward;
+        const double W0 = xn.W;
+        const int N0 = xn.N;
+        const int lk = xn.link, par = (lk & 0xff) - 1, mv = (lk >> 8) & 15, pl = lk >> 12;
         const double rw = valid ? (double)rwf : 0.0;
         const bool same = valid & (pl == cp);
         MZ_TS(0);  // [0] backup: expand + path node loads
@@ -346,7 +379,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             const int N = N0 + 1;
             const double Q = W / (double)N;
             const double v = board ? (rw + g * -Q) : (rw + g * Q);
-            x->W = W; x->N = N;
+            x->W = W; x->N = (short)N;
             if (par >= 0) {
                 Entry2* en = entry2_row(smem, P, e, par) + mv;
                 en->vq = v; en->cn = (short)N; en->c = (short)p;
@@ -380,6 +413,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             st.drift += (d_lo > d_hi ? d_lo : d_hi) * 1.000001 + 1e-12;
         } else {
             st.epoch++;  // normalisation may switch on: nothing cached before survives
+            st.qref = mn;
         }
         if (a0 == 0 && env_ok) MZ_COUNT(3, 1);
     }
@@ -389,7 +423,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         // nodes get fresh entries in pass 2 below
         if (switched_on) {
             SelCache* cbase = cache_at(smem, P, e, 0);
-            for (int i = a0; i < P.NN; i += 16) cbase[i].t = __uint_as_float(0xff800000u);
+            for (int i = a0; i < P.NN; i += 16) { cbase[i].t = __uint_as_float(0xff800000u); cbase[i].a = __uint_as_float(0xff800000u); }
         }
     }
     MZ_TS(4);  // [4] backup: drift / rinv bookkeeping + stores
@@ -411,7 +445,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             Entry2* er = entry2_row(smem, P, e, p);
             float best = __uint_as_float(0xff800000u), second = __uint_as_float(0xff800000u);
             int besta = 0, cnt = 0;
-            // CH actions per round (their LDS reads overlap); 2 when there are only 2 actions: padding a round costs real work
+            // CH actions per round (their LDS reads overlap)
             auto rank_actions = [&](auto ch_tag) {
                 constexpr int CH = decltype(ch_tag)::value;
                 for (int a4 = 0; a4 < P.A; a4 += CH) {
@@ -444,14 +478,38 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                     }
                 }
             };
-            if (P.A <= 2) rank_actions(std::integral_constant<int, 2>{});
-            else rank_actions(std::integral_constant<int, 4>{});
-            MZ_TS(5);  // [5] backup pass 2: per-action loop
-            SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
-            cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
-            cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : __uint_as_float(0xff800000u);
-            *cache_at(smem, P, e, p) = cc;
-            decided = thr < cc.t;
+            if (P.A == 2) {
+                // two actions: candidate = first maximum of the (un-checked) ranking; whether the next descents may follow it
+                // is decided by the exact lead test (header, "TWO ACTIONS"), here and at every visit
+                const Entry2 e0 = er[0], e1 = er[1];
+                const double f0 = frow[e0.cn], f1 = frow[e1.cn], p0 = prior[0], p1 = prior[1];
+                const float ua0 = child_u(p0, f0, prior_f32), ua1 = child_u(p1, f1, prior_f32);  // this node's N (and one child's) just changed
+                er[0].U = ua0; er[1].U = ua1;
+                const bool v0 = e0.cn > 0, v1 = e1.cn > 0;
+                const float q0 = norm ? (float)((e0.vq - mn) * st.rinv) : (float)e0.vq, q1 = norm ? (float)((e1.vq - mn) * st.rinv) : (float)e1.vq;
+                const bool b1 = ((v1 ? q1 : 0.0f) + ua1) > ((v0 ? q0 : 0.0f) + ua0);
+                const double vb = b1 ? e1.vq : e0.vq, vo = b1 ? e0.vq : e1.vq;
+                const bool visb = b1 ? v1 : v0, viso = b1 ? v0 : v1;
+                bestc = b1 ? (int)e1.c : (int)e0.c;
+                MZ_TS(5);  // [5] backup pass 2: per-action loop
+                SelCache cc;
+                cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+                cc.t = b1 ? ua1 - ua0 : ua0 - ua1;
+                const float qa = (visb & viso) ? (float)(vb - vo) : (visb ? (float)(vb - st.qref) : (viso ? (float)(st.qref - vo) : 0.0f));
+                cc.a = norm ? qa : __uint_as_float(0xff800000u);  // raw-Q levels (before normalisation switches on) are evaluated at visit time
+                cc.k = (visb == viso) ? 0.0f : (visb ? 1.0f : -1.0f);
+                *cache_at(smem, P, e, p) = cc;
+                decided = fmaf(fmaf(cc.k, (float)(st.qref - mn), cc.a), norm ? (float)st.rinv : 0.0f, cc.t) > kCacheSlack;
+            } else {
+                rank_actions(std::integral_constant<int, 4>{});
+                MZ_TS(5);  // [5] backup pass 2: per-action loop
+                SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
+                cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+                cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : __uint_as_float(0xff800000u);
+                cc.a = 0.0f; cc.k = 0.0f;
+                *cache_at(smem, P, e, p) = cc;
+                decided = thr < cc.t;
+            }
         }
         if (L <= 16) {
             // lane a0 owns path position L-1-a0 (lane 0: the new leaf, lane L-1: the root); the next descent retraces the

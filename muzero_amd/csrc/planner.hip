@@ -190,11 +190,11 @@ static void compute_layout(mz_planner* p) {
     // tree_mode 2 layout (mz_tree2.h) replaces t_nodes / t_child / t_ftab when it fits in LDS
     p->lds_mode0 = s.lds_bytes;
     p->tree2_ok = false;
-    if (s.A <= 16) {
+    if (s.A <= 16 && s.NN < 255) {
         b = o.total_floats * 4;
-        const int n2 = take(16 * s.NN * 24, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
+        const int n2 = take(16 * s.NN * 16, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
                   p0 = take(16 * s.A * 4, 16), mmo = take(16 * 2 * 8, 16), se = take(128 * 4, 16), pt = take(32 * 8, 16),
-                  ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * (s.NN + 1) * 8, 16), pa = take(16 * (s.NN + 3) * 2, 16),
+                  ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * (s.NN + 1) * 16, 16), pa = take(16 * (s.NN + 3) * 2, 16),
                   ve = take(16 * 32, 16);
         const int total = (b + 15) & ~15;
         if (total <= 160 * 1024) {

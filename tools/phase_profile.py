@@ -65,6 +65,9 @@ def main():
     if cn[0]:
         print(f'tree counters (counters build; timings below are distorted): levels {cn[0]}, cache hits {cn[1]} ({100 * cn[1] / cn[0]:.1f}%), '
               f'descents {cn[2]}, mean depth {cn[0] / max(cn[2], 1):.2f}, min-max changes per descent {cn[3] / max(cn[2], 1):.3f}')
+    if cn[2] and cn[4]:
+        print(f'level evaluations (2-action path): {cn[4] / cn[2]:.2f} per descent; both children visited {100 * cn[5] / cn[4]:.1f}%, of all: cached choice '
+              f'still stood {100 * cn[6] / cn[4]:.1f}%, one unvisited + still stood {100 * cn[7] / cn[4]:.1f}%; min-max changes per descent {cn[3] / cn[2]:.3f}')
     print(f'{g}: total stamped ticks per move (block 0): {total:.0f}  (s_memtime ticks, 100 MHz on gfx950)')
     print(f'  {"root: noise + obs":18s} {root_noise:10.0f}  {100 * root_noise / total:5.1f}%')
     for i, name in enumerate(NAMES):
