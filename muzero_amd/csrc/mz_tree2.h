@@ -97,6 +97,9 @@ __device__ __forceinline__ float norm_q(double v, double mn, double mx, double r
 __device__ __forceinline__ float child_u(double prior_a, double f, bool prior_f32) {
     return prior_f32 ? ((float)prior_a * (float)f) : (float)(prior_a * f);
 }
+// two-action lead test (header, "TWO ACTIONS"): the float32 reciprocal of the range; select and backup must use this very
+// expression -- the backup's resume point promises what the next descent's test will say
+__device__ __forceinline__ float lead_r32(double mn, double mx) { return mx > mn ? __builtin_amdgcn_rcpf((float)(mx - mn)) : 0.0f; }
 constexpr float kCacheSlack = 4e-5f;  // float32 rounding of child_Q / child_U / their sum, for |ucb| < 64
 
 template <int CTRL>
@@ -180,7 +183,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
     const double mn = mm[0], mx = mm[1];
     const bool norm = mx > mn, lane_ok = a0 < P.A, two = P.A == 2;
-    const float dmp = (float)(st.qref - mn), r32 = norm ? (float)st.rinv : 0.0f;  // two actions: exact lead test (header)
+    const float dmp = (float)(st.qref - mn), r32 = lead_r32(mn, mx);  // two actions: exact lead test (header)
     const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
     int n = env_ok ? (resume & 0xffff) : SENT, ties = sel[3];
     int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
@@ -222,7 +225,8 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                 // TWO actions: every lane evaluates action (lane & 1) and takes the other one's value and child from its
                 // neighbour (one quad permute each) -- no segment reduction, no ballot, no child broadcast
                 const Entry2 en = entry2_row(smem, P, e, live ? n : 0)[a0 & 1];
-                const float u = puct_entry(en, mn, mx, st.rinv, norm);
+                const double rinv2 = norm ? 1.0 / (mx - mn) : 0.0;  // two-action searches keep no reciprocal: evaluations are rare
+                const float u = puct_entry(en, mn, mx, rinv2, norm);
                 MZ_TS(4);  // [4] phase B: entry read + pUCT value
                 const float uo = __int_as_float(dpp_i<0xb1>(__float_as_int(u)));  // quad_perm [1,0,3,2]
                 const int co = dpp_i<0xb1>((int)en.c);
@@ -405,13 +409,18 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     EnvCacheState st = *stp;
     bool switched_on = false;
     if (mn != mn0 || mx != mx0) {
-        st.rinv = mx > mn ? 1.0 / (mx - mn) : 0.0;  // the one division per min-max change (norm_q)
         switched_on = !(mx0 > mn0);
-        if (mx0 > mn0) {
+        if (P.A == 2) {
+            // exact lead test: no drift, and the reciprocal is formed where it is needed
+        } else if (mx0 > mn0) {
+            st.rinv = 1.0 / (mx - mn);  // the one division per min-max change (norm_q)
             // D_k is only an upper bound: the products are within 2 ulp of the quotients, the 1.000001 factor covers that
             const double d_lo = (mn0 - mn) * st.rinv, d_hi = (mx - mx0) * st.rinv;
             st.drift += (d_lo > d_hi ? d_lo : d_hi) * 1.000001 + 1e-12;
         } else {
+            st.rinv = mx > mn ? 1.0 / (mx - mn) : 0.0;
+        }
+        if (switched_on) {
             st.epoch++;  // normalisation may switch on: nothing cached before survives
             st.qref = mn;
         }
@@ -486,7 +495,8 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 const float ua0 = child_u(p0, f0, prior_f32), ua1 = child_u(p1, f1, prior_f32);  // this node's N (and one child's) just changed
                 er[0].U = ua0; er[1].U = ua1;
                 const bool v0 = e0.cn > 0, v1 = e1.cn > 0;
-                const float q0 = norm ? (float)((e0.vq - mn) * st.rinv) : (float)e0.vq, q1 = norm ? (float)((e1.vq - mn) * st.rinv) : (float)e1.vq;
+                const float r32n = lead_r32(mn, mx);
+                const float q0 = norm ? (float)(e0.vq - mn) * r32n : (float)e0.vq, q1 = norm ? (float)(e1.vq - mn) * r32n : (float)e1.vq;
                 const bool b1 = ((v1 ? q1 : 0.0f) + ua1) > ((v0 ? q0 : 0.0f) + ua0);
                 const double vb = b1 ? e1.vq : e0.vq, vo = b1 ? e0.vq : e1.vq;
                 const bool visb = b1 ? v1 : v0, viso = b1 ? v0 : v1;
@@ -499,7 +509,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 cc.a = norm ? qa : __uint_as_float(0xff800000u);  // raw-Q levels (before normalisation switches on) are evaluated at visit time
                 cc.k = (visb == viso) ? 0.0f : (visb ? 1.0f : -1.0f);
                 *cache_at(smem, P, e, p) = cc;
-                decided = fmaf(fmaf(cc.k, (float)(st.qref - mn), cc.a), norm ? (float)st.rinv : 0.0f, cc.t) > kCacheSlack;
+                decided = fmaf(fmaf(cc.k, (float)(st.qref - mn), cc.a), r32n, cc.t) > kCacheSlack;
             } else {
                 rank_actions(std::integral_constant<int, 4>{});
                 MZ_TS(5);  // [5] backup pass 2: per-action loop
