@@ -335,6 +335,8 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     const int L = env_ok ? depth + 1 : 0;  // path nodes including the new one
     const double g = P.discount;
     const bool board = P.board != 0;
+    EnvCacheState st = *stp;  // read with the other per-env words: by the time it is needed the round trip is over
+    int n_after = 0;          // this lane's node's visit count after pass 1 (single-chunk paths: pass 2 need not re-read it)
     MZ_TS_DECL
     MZ_TS_START();
     if (a0 == 0 && env_ok) {  // expand (mcts.py:386); LDS operations of one wave execute in order: later reads see this
@@ -384,6 +386,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             const double Q = W / (double)N;
             const double v = board ? (rw + g * -Q) : (rw + g * Q);
             x->W = W; x->N = (short)N;
+            n_after = N;
             if (par >= 0) {
                 Entry2* en = entry2_row(smem, P, e, par) + mv;
                 en->vq = v; en->cn = (short)N; en->c = (short)p;
@@ -406,7 +409,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     }
     MZ_TS(3);  // [3] backup: min-max reduction
     // cache-validity bookkeeping for the min-max change of this backup (see header)
-    EnvCacheState st = *stp;
     bool switched_on = false;
     if (mn != mn0 || mx != mx0) {
         switched_on = !(mx0 > mn0);
@@ -449,7 +451,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         bool decided = false;  // the refreshed cache entry will let the next descent pass through p without evaluating it
         int bestc = -1;
         if (valid) {
-            const int Np = node2_at(smem, P, e, p)->N;
+            const int Np = L <= 16 ? n_after : (int)node2_at(smem, P, e, p)->N;
             const double* frow = ftab + tri(Np);
             Entry2* er = entry2_row(smem, P, e, p);
             float best = __uint_as_float(0xff800000u), second = __uint_as_float(0xff800000u);
