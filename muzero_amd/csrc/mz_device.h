@@ -119,6 +119,56 @@ __device__ __forceinline__ float row2_logits_to_scalar(float l0, float l1, bool 
     return signed_parabolic(butterfly16(t));
 }
 
+// Two rows at once (the reward and the value head of one env on the same 16 lanes): the same arithmetic as two calls of
+// row2_logits_to_scalar, written as ONE basic block so that the two latency-bound chains (DPP reductions, exp polynomial,
+// IEEE division, sqrt) interleave; behind the callers' per-head `S == 1` branches they ran one after the other.
+__device__ __forceinline__ void butterfly16_max2(float& a, float& b) {
+    asm volatile("s_nop 0\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void rows2_logits_to_scalars(const float (&l0)[2], const float (&l1)[2], const bool (&has0)[2], const bool (&has1)[2],
+                                                        const int (&S)[2], int j, float (&out)[2]) {
+    const float ninf = __uint_as_float(0xff800000u);
+    float m[2], e0[2], e1[2], a[2], sum[2], t[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        m[r] = has0[r] ? l0[r] : ninf;
+        m[r] = (has1[r] & (l1[r] > m[r])) ? l1[r] : m[r];
+    }
+    butterfly16_max2(m[0], m[1]);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const float x0 = expf_det((has0[r] ? l0[r] : m[r]) - m[r]), x1 = expf_det((has1[r] ? l1[r] : m[r]) - m[r]);
+        e0[r] = has0[r] ? x0 : 0.0f;
+        e1[r] = has1[r] ? x1 : 0.0f;
+        a[r] = 0.0f;
+        a[r] = has0[r] ? a[r] + e0[r] : a[r];
+        a[r] = has1[r] ? a[r] + e1[r] : a[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) sum[r] = butterfly16(a[r]);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int half = (S[r] - 1) / 2;
+        const float p0 = e0[r] / sum[r], p1 = e1[r] / sum[r];
+        const float t0 = p0 * (float)(j - half), t1 = p1 * (float)(j + 16 - half);
+        t[r] = 0.0f;
+        t[r] = has0[r] ? t[r] + t0 : t[r];
+        t[r] = has1[r] ? t[r] + t1 : t[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) t[r] = butterfly16(t[r]);
+#pragma unroll
+    for (int r = 0; r < 2; r++) out[r] = signed_parabolic(t[r]);
+}
+
 // logits_to_transformed_expected_value, util.py:70-93: softmax -> E[linspace(-(S-1)/2, (S-1)/2, S)] -> signed_parabolic,
 // computed by the 16 lanes of a segment on one row `lg` (LDS, overwritten with the exponentials).  S == 1: identity.
 __device__ __forceinline__ float row_logits_to_scalar(float* lg, int S, int j) {

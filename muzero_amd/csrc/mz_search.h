@@ -490,9 +490,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
 
     int resume = 0;
     const int cp0 = env_ok ? P.cur[env_g] : 0, op0 = env_ok ? P.opp[env_g] : 0;  // the root's players: read once per move, not per descent
+    Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
+    tree2_env_init(T, P);
     for (int s = 0; s < P.S; s++) {
         int lp_unused, la_unused;
-        if (P.tree_mode == 2) tree2_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused, cp0, op0, resume);
+        if (P.tree_mode == 2) tree2_select<true>(smem, P, tid, env_ok, env_g, T, cp0, op0, resume);
         else tree_select(smem, P, tid, env_ok, env_g, lp_unused, la_unused);
         __syncthreads();
         const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
             r32 = lds[P.o.OUT + e * 4 + 0];
             v32 = lds[P.o.OUT + e * 4 + 1];
         }
-        if (P.tree_mode == 2) resume = tree2_backup(smem, P, tid, env_ok, s, r32, v32);
+        if (P.tree_mode == 2) resume = tree2_backup(smem, P, tid, env_ok, s, r32, v32, T);
         else if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
         __syncthreads();
     }

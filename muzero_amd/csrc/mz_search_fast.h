@@ -343,10 +343,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
 
     int resume = 0;
     const int cp0 = env_ok ? Pm.cur[env_g] : 0, op0 = env_ok ? Pm.opp[env_g] : 0;  // the root's players: read once per move, not per descent
+    Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
+    tree2_env_init(T, Pm);
     for (int s = 0; s < Pm.S; s++) {
         int lp, la;
-        if (Pm.tree_mode == 2) tree2_select(smem, Pm, tid, env_ok, env_g, lp, la, cp0, op0, resume);
-        else tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
+        if (Pm.tree_mode == 2) {
+            tree2_select(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
+            lp = T.lp; la = T.la;
+        } else {
+            tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
+        }
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
         {
@@ -476,6 +482,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
             const float* fr = reinterpret_cast<const float*>(PBr);
             const float* fv = reinterpret_cast<const float*>(PBv);
             float rew, val;
+            if (net.Sr != 1 && net.Sv != 1) {  // both heads categorical (every single-player configuration): the two rows interleaved
+                const bool hr0 = a0 < net.Sr, hr1 = a0 + 16 < net.Sr, hv0 = a0 < net.Sv, hv1 = a0 + 16 < net.Sv;
+                const float l0[2] = {head_logit<TR>(fr, hr0 ? a0 : 0, e), head_logit<TV>(fv, hv0 ? a0 : 0, e)};
+                const float l1[2] = {head_logit<TR>(fr, hr1 ? a0 + 16 : 0, e), head_logit<TV>(fv, hv1 ? a0 + 16 : 0, e)};
+                const bool h0[2] = {hr0, hv0}, h1[2] = {hr1, hv1};
+                const int SS[2] = {net.Sr, net.Sv};
+                float out[2];
+                rows2_logits_to_scalars(l0, l1, h0, h1, SS, a0, out);
+                rew = out[0];
+                val = out[1];
+            } else {
             if (net.Sr == 1) {
                 rew = head_logit<TR>(fr, 0, e);
             } else {
@@ -490,8 +507,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
                 const float lv0 = head_logit<TV>(fv, v0 ? a0 : 0, e), lv1 = head_logit<TV>(fv, v1 ? a0 + 16 : 0, e);
                 val = row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
             }
+            }
             MZ_STAMP(8);  // softmax + expectation + transform
-            if (Pm.tree_mode == 2) resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val);
+            if (Pm.tree_mode == 2) resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val, T);
             else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
         }
         if (Pm.tree_mode != 2) __syncthreads();  // mode 2: backup and the next select of an env run on the same 16 lanes

@@ -68,13 +68,25 @@ struct __attribute__((aligned(16))) SelCache {  // 16 bytes: one ds_read_b128
                  // A == 2: ud = child_U(best) - child_U(other)
     float a, k;  // A == 2 (see "TWO ACTIONS" in the header): the best action's lead is (a + k * (qref - min)) * rinv + ud
 };
-struct EnvCacheState {  // per env, 32 bytes
-    double drift;  // sum of D_k
-    double rinv;   // RN(1 / (max - min)) of the env's current min-max pair (valid while max > min)
-    double qref;   // A == 2: the env's minimum when normalisation switched on (any fixed point of [min, max] would do)
-    int epoch;
-    int pad;
+// Per-env search state that select and backup hand to each other IN REGISTERS (identical in the env's 16 lanes: every
+// update is computed segment-uniformly) -- through LDS each hand-over cost a write, a read and their round trips, ~1 k
+// cycles per simulation for a wave that runs alone on its SIMD.
+struct Tree2Env {
+    double mn, mx;   // MinMaxStats (mcts.py:36-48)
+    double drift;    // A > 2: sum of D_k
+    double rinv;     // A > 2: RN(1 / (max - min)) of the current min-max pair (valid while max > min)
+    double qref;     // A == 2: the env's minimum when normalisation switched on (any fixed point of [min, max] would do)
+    int epoch, ties; // normalisation switch-ons; tie draws consumed so far (indexes the tie RNG stream, mcts.py:124)
+    int lp, la, cp, depth;  // the last descent: leaf parent, leaf action, player to move at the leaf, expanded nodes on the path
 };
+__device__ __forceinline__ void tree2_env_init(Tree2Env& t, const SearchParams& P) {
+    t.mn = P.has_bounds ? P.kb_min : __longlong_as_double(0x7ff0000000000000LL);  // MinMaxStats, mcts.py:36-38
+    t.mx = P.has_bounds ? P.kb_max : __longlong_as_double(0xfff0000000000000LL);
+    t.drift = 0.0;
+    t.rinv = P.has_bounds ? 1.0 / (P.kb_max - P.kb_min) : 0.0;
+    t.qref = P.has_bounds ? P.kb_min : 0.0;
+    t.epoch = 0; t.ties = 0; t.lp = 0; t.la = 0; t.cp = 0; t.depth = 0;
+}
 
 // float32(MinMaxStats.normalize(v)) exactly as the reference computes it, usually without the division (see header).
 // Straight-line: the division sits behind a wave-level test that is almost never true.
@@ -144,12 +156,6 @@ __device__ __forceinline__ void tree2_init(unsigned char* smem, const SearchPara
     for (int i = tid; i < TILE_E * P.NN * P.A; i += WG_THREADS) { en[i].vq = 0.0; en[i].U = 0.0f; en[i].cn = 0; en[i].c = -1; }
     SelCache* c = reinterpret_cast<SelCache*>(smem + P.t_cache);
     for (int i = tid; i < TILE_E * (P.NN + 1); i += WG_THREADS) { c[i].packed = 0xffff; c[i].t = __uint_as_float(0xff800000u); c[i].a = __uint_as_float(0xff800000u); c[i].k = 0.0f; }  // -inf: never a hit
-    if (tid < TILE_E) {
-        EnvCacheState* st = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + tid;
-        st->drift = 0.0; st->epoch = 0;
-        st->rinv = P.has_bounds ? 1.0 / (P.kb_max - P.kb_min) : 0.0;
-        st->qref = P.has_bounds ? P.kb_min : 0.0;
-    }
     if ((tid & 15) == 0) {
         const int e = tid >> 4;
         Node2* r = node2_at(smem, P, e, 0);
@@ -172,20 +178,19 @@ __device__ __forceinline__ float puct_entry(const Entry2& en, double mn, double 
 // (best_child, mcts.py:104-127).
 // `resume` (from the previous tree2_backup; 0 for the first descent): node to start at | its depth << 16 -- the path row
 // still holds the nodes above it.  `cp0` / `op0`: the env's current / opponent player at the root.
-__device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, int& leaf_parent,
-                                             int& leaf_action, int cp0, int op0, int resume = 0) {
+template <bool PUBLISH = false>
+__device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, Tree2Env& T, int cp0,
+                                             int op0, int resume = 0) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
-    const double* mm = reinterpret_cast<const double*>(smem + P.t_mm) + e * 2;
-    int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
     short* path = path_row(smem, P, e);
     const SelCache* cb = cache_at(smem, P, e, 0);
-    const EnvCacheState st = reinterpret_cast<const EnvCacheState*>(smem + P.t_ver)[e];
+    const Tree2Env& st = T;
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
-    const double mn = mm[0], mx = mm[1];
+    const double mn = T.mn, mx = T.mx;
     const bool norm = mx > mn, lane_ok = a0 < P.A, two = P.A == 2;
     const float dmp = (float)(st.qref - mn), r32 = lead_r32(mn, mx);  // two actions: exact lead test (header)
     const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
-    int n = env_ok ? (resume & 0xffff) : SENT, ties = sel[3];
+    int n = env_ok ? (resume & 0xffff) : SENT, ties = T.ties;
     int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
     MZ_TS_DECL
     MZ_TS_START();
@@ -307,35 +312,31 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
         MZ_TS(7);  // [7] phase B: bookkeeping
     }
     if (a0 == 0 && env_ok) MZ_COUNT(2, 1);
-    if (a0 == 0) {
-        // players swap at every level (mcts.py:379): the leaf's player follows from the parity of the depth
-        sel[0] = lp; sel[1] = la; sel[2] = (k & 1) ? op0 : cp0; sel[3] = ties;
-        reinterpret_cast<int*>(smem + P.t_sel)[80 + e] = k;  // expanded nodes on the path (root .. leaf parent)
+    // players swap at every level (mcts.py:379): the leaf's player follows from the parity of the depth
+    T.lp = lp; T.la = la; T.cp = (k & 1) ? op0 : cp0; T.ties = ties; T.depth = k;  // k: expanded nodes on the path (root .. leaf parent)
+    if (PUBLISH && a0 == 0) {  // kernels whose network evaluation reads the leaf from LDS
+        int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
+        sel[0] = lp; sel[1] = la;
     }
     MZ_TS(8);  // [8] epilogue (sel[] writes)
     MZ_TS_COUNT(9);  // [9] calls
     MZ_TS_FLUSH(0);
-    leaf_parent = lp;
-    leaf_action = la;
 }
 
 // expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
 // the path row as written by tree2_select of the same simulation
 // returns the resume point of the next descent (see header)
-__device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32) {
+__device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
+                                            Tree2Env& T) {
     const int e = tid >> 4, a0 = tid & 15;
-    const int* sel = reinterpret_cast<const int*>(smem + P.t_sel) + e * 4;
-    double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
-    EnvCacheState* stp = reinterpret_cast<EnvCacheState*>(smem + P.t_ver) + e;
     const short* path = path_row(smem, P, e);
     const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
     const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
-    const int lp = sel[0], la = sel[1], cp = sel[2], nw = s + 1;
-    const int depth = reinterpret_cast<const int*>(smem + P.t_sel)[80 + e];
-    const int L = env_ok ? depth + 1 : 0;  // path nodes including the new one
+    const int lp = T.lp, la = T.la, cp = T.cp, nw = s + 1;
+    const int L = env_ok ? T.depth + 1 : 0;  // path nodes including the new one
     const double g = P.discount;
     const bool board = P.board != 0;
-    EnvCacheState st = *stp;  // read with the other per-env words: by the time it is needed the round trip is over
+    Tree2Env& st = T;
     int n_after = 0;          // this lane's node's visit count after pass 1 (single-chunk paths: pass 2 need not re-read it)
     MZ_TS_DECL
     MZ_TS_START();
@@ -343,7 +344,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         Node2* nd = node2_at(smem, P, e, nw);
         nd->W = 0.0; nd->N = 0; nd->reward = r32; nd->link = node_link(lp, la, cp);
     }
-    double mn = mm[0], mx = mm[1];
+    double mn = T.mn, mx = T.mx;
     const double mn0 = mn, mx0 = mx;
     double val_in = (double)v32;
     // pass 1: statistics (lane i owns the i-th node counted from the leaf)
@@ -428,7 +429,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         }
         if (a0 == 0 && env_ok) MZ_COUNT(3, 1);
     }
-    if (a0 == 0 && env_ok) { mm[0] = mn; mm[1] = mx; *stp = st; }
+    T.mn = mn; T.mx = mx;
     if (__any(switched_on)) {
         // normalisation may have switched on: no cached choice of this env survives (rare: once per search); the path
         // nodes get fresh entries in pass 2 below
