@@ -497,22 +497,22 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 const double f0 = frow[e0.cn], f1 = frow[e1.cn], p0 = prior[0], p1 = prior[1];
                 const float ua0 = child_u(p0, f0, prior_f32), ua1 = child_u(p1, f1, prior_f32);  // this node's N (and one child's) just changed
                 er[0].U = ua0; er[1].U = ua1;
+                // the lead of action 1 over action 0 (header, "TWO ACTIONS"); its sign IS the ranking, so no separate one is made
                 const bool v0 = e0.cn > 0, v1 = e1.cn > 0;
-                const float r32n = lead_r32(mn, mx);
-                const float q0 = norm ? (float)(e0.vq - mn) * r32n : (float)e0.vq, q1 = norm ? (float)(e1.vq - mn) * r32n : (float)e1.vq;
-                const bool b1 = ((v1 ? q1 : 0.0f) + ua1) > ((v0 ? q0 : 0.0f) + ua0);
-                const double vb = b1 ? e1.vq : e0.vq, vo = b1 ? e0.vq : e1.vq;
-                const bool visb = b1 ? v1 : v0, viso = b1 ? v0 : v1;
+                const float r32n = lead_r32(mn, mx), dmpn = (float)(st.qref - mn);
+                const double x0 = v0 ? e0.vq : st.qref, x1 = v1 ? e1.vq : st.qref;  // an unvisited child's Q term is 0: it enters through k
+                const float a10 = (float)(x1 - x0), k10 = (float)((v1 ? 1 : 0) - (v0 ? 1 : 0)), ud10 = ua1 - ua0;
+                const float d10 = fmaf(fmaf(k10, dmpn, a10), r32n, ud10);
+                const bool b1 = d10 > 0.0f;  // (a lead within the slack -- ties included -- is never followed: the level is evaluated at visit time)
                 bestc = b1 ? (int)e1.c : (int)e0.c;
                 MZ_TS(5);  // [5] backup pass 2: per-action loop
                 SelCache cc;
                 cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | (bestc << 16);
-                cc.t = b1 ? ua1 - ua0 : ua0 - ua1;
-                const float qa = (visb & viso) ? (float)(vb - vo) : (visb ? (float)(vb - st.qref) : (viso ? (float)(st.qref - vo) : 0.0f));
-                cc.a = norm ? qa : __uint_as_float(0xff800000u);  // raw-Q levels (before normalisation switches on) are evaluated at visit time
-                cc.k = (visb == viso) ? 0.0f : (visb ? 1.0f : -1.0f);
+                cc.t = b1 ? ud10 : -ud10;
+                cc.a = norm ? (b1 ? a10 : -a10) : __uint_as_float(0xff800000u);  // raw-Q levels (before normalisation switches on) are evaluated at visit time
+                cc.k = b1 ? k10 : -k10;
                 *cache_at(smem, P, e, p) = cc;
-                decided = fmaf(fmaf(cc.k, (float)(st.qref - mn), cc.a), r32n, cc.t) > kCacheSlack;
+                decided = norm & (fabsf(d10) > kCacheSlack);  // == what the next descent's test computes from cc (negation is exact)
             } else {
                 rank_actions(std::integral_constant<int, 4>{});
                 MZ_TS(5);  // [5] backup pass 2: per-action loop
