@@ -111,7 +111,12 @@ __device__ __forceinline__ float child_u(double prior_a, double f, bool prior_f3
 }
 // two-action lead test (header, "TWO ACTIONS"): the float32 reciprocal of the range; select and backup must use this very
 // expression -- the backup's resume point promises what the next descent's test will say
-__device__ __forceinline__ float lead_r32(double mn, double mx) { return mx > mn ? __builtin_amdgcn_rcpf((float)(mx - mn)) : 0.0f; }
+__device__ __forceinline__ float lead_r32(double mn, double mx) {
+    // NaN (the test then fails and the level is evaluated) while normalisation is off, and for ranges so small that the
+    // float32 parts of the test would leave the normal range
+    const float rg = (float)(mx - mn);
+    return rg > 1e-30f ? __builtin_amdgcn_rcpf(rg) : __uint_as_float(0x7fc00000u);
+}
 constexpr float kCacheSlack = 4e-5f;  // float32 rounding of child_Q / child_U / their sum, for |ucb| < 64
 
 template <int CTRL>
@@ -202,7 +207,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
             SelCache cc = cb[n];
             for (;;) {
                 MZ_TS_COUNT(1);  // [1] phase-A iterations
-                // (an entry stored before normalisation switched on has a = -inf: -inf * 0 is NaN, the test fails)
+                // (while normalisation is off r32 is NaN, and entries stored then carry a = -inf: the test fails)
                 const bool adv = TWO ? (fmaf(fmaf(cc.k, dmp, cc.a), r32, cc.t) > kCacheSlack) : (thr < cc.t);
                 const int c = cc.packed >> 16;
                 const bool stop = adv & (c < 0);

@@ -271,6 +271,37 @@ def test_full_size_c3_properties_and_oracle_sample(oracle):
         np.testing.assert_array_equal(r1[k][sub], o[k])
 
 
+def test_full_size_c2_properties_and_oracle_sample(oracle):
+    """BASELINE configs[1] at full size (CartPole MLP 512/64/31, 4096 envs, 50 simulations, no value bounds: the moving min-max
+    pair and the two-action exact lead test of mz_tree2.h) in parity mode: every 2nd env (2048 searches, 102 400 simulations) is
+    checked bit-exactly against the oracle, all envs against the size-independent properties."""
+    case = mlp_case('cartpole')
+    net = build_mlp(case)
+    onet = _oracle_net(oracle, net, 'mlp')
+    B, S, A = 4096, 50, 2
+    kw = dict(num_simulations=S, discount=0.997, root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    rs = np.random.RandomState(77)
+    obs = rs.uniform(-1.5, 1.5, size=(B,) + tuple(case[1])).astype(np.float32)
+    mask = np.ones((B, A), bool)
+    cur = np.ones(B, np.int32)
+    temp = rs.choice([1.0, 0.5, 0.25], size=B)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie, u_final = rs.rand(B, 4 * S + 8), rs.rand(B)
+    p = _planner(net, B, **kw)
+    r1 = p.search(obs, mask, cur, cur, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    r2 = p.search(obs, mask, cur, cur, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    for k in ('visits', 'pi', 'action', 'root_value'):
+        np.testing.assert_array_equal(r1[k], r2[k])
+    v = r1['visits']
+    assert (v.sum(1) == S).all()
+    sub = np.arange(0, B, 2)
+    ocfg = oracle.make_config(A, S, 0.997, False, None, 0.25, 0.25)
+    o = oracle.uct_search_batch(ocfg, onet, obs[sub], mask[sub].astype(np.uint8), cur[sub], cur[sub], temp[sub], False, noise=noise[sub],
+                                u_tie=u_tie[sub], u_final=u_final[sub])
+    for k in ('visits', 'pi', 'action', 'root_value'):
+        np.testing.assert_array_equal(r1[k][sub], o[k])
+
+
 def test_selfplay_episode_matches_reference_fixture(oracle):
     """pipeline.py:41-167 on TicTacToe replayed through uct_search (B=1 API) with the recorded draws."""
     from muzero_amd import mcts
