@@ -267,25 +267,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     // ---- tables, tree, root (identical to k_search) ----
     stage_biases(net, lds, tid);
     {
-        if (Pm.tree_mode == 2) {
-            tree2_init(smem, Pm, tid, env_ok, env_g);
-        } else {
-            double* ft = reinterpret_cast<double*>(smem + Pm.t_ftab);
-            for (int i = tid; i < (Pm.S + 1) * (Pm.S + 1); i += WG_THREADS) ft[i] = Pm.ftab[i];
-            short* ch = reinterpret_cast<short*>(smem + Pm.t_child);
-            for (int i = tid; i < TILE_E * Pm.NN * Pm.A; i += WG_THREADS) ch[i] = -1;
-            if (a0 == 0) {
-                TreeNode* r = node_at(smem, Pm, e, 0);
-                r->W = 0.0; r->vq = 0.0; r->N = 0; r->reward = 0.0f; r->parent = -1; r->move = -1;
-                r->player = env_ok ? Pm.cur[env_g] : 0;
-            }
-        }
+        tree2_init(smem, Pm, tid, env_ok, env_g);  // (this kernel is tree_mode 2 only: the launcher sends other layouts to k_search)
         if (a0 == 0) {
-            double* mm = reinterpret_cast<double*>(smem + Pm.t_mm) + e * 2;
-            mm[0] = Pm.has_bounds ? Pm.kb_min : __longlong_as_double(0x7ff0000000000000LL);
-            mm[1] = Pm.has_bounds ? Pm.kb_max : __longlong_as_double(0xfff0000000000000LL);
-            int* sel = reinterpret_cast<int*>(smem + Pm.t_sel) + e * 4;
-            sel[0] = sel[1] = sel[2] = sel[3] = 0;
             src[e] = env_ok ? Pm.obs + (size_t)env_g * net.in_dim : nullptr;
             dst[e] = env_ok ? Pm.hidden + (size_t)env_g * Pm.NN * net.H : nullptr;
         }
@@ -346,13 +329,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
     tree2_env_init(T, Pm);
     for (int s = 0; s < Pm.S; s++) {
-        int lp, la;
-        if (Pm.tree_mode == 2) {
-            tree2_select(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
-            lp = T.lp; la = T.la;
-        } else {
-            tree_select(smem, Pm, tid, env_ok, env_g, lp, la);
-        }
+        tree2_select(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
+        const int lp = T.lp, la = T.la;
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
         {
@@ -509,16 +487,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
             }
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            if (Pm.tree_mode == 2) resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val, T);
-            else if (a0 == 0 && env_ok) tree_expand_backup(smem, Pm, e, s, rew, val);
+            resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val, T);  // backup and the next select of an env run on the same 16 lanes: no barrier
         }
-        if (Pm.tree_mode != 2) __syncthreads();  // mode 2: backup and the next select of an env run on the same 16 lanes
         MZ_STAMP(9);  // expand + backup
     }
-    if (a0 == 0 && env_ok) {
-        if (Pm.tree_mode == 2) tree2_finish(smem, Pm, e, env_g);
-        else tree_finish(smem, Pm, e, env_g);
-    }
+    if (a0 == 0 && env_ok) tree2_finish(smem, Pm, e, env_g);
     if constexpr (FUSE)
         if (env_ok) env_step_group(Pm.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
     MZ_STAMP(10);  // play policy + action

@@ -718,7 +718,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         hipLaunchKernelGGL(k_gtree_finish, grid, block, 0, p->stream, G);
     } else
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
-    else if (p->fast_planes && !p->force_generic) {
+    else if (p->fast_planes && !p->force_generic && s.tree_mode == 2) {  // (k_search_fast is written for the tree_mode 2 layout)
         const int two = p->net.L[L_VAL1].n_tiles == 2;
 #define MZ_FAST(PL, T) do { if (fenv) hipLaunchKernelGGL((k_search_fast<PL, T, T, true>), grid, block, s.lds_bytes, p->stream, s, p->fw); \
                             else hipLaunchKernelGGL((k_search_fast<PL, T, T, false>), grid, block, s.lds_bytes, p->stream, s, p->fw); } while (0)
