@@ -235,7 +235,11 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                 // TWO actions: every lane evaluates action (lane & 1) and takes the other one's value and child from its
                 // neighbour (one quad permute each) -- no segment reduction, no ballot, no child broadcast
                 const Entry2 en = entry2_row(smem, P, e, live ? n : 0)[a0 & 1];
-                const double rinv2 = norm ? 1.0 / (mx - mn) : 0.0;  // two-action searches keep no reciprocal: evaluations are rare
+                // two-action searches keep no reciprocal: evaluations are rare.  (The empty asm pins the division inside this
+                // rarely taken block: left alone, hipcc hoists the loop-invariant quotient to the top of every descent.)
+                double range = mx - mn;
+                asm volatile("" : "+v"(range));
+                const double rinv2 = norm ? 1.0 / range : 0.0;
                 const float u = puct_entry(en, mn, mx, rinv2, norm);
                 MZ_TS(4);  // [4] phase B: entry read + pUCT value
                 const float uo = __int_as_float(dpp_i<0xb1>(__float_as_int(u)));  // quad_perm [1,0,3,2]
