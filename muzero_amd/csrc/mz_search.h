@@ -30,7 +30,7 @@ struct SearchParams {
     MlpLds o;
     // LDS byte offsets of the tree part
     int t_nodes, t_child, t_prior, t_pi0, t_mm, t_sel, t_ftab, t_ptr, t_tmp;
-    // tree_mode 2 layout (mz_tree2.h): 24-byte nodes, per-(node, action) child entries, selection cache, path, version
+    // tree_mode 2 layout (mz_tree2.h): 16-byte nodes, per-(node, action) child entries, selection cache, path (t_ver: unused, kept for layout stability)
     int t2_nodes, t2_entries, t_cache, t_path, t_ver, t2_ftab;
     int tree_mode;  // 0: reference-order tree walk (mz_search.h); 2: entry table + selection cache + lane-parallel backup (mz_tree2.h, A <= 16)
     const double* ftab_tri;  // [(S+1)(S+2)/2]: ftab restricted to n_child <= N

@@ -29,7 +29,7 @@
 //     float32, within 3e-6 of what the evaluation would compute (every term is bounded by the range, so float32 rounding of
 //     the parts stays relative to normalised units).  D > slack proves the evaluation would pick the same action without
 //     a tie; 91 % of the level evaluations that the drift bound forced at 4096 CartPole envs re-confirmed the cached choice.
-//   * a DESCENT is therefore mostly a chain of single 8-byte cache reads, software-pipelined: the next level's entry is
+//   * a DESCENT is therefore mostly a chain of single 16-byte cache reads, software-pipelined: the next level's entry is
 //     requested before the loop's exit test resolves (measured on gfx950 with one wave per SIMD, tools/micro/chase.hip:
 //     a bare dependent ds_read_b64 chain costs 69 cycles per level, the first version of this loop -- lane predicates
 //     bouncing between VALU compares and SALU mask logic, two branches -- 305, this form 180).  A segment that has
