@@ -204,8 +204,16 @@ struct PadSlots {
 };
 
 // min / max of two non-NaN floats as ONE v_med3_f32 (fminf / fmaxf add a canonicalising v_max x, x per operand)
-__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __uint_as_float(0xff800000u)); }
-__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __uint_as_float(0x7f800000u)); }
+// one v_med3_f32 each: with a literal infinity hipcc folds fmed3 into maxnum / minnum and renders those as canonicalise
+// (v_max x, x) + the operation -- two issue slots per element on ~170 elements per simulation -- so the infinity is made opaque.
+// (Inline-asm v_max / v_min would be shorter still, but the hazard recogniser does not see into asm: no wait states after the
+// MFMA that produces the operand -- measured as a parity failure.)  Operands are never NaN here.
+__device__ __forceinline__ float opaque_f32(unsigned int bits) {
+    asm("" : "+s"(bits));
+    return __uint_as_float(bits);
+}
+__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, opaque_f32(0xff800000u)); }
+__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, opaque_f32(0x7f800000u)); }
 // all-lane min / max over the four 16-lane rows of a wave (same lane & 15): v_permlane16_swap / v_permlane32_swap
 // exchange whole rows between two registers, so min(r[0], r[1]) is the xor-16 (xor-32) butterfly step in every lane
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -224,7 +232,7 @@ __device__ __forceinline__ float rows_max(float v) {
 
 template <int N>
 __device__ __forceinline__ void relu_tiles(f32x4 (&a)[N]) {
-    const float inf = __uint_as_float(0x7f800000u);
+    const float inf = opaque_f32(0x7f800000u);
 #pragma unroll
     for (int j = 0; j < N; j++) {
 #pragma unroll
