@@ -16,8 +16,12 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmzplanner_hip.so')
 SOURCES = ['planner.hip']
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs where they fit.  The search kernels read every accumulator
+# with VALU code right after the layer (ReLU, normalisation, partial sums); in the default AGPR form each of those reads is a
+# v_accvgpr_read first (96 per simulation in k_search_fast: +2 % on C2, measured), and no kernel of this library needs the
+# second register file (none spills either way).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17', '-Wall', '-Wno-unused-function',
-         '-Wno-pass-failed']
+         '-Wno-pass-failed', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 
 
 def _deps():
