@@ -20,8 +20,10 @@ SOURCES = ['planner.hip']
 # with VALU code right after the layer (ReLU, normalisation, partial sums); in the default AGPR form each of those reads is a
 # v_accvgpr_read first (96 per simulation in k_search_fast: +2 % on C2, measured), and no kernel of this library needs the
 # second register file (none spills either way).
+# -amdgpu-sched-strategy=max-ilp: the search kernels run ONE wave per SIMD (LDS-bound occupancy), so the default strategy's
+# occupancy-driven register economy buys nothing; scheduling for ILP does (+2 % C2, +1 % C3, conv kernels unchanged: measured).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17', '-Wall', '-Wno-unused-function',
-         '-Wno-pass-failed', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+         '-Wno-pass-failed', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-mllvm', '-amdgpu-sched-strategy=max-ilp']
 
 
 def _deps():
