@@ -250,7 +250,7 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
 
 // P = num_planes (256 or 512); TR / TV: tiles of the reward / value support (1 or 2)
 // FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
-template <int P, int TR, int TV, bool FUSE = false>
+template <int P, int TR, int TV, bool FUSE = false, bool TWO = false>
 __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
     constexpr int RD = kFastRD;
     using C = FastCfg<P, TR, TV, RD>;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
 #pragma unroll
         for (int j = 0; j < NT; j++) ring[i][j] = bload(ws, voff, i * NT + j);
     }
-    const int x_last = net.L[L_DYN0].last_steps;  // k-steps of the action block (1..4)
+    const int x_last = TWO ? 1 : net.L[L_DYN0].last_steps;  // k-steps of the action block (1..4)
     // MFMA-side env of this lane (D column) and its hidden-state rows in the HBM node store
     const int e2 = lane & 15, q = lane >> 4;
     const int env2 = blockIdx.x * TILE_E + e2;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
     tree2_env_init(T, Pm);
     for (int s = 0; s < Pm.S; s++) {
-        tree2_select(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
+        tree2_select<false, TWO ? 2 : 0>(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
         const int lp = T.lp, la = T.la;
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
             }
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            resume = tree2_backup(smem, Pm, tid, env_ok, s, rew, val, T);  // backup and the next select of an env run on the same 16 lanes: no barrier
+            resume = tree2_backup<TWO ? 2 : 0>(smem, Pm, tid, env_ok, s, rew, val, T);  // backup and the next select of an env run on the same 16 lanes: no barrier
         }
         MZ_STAMP(9);  // expand + backup
     }

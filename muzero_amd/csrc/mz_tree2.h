@@ -183,7 +183,9 @@ __device__ __forceinline__ float puct_entry(const Entry2& en, double mn, double 
 // (best_child, mcts.py:104-127).
 // `resume` (from the previous tree2_backup; 0 for the first descent): node to start at | its depth << 16 -- the path row
 // still holds the nodes above it.  `cp0` / `op0`: the env's current / opponent player at the root.
-template <bool PUBLISH = false>
+// AM: what the caller knows about the action count at compile time (-1 nothing, 2 exactly two actions, 0 more than two) --
+// the benchmark kernels fix it, which removes the other path's code and scalars from their simulation loop
+template <bool PUBLISH = false, int AM = -1>
 __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int env_g, Tree2Env& T, int cp0,
                                              int op0, int resume = 0) {
     const int e = tid >> 4, a0 = tid & 15, seg = (tid & 63) >> 4;
@@ -192,7 +194,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     const Tree2Env& st = T;
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
     const double mn = T.mn, mx = T.mx;
-    const bool norm = mx > mn, lane_ok = a0 < P.A, two = P.A == 2;
+    const bool norm = mx > mn, lane_ok = a0 < P.A, two = AM < 0 ? P.A == 2 : AM == 2;
     const float dmp = (float)(st.qref - mn), r32 = lead_r32(mn, mx);  // two actions: exact lead test (header)
     const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
     int n = env_ok ? (resume & 0xffff) : SENT, ties = T.ties;
@@ -231,7 +233,7 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
         {
             const bool live = n != SENT;
             int as, cs;
-            if (P.A == 2) {
+            if (two) {
                 // TWO actions: every lane evaluates action (lane & 1) and takes the other one's value and child from its
                 // neighbour (one quad permute each) -- no segment reduction, no ballot, no child broadcast
                 const Entry2 en = entry2_row(smem, P, e, live ? n : 0)[a0 & 1];
@@ -335,9 +337,11 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
 // expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
 // the path row as written by tree2_select of the same simulation
 // returns the resume point of the next descent (see header)
+template <int AM = -1>
 __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
                                             Tree2Env& T) {
     const int e = tid >> 4, a0 = tid & 15;
+    const bool two = AM < 0 ? P.A == 2 : AM == 2;
     const short* path = path_row(smem, P, e);
     const double* ftab = reinterpret_cast<const double*>(smem + P.t2_ftab);
     const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
@@ -422,7 +426,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     bool switched_on = false;
     if (mn != mn0 || mx != mx0) {
         switched_on = !(mx0 > mn0);
-        if (P.A == 2) {
+        if (two) {
             // exact lead test: no drift, and the reciprocal is formed where it is needed
         } else if (mx0 > mn0) {
             st.rinv = 1.0 / (mx - mn);  // the one division per min-max change (norm_q)
@@ -499,7 +503,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                     }
                 }
             };
-            if (P.A == 2) {
+            if (two) {
                 // two actions: candidate = first maximum of the (un-checked) ranking; whether the next descents may follow it
                 // is decided by the exact lead test (header, "TWO ACTIONS"), here and at every visit
                 const Entry2 e0 = er[0], e1 = er[1];

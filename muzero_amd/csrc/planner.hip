@@ -384,14 +384,11 @@ static int planner_init(mz_planner* p, bool conv) {
     if (c.hidden_dim == 64 && (c.num_planes == 256 || c.num_planes == 512) && c.num_actions <= 16 && c.value_support_size <= 32 &&
         c.reward_support_size <= 32 && (c.value_support_size + 15) / 16 == (c.reward_support_size + 15) / 16) {
         p->fast_planes = c.num_planes;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<512, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+#define MZ_FAST_LDS(PL, T, F, W) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<PL, T, T, F, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
+#define MZ_FAST_LDS4(PL, T) MZ_FAST_LDS(PL, T, false, false); MZ_FAST_LDS(PL, T, false, true); MZ_FAST_LDS(PL, T, true, false); MZ_FAST_LDS(PL, T, true, true)
+        MZ_FAST_LDS4(256, 1); MZ_FAST_LDS4(256, 2); MZ_FAST_LDS4(512, 1); MZ_FAST_LDS4(512, 2);
+#undef MZ_FAST_LDS4
+#undef MZ_FAST_LDS
     }
     return MZ_OK;
 }
@@ -720,10 +717,13 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
     else if (p->fast_planes && !p->force_generic && s.tree_mode == 2) {  // (k_search_fast is written for the tree_mode 2 layout)
         const int two = p->net.L[L_VAL1].n_tiles == 2;
-#define MZ_FAST(PL, T) do { if (fenv) hipLaunchKernelGGL((k_search_fast<PL, T, T, true>), grid, block, s.lds_bytes, p->stream, s, p->fw); \
-                            else hipLaunchKernelGGL((k_search_fast<PL, T, T, false>), grid, block, s.lds_bytes, p->stream, s, p->fw); } while (0)
+#define MZ_FAST4(PL, T, F, W) hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W>), grid, block, s.lds_bytes, p->stream, s, p->fw)
+#define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, true); else MZ_FAST4(PL, T, true, false); } \
+                            else { if (two_act) MZ_FAST4(PL, T, false, true); else MZ_FAST4(PL, T, false, false); } } while (0)
+        const bool two_act = c.num_actions == 2;  // compile-time two-action specialisation of the tree code (mz_tree2.h, AM)
         if (p->fast_planes == 512) { if (two) MZ_FAST(512, 2); else MZ_FAST(512, 1); }
         else { if (two) MZ_FAST(256, 2); else MZ_FAST(256, 1); }
+#undef MZ_FAST4
 #undef MZ_FAST
     }
     else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
