@@ -468,7 +468,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams P
             const float* fr = reinterpret_cast<const float*>(PBr);
             const float* fv = reinterpret_cast<const float*>(PBv);
             float rew, val;
-            if (net.Sr != 1 && net.Sv != 1) {  // both heads categorical (every single-player configuration): the two rows interleaved
+            if (TWO || (net.Sr != 1 && net.Sv != 1)) {  // both heads categorical (TWO: guaranteed by the launcher) (every single-player configuration): the two rows interleaved
                 const bool hr0 = a0 < net.Sr, hr1 = a0 + 16 < net.Sr, hv0 = a0 < net.Sv, hv1 = a0 + 16 < net.Sv;
                 const float l0[2] = {head_logit<TR>(fr, hr0 ? a0 : 0, e), head_logit<TV>(fv, hv0 ? a0 : 0, e)};
                 const float l1[2] = {head_logit<TR>(fr, hr1 ? a0 + 16 : 0, e), head_logit<TV>(fv, hv1 ? a0 + 16 : 0, e)};

@@ -348,7 +348,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     const int lp = T.lp, la = T.la, cp = T.cp, nw = s + 1;
     const int L = env_ok ? T.depth + 1 : 0;  // path nodes including the new one
     const double g = P.discount;
-    const bool board = P.board != 0;
+    const bool board = AM == 2 ? false : P.board != 0;  // (the launcher picks AM == 2 for single-player searches only)
     Tree2Env& st = T;
     int n_after = 0;          // this lane's node's visit count after pass 1 (single-chunk paths: pass 2 need not re-read it)
     MZ_TS_DECL

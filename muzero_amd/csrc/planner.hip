@@ -720,7 +720,8 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
 #define MZ_FAST4(PL, T, F, W) hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W>), grid, block, s.lds_bytes, p->stream, s, p->fw)
 #define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, true); else MZ_FAST4(PL, T, true, false); } \
                             else { if (two_act) MZ_FAST4(PL, T, false, true); else MZ_FAST4(PL, T, false, false); } } while (0)
-        const bool two_act = c.num_actions == 2;  // compile-time two-action specialisation of the tree code (mz_tree2.h, AM)
+        // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
+        const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
         if (p->fast_planes == 512) { if (two) MZ_FAST(512, 2); else MZ_FAST(512, 1); }
         else { if (two) MZ_FAST(256, 2); else MZ_FAST(256, 1); }
 #undef MZ_FAST4
