@@ -187,7 +187,7 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
     if rank == 0:
         sims_per_s = world * B * S * args.steps / elapsed
         ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
-        dom_kernel = {'c3': 'mz::k_search_fast<256, 1, 1, true>', 'c4': 'mz::k_res_tower<5>', 'c5': 'mz::k_conv3x3<15, 1, true>'}[name]
+        dom_kernel = {'c3': 'mz::k_search_fast<256, 1, 1, true, false>', 'c4': 'mz::k_res_tower<5>', 'c5': 'mz::k_conv3x3<15, 1, true>'}[name]
         traffic, traffic_src = profiled_traffic(name, dom_kernel.replace('mz::', '')) if (B == envs and S == sims) else (None, None)
         achieved = flop_per_move / (ms * 1e-3) / 1e12
         cpu = None
@@ -430,7 +430,7 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,2,2,false>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,2,2,false,true>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes of HBM per launch', 'traffic_source': traffic_src,
                 'algorithmic_hbm_bytes_per_launch': B * (S * 2 * 64 * 4 + 20 * 4 + 64 * 4 + 2 * 8 + 16),
                 'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,
