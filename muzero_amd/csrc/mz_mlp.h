@@ -87,6 +87,14 @@ struct MlpLds {
     int total_floats;
 };
 
+// one global_load_dwordx4: read through HIP's float4 struct the four components are separate scalar loads to the optimiser,
+// which re-merges them only some of the time -- the root inference's K-split loops ran on dword loads with one 64-bit
+// address each (2.5x slower than their MFMAs)
+__device__ __forceinline__ float4 ldg4(const float4* p) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // 4 k-steps (or `steps` of them) of one block for NACC accumulators
 template <int NACC>
 __device__ __forceinline__ void mma_block(f32x4 (&acc)[NACC], const float4 (&w)[NACC], const float4 x, int steps) {
@@ -142,19 +150,19 @@ __device__ __forceinline__ void gemm_chunk(const MlpLayer& L, const float* __res
     float4 w0[NACC], w1[NACC];
     const int g1 = L.kg > 1 ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < NACC; j++) w0[j] = wp[j][0];
+    for (int j = 0; j < NACC; j++) w0[j] = ldg4(&wp[j][0]);
 #pragma unroll
-    for (int j = 0; j < NACC; j++) w1[j] = wp[j][g1 * 64];
+    for (int j = 0; j < NACC; j++) w1[j] = ldg4(&wp[j][g1 * 64]);
     int g = 0;
     for (; g + 2 < L.kg; g += 2) {
         const float4 x0 = xp[g * 64], x1 = xp[(g + 1) * 64];
         const int gn = g + 3 < L.kg ? g + 3 : L.kg - 1;
         mma_block_full<NACC>(acc, w0, x0);
 #pragma unroll
-        for (int j = 0; j < NACC; j++) w0[j] = wp[j][(g + 2) * 64];
+        for (int j = 0; j < NACC; j++) w0[j] = ldg4(&wp[j][(g + 2) * 64]);
         mma_block_full<NACC>(acc, w1, x1);
 #pragma unroll
-        for (int j = 0; j < NACC; j++) w1[j] = wp[j][gn * 64];
+        for (int j = 0; j < NACC; j++) w1[j] = ldg4(&wp[j][gn * 64]);
     }
     if (L.kg - g == 2) {
         mma_block_full<NACC>(acc, w0, xp[g * 64]);
@@ -184,6 +192,9 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
     }
     const float4* xp = reinterpret_cast<const float4*>(Xs) + lane;
     constexpr int PD = NT2 == 1 ? 4 : 2;
+#ifdef MZ_STAMPS
+    const long long _gt0 = (blockIdx.x == 0 && threadIdx.x == 0) ? (long long)__builtin_readcyclecounter() : 0;
+#endif
     if (L.kg == 4 * L.kq && L.last_steps == 4 && L.kq % PD == 0) {
         // K a multiple of 64 * PD (every shipped configuration): four equal quarters of full blocks; PD rounds of weights in
         // flight in statically named register sets (see gemm_chunk), straight-line body
@@ -193,7 +204,7 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
 #pragma unroll
             for (int c = 0; c < 4; c++) {
 #pragma unroll
-                for (int j = 0; j < NT2; j++) wr[d][c][j] = wp[j][(c * L.kq + d) * 64];
+                for (int j = 0; j < NT2; j++) wr[d][c][j] = ldg4(&wp[j][(c * L.kq + d) * 64]);
             }
         }
         for (int gg0 = 0; gg0 < L.kq; gg0 += PD) {
@@ -215,7 +226,7 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
 #pragma unroll
-                    for (int j = 0; j < NT2; j++) wr[d][c][j] = wp[j][(c * L.kq + gw) * 64];
+                    for (int j = 0; j < NT2; j++) wr[d][c][j] = ldg4(&wp[j][(c * L.kq + gw) * 64]);
                 }
             }
         }
@@ -226,7 +237,7 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
         for (int c = 0; c < 4; c++) {
             const int g = c * L.kq < L.kg ? c * L.kq : 0;
 #pragma unroll
-            for (int j = 0; j < NT2; j++) w[c][j] = wp[j][g * 64];
+            for (int j = 0; j < NT2; j++) w[c][j] = ldg4(&wp[j][g * 64]);
         }
         for (int gg = 0; gg < L.kq; gg++) {
 #pragma unroll
@@ -234,7 +245,7 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
                 const int g = c * L.kq + gg + 1;
                 const int gl = (gg + 1 < L.kq && g < L.kg) ? g : 0;
 #pragma unroll
-                for (int j = 0; j < NT2; j++) wn[c][j] = wp[j][gl * 64];
+                for (int j = 0; j < NT2; j++) wn[c][j] = ldg4(&wp[j][gl * 64]);
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -256,6 +267,9 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
             }
         }
     }
+#ifdef MZ_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_root_ts[7] += (long long)__builtin_readcyclecounter() - _gt0;  // K-split GEMM loops of wave 0 (diagnostic)
+#endif
 #pragma unroll
     for (int j = 0; j < NT2; j++) {
         const f32x4 y = ((acc[j][0] + acc[j][1]) + acc[j][2]) + acc[j][3];
@@ -450,7 +464,7 @@ __device__ __forceinline__ float prefetch_root_weights(const MlpNet& net, const 
     for (int li = 0; li < n_layers; li++) {
         const MlpLayer& L = net.L[layers[li]];
         const int lines = L.n_tiles * L.kg * 8;  // 1 KiB per (tile, block) = 8 lines of 128 B
-        for (int i = part * WG_THREADS + tid; i < lines; i += parts * WG_THREADS) acc += __builtin_nontemporal_load(L.w + (size_t)i * 32);
+        for (int i = part * WG_THREADS + tid; i < lines; i += parts * WG_THREADS) acc += L.w[(size_t)i * 32];  // (a plain load: a non-temporal one would not leave the line in L2)
     }
     return acc;
 }

@@ -57,7 +57,7 @@ def main():
               f'pick+child {ts[6] / max(ts[3], 1):.0f}, bookkeeping {ts[7] / max(ts[3], 1):.0f} each; epilogue {ts[8] / d:.0f}')
     if ts[24]:
         d = float(n + 5)  # every move of this process ran the root once
-        print('root inference (per move): ' + ', '.join(f'{nm} {ts[24 + i] / d:.0f}' for i, nm in enumerate(['rep0', 'rep1', 'normalise', 'pol0+val0', 'pol1+val1', 'softmax+scalars', 'root prior'])))
+        print('root inference (per move): ' + ', '.join(f'{nm} {ts[24 + i] / d:.0f}' for i, nm in enumerate(['rep0', 'rep1', 'normalise', 'pol0+val0', 'pol1+val1', 'softmax+scalars', 'root prior', '(K-split GEMM loops of wave 0, all layers)'])))
     if ts[21]:
         d = float(ts[21])
         print(f'tree2_backup (per call): expand+loads {ts[12] / d:.0f}, value chain {ts[13] / d:.0f}, update {ts[14] / d:.0f}, min-max reduce {ts[15] / d:.0f}, '
