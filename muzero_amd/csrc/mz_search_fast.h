@@ -251,7 +251,7 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
 // P = num_planes (256 or 512); TR / TV: tiles of the reward / value support (1 or 2)
 // FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
 template <int P, int TR, int TV, bool FUSE = false, bool TWO = false>
-__global__ __launch_bounds__(WG_THREADS) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
     constexpr int RD = kFastRD;
     using C = FastCfg<P, TR, TV, RD>;
     constexpr int NT = C::NT;
