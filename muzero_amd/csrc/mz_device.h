@@ -328,16 +328,27 @@ struct Philox {
 __device__ inline double gamma_sample(Philox& g, double alpha) {
     if (alpha == 1.0) return -log(1.0 - g.uniform());
     if (alpha < 1.0) {
+        // float32 hardware log2 / exp2 (v_log_f32, v_exp_f32) with the power's exponent split off into a float64 ldexp: the
+        // rejection loop runs until the slowest of a wave's 64 lanes accepts (~5 rounds), and with ocml's float64 log + pow a
+        // round was ~1.5 k cycles -- 13 k cycles per move for noise whose distribution, not whose bits, is the contract
+        // (tests/test_gpu_rng.py).  The split keeps float64's range: for alpha = 0.03 a plain float32 power underflows for
+        // U < 0.07, both components of a 2-action draw vanish and the uniform fallback biases the variance (measured).
+        const float ia = (float)(1.0 / alpha), fa = (float)alpha, ln2 = 0.69314718056f;
+        auto pow2d = [](float t) {  // 2 ** t as a double, t clamped to the float64 exponent range
+            t = __builtin_amdgcn_fmed3f(t, -1070.0f, 1020.0f);
+            const float fl = floorf(t);
+            return ldexp((double)__builtin_amdgcn_exp2f(t - fl), (int)fl);
+        };
         for (int it = 0; it < 256; it++) {
-            double U = g.uniform();
-            double V = -log(1.0 - g.uniform());
-            if (U <= 1.0 - alpha) {
-                double X = pow(U, 1.0 / alpha);
+            const float U = (float)g.uniform();
+            const double V = (double)(-ln2 * __builtin_amdgcn_logf(1.0f - (float)g.uniform()));
+            if (U <= 1.0f - fa) {
+                const double X = pow2d(ia * __builtin_amdgcn_logf(U));
                 if (X <= V) return X;
             } else {
-                double Y = -log((1.0 - U) / alpha);
-                double X = pow(1.0 - alpha + alpha * Y, 1.0 / alpha);
-                if (X <= V + Y) return X;
+                const float Y = -ln2 * __builtin_amdgcn_logf((1.0f - U) / fa);
+                const double X = pow2d(ia * __builtin_amdgcn_logf(1.0f - fa + fa * Y));
+                if (X <= V + (double)Y) return X;
             }
         }
         return 0.0;
