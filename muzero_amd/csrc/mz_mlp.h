@@ -277,6 +277,40 @@ __device__ __forceinline__ void gemm_chunk_split(const MlpLayer& L, const float*
     }
 }
 
+// K-split layer with ONE output tile (a policy head with A <= 16): its four quarter chains dealt to the four waves -- on one
+// wave, as gemm_chunk_split runs them, the other three idle for the whole layer.  The partial tiles meet in `scratch`
+// (4 x 64 float4); wave 0 adds them in gemm_chunk_split's order, so the sums are the same.  Every thread of the workgroup
+// must call this (one barrier inside); returns false, having done nothing, when the layer is not of that shape.
+template <typename Epi>
+__device__ __forceinline__ bool gemm_one_tile_across_waves(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs,
+                                                           float* scratch, int wave, int lane, bool active, Epi epi) {
+    constexpr int KQ = 8;  // blocks per quarter kept in flight at once
+    if (!(L.split && L.n_tiles == 1 && L.kg == 4 * L.kq && L.last_steps == 4 && L.kq <= KQ)) return false;
+    if (active) {
+        const int q = lane >> 4;
+        f32x4 acc[1];
+        const float4 bv = *reinterpret_cast<const float4*>(lds + L.b_lds + q * 4);
+        acc[0] = wave == 0 ? f32x4{bv.x, bv.y, bv.z, bv.w} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // quarter 0 starts from the bias
+        const float4* wp = reinterpret_cast<const float4*>(L.w) + (size_t)(wave * L.kq) * 64 + lane;
+        const float4* xp = reinterpret_cast<const float4*>(Xs) + (size_t)(wave * L.kq) * 64 + lane;
+        float4 w[KQ][1];
+#pragma unroll
+        for (int g = 0; g < KQ; g++) w[g][0] = ldg4(&wp[(g < L.kq ? g : 0) * 64]);
+#pragma unroll
+        for (int g = 0; g < KQ; g++)
+            if (g < L.kq) mma_block_full<1>(acc, w[g], xp[g * 64]);
+        reinterpret_cast<float4*>(scratch)[wave * 64 + lane] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    }
+    __syncthreads();
+    if (active && wave == 0) {
+        const float4* sc = reinterpret_cast<const float4*>(scratch) + lane;
+        const float4 c0 = sc[0], c1 = sc[64], c2 = sc[128], c3 = sc[192];
+        const f32x4 y = {((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z, ((c0.w + c1.w) + c2.w) + c3.w};
+        epi(0, y);
+    }
+    return true;
+}
+
 template <typename Epi>
 __device__ __forceinline__ void gemm_layer(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs, int wave_slot,
                                            int lane, Epi epi) {
@@ -492,9 +526,12 @@ __device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds
     }
     __syncthreads();
     MZ_ROOT_TS(3);
-    if (active) {
-        gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-        if (want_value) gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+    // (without the value head the V1 buffer is free: scratch for the policy layer's partial tiles)
+    if (want_value || !gemm_one_tile_across_waves(net.L[L_POL1], lds, lds + o.H1, lds + o.V1, wave, lane, active, EpiLogits{lds + o.LG, o.lg_stride, lane})) {
+        if (active) {
+            gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+            if (want_value) gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+        }
     }
     __syncthreads();
     MZ_ROOT_TS(4);
