@@ -243,6 +243,86 @@ __device__ inline int group_or16(int v) {
     return v;
 }
 
+// Stones of `colour` in a row from (r, c) exclusive in direction (dr, dc), on a bitboard (bit = row * n + column)
+__device__ inline int board_line_bits(unsigned int stones, int n, int r, int c, int dr, int dc) {
+    int k = 0;
+    r += dr; c += dc;
+    while (r >= 0 && r < n && c >= 0 && c < n && ((stones >> (r * n + c)) & 1u)) { k++; r += dr; c += dc; }
+    return k;
+}
+
+// BoardGameEnv.step for boards of at most 16 points (TicTacToe): lane i owns point i, the whole pre-move state is fetched in
+// ONE batch of loads, the win test runs on a bitboard built by a ballot, and everything is stored afterwards -- two global
+// round trips per move instead of the strided version's dozen.  Same results as board_step_group (tests: device env vs the
+// oracle env).  `lane` 0..15; the group is 16 consecutive lanes of one wave, all of them active.
+__device__ inline void board_step_small(const EnvLaunch& L, int e, int lane, int a, float& reward, bool& done) {
+    const int n = L.env.bn, nn = L.env.nn;
+    signed char* b = L.env.board + (size_t)e * nn;
+    signed char* pl = L.env.planes + (size_t)e * 8 * nn;
+    const int me = L.env.player[e], opp = 3 - me, st = L.env.steps[e];
+    signed char* mine = pl + (me - 1) * 4 * nn;
+    const signed char* theirs = pl + (opp - 1) * 4 * nn;
+    const bool cell = lane < nn;
+    const int i = cell ? lane : 0;
+    const signed char bi = b[i];
+    const signed char m0 = mine[i], m1 = mine[nn + i], m2 = mine[2 * nn + i];
+    const signed char t0 = theirs[i], t1 = theirs[nn + i], t2 = theirs[2 * nn + i], t3 = theirs[3 * nn + i];
+    const int base = (int)(__lane_id() & 48u);
+    const unsigned int my_stones = (unsigned int)(__ballot(cell && bi == me) >> base) & 0xffffu;
+    const unsigned int open = (unsigned int)(__ballot(cell && bi == 0 && i != a) >> base) & 0xffffu;  // empty points other than the one just played
+    int winner = 0;
+    reward = 0.0f;
+    if (a == nn) {  // resign (games/env.py:134-136)
+        reward = -1.0f;
+        winner = opp;
+    } else if (st >= (L.env.win - 1) * 2) {  // games/tictactoe.py:37-38 with the pre-increment step count
+        const int r = a / n, c = a % n;
+        const int dirs[4][2] = {{0, 1}, {1, 0}, {1, 1}, {-1, 1}};
+        for (int d = 0; d < 4; d++)
+            if (1 + board_line_bits(my_stones, n, r, c, dirs[d][0], dirs[d][1]) + board_line_bits(my_stones, n, r, c, -dirs[d][0], -dirs[d][1]) >= L.env.win) winner = me;
+        if (winner) reward = 1.0f;
+    }
+    done = winner != 0 || open == 0;
+    float* o = L.obs + (size_t)e * 9 * nn;
+    if (!done) {
+        const signed char nm0 = (signed char)((bi == me || i == a) ? 1 : 0);  // the mover's history after this move: [stones now, m0, m1, m2]
+        if (cell) {
+            mine[i] = nm0; mine[nn + i] = m0; mine[2 * nn + i] = m1; mine[3 * nn + i] = m2;
+            // observation of the next side to move (games/env.py:242-271): its own history, the mover's, the colour plane
+            o[0 * nn + i] = (float)t0; o[1 * nn + i] = (float)nm0;
+            o[2 * nn + i] = (float)t1; o[3 * nn + i] = (float)m0;
+            o[4 * nn + i] = (float)t2; o[5 * nn + i] = (float)m1;
+            o[6 * nn + i] = (float)t3; o[7 * nn + i] = (float)m2;
+            o[8 * nn + i] = opp == 1 ? 1.0f : 0.0f;
+            if (i == a) { b[i] = (signed char)me; L.mask[(size_t)e * (nn + 1) + a] = 0; }
+        }
+        if (lane == 0) {
+            L.env.player[e] = opp;
+            L.env.steps[e] = st + 1;
+            L.cur[e] = opp;
+            L.opp[e] = me;
+        }
+    } else {  // auto-reset (pipeline.py:111-113)
+        if (cell) {
+            b[i] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) { pl[t * nn + i] = 0; o[t * nn + i] = 0.0f; }
+            o[8 * nn + i] = 1.0f;
+            L.mask[(size_t)e * (nn + 1) + i] = 1;
+        }
+        if (lane == 0) {
+            L.mask[(size_t)e * (nn + 1) + nn] = 1;
+            atomicAdd(&L.env.counters[2], 1ULL);
+            atomicAdd(&L.env.counters[3], (unsigned long long)(st + 1));
+            L.env.steps[e] = 0;
+            L.env.episode[e] += 1;
+            L.env.player[e] = 1;
+            L.cur[e] = 1;
+            L.opp[e] = 2;
+        }
+    }
+}
+
 // BoardGameEnv.step (games/env.py:117-154) by the 16 lanes of an env's group (16 consecutive lanes of one wave).  Every
 // lane reads the pre-move state; the bulk moves (history shift, next observation, reset) are strided over the group.
 // Lanes of a wave run in lock-step and vector memory operations of a wave are served in issue order, so a location is
@@ -365,7 +445,8 @@ __device__ inline void env_step_group(const EnvLaunch& L, int e, int lane) {
     const int a = __shfl(lane == 0 ? L.action[e] : 0, 0, 16);  // lane 0 may have stored it a moment ago (fused search)
     float reward;
     bool done;
-    board_step_group(L, e, lane, a, reward, done);
+    if (L.env.nn <= 16) board_step_small(L, e, lane, a, reward, done);
+    else board_step_group(L, e, lane, a, reward, done);
     if (lane == 0) env_record(L, e, a, reward, done);
 }
 

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         MZ_STAMP(9);  // expand + backup
     }
-    if (a0 == 0 && env_ok) tree2_finish(smem, Pm, e, env_g);
+    if (env_ok) tree2_finish_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
     if constexpr (FUSE)
         if (env_ok) env_step_group(Pm.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
     MZ_STAMP(10);  // play policy + action

@@ -562,3 +562,71 @@ __device__ __forceinline__ void tree2_finish(unsigned char* smem, const SearchPa
     const Node2* root = node2_at(smem, P, e, 0);
     play_from_visits(smem, P, e, env_g, rv, root->W, root->N);
 }
+
+// The same play step (generate_play_policy + the action draw, mcts.py:391-407) by the env's 16 lanes, A <= 16: lane a owns
+// action a -- its mask byte, its power, its division and its cdf prefix -- where one lane ran ten dependent global loads and
+// twenty float64 divisions in a row (TicTacToe: 20 k cycles per move).  The sums keep the reference's orders: numpy's pairwise
+// np.sum over the A powers (every lane adds them itself), left-to-right prefix sums for np.cumsum.  Results identical to
+// play_from_visits; all 16 lanes of the env must call it.
+__device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g) {
+    const int A = P.A;
+    const bool mine = a0 < A;
+    const int a = mine ? a0 : 0;
+    double* tmp = reinterpret_cast<double*>(smem + P.t_tmp) + e * A;
+    const Node2 root = *node2_at(smem, P, e, 0);
+    int v = entry2_row(smem, P, e, 0)[a].cn;
+    if (P.has_mask && !P.mask[(size_t)env_g * A + a]) v = 0;
+    const bool legal = !P.has_mask || P.mask[(size_t)env_g * A + a] != 0;
+    if (mine && P.out_visits) P.out_visits[(size_t)env_g * A + a] = v;
+    const double T = P.temperature[env_g];
+    double ex = 1.0;
+    if (T > 0.0) {
+        ex = 1.0 / T;
+        ex = ex < 5.0 ? ex : 5.0;
+        ex = ex > 1.0 ? ex : 1.0;
+    }
+    // argmax with the first maximum winning: key = visits * 16 + (15 - action)
+    int best = 15 - (row_max_i(mine ? v * 16 + (15 - a) : -1) & 15);
+    double t = (T > 0.0) ? pow_policy((double)v, ex) : (double)v;
+    if (mine) tmp[a] = t;
+    double s = np_sum_f64(tmp, A);  // (LDS operations of a wave are in order: every lane sees all A powers)
+    if (!(s > 0.0)) {  // every visit went to an illegal root child: see play_from_visits
+        if (P.rng_mode != 0) {
+            const unsigned lm = (unsigned)(__ballot(mine && legal) >> (__lane_id() & 48u)) & 0xffffu;
+            t = (mine && legal) ? 1.0 : 0.0;
+            s = 0.0;
+            for (int j = 0; j < A; j++) s = s + (((lm >> j) & 1u) ? 1.0 : 0.0);
+            best = lm ? __ffs((int)lm) - 1 : 0;
+        }
+    }
+    const double pi = t / s;
+    if (mine) tmp[a] = pi;
+    // lane 0 stores the whole policy: the fused env step's record (env_record, same lane) reads it back from global memory
+    // moments later, and only a lane's OWN stores are certain to be visible to its loads
+    if (a0 == 0)
+        for (int j = 0; j < A; j++) P.out_pi[(size_t)env_g * A + j] = tmp[j];
+    int action = best;
+    if (!P.deterministic) {
+        double uu;
+        if (P.rng_mode == 0) uu = P.u_final[env_g];
+        else {
+            Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x30000000u);
+            uu = g.uniform();
+            if (P.dbg_ufinal && a0 == 0) P.dbg_ufinal[env_g] = uu;
+        }
+        // np.random.choice(p=pi): cdf = cumsum(pi); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
+        double c = 0.0, last = 0.0;
+        for (int j = 0; j < A; j++) {
+            last = last + tmp[j];
+            c = j <= a ? last : c;
+        }
+        const unsigned le = (unsigned)(__ballot(mine && (c / last <= uu)) >> (__lane_id() & 48u)) & 0xffffu;
+        const int idx = le ? 32 - __clz((int)le) : 0;  // one past the last action whose cdf value is <= u
+        action = idx >= A ? A - 1 : idx;
+    }
+    if (a0 == 0) {
+        P.out_action[env_g] = action;
+        P.out_root[env_g] = root.N > 0 ? root.W / (double)root.N : 0.0;
+    }
+}
+
