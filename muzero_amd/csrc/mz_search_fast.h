@@ -292,7 +292,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     __syncthreads();
     {
         MZ_ROOT_TS_START();
-        if (a0 == 0 && env_ok) root_prior(smem, Pm, e, env_g);
+        if (env_ok) root_prior_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
         MZ_ROOT_TS(6);
     }
 

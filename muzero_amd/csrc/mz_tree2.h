@@ -630,3 +630,48 @@ __device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const Se
     }
 }
 
+// root_prior (mz_search.h) by the env's 16 lanes, A <= 16: lane a owns action a's mask byte, mix and divisions; the sums are
+// added by every lane itself in the reference's orders (the production noise's plain left-to-right sum, numpy's np.sum for the
+// renormalisation).  Same values as root_prior; all 16 lanes of the env must call it.
+__device__ __forceinline__ void root_prior_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g) {
+    const int A = P.A;
+    const bool mine = a0 < A;
+    const int a = mine ? a0 : 0;
+    double* prior = reinterpret_cast<double*>(smem + P.t_prior) + e * A;
+    float* pi0 = reinterpret_cast<float*>(smem + P.t_pi0) + e * A;
+    double* tmp = reinterpret_cast<double*>(smem + P.t_tmp) + e * A;
+    const bool legal = !P.has_mask || P.mask[(size_t)env_g * A + a] != 0;
+    if (P.noise_mode != 0) {
+        double nz;
+        if (P.noise_mode == 1) {
+            nz = P.noise[(size_t)env_g * A + a];
+        } else {  // tmp[] holds the gamma draws of root_noise_lanes
+            double s = 0.0;
+            for (int j = 0; j < A; j++) s += tmp[j];
+            nz = s > 0.0 ? tmp[a] / s : 1.0 / (double)A;
+            if (P.dbg_noise && mine) P.dbg_noise[(size_t)env_g * A + a] = nz;
+        }
+        const float om = (float)(1.0 - P.eps);
+        const float t = om * pi0[a];      // float32 product (python scalar * float32 array)
+        const double en = P.eps * nz;     // float64
+        double pr = (double)t + en;
+        if (P.has_mask) {
+            if (!legal) pr = 0.0;
+            if (mine) prior[a] = pr;
+            const double s = np_sum_f64(prior, A);  // (LDS operations of a wave are in order)
+            if (s > 0) pr = pr / s;
+        }
+        if (mine) prior[a] = pr;
+    } else {
+        float p0 = pi0[a];
+        if (P.has_mask) {
+            if (!legal) p0 = 0.0f;
+            if (mine) pi0[a] = p0;
+            const float s = np_sum_f32(pi0, A);
+            if (s > 0) p0 = p0 / s;
+            if (mine) pi0[a] = p0;
+        }
+        if (mine) prior[a] = (double)p0;
+    }
+}
+
