@@ -38,7 +38,9 @@ MAC_VALUE = 64 * 512 + 512 * 31
 MAC_POLICY = 64 * 512 + 512 * 2
 MAC_REPRESENT = 20 * 512 + 512 * 64
 FLOP_PER_SIM = 2 * (MAC_TRANSITION + MAC_REWARD + MAC_VALUE)          # 327 680
-FLOP_PER_ROOT = 2 * (MAC_REPRESENT + MAC_POLICY + MAC_VALUE)          # 250 880
+# root: representation + policy head only -- the search discards the root's value (mcts.py:356-367) and the kernel does not
+# evaluate that head (mz_search_fast.h: mlp_initial_tile(..., want_value = false)), so it is not counted
+FLOP_PER_ROOT = 2 * (MAC_REPRESENT + MAC_POLICY)                      # 153 600
 PEAK_FP32_MFMA_TFLOPS = 157.3                                         # MI355X_MICROARCH.md, v_mfma_f32_*_f32 dense peak
 
 
@@ -99,7 +101,7 @@ def conv_flops(case):
         rep = c * 128 * 9 * 48 * 48 + 4 * 128 * 128 * 9 * 48 * 48 + 128 * P * 9 * 24 * 24 + 4 * P * P * 9 * 24 * 24 + 4 * P * P * 9 * 12 * 12
     else:
         rep = c * P * 9 * px + res
-    root = rep + res + (2 * P * px + 2 * px * A) + (P * px + px * Sv)
+    root = rep + res + (2 * P * px + 2 * px * A)  # (the root's value head is discarded by the search, mcts.py:356-367: not counted)
     return 2 * sim, 2 * root
 
 
@@ -141,7 +143,13 @@ def conv_cpu_baseline(name, case, net, kw, full_sims):
                        f'{t_root:.2f} s per root inference per thread; rate of whole {full_sims}-simulation moves')
 
 
-def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev='cuda'):
+DOMINANT = {'c3': 'k_search_fast<256', 'c4': 'k_res_tower<', 'c5': 'k_conv3x3<15'}  # dominant kernel of each workload (substring of its rocprof name)
+
+
+def measure_workload(args, name, rank, local_rank, world, torch, dist, red_dev, steps, warmup, preheat, with_cpu, with_sustained):
+    """One of the other BASELINE.json configs (c3 / c4 / c5) measured exactly like the headline: `warmup` untimed lock-step
+    moves, then `steps` timed ones between barriers, MAX over ranks; HIP-event pairs on the planner stream around each move's
+    kernel sequence give the roofline figure.  Returns the record (rank 0; None elsewhere)."""
     from helpers import build_conv, build_mlp, mlp_case
     from muzero_amd import planner as pl
 
@@ -167,14 +175,14 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
         if world > 1:
             dist.barrier()
 
-    if args.preheat and name == 'c3':  # see the C2 path: out of the idle clocks (one move of the conv workloads is long enough by itself)
-        p.selfplay_step(T, args.preheat)
-    if args.warmup:
-        p.selfplay_step(T, args.warmup)
+    if preheat and name == 'c3':  # see the C2 path: out of the idle clocks (one move of the conv workloads is long enough by itself)
+        p.selfplay_step(T, preheat)
+    if warmup:
+        p.selfplay_step(T, warmup)
     sync()
     p.profile_begin()
     t0 = time.perf_counter()
-    p.selfplay_step(T, args.steps)
+    p.selfplay_step(T, steps)
     sync()
     elapsed = time.perf_counter() - t0
     prof = p.profile_end()
@@ -182,54 +190,111 @@ def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev=
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # C3: transition 35 328 + reward 16 640 + value 16 640 MAC per simulation; root 37 120 + 18 944 + 16 640
-    f_sim, f_root = (2 * 68608, 2 * 72704) if name == 'c3' else conv_flops(case)
+    # C3: transition 35 328 + reward 16 640 + value 16 640 MAC per simulation; root 37 120 + 18 944 (representation +
+    # policy; the root's value head is discarded by the search and not evaluated by the kernel: not counted)
+    f_sim, f_root = (2 * 68608, 2 * 56064) if name == 'c3' else conv_flops(case)
     flop_per_move = B * (S * f_sim + f_root)
-    sustained = None if args.no_sustained else sustained_leg(p, T, 1e3 * elapsed / args.steps, flop_per_move)
+    sustained = sustained_leg(p, T, 1e3 * elapsed / steps, flop_per_move) if with_sustained else None
+    rec = None
     if rank == 0:
-        sims_per_s = world * B * S * args.steps / elapsed
+        sims_per_s = world * B * S * steps / elapsed
         ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
-        dom_kernel = {'c3': 'mz::k_search_fast<256, 1, 1, true, false>', 'c4': 'mz::k_res_tower<5>', 'c5': 'mz::k_conv3x3<15, 1, true>'}[name]
-        traffic, traffic_src = profiled_traffic(name, dom_kernel.replace('mz::', '')) if (B == envs and S == sims) else (None, None)
+        traffic, traffic_src = profiled_traffic(name, DOMINANT[name]) if (B == envs and S == sims) else (None, 'non-default workload size')
         achieved = flop_per_move / (ms * 1e-3) / 1e12
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = conv_cpu_baseline(name, case, net, kw, S)
-        print(json.dumps({
+        ms_step = 1e3 * elapsed / steps
+        cpu = conv_cpu_baseline(name, case, net, kw, S) if (world == 1 and with_cpu) else None
+        rec = {
             'cpu_baseline': cpu,
             'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)', 'value': sims_per_s, 'unit': 'sims/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'steps': steps, 'warmup': warmup, 'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{name.upper()}: {case[1]} net {case[5]} planes / {case[4]} blocks, obs {case[2]}, A={case[3]}, {S} sims/move, '
                                    f'{B} envs per MI355X, {env_kind} device env, ' + ('LDS-resident trees' if name == 'c3' else 'HBM-resident trees'),
                        'envs_per_gpu': B, 'sims_per_move': S, 'parallelism': f'env-sharded x{world}', 'weights': 'seeded random init'},
             'env_steps_per_sec': sims_per_s / S,
-            'roofline': {'bound': 'mfma', 'kernel': dom_kernel + ('' if name == 'c3' else ' (dominant kernel; the whole per-move kernel sequence is timed)'), 'achieved': achieved,
-                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'kernel': 'mz::' + DOMINANT[name] + ('...> (the one kernel of a move: search + env step fused)' if name == 'c3'
+                                                                               else '...> (dominant kernel; the whole per-move kernel sequence is timed)'),
+                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                         'frac_step': flop_per_move / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_unit': 'bytes of HBM per launch of the dominant kernel', 'traffic_source': traffic_src,
                          'avg_move_ms': ms, 'flop_per_move': flop_per_move, 'flop_per_sim': f_sim,
                          'timed_with': 'hipEvent pairs on the planner stream around each move\'s kernel sequence'},
             'sustained': sustained,
-        }), flush=True)
+        }
+    p.close()
+    del p, net
+    torch.cuda.empty_cache()
+    return rec
+
+
+def run_conv_workload(args, name, rank, local_rank, world, torch, dist, red_dev='cuda', backend='nccl'):
+    rec = measure_workload(args, name, rank, local_rank, world, torch, dist, red_dev, args.steps, args.warmup, args.preheat,
+                           not args.no_cpu_baseline, not args.no_sustained)
+    if rank == 0:
+        rec['distributed'] = dist_record(dist, world, backend)
+        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def dist_record(dist, world, backend):
+    """What the process group really was: the first multi-GPU run is also the first time RCCL sees N ranks."""
+    if world > 1:
+        return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'requested_backend': backend,
+                'note': 'backend "nccl" is RCCL on ROCm; used only for the barriers and the MAX of the elapsed time (no data-path collective)'}
+    return {'backend': None, 'world_size': 1}
+
+
+# the other BASELINE.json configs inside the default (headline) run: (timed moves, warm-up moves)
+CONFIG_LEGS = {'c3': (200, 20), 'c4': (4, 1), 'c5': (2, 1)}
+
+
+def configs_leg(args, rank, local_rank, world, torch, dist, red_dev):
+    """BASELINE.json lists five configs; the headline line is C2.  This leg times a few lock-step moves of C3, C4 and C5 in the
+    same driver-run process (same measurement as `--workload cN`, fewer moves; full-size batches, all simulations), so every
+    config has a driver-timed figure with its own roofline sub-record every round."""
+    import types
+
+    out = {}
+    for name, (steps, warm) in CONFIG_LEGS.items():
+        a = types.SimpleNamespace(envs=0, sims=0)
+        r = measure_workload(a, name, rank, local_rank, world, torch, dist, red_dev, steps, warm, 0, False, False)
+        if rank == 0:
+            rf = r['roofline']
+            out[name] = {'workload': r['config']['workload'], 'value': r['value'], 'unit': r['unit'], 'env_steps_per_sec': r['env_steps_per_sec'],
+                         'steps': steps, 'warmup': warm, 'ms_per_step': r['ms_per_step'], 'n_gpus': world,
+                         'roofline': {k: rf[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_step', 'traffic', 'traffic_source',
+                                                         'avg_move_ms', 'flop_per_move')}}
+    return out
+
+
+PROFILE_ROUND = 'round3'
+
+
 def profiled_traffic(workload, kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this very command
-    (profiles/round2/<workload>/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    (profiles/<round>/<workload>/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the run, so this is the profiled
-    figure for the default workload sizes, or None."""
-    path = os.path.join(REPO, 'profiles', 'round2', workload, 'pmc_summary.json')
+    figure for the default workload sizes -- and only if the summary was measured on the kernel sources this run was
+    built from (`_source_fingerprint` == muzero_amd.build.source_fingerprint()): a stale profile yields None, never a
+    number that silently belongs to another kernel."""
+    from muzero_amd import build as mz_build
+
+    rel = os.path.join('profiles', PROFILE_ROUND, workload, 'pmc_summary.json')
     try:
-        pm = json.load(open(path))['pmc']
+        doc = json.load(open(os.path.join(REPO, rel)))
+        pm = doc['pmc']
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, f'{rel}: not found'
+    fp = mz_build.source_fingerprint()
+    if doc.get('_source_fingerprint') != fp:
+        return None, f'{rel} was measured on kernel sources {doc.get("_source_fingerprint")} (commit {doc.get("_git_head")}); this run is built from {fp}: stale, not reported'
     for name, e in pm.items():
         if kernel_substr in name and '_hbm_bytes_per_launch' in e:
-            return e['_hbm_bytes_per_launch']['total'], f'profiles/round2/{workload}/pmc_summary.json ({name}; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)'
-    return None, None
+            return e['_hbm_bytes_per_launch']['total'], (f'{rel} ({name}; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch; kernel sources {fp}, '
+                                                         f'commit {doc.get("_git_head")})')
+    return None, f'{rel}: kernel not in the summary'
 
 
 def launch_ranks(args, argv):
@@ -323,6 +388,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 2 s sustained leg')
     ap.add_argument('--no-e2e', action='store_true', help='skip the env-steps-into-replay leg')
+    ap.add_argument('--no-configs', action='store_true', help='skip the C3 / C4 / C5 legs of the default run')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -361,7 +427,7 @@ def main():
         dist.barrier()
 
     if args.workload != 'c2':
-        return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist, red_dev)
+        return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist, red_dev, backend)
 
     from helpers import build_mlp, mlp_case
     from muzero_amd import planner as pl
@@ -409,6 +475,10 @@ def main():
         e2e = e2e_leg(p, pl, pl.ENV_CARTPOLE, 1.0, (4, 5),
                       types.SimpleNamespace(is_board_game=False, acc_seq_length=200, unroll_steps=5, td_steps=10, discount=0.997))
         e2e['fraction_of_planner_rate'] = e2e['env_steps_per_sec'] / (B * args.steps / elapsed)
+    p.close()
+    del p
+    torch.cuda.empty_cache()
+    configs = None if args.no_configs or args.envs or args.sims else configs_leg(args, rank, local_rank, world, torch, dist, red_dev)
 
     if rank == 0:
         total_sims = world * B * S * args.steps
@@ -417,7 +487,7 @@ def main():
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this very
         # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the profiled workload.
-        traffic, traffic_src = (profiled_traffic('c2', 'k_search_fast<512') if (B == 4096 and S == 50) else (None, None))
+        traffic, traffic_src = (profiled_traffic('c2', 'k_search_fast<512') if (B == 4096 and S == 50) else (None, 'non-default workload size'))
         out = {
             'metric': 'self-play MCTS sims/sec (env-steps/sec = value / sims_per_move)',
             'value': sims_per_s,
@@ -440,13 +510,18 @@ def main():
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
                 'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,2,2,false,true>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes of HBM per launch', 'traffic_source': traffic_src,
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                # the same FLOPs over the driver-timed step (env kernels and launch gaps included), not only the search kernel
+                'frac_step': flop_per_launch / (1e-3 * 1e3 * elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'traffic': traffic, 'traffic_unit': 'bytes of HBM per launch', 'traffic_source': traffic_src,
                 'algorithmic_hbm_bytes_per_launch': B * (S * 2 * 64 * 4 + 20 * 4 + 64 * 4 + 2 * 8 + 16),
                 'avg_launch_ms': k_ms, 'launches': prof['search_kernel_launches'], 'flop_per_launch': flop_per_launch,
                 'flop_per_sim': FLOP_PER_SIM, 'timed_with': 'hipEvent pairs on the planner stream',
             },
             'sustained': sustained,
             'e2e': e2e,
+            'configs': configs,
+            'distributed': dist_record(dist, world, backend),
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, sample_envs=B)

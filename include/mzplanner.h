@@ -139,7 +139,8 @@ int mz_selfplay_counters(mz_planner* p, int64_t out[4]);
  * All pointers are DEVICE pointers (e.g. the storages of muzero_amd.replay.PrioritizedReplay(device='cuda')); the caller
  * keeps them alive while attached.  Items of one environment appear in step order; environments interleave (the
  * reference's actors are independent processes).  Call BEFORE mz_selfplay_reset (the record ring is sized to hold an open
- * trajectory); ring == NULL detaches.  mz_selfplay_read then returns at most the moves the record ring holds. */
+ * trajectory); ring == NULL detaches.  Attach and detach drain the planner's stream, so after a detach the counter and the
+ * priorities are final.  mz_selfplay_read then returns at most the moves the record ring holds. */
 typedef struct {
     int64_t capacity;     /* ring slots; slot of the i-th item ever added = i % capacity */
     float* state;         /* [capacity, obs_c*obs_h*obs_w] */
@@ -148,7 +149,10 @@ typedef struct {
     float* value;         /* [capacity, unroll_steps] */
     float* reward;        /* [capacity, unroll_steps] */
     float* priority;      /* [capacity] */
-    int64_t* num_added;   /* one counter, incremented atomically by the device */
+    int64_t* num_added;   /* one counter, read at attach (the write cursor starts there) and from then on only PUBLISHED by the
+                           * device: it advances after each lock-step move, once every slot below the new value is completely
+                           * written (state, windows, priority), so a reader on another stream never sees a half-filled slot.
+                           * The caller must not write it while attached. */
     int32_t* origin;      /* optional [capacity]: index of the environment that produced the item, or NULL */
     int32_t acc_seq_length, unroll_steps, td_steps;  /* MuZeroConfig fields (config.py:58-94) */
 } mz_replay_ring;

@@ -32,6 +32,21 @@ def _deps():
         [os.path.join(HERE, '..', 'include', 'mzplanner.h'), os.path.abspath(__file__)]
 
 
+def source_fingerprint():
+    """sha256 over everything the kernels are compiled from (csrc/*, the C header, the compiler flags): what ties a committed
+    profile (profiles/<round>/*/pmc_summary.json, written by tools/pmc_summary.py) to the build it was measured on.  bench.py
+    reports `roofline.traffic` only from a summary whose fingerprint equals that of the sources it runs."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in _deps()[:-1]:  # (not this script: its flags are hashed below, its comments are not the build)
+        h.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True

@@ -340,8 +340,11 @@ __device__ inline double gamma_sample(Philox& g, double alpha) {
             return ldexp((double)__builtin_amdgcn_exp2f(t - fl), (int)fl);
         };
         for (int it = 0; it < 256; it++) {
-            const float U = (float)g.uniform();
-            const double V = (double)(-ln2 * __builtin_amdgcn_logf(1.0f - (float)g.uniform()));
+            // (float)uniform() can round up to 1.0f (probability 2^-25 per draw): then 1 - U == 0, Y == +inf and the acceptance
+            // test inf <= inf would pass a clamped 2^1020 -- the float64 original cannot reach U == 1, so neither may this
+            const float one_m = 0x1.fffffep-1f;  // 1 - 2^-24
+            const float U = fminf((float)g.uniform(), one_m);
+            const double V = (double)(-ln2 * __builtin_amdgcn_logf(1.0f - fminf((float)g.uniform(), one_m)));
             if (U <= 1.0f - fa) {
                 const double X = pow2d(ia * __builtin_amdgcn_logf(U));
                 if (X <= V) return X;

@@ -475,7 +475,8 @@ struct ReplayRing {
     float* value;         // [capacity][K]
     float* reward;        // [capacity][K]
     float* priority;      // [capacity]
-    long long* num_added; // device counter
+    long long* num_added; // COMMITTED items: published by k_epi_publish after every k_epilogue launch, when all slots below it are filled
+    long long* ctr;       // planner-owned: reserved write cursor (atomicAdd in k_epilogue)
     int* origin;          // optional [capacity]: env that produced the item (tests), or null
     int acc, K, td, board;
     double pw[34];        // discount ** i, i = 0..td (host libm pow == Python float pow)
@@ -508,7 +509,8 @@ __device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int 
     }
     __syncthreads();
     __shared__ long long base_s;
-    if (lane == 0) base_s = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(R.num_added), (unsigned long long)n);
+    // slots are RESERVED here and published (R.num_added) only when the whole launch has filled its slots: see k_epi_publish
+    if (lane == 0) base_s = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(R.ctr), (unsigned long long)n);
     __syncthreads();
     const long long base = base_s;
     // the n items are written with the wave's lanes spread over (item, element) pairs: a flush emits acc_seq_length items at once
@@ -546,17 +548,27 @@ __global__ __launch_bounds__(64) void k_epilogue(const EpiLaunch E) {
     int len = (int)(E.move_abs + 1 - start);
     const bool done = V.r_done[(size_t)(E.move_abs % V.ring_len) * E.B + e] != 0;
     const bool flush = !R.board && len == R.acc + R.K + R.td;
-    if (!flush && !done) return;
-    if (flush) {
-        epi_emit(E, e, start, len, R.acc, z, lane);
-        start += R.acc;
-        len -= R.acc;
+    if (flush || done) {
+        if (flush) {
+            epi_emit(E, e, start, len, R.acc, z, lane);
+            start += R.acc;
+            len -= R.acc;
+        }
+        if (done) {
+            epi_emit(E, e, start, len, len, z, lane);
+            start = E.move_abs + 1;
+        }
+        if (lane == 0) V.ep_start[e] = start;
     }
-    if (done) {
-        epi_emit(E, e, start, len, len, z, lane);
-        start = E.move_abs + 1;
-    }
-    if (lane == 0) V.ep_start[e] = start;
+}
+
+// Publish: the host (replay.num_added / sample on another stream) may only see a count whose slots are all filled.  Slots are
+// reserved inside k_epilogue (R.ctr[0]); this one-thread kernel, next on the same stream -- i.e. after every workgroup of the
+// epilogue has finished and its writes are visible -- copies the reserved cursor to the committed counter the host reads.
+// (A last-workgroup-done counter inside k_epilogue did the same with 4096 same-address atomics per move: -9 % on the C2
+// env-steps-into-replay rate, measured.)
+__global__ void k_epi_publish(const ReplayRing R) {
+    *reinterpret_cast<volatile long long*>(R.num_added) = *reinterpret_cast<volatile long long*>(R.ctr);
 }
 
 }  // namespace mz

@@ -115,6 +115,7 @@ struct mz_planner {
     int ring_len = 0, ring_pos = 0, ring_count = 0;
     bool has_replay = false;
     ReplayRing replay{};
+    long long* d_epi_ctr = nullptr;  // reserved write cursor of the attached replay ring (k_epilogue reserves, k_epi_publish commits)
     long long selfplay_moves = 0;  // moves since mz_selfplay_reset
 
     // profiling
@@ -409,6 +410,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     if (p->d_stream[0]) (void)hipFree(p->d_stream[0]);
     if (p->d_bias_all) (void)hipFree(p->d_bias_all);
     if (p->d_dbg_noise) { (void)hipFree(p->d_dbg_noise); (void)hipFree(p->d_dbg_utie); (void)hipFree(p->d_dbg_ufinal); }
+    if (p->d_epi_ctr) (void)hipFree(p->d_epi_ctr);
     void* cbufs[] = {p->d_pi_scratch, p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
     for (void* b : cbufs)
         if (b) (void)hipFree(b);
@@ -872,6 +874,7 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
             EpiLaunch E{};
             E.env = p->env; E.ring = p->replay; E.B = c.num_envs; E.move_abs = p->selfplay_moves;
             hipLaunchKernelGGL(k_epilogue, dim3(c.num_envs), dim3(64), (size_t)p->ring_len * sizeof(double), p->stream, E);
+            hipLaunchKernelGGL(k_epi_publish, dim3(1), dim3(1), 0, p->stream, p->replay);
         }
         p->selfplay_moves++;
     };
@@ -908,6 +911,8 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
 
 extern "C" int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ring) {
     if (!p) return fail(MZ_E_INVALID, "null planner");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));  // attach / detach drain the planner: after a detach the caller owns counter and priorities again
     if (!ring) {
         p->has_replay = false;
         return MZ_OK;
@@ -923,6 +928,12 @@ extern "C" int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ri
     R.value = ring->value; R.reward = ring->reward; R.priority = ring->priority; R.num_added = reinterpret_cast<long long*>(ring->num_added);
     R.origin = ring->origin; R.acc = ring->acc_seq_length; R.K = ring->unroll_steps; R.td = ring->td_steps; R.board = c.is_board_game;
     for (int i = 0; i <= R.td; i++) R.pw[i] = std::pow(c.discount, (double)i);  // Python's discount ** i (pipeline.py:663-666)
+    // the device-owned write cursor starts at the caller's count; the caller's counter is from now on only PUBLISHED to
+    if (!p->d_epi_ctr) HIPCHK(hipMalloc(&p->d_epi_ctr, 2 * sizeof(long long)));
+    HIPCHK(hipMemsetAsync(p->d_epi_ctr, 0, 2 * sizeof(long long), p->stream));
+    HIPCHK(hipMemcpyAsync(p->d_epi_ctr, R.num_added, sizeof(long long), hipMemcpyDeviceToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    R.ctr = p->d_epi_ctr;
     p->has_replay = true;
     p->env_kind = MZ_ENV_NONE;  // the record ring must be re-sized: mz_selfplay_reset next
     return MZ_OK;

@@ -266,9 +266,12 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
             path = save(f'{ckpt_prefix}_{train_steps_counter.value}')
             if path is not None:
                 checkpoint_files.append(path)
-            # actors in this process see the new tensors' versions; actors in other processes (shared-memory parameters)
-            # see train_steps_counter cross a checkpoint_interval boundary -- pipeline.run_self_play reloads on either
-            actor_network.load_state_dict(network.state_dict())
+            # new values first, THEN the signal: actors in this process see the tensors' versions change, actors in other
+            # processes (shared-memory parameters) see the shared `weights_epoch` buffer -- pipeline.run_self_play reloads on either
+            if hasattr(actor_network, 'publish_weights'):
+                actor_network.publish_weights(network.state_dict())
+            else:
+                actor_network.load_state_dict(network.state_dict())
             actor_network.eval()
         if config.train_delay is not None and config.train_delay > 0 and train_steps_counter.value > 1:
             time.sleep(config.train_delay)

@@ -213,6 +213,15 @@ class MuZeroNet(nn.Module):
         self.reward_support_size = reward_support_size
         self._engine = None
         self._engine_version = None
+        # Published-weights epoch: bumped by `publish_weights` AFTER the new values are in place.  A non-persistent buffer, so
+        # the state_dict / checkpoint layout stays the reference's, and `share_memory()` shares it with the parameters: it is
+        # the refresh signal that crosses process boundaries (tensor._version does not).
+        self.register_buffer('weights_epoch', torch.zeros(1, dtype=torch.int64), persistent=False)
+
+    def publish_weights(self, state_dict) -> None:
+        """What the learner does for its actors at a checkpoint boundary (pipeline.py:261-267): new values first, signal after."""
+        self.load_state_dict(state_dict)
+        self.weights_epoch.add_(1)
 
     # --- tensor API (learner side, autograd) ------------------------------------------------
     def represent(self, x: torch.Tensor) -> torch.Tensor:

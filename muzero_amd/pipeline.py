@@ -128,13 +128,16 @@ def aggregate_throughput(local_units: float, local_seconds: float):
     return float(units.item() / secs.item()), float(units.item()), float(secs.item())
 
 
-def weights_key(network, train_steps_counter, config):
+def weights_key(network, train_steps_counter=None, config=None):
     """What an actor watches to know that the learner refreshed `network` (pipeline.py:261-267: every checkpoint_interval
     train steps).  In one process the tensors' version counters change; in another process (the reference's layout:
-    shared-memory parameters, mp.Process actors) only the storage changes, so the shared train-step counter crossing a
-    checkpoint_interval boundary is the signal that travels."""
-    every = max(1, int(getattr(config, 'checkpoint_interval', 1) or 1))
-    return network._weights_version(), int(train_steps_counter.value) // every
+    shared-memory parameters, mp.Process actors) only the storage changes, so the signal that travels is the network's
+    `weights_epoch` -- a shared-memory buffer the learner bumps AFTER `load_state_dict` (`MuZeroNet.publish_weights`).
+    (Round 2 keyed on the train-step counter crossing a checkpoint_interval boundary: that fires BEFORE the learner has
+    written the checkpoint and copied the weights, so a remote actor reloaded the old values and stayed one checkpoint
+    behind.)  `train_steps_counter` / `config` are accepted for the old call sites and ignored."""
+    epoch = getattr(network, 'weights_epoch', None)
+    return network._weights_version(), (int(epoch.item()) if epoch is not None else 0)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -216,12 +219,13 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
 
     tracker = mzm.ActorMetrics(mzm.run_file(config, f'actor{rank}', tag), num_envs)  # trackers.py:74-80 tag names
 
-    version = weights_key(network, train_steps_counter, config)
+    version = weights_key(network)
     played = 0
     while not stop_event.is_set() and (max_moves is None or played < max_moves):
-        if weights_key(network, train_steps_counter, config) != version:  # learner pushed new weights (pipeline.py:266)
+        key = weights_key(network)  # read BEFORE copying: a publish that lands during the copy makes the next check fire again
+        if key != version:  # learner pushed new weights (pipeline.py:266)
             p.load_state_dict(network.state_dict())
-            version = weights_key(network, train_steps_counter, config)
+            version = key
         n = moves_per_drain if max_moves is None else min(moves_per_drain, max_moves - played)
         # classic/atari schedules depend on train steps only; board games on the env's own step count (config.py:236-267)
         T = -1.0 if config.is_board_game else float(config.visit_softmax_temperature_fn(0, train_steps_counter.value))

@@ -287,7 +287,10 @@ class Planner:
         return origin
 
     def detach_replay(self):
+        """Drains the planner's stream, detaches the epilogue and hands counter / priorities back to the replay's host side."""
         _chk(self.lib.mz_selfplay_attach_replay(self.h, None))
+        if self._replay_keepalive is not None:
+            self._replay_keepalive[0].detach_device_writer()
         self._replay_keepalive = None
 
     def selfplay_counters(self):

@@ -13,7 +13,13 @@ instead of letting the process die.  With the default `device='cpu'` it is a dro
 
 Thread safety: the collector thread adds while the learner thread samples (pipeline.py:491-538 vs :238-255).  The
 reference swaps one tuple per slot atomically; here the five field writes of an add and the gather of a sample hold one
-lock, so a batch never contains a torn transition.  Sampling semantics are the reference's,
+lock, so a batch never contains a torn transition written by a HOST writer.  While a planner's device epilogue is attached
+the DEVICE owns the write cursor and the priorities: the host never writes the counter (add / add_batch / reset raise),
+`update_priorities` scatters only the touched entries on the device, and what the host reads as `num_added` is the
+COMMITTED count -- published by the epilogue kernel after every slot below it has been filled (mz_env.h, k_epilogue) -- so
+a batch never contains a slot that is still being written for the first time.  (Once the ring has wrapped, a slot may be
+overwritten while it is gathered -- the reference's actors / learner threads have the same window per tuple swap.)
+Sampling semantics are the reference's,
 draw for draw: uniform replay draws `random_state.uniform(0, size, batch).astype(int64)` (`replay.py:87-89`),
 prioritized replay draws from the process-global `np.random.choice` (`replay.py:90-98`; an upstream quirk kept on
 purpose) with importance weights `((1/size) / p_i)^beta / max`."""
@@ -75,9 +81,14 @@ class PrioritizedReplay:
         if self._dev.type == 'cuda':
             free = torch.cuda.mem_get_info(self._dev)[0]
         else:
-            import psutil
+            # host rings are committed lazily (torch.zeros maps zero pages), exactly like the reference's list that grows
+            # as items arrive: refuse only what can never fit, i.e. more than the machine's physical memory
+            import os
 
-            free = psutil.virtual_memory().available
+            try:
+                free = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 0.9
+            except (ValueError, OSError, AttributeError):
+                free = float('inf')
         if need > 0.9 * free:
             raise MemoryError(f'replay of {self._cap} items needs {need / 2**30:.1f} GiB on {self._dev} but only {free / 2**30:.1f} GiB are free: '
                               f'lower the capacity or store states in a narrower dtype (state_dtype=torch.float16 / torch.uint8)')
@@ -93,11 +104,16 @@ class PrioritizedReplay:
             if tuple(shp) != tuple(self._ring[f].shape[1:]):
                 raise ValueError(f'Transition.{f} has shape {tuple(shp)}, the replay holds {tuple(self._ring[f].shape[1:])}')
 
+    def _host_writer_only(self, what: str) -> None:
+        if self._attached is not None:
+            raise RuntimeError(f'PrioritizedReplay.{what}: a planner device epilogue is attached and owns the write cursor of this ring; '
+                               f'detach it first (Planner.detach_replay + PrioritizedReplay.detach_device_writer)')
+
     def add(self, item: Transition, priority: float) -> None:
         """One item into the ring slot `num_added % capacity` (replay.py:67-75)."""
         self._check_priorities(priority)
         with self._lock:
-            self._sync_attached()
+            self._host_writer_only('add')
             if self._ring is None:
                 self._allocate(item)
             arrs = [np.ascontiguousarray(x) for x in item]
@@ -107,14 +123,13 @@ class PrioritizedReplay:
                 self._ring[name][slot] = torch.from_numpy(a).to(self._ring[name].dtype)
             self._prio[slot] = priority
             self._count += 1
-            self._push_attached()
 
     def add_batch(self, items: Transition, priorities: Sequence[float]) -> None:
         """n items at once (fields stacked on axis 0): the form the device-resident actor produces."""
         self._check_priorities(priorities)
         n = len(priorities)
         with self._lock:
-            self._sync_attached()
+            self._host_writer_only('add_batch')
             if self._ring is None:
                 self._allocate(Transition(*[np.asarray(x)[0] for x in items]))
             self._check_shapes([tuple(x.shape[1:]) for x in items])
@@ -125,7 +140,6 @@ class PrioritizedReplay:
                 self._ring[name][tslots] = x.to(self._dev, dtype=self._ring[name].dtype)
             self._prio[slots] = np.asarray(priorities, np.float32)
             self._count += n
-            self._push_attached()
 
     def get(self, indices: Sequence[int]) -> List[Transition]:
         """Items by index (replay.py:77-79)."""
@@ -135,8 +149,11 @@ class PrioritizedReplay:
 
     # ---- device epilogue (Planner.attach_replay): the planner writes items and priorities, this class only counts ----
     def attach_device_writer(self):
-        """Tensors a device-side writer needs besides the ring: float32 priorities [capacity] and the uint64 `num_added`
-        counter, both on the replay's device.  Host-side bookkeeping is refreshed from them before every use."""
+        """Tensors a device-side writer needs besides the ring: float32 priorities [capacity] and the int64 COMMITTED
+        `num_added` counter, both on the replay's device, initialised from the host's bookkeeping.  From here on the device
+        owns both: the host only reads the counter (the writer publishes it after the slots below it are filled) and
+        scatters single priorities (`update_priorities`); it never writes the counter or the whole priority array, so
+        nothing the GPU wrote in the meantime can be lost."""
         if self._ring is None:
             raise RuntimeError('allocate() the ring before attaching a device writer')
         if self._attached is None:
@@ -145,17 +162,18 @@ class PrioritizedReplay:
             self._attached = (prio, count)
         return self._attached
 
+    def detach_device_writer(self) -> None:
+        """Take the bookkeeping back to the host (after Planner.detach_replay, which drains the planner's stream)."""
+        with self._lock:
+            self._sync_attached()
+            self._attached = None
+
     def _sync_attached(self) -> None:
+        """read-only refresh of the host's view from the device-owned counter and priorities"""
         if self._attached is not None:
             prio, count = self._attached
             self._count = int(count.item())
             self._prio = prio.cpu().numpy()
-
-    def _push_attached(self) -> None:
-        if self._attached is not None:
-            prio, count = self._attached
-            prio.copy_(torch.from_numpy(self._prio))
-            count.fill_(self._count)
 
     # ---- sampling ----
     def _draw(self, batch_size: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -199,10 +217,16 @@ class PrioritizedReplay:
         if not np.isfinite(pr).all() or (pr < 0.0).any():
             raise ValueError('Priorities must be finite and positive.')
         with self._lock:
-            self._sync_attached()
+            if self._attached is not None:
+                # the device owns the array: scatter only the touched entries (last value per repeated index), on the device
+                last = {int(i): float(v) for i, v in zip(indices, pr)}
+                if last:
+                    idx = torch.tensor(list(last.keys()), dtype=torch.int64, device=self._dev)
+                    val = torch.tensor(list(last.values()), dtype=torch.float32, device=self._dev)
+                    self._attached[0].index_copy_(0, idx, val)
+                return
             for i, v in zip(indices, pr):
                 self._prio[i] = v
-            self._push_attached()
 
     # ---- bookkeeping (replay.py:115-142) ----
     def _live_count(self) -> int:
@@ -216,8 +240,8 @@ class PrioritizedReplay:
 
     def reset(self) -> None:
         with self._lock:
+            self._host_writer_only('reset')
             self._count = 0
-            self._push_attached()
 
     def get_state(self) -> Mapping[Text, Any]:
         self._sync_attached()

@@ -14,6 +14,9 @@ Groups:
   tree   G1  reference uct_search (mcts.py:302-407) driven by a scripted fake network
   nets   G2  MuZeroMLPNet / MuZeroBoardGameNet / MuZeroAtariNet initial+recurrent inference
   search G3  end-to-end uct_search with real (seeded random-weight) networks
+  ckpt   G3  the same on the SHIPPED trained checkpoints (saved_checkpoints/*): inputs, recorded draws and the reference's
+             outputs only -- the weights never leave /root/reference, so the test that replays these through the oracle
+             (tests/test_oracle_ckpt.py) runs in the build container only
   pipe   G4  pipeline/util/mcts helper functions (incl. the reference's own KATs)
   env    G5  TicTacToe / Gomoku scripted games (incl. the reference tests' win lines)
   learn  L   PrioritizedReplay sampling, calc_loss (loss, priorities, gradients), 3 optimizer steps, 2-hot projection
@@ -473,9 +476,60 @@ def gen_search():
     np.savez_compressed(os.path.join(GOLDEN_DIR, 'search_cases.npz'), **out)
     print('search: done')
 
-    # Shipped-checkpoint searches (checkpoints cannot travel: these fixtures are only usable in the
-    # build container and are therefore NOT committed; the test that uses them is skipped when
-    # /root/reference is absent).
+
+
+# --------------------------------------------------------------------------------------------
+# G3 on the shipped checkpoints (pipeline.py:810-817 loads them the same way).  Trained networks are where
+# near-ties live: value ranges are realistic (CartPole values ~ tens, TicTacToe in [-1, 1]) instead of the degenerate ones of
+# random weights.  Only inputs / draws / outputs are stored.
+# --------------------------------------------------------------------------------------------
+CKPT_DIR = '/root/reference/saved_checkpoints'
+CKPT_CASES = [  # name, file, input shape, actions, planes, support, (discount, sims, board, bounds)
+    ('cartpole', 'CartPole-v1_train_steps_44800', (4, 5), 2, 512, 31, (0.997, 50, False, None)),
+    ('lunar', 'LunarLander-v2_train_steps_58400', (4, 9), 4, 512, 31, (0.997, 50, False, None)),
+    ('tictactoe', 'TicTacToe_train_steps_35000', (9, 3, 3), 10, 256, 1, (1.0, 25, True, (-1, 1))),
+]
+
+
+def gen_ckpt():
+    out = {}
+    rng = np.random.RandomState(4242)
+    for name, fname, ishape, A, P, sup, (disc, sims, board, bounds) in CKPT_CASES:
+        net = ref_network.MuZeroMLPNet(ishape, A, P, sup, sup, 64)
+        ck = torch.load(os.path.join(CKPT_DIR, fname), map_location='cpu', weights_only=False)
+        net.load_state_dict(ck['network'])
+        net.eval()
+        cfg = make_config(disc, 0.25, sims, board, bounds, sup, sup)
+        for k, v in cfg_arrays(cfg).items():
+            out[f'{name}_{k}'] = v
+        n = 0
+        for j in range(16):
+            if board:
+                env = TicTacToeEnv()
+                obs = env.reset()
+                for _ in range(rng.randint(0, 6)):
+                    legal = np.where(env.actions_mask[:9])[0]
+                    obs, _, done, _ = env.step(int(rng.choice(legal)))
+                    if done:
+                        break
+                if env.is_game_over:
+                    env = TicTacToeEnv()
+                    obs = env.reset()
+                obs, mask, players = obs.astype(np.int8), env.actions_mask.copy(), (env.current_player, env.opponent_player)
+            else:
+                D = ishape[1] - 1
+                scale = 0.2 if name == 'cartpole' else 1.0  # CartPole states near the upright pole; LunarLander's 8 features ~ U(-1, 1)
+                obs = rng.uniform(-scale, scale, size=ishape).astype(np.float32)
+                obs[:, D] = (rng.randint(0, A, size=ishape[0]) + 1) / float(A)  # the action plane of StackFrameAndAction (gym_env.py:319-322)
+                mask, players = np.ones(A, bool), (1, 1)
+            for seed in range(2):
+                T = [1.0, 0.25][seed] if not board else [1.0, 0.1][seed]
+                det = (j % 4 == 3) and seed == 1
+                _search_case(net, cfg, obs, mask, players, T, det, 3000 + 10 * j + seed, f'{name}_{n}', out, A)
+                n += 1
+        out[f'{name}_n'] = np.int32(n)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'ckpt_cases.npz'), **out)
+    print('ckpt: done,', len(out), 'arrays')
 
 
 # --------------------------------------------------------------------------------------------
@@ -1020,7 +1074,7 @@ def gen_classic():
     print('classic: done,', len(out), 'arrays')
 
 
-GROUPS = dict(classic=gen_classic, tree=gen_tree, nets=gen_nets, search=gen_search, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
+GROUPS = dict(classic=gen_classic, tree=gen_tree, nets=gen_nets, search=gen_search, ckpt=gen_ckpt, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
 
 if __name__ == '__main__':
     os.makedirs(GOLDEN_DIR, exist_ok=True)

@@ -126,7 +126,7 @@ def test_learner_gradient_allreduce_world2():
     assert res['differ_local'] and res['ok_mean'] and res['same']
 
 
-def _actor_side(actor, counter, ready, go, out):
+def _actor_side(actor, counter, ready, go1, mid, go2, out):
     """Runs in a SPAWNED process, like the reference's actors (classic/run_training.py:168-186): watches the shared network."""
     sys.path.insert(0, REPO)
     import types
@@ -137,16 +137,20 @@ def _actor_side(actor, counter, ready, go, out):
     k0 = pipeline.weights_key(actor, counter, cfg)
     w0 = float(next(actor.parameters()).flatten()[0])
     ready.set()
-    go.wait(60)
+    go1.wait(60)  # the train-step counter has crossed the boundary, the weights have NOT been published yet
     k1 = pipeline.weights_key(actor, counter, cfg)
-    w1 = float(next(actor.parameters()).flatten()[0])
-    out.put((k0 != k1, w0, w1))
+    mid.set()
+    go2.wait(60)  # now they have
+    k2 = pipeline.weights_key(actor, counter, cfg)
+    w2 = float(next(actor.parameters()).flatten()[0])
+    out.put((k0 == k1, k1 != k2, w0, w2))
 
 
 def test_weight_refresh_signal_crosses_processes():
-    """tensor._version does not cross processes.  An actor in another process must still notice that the learner
-    loaded new weights into the shared-memory actor network: the train-step counter crossing a checkpoint_interval
-    boundary is part of the key run_self_play watches, and the shared storage then holds the new values."""
+    """ADVICE r1 + r2: tensor._version does not cross processes, and the train-step counter crosses a checkpoint boundary
+    BEFORE the learner has copied the weights (learner.run_training: counter += 1, checkpoint, barrier, load_state_dict).  An
+    actor in another process must not take the counter for the signal (it would reload the old values and stay one
+    checkpoint behind); it must see the shared `weights_epoch` buffer, bumped after the new values are in place."""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import torch
 
@@ -155,19 +159,22 @@ def test_weight_refresh_signal_crosses_processes():
     ctx = mp.get_context('spawn')
     actor = build_mlp(mlp_case('tiny'))
     actor.share_memory()
+    assert actor.weights_epoch.is_shared() and 'weights_epoch' not in actor.state_dict()  # checkpoint layout unchanged
     counter = ctx.Value('i', 3)
-    ready, go, out = ctx.Event(), ctx.Event(), ctx.SimpleQueue()
-    proc = ctx.Process(target=_actor_side, args=(actor, counter, ready, go, out))
+    ready, go1, mid, go2, out = ctx.Event(), ctx.Event(), ctx.Event(), ctx.Event(), ctx.SimpleQueue()
+    proc = ctx.Process(target=_actor_side, args=(actor, counter, ready, go1, mid, go2, out))
     proc.start()
     assert ready.wait(120)
+    counter.value = 5  # run_training: train_steps_counter.value += 1 happens first ...
+    go1.set()
+    assert mid.wait(60)
     new = {k: v + 1.0 if v.dtype.is_floating_point else v for k, v in actor.state_dict().items()}
-    actor.load_state_dict(new)  # what run_training does at a checkpoint (in place: the shared storage changes)
-    counter.value = 5
-    go.set()
+    actor.publish_weights(new)  # ... the copy (in place: the shared storage changes) and the signal after it
+    go2.set()
     proc.join(timeout=60)
     assert proc.exitcode == 0
-    changed, w0, w1 = out.get()
-    assert changed and abs((w1 - w0) - 1.0) < 1e-6
+    quiet_before, fired_after, w0, w2 = out.get()
+    assert quiet_before and fired_after and abs((w2 - w0) - 1.0) < 1e-6
 
 
 def _train_worker(rank, world, port, out, tmp):

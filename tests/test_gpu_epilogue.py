@@ -114,3 +114,58 @@ def test_run_self_play_writes_into_a_device_replay():
     batch, _, _ = rp.sample_tensors(32)
     assert batch.state.shape == (32, 9, 3, 3) and batch.action.dtype == torch.int8 and batch.pi_prob.shape == (32, 5, 10)
     assert set(np.unique(batch.value.cpu().numpy())).issubset({-1.0, 0.0, 1.0})
+
+
+def test_host_reads_and_priority_updates_race_free_while_moves_are_in_flight():
+    """mz_selfplay_step returns without synchronising; a learner thread samples and updates priorities while
+    epilogue kernels are still writing.  The host never writes the counter or the whole priority array (the device owns
+    them), and the counter it reads is the COMMITTED one: it never moves backwards, every slot below it is completely
+    written, no priority the GPU wrote is lost, and the final count equals that of an undisturbed run."""
+    from muzero_amd import planner as pl
+    from muzero_amd.replay import PrioritizedReplay
+
+    cfg = types.SimpleNamespace(is_board_game=False, acc_seq_length=6, unroll_steps=5, td_steps=3, discount=0.997)
+    net = build_mlp(mlp_case('cartpole'))
+
+    def run(disturb):
+        p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=512, seed=11, num_simulations=8, discount=0.997), 0)
+        p.load_state_dict(net.state_dict())
+        rp = PrioritizedReplay(1 << 17, 1.0, 1.0, np.random.RandomState(0), device='cuda')
+        origin = p.attach_replay(rp, cfg, obs_shape=(4, 5), with_origin=True)
+        p.selfplay_reset(pl.ENV_CARTPOLE)
+        marked, seen = set(), 0
+        for _ in range(40):
+            p.selfplay_step(1.0, 3)  # asynchronous: the epilogue kernels of these moves are still queued / running
+            if not disturb:
+                continue
+            n = rp.num_added
+            assert n >= seen
+            seen = n
+            if n >= 64:
+                batch, idx, w = rp.sample_tensors(64)
+                assert (idx < n).all() or rp.num_added >= idx.max() + 1
+                assert (origin[torch.from_numpy(idx).cuda()] >= 0).all()  # the emit that filled the slot had finished
+                np.testing.assert_allclose(batch.pi_prob.sum(-1).cpu().numpy(), 1.0, atol=1e-6)
+                assert float(batch.state.abs().sum(dim=(1, 2)).min()) > 0.0  # CartPole stacks carry the action plane: never all zero
+                rp.update_priorities(idx, np.full(64, 7.0))
+                marked.update(int(i) for i in idx)
+        p.synchronize()
+        n = rp.num_added
+        prio = rp._attached[0].cpu().numpy()
+        with pytest.raises(RuntimeError):
+            rp.add(rp.get([0])[0], 1.0)  # the device owns the write cursor while attached
+        p.detach_replay()
+        assert rp._attached is None and rp.num_added == n
+        p.close()
+        return n, prio, marked
+
+    n0, prio0, _ = run(False)
+    n1, prio1, marked = run(True)
+    assert n0 == n1 and n1 < (1 << 17) and len(marked) > 100
+    for i in range(n1):
+        if i in marked:
+            assert prio1[i] == np.float32(7.0)
+    unmarked = np.array([i for i in range(n1) if i not in marked])
+    assert (prio1[unmarked] > 0).all()  # |root value - n-step target| written by the epilogue, not a stale host zero
+    # the multiset of device-written priorities is that of the undisturbed run (slot order depends on atomicAdd order)
+    assert np.isin(prio1[unmarked], prio0[:n0]).all()

@@ -217,3 +217,67 @@ def test_run_self_play_gomoku_conv_net_emits_mc_return_items():
         assert tr.state.shape == (9, 9, 9) and set(np.unique(tr.state)).issubset({0.0, 1.0})
         assert tr.action.shape == (5,) and tr.pi_prob.shape == (5, 82) and tr.value.shape == (5,)
         assert set(np.unique(tr.value)).issubset({-1.0, 0.0, 1.0}) and np.isfinite(prio)
+
+
+@pytest.mark.parametrize('game', ['cartpole', 'tictactoe'])
+def test_selfplay_search_outputs_equal_oracle_search(oracle, game):
+    """the SEARCH a device self-play move runs (pipeline.py:95-113) -- for TicTacToe the FUSE = true
+    instantiation of k_search_fast, which is the C3 bench kernel, for CartPole the two-action one behind k_env_pre / k_env_step
+    -- compared with the oracle, not just checked for being a distribution: every move's recorded observation, legal mask,
+    player to move and temperature, plus the Philox draws that move consumed (mz_debug_capture_rng), go through
+    oracle.uct_search_batch; policy, root value and sampled action must be EQUAL.  >= 256 envs x >= 40 moves, across auto-resets."""
+    import ctypes as C
+
+    from test_oracle_nets import _oracle_net
+    from muzero_amd import planner as pl
+
+    board = game == 'tictactoe'
+    case = mlp_case(game)
+    net = build_mlp(case)
+    A, S, B, M = case[2], (25 if board else 50), 256, 40
+    kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None,
+              root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    p = _planner(net, B, seed=77, **kw)
+    p.lib.mz_debug_capture_rng.argtypes = [C.c_void_p, C.c_int32]
+    p.lib.mz_debug_read_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert p.lib.mz_debug_capture_rng(p.h, 1) == 0
+    p.selfplay_reset(pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE)
+    onet = _oracle_net(oracle, net, 'mlp')
+    cfg = oracle.make_config(A, S, kw['discount'], board, kw['known_bounds'], 0.25, 0.25)
+    envs = [oracle.BoardEnv(3, 4, 3) for _ in range(B)] if board else None
+    if board:
+        for e in envs:
+            e.reset()
+    steps = np.zeros(B, np.int64)  # env steps of the running episode (the board games' temperature schedule, config.py:236-241)
+    finished = 0
+    for m in range(M):
+        p.selfplay_step(-1.0 if board else 1.0, 1)
+        noise = np.empty((B, A), np.float64)
+        utie = np.empty((B, p.max_ties), np.float64)
+        ufin = np.empty(B, np.float64)
+        assert p.lib.mz_debug_read_rng(p.h, noise.ctypes.data_as(C.c_void_p), utie.ctypes.data_as(C.c_void_p), ufin.ctypes.data_as(C.c_void_p)) == 0
+        rec = p.selfplay_read(1)
+        obs = rec['obs'][0].reshape((B,) + tuple(case[1]))
+        if board:
+            mask = np.stack([e.actions_mask for e in envs]).astype(np.uint8)
+            cur = np.array([e.current_player for e in envs], np.int32)
+            np.testing.assert_array_equal(rec['player'][0], cur)
+            opp = 3 - cur
+            T = np.where(steps < 6, 1.0, 0.1)
+        else:
+            mask, cur, opp, T = np.ones((B, A), np.uint8), 1, 1, 1.0
+        o = oracle.uct_search_batch(cfg, onet, obs, mask, cur, opp, T, False, noise=noise, u_tie=utie, u_final=ufin)
+        np.testing.assert_array_equal(rec['pi'][0], o['pi'], err_msg=f'move {m}: policy')
+        np.testing.assert_array_equal(rec['root_value'][0], o['root_value'], err_msg=f'move {m}: root value')
+        np.testing.assert_array_equal(rec['action'][0], o['action'], err_msg=f'move {m}: action')
+        done = rec['done'][0].astype(bool)
+        finished += int(done.sum())
+        steps = np.where(done, 0, steps + 1)
+        if board:
+            for b in range(B):
+                _, _, d = envs[b].step(int(rec['action'][0, b]))
+                assert d == bool(done[b])
+                if d:
+                    envs[b].reset()
+    assert finished > (B if board else B // 2)  # the comparison ran across auto-resets
+    p.close()

@@ -142,3 +142,29 @@ def test_run_training_loop_with_collector_thread(tmp_path):
         assert torch.equal(v, net.state_dict()[k])
     ck = load_checkpoint(str(tmp_path / 'train_steps_6_final'), torch.device('cpu'))
     assert set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'} and ck['train_steps'] == 6
+
+
+def test_attached_device_writer_owns_cursor_and_priorities():
+    """while a device epilogue is attached the host never writes the counter or the whole priority array."""
+    from muzero_amd.replay import PrioritizedReplay, Transition
+
+    rp = PrioritizedReplay(8, 1.0, 1.0, np.random.RandomState(0))
+    item = Transition(np.zeros((4, 5), np.float32), np.zeros(5, np.int8), np.full((5, 2), 0.5, np.float32), np.zeros(5, np.float32), np.zeros(5, np.float32))
+    for i in range(3):
+        rp.add(item, float(i + 1))
+    prio, count = rp.attach_device_writer()
+    assert int(count.item()) == 3 and prio[:3].tolist() == [1.0, 2.0, 3.0]
+    # the "device" adds two items and publishes the count
+    prio[3] = 9.0
+    prio[4] = 8.0
+    count.fill_(5)
+    rp.update_priorities([1, 1, 4], [5.0, 6.0, 4.0])  # scatters three entries, last value per repeated index; nothing else
+    assert prio[:5].tolist() == [1.0, 6.0, 3.0, 9.0, 4.0] and int(count.item()) == 5
+    assert rp.num_added == 5 and rp.size == 5
+    for call in (lambda: rp.add(item, 1.0), lambda: rp.reset(), lambda: rp.add_batch(Transition(*[np.asarray(x)[None] for x in item]), [1.0])):
+        with pytest.raises(RuntimeError):
+            call()
+    rp.detach_device_writer()
+    assert rp.num_added == 5 and rp._prio[:5].tolist() == [1.0, 6.0, 3.0, 9.0, 4.0]
+    rp.add(item, 2.5)
+    assert rp.num_added == 6

@@ -13,7 +13,19 @@ from collections import defaultdict
 
 def main():
     d, targs, pargs = sys.argv[1], sys.argv[2], sys.argv[3]
-    out = {'_trace_command': f'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {targs}',
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    from muzero_amd import build as mz_build
+
+    head = None
+    try:
+        import subprocess
+
+        head = subprocess.check_output(['git', '-C', repo, 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()[:12]
+    except Exception:  # the GPU box gets a snapshot without .git: tools/stamp_profiles.py adds the commit when the summary is copied into profiles/
+        pass
+    out = {'_source_fingerprint': mz_build.source_fingerprint(), '_git_head': head,
+           '_trace_command': f'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {targs}',
            '_pmc_command': f'rocprofv3 --kernel-trace --output-format csv --pmc <group> -- python3 bench.py {pargs}  (one run per counter group)'}
     stats = glob.glob(os.path.join(d, 'trace', '**', '*_kernel_stats.csv'), recursive=True)
     if stats:

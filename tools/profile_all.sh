@@ -23,7 +23,7 @@ run() {  # name, trace args, pmc args
 }
 for W in "$@"; do
   case $W in
-    c2) run c2 "--steps 10 --warmup 2 --no-cpu-baseline --no-sustained --no-e2e" "--steps 4 --warmup 1 --preheat 0 --no-cpu-baseline --no-sustained --no-e2e" ;;
+    c2) run c2 "--steps 10 --warmup 2 --no-cpu-baseline --no-sustained --no-e2e --no-configs" "--steps 4 --warmup 1 --preheat 0 --no-cpu-baseline --no-sustained --no-e2e --no-configs" ;;
     c3) run c3 "--workload c3 --steps 10 --warmup 2 --no-cpu-baseline --no-sustained" "--workload c3 --steps 4 --warmup 1 --preheat 0 --no-cpu-baseline --no-sustained" ;;
     c4) run c4 "--workload c4 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c4 --steps 1 --warmup 0 --sims 3 --no-cpu-baseline --no-sustained" ;;
     c5) run c5 "--workload c5 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c5 --steps 1 --warmup 0 --sims 2 --no-cpu-baseline --no-sustained" ;;

@@ -5,8 +5,8 @@ tag=${1:-q}
 out=gpurun_out/$tag
 mkdir -p $out
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $out/parity.txt 2>&1; tail -2 $out/parity.txt
-python bench.py --no-cpu-baseline --no-sustained --no-e2e > $out/bench_c2.json 2> $out/bench_c2.err
-python bench.py --workload c3 --no-cpu-baseline --no-sustained --no-e2e > $out/bench_c3.json 2> $out/bench_c3.err
+python bench.py --no-cpu-baseline --no-sustained --no-e2e --no-configs > $out/bench_c2.json 2> $out/bench_c2.err
+python bench.py --workload c3 --no-cpu-baseline --no-sustained --no-e2e --no-configs > $out/bench_c3.json 2> $out/bench_c3.err
 python - <<PY
 import json
 for n in ("c2", "c3"):
