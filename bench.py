@@ -7,8 +7,8 @@
 Workload (BASELINE.json configs[1], "C2"): CartPole-v1, 50 simulations per move, 4096 parallel environments per GPU,
 MuZeroMLPNet 512/64/31 (seeded random-init weights, synthetic data), device-resident CartPole environments with
 auto-reset, on-device Philox randomness, temperature 1.0.  One "step" = one lock-step self-play move for all
-environments of a rank: temperature kernel -> fused search kernel (root inference + 50 x {select, dynamics/reward/value
-inference, expand, backup} + play policy + action sample) -> env.step/record kernel.  All inputs are resident in HBM.
+environments of a rank = ONE kernel launch: temperature + record, root inference, 50 x {select, dynamics/reward/value inference,
+expand, backup}, play policy + action sample, env.step + record + auto-reset.  All inputs are resident in HBM.
 
 Multi-GPU: environments are independent (one planner per GPU, envs sharded by rank, no data-path collective);
 torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.  scaling = "weak".
@@ -509,7 +509,7 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512,2,2,false,true>', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, true, true, true> (P, TR, TV, FUSE, TWO, HW: the one kernel of a move -- search + env step, 8 waves)', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 # the same FLOPs over the driver-timed step (env kernels and launch gaps included), not only the search kernel
                 'frac_step': flop_per_launch / (1e-3 * 1e3 * elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,

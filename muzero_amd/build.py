@@ -91,7 +91,18 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_variant(out, extra):
+    """A/B measurements (tools/ab_bench.py): the library with extra -D flags under another name; never loaded by the product path."""
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    subprocess.check_call([hipcc] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out])
+    return out
+
+
 if __name__ == '__main__':
+    if '--variant' in sys.argv:  # python -m muzero_amd.build --variant out.so -DX=1 ...
+        i = sys.argv.index('--variant')
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        sys.exit(0)
     if '--stamps' in sys.argv:
         print(build_stamps(counters='--counters' in sys.argv))
         sys.exit(0)

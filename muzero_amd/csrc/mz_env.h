@@ -436,6 +436,60 @@ __device__ inline void env_step_one(const EnvLaunch& L, int e) {  // CartPole / 
     }
     env_record(L, e, a, reward, done);
 }
+// ---- CartPole inside the search kernel (fused self-play move): the step's inputs -- physics state, step count, the three newest
+// observation rows -- do not depend on the action, so lane 0 of the env requests them BEFORE the play-policy phase of the search
+// (one batch of independent loads whose round trip hides under that phase), and the action / policy / root value arrive in
+// registers instead of being read back from the global stores that have just been issued.  env_step_one fetched everything after
+// the action was known: four dependent global round trips at the tail of a kernel whose other lanes had nothing left to do.
+struct CartPolePre {
+    double s[4];
+    float o[15];
+    int steps;
+};
+__device__ __forceinline__ void cartpole_prefetch(const EnvLaunch& L, int e, CartPolePre& pre) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) pre.s[i] = L.env.cp_state[e * 4 + i];
+    const float* o = L.obs + (size_t)e * 20;
+#pragma unroll
+    for (int i = 0; i < 15; i++) pre.o[i] = o[i];
+    pre.steps = L.env.steps[e];
+}
+// == env_step_one (CartPole branch) + env_record with everything passed in; `pi`: the env's policy (float64, A = 2)
+__device__ __forceinline__ void cartpole_step_prefetched(const EnvLaunch& L, int e, CartPolePre& pre, int a, double root, const double* pi) {
+    double s[4] = {pre.s[0], pre.s[1], pre.s[2], pre.s[3]};
+    const bool term = cartpole_physics(s, a);
+    const int st = pre.steps + 1;
+    const bool done = term || st >= 500;
+    if (!done) {
+        L.env.steps[e] = st;
+        for (int i = 0; i < 4; i++) L.env.cp_state[e * 4 + i] = s[i];
+        float* o = L.obs + (size_t)e * 20;  // appendleft (gym_env.py:317-324)
+#pragma unroll
+        for (int i = 0; i < 15; i++) o[5 + i] = pre.o[i];
+        for (int i = 0; i < 4; i++) o[i] = (float)s[i];
+        o[4] = (float)((a + 1) / (double)2);
+    } else {
+        atomicAdd(&L.env.counters[2], 1ULL);
+        atomicAdd(&L.env.counters[3], (unsigned long long)st);
+        L.env.steps[e] = 0;
+        L.env.episode[e] += 1;
+        cartpole_fresh(L, e, s);
+        for (int i = 0; i < 4; i++) L.env.cp_state[e * 4 + i] = s[i];
+        cartpole_obs_reset(L, e, s);
+    }
+    const size_t rec = (size_t)L.slot * L.B + e;
+    L.env.r_action[rec] = a;
+    L.env.r_reward[rec] = 1.0f;
+    L.env.r_root[rec] = root;
+    L.env.r_done[rec] = done ? 1 : 0;
+    L.env.r_pi[rec * 2] = pi[0];
+    L.env.r_pi[rec * 2 + 1] = pi[1];
+    if (e == 0) {
+        atomicAdd(&L.env.counters[0], (unsigned long long)L.B);
+        atomicAdd(&L.env.counters[1], (unsigned long long)L.B * (unsigned long long)L.sims);
+    }
+}
+
 // env.step of one env by its 16-lane group (`lane` 0..15; all 16 lanes call this)
 __device__ inline void env_step_group(const EnvLaunch& L, int e, int lane) {
     if (L.env.kind != ENV_TICTACTOE && L.env.kind != ENV_GOMOKU) {

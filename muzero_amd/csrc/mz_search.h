@@ -80,6 +80,8 @@ struct SearchParams {
     // runs env_pre_one before the search (temperature, record of player / observation) and env_step_group after it
     int fuse_env;
     EnvLaunch fenv;
+    // k_search_fast with helper waves (mz_search_fast.h): bit 0: the helpers normalise the new state, bit 1: they reduce the reward row
+    int hwx;
 };
 
 // the pre-search half of a fused self-play move for env e (global id env_g); call with the env's 16 lanes

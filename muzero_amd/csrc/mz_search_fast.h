@@ -34,6 +34,10 @@ namespace mz {
 #define MZ_FAST_RD 3
 #endif
 constexpr int kFastRD = MZ_FAST_RD;  // depth of the weight ring: the stream runs kFastRD - 1 slots ahead of the MFMAs
+#ifndef MZ_FAST_HW
+#define MZ_FAST_HW 1
+#endif
+constexpr bool kFastHW = MZ_FAST_HW != 0;  // helper waves (see k_search_fast); 0: the 4-wave kernel (A/B measurements)
 
 struct FastWeights {
     const float4* stream;
@@ -250,21 +254,39 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
 
 // P = num_planes (256 or 512); TR / TV: tiles of the reward / value support (1 or 2)
 // FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
-template <int P, int TR, int TV, bool FUSE = false, bool TWO = false>
-__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
+// HW: HELPER WAVES.  The workgroup has 8 waves (two per SIMD; the kernel stays under 256 registers, so both fit): waves 0-3 are the
+// kernel as ever, waves 4-7 take VALU work that does not have to wait for the MFMA stream of its own simulation -- the new state's
+// normalisation + node-store write (while the reward head multiplies), the reward row's softmax (while the value head multiplies),
+// the root's Dirichlet draws (while the root inference multiplies) -- and otherwise sleep at the workgroup barriers.  Same
+// arithmetic, same results.  What this buys is LATENCY only: on gfx950 fp32 MFMAs and VALU instructions execute on the same
+// ALUs (matrix fp32 peak == packed vector fp32 peak), so neither a lone wave (tools/micro/mfma_valu.hip: one independent v_fma_f32
+// between two MFMAs costs +13 cycles, every further one +5; only LDS reads ride for free) nor a second wave of the SIMD (measured
+// here: the reward head slows down by about the issue cycles of the normalisation that runs beside it) hides VALU ISSUE under
+// MFMAs -- but the DPP / LDS / division latencies of those side jobs, which a lone wave sits through, overlap.  C2: -2.3 % with
+// both jobs moved; the MSE heads of C3 have no softmax and its normalisation alone is +1 %: the launcher picks (SearchParams::hwx).
+// (Tried on top and measured, not kept: the hidden states of all nodes in the helper waves' REGISTERS -- v[64:239] indexed with
+// s_set_gpr_idx from one inline-asm loop, 8 more nodes in the LDS the root buffers leave free, no HBM node store at all.  Correct,
+// but the publish -> barrier -> indexed read -> LDS -> barrier chain costs what the MALL round trip of the HBM gather costs:
+// 746.8 vs 744.7 us per C2 move.)
+template <int P, int TR, int TV, bool FUSE = false, bool TWO = false, bool HW = false>
+__global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((amdgpu_waves_per_eu(HW ? 2 : 1, HW ? 2 : 1))) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
     constexpr int RD = kFastRD;
     using C = FastCfg<P, TR, TV, RD>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lds = reinterpret_cast<float*>(smem);
-    const int tid = threadIdx.x, e = tid >> 4, a0 = tid & 15, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool main_w = !HW || wave8 < WG_WAVES;  // waves 0-3: the search as ever; waves 4-7 (HW): helpers
+    const int tid = threadIdx.x & (WG_THREADS - 1), e = tid >> 4, a0 = tid & 15, lane = tid & 63;  // (helpers: their index among the helper threads)
+    const int wave = wave8 & (WG_WAVES - 1);
     const int env_g = blockIdx.x * TILE_E + e;
     const bool env_ok = env_g < Pm.B;
-    if constexpr (FUSE) fused_env_pre(Pm, a0, env_g, env_ok);
+    if constexpr (FUSE) { if (main_w) fused_env_pre(Pm, a0, env_g, env_ok); }
+    const bool hwx = HW && (Pm.hwx & 1) != 0;   // helpers normalise the new state and write it to the node store
+    const bool hwx2 = HW && (Pm.hwx & 2) != 0;  // helpers reduce the reward row
     const MlpNet& net = Pm.net;
     const int root_layers[4] = {L_REP0, L_REP1, L_POL0, L_POL1};
-    const float warm = prefetch_root_weights(net, root_layers, 4, tid);
+    const float warm = main_w ? prefetch_root_weights(net, root_layers, 4, tid) : 0.0f;
     const MlpLds& o = Pm.o;
     float* pi0 = reinterpret_cast<float*>(smem + Pm.t_pi0);
     const float** src = reinterpret_cast<const float**>(smem + Pm.t_ptr);
@@ -273,8 +295,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     MZ_STAMP_DECL
     MZ_STAMP_START();
     // ---- tables, tree, root (identical to k_search) ----
-    stage_biases(net, lds, tid);
-    {
+    if (main_w) {
+        stage_biases(net, lds, tid);
         tree2_init(smem, Pm, tid, env_ok, env_g);  // (this kernel is tree_mode 2 only: the launcher sends other layouts to k_search)
         if (a0 == 0) {
             src[e] = env_ok ? Pm.obs + (size_t)env_g * net.in_dim : nullptr;
@@ -283,16 +305,19 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
     __syncthreads();
     MZ_STAMP(2);  // root: bias staging + tree tables
-    root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
-    load_obs(net, lds + o.X, src, tid);
+    // HW: the helpers draw the Dirichlet noise (into the t_tmp rows, read by the root prior after the inference's barriers) while
+    // waves 0-3 load the observation and run the root inference
+    if (!HW) root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
+    if (main_w) load_obs(net, lds + o.X, src, tid);
     __syncthreads();
     MZ_STAMP(15);  // root: Dirichlet draws + observation load
-    mlp_initial_tile(net, o, lds, dst, pi0, tid, true, false);  // the root's value is discarded (mcts.py:356-367)
+    if (HW && !main_w) root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
+    mlp_initial_tile(net, o, lds, dst, pi0, (int)threadIdx.x, main_w, false);  // the root's value is discarded (mcts.py:356-367)
     if (Pm.S < 0) Pm.hidden[0] = warm;  // never true: keeps the prefetch loads alive
     __syncthreads();
     {
         MZ_ROOT_TS_START();
-        if (env_ok) root_prior_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
+        if (main_w && env_ok) root_prior_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
         MZ_ROOT_TS(6);
     }
 
@@ -301,10 +326,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     WSrc ws = make_wsrc(FW.stream, FW.bytes, wave * C::SL * NT * 1024);
     ws.cur = ws.base + (RD - 1) * NT * 1024;  // the ring is primed with slots 0 .. RD-2
     float4 ring[RD][NT];
+    if (main_w) {
 #pragma unroll
-    for (int i = 0; i < RD - 1; i++) {
+        for (int i = 0; i < RD - 1; i++) {
 #pragma unroll
-        for (int j = 0; j < NT; j++) ring[i][j] = bload(ws, voff, i * NT + j);
+            for (int j = 0; j < NT; j++) ring[i][j] = bload(ws, voff, i * NT + j);
+        }
     }
     const int x_last = TWO ? 1 : net.L[L_DYN0].last_steps;  // k-steps of the action block (1..4)
     // MFMA-side env of this lane (D column) and its hidden-state rows in the HBM node store
@@ -319,13 +346,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     float4* const PB = reinterpret_cast<float4*>(lds + o.H1);
     float4* const PBr = reinterpret_cast<float4*>(lds + o.V1);
     float4* const PBv = PBr + 4 * TR * 64;
+    float* const rew_x = lds + o.OUT;  // HW: the helpers' reward scalars, [16 envs] (the OUT block is free: the root's value head is not evaluated)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 xs0[5] = {zero4, zero4, zero4, zero4, zero4};
     NoHook nohook;
     // quarter chains 1..3 of a K-split layer start from +0, quarter 0 from the bias: one pointer select per layer instead
     // of a branch per component (the PM block is free in this kernel: 128 zeros)
     float* const zeros = lds + o.PM;
-    if (tid < 128) zeros[tid] = 0.0f;
+    if (main_w && tid < 128) zeros[tid] = 0.0f;
     const float* const b_d2 = wave == 0 ? bias + net.L[L_DYN1].b_lds : zeros;
     const float* const b_r2 = wave == 0 ? bias + net.L[L_REW1].b_lds : zeros;
     const float* const b_v2 = wave == 0 ? bias + net.L[L_VAL1].b_lds : zeros;
@@ -336,15 +364,81 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int cp0 = env_ok ? Pm.cur[env_g] : 0, op0 = env_ok ? Pm.opp[env_g] : 0;  // the root's players: read once per move, not per descent
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
     tree2_env_init(T, Pm);
+    // un-normalised state h (64 x 16) from the four waves' partial tiles, ((c0 + c1) + c2) + c3
+    auto rebuild_h = [&](f32x4 (&h)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 c0 = PB[(0 * 4 + t) * 64 + lane], c1 = PB[(1 * 4 + t) * 64 + lane], c2 = PB[(2 * 4 + t) * 64 + lane],
+                         c3 = PB[(3 * 4 + t) * 64 + lane];
+            h[t] = f32x4{((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
+                         ((c0.w + c1.w) + c2.w) + c3.w};
+        }
+    };
+    // normalisation (util.py:31-36) of this wave's tile of h -> LDS (value head input) and the HBM node store
+    // (the four tiles by value: through a reference to the array the `hw = h[wave]` selects below become ONE load through a selected
+    // address, which pins the array in scratch memory -- a round trip per simulation, measured in the ISA)
+    auto normalise_store = [&](const f32x4 h0, const f32x4 h1_, const f32x4 h2, const f32x4 h3, int s) {
+        // min / max over the 64 features: 16 in this lane, the rest in the lanes of the other three rows (same env)
+        float mn = h0[0], mx = h0[0];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            mn = fmin2(h0[r], mn); mx = fmax2(h0[r], mx);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            mn = fmin2(h1_[r], mn); mx = fmax2(h1_[r], mx);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            mn = fmin2(h2[r], mn); mx = fmax2(h2[r], mx);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            mn = fmin2(h3[r], mn); mx = fmax2(h3[r], mx);
+        }
+        mn = rows_min(mn);
+        mx = rows_max(mx);
+        const float d = (mx - mn) + 1e-8f;
+        f32x4 hw = h0;
+        if (wave == 1) hw = h1_;
+        if (wave == 2) hw = h2;
+        if (wave == 3) hw = h3;
+        const float4 hs = make_float4((hw[0] - mn) / d, (hw[1] - mn) / d, (hw[2] - mn) / d, (hw[3] - mn) / d);
+        reinterpret_cast<float4*>(lds + o.HS)[wave * 64 + lane] = hs;
+        if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = hs;
+    };
+    const bool cat_heads = TWO || (net.Sr != 1 && net.Sv != 1);  // both heads categorical (TWO: guaranteed by the launcher)
+    if (HW && !main_w) {
+        // ================= helper waves: the same barriers per simulation as waves 0-3 =================
+        for (int s = 0; s < Pm.S; s++) {
+            __syncthreads();  // B0 (X ready)
+            __syncthreads();  // B1 (dynamics partial tiles ready)
+            if (hwx) {
+                f32x4 h[4];
+                rebuild_h(h);
+                normalise_store(h[0], h[1], h[2], h[3], s);
+            }
+            __syncthreads();  // B2 (reward partial tiles ready; HS written)
+            if (hwx2 && cat_heads) {  // the reward row: softmax -> expectation -> signed_parabolic (util.py:70-93), 16 lanes per env
+                const float* fr = reinterpret_cast<const float*>(PBr);
+                const bool r0 = a0 < net.Sr, r1 = a0 + 16 < net.Sr;
+                const float lr0 = head_logit<TR>(fr, r0 ? a0 : 0, e), lr1 = head_logit<TR>(fr, r1 ? a0 + 16 : 0, e);
+                const float rew = row2_logits_to_scalar(lr0, lr1, r0, r1, net.Sr, a0);
+                if (a0 == 0) rew_x[e] = rew;
+            }
+            __syncthreads();  // B3 (value partial tiles ready; reward scalars written)
+        }
+        return;
+    }
     for (int s = 0; s < Pm.S; s++) {
         tree2_select<false, TWO ? 2 : 0>(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
         const int lp = T.lp, la = T.la;
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
         {
+            float* X = lds + o.X;
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (env_ok) hv = *reinterpret_cast<const float4*>(hid_sel + (size_t)lp * 64 + a0 * 4);
-            float* X = lds + o.X;
             reinterpret_cast<float4*>(X)[(a0 >> 2) * 64 + (a0 & 3) * 16 + e] = hv;  // pk(4 a0 .. 4 a0 + 3, e)
             X[pk_act(a0, e, 4)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;
         }
@@ -378,36 +472,9 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         __syncthreads();
         MZ_STAMP(4);  // dynamics layer 2 (partials)
         // ---- every wave rebuilds the whole un-normalised state h (64 x 16) from the partials; normalisation
-        // (util.py:31-36) of its own tile goes to LDS (value head input) and to the HBM node store ----
-        {
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const float4 c0 = PB[(0 * 4 + t) * 64 + lane], c1 = PB[(1 * 4 + t) * 64 + lane], c2 = PB[(2 * 4 + t) * 64 + lane],
-                             c3 = PB[(3 * 4 + t) * 64 + lane];
-                h[t] = f32x4{((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
-                             ((c0.w + c1.w) + c2.w) + c3.w};
-            }
-            // min / max over the 64 features: 16 in this lane, the rest in the lanes of the other three rows (same env)
-            float mn = h[0][0], mx = h[0][0];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    mn = fmin2(h[t][r], mn);
-                    mx = fmax2(h[t][r], mx);
-                }
-            }
-            mn = rows_min(mn);
-            mx = rows_max(mx);
-            const float d = (mx - mn) + 1e-8f;
-            f32x4 hw = h[0];
-            if (wave == 1) hw = h[1];
-            if (wave == 2) hw = h[2];
-            if (wave == 3) hw = h[3];
-            const float4 hs = make_float4((hw[0] - mn) / d, (hw[1] - mn) / d, (hw[2] - mn) / d, (hw[3] - mn) / d);
-            reinterpret_cast<float4*>(lds + o.HS)[wave * 64 + lane] = hs;
-            if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = hs;
-        }
+        // (util.py:31-36) of its own tile goes to LDS (value head input) and to the HBM node store (HW: by the helpers) ----
+        rebuild_h(h);
+        if (!hwx) normalise_store(h[0], h[1], h[2], h[3], s);
         MZ_STAMP(5);  // reduce + normalise + hidden store
         // ---- reward head on the UN-normalised state (network.py:195-196): layer 1 from registers, layer 2 K-split ----
         {
@@ -463,12 +530,16 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
         // the results are segment-uniform, so the env's lanes go straight on to expand + backup
         {
-            // (tried: the reward row's softmax staged into the value head's MFMA slots -- VALU between the dependent MFMAs of a
-            // lone wave slowed the MFMA stream by more than the softmax costs here: 7.9 k -> 10.0 k cycles for 1.8 k saved)
+            // (a lone wave cannot hide this under its own MFMAs -- tools/micro/mfma_valu.hip; HW: the reward row is the helpers')
             const float* fr = reinterpret_cast<const float*>(PBr);
             const float* fv = reinterpret_cast<const float*>(PBv);
             float rew, val;
-            if (TWO || (net.Sr != 1 && net.Sv != 1)) {  // both heads categorical (TWO: guaranteed by the launcher) (every single-player configuration): the two rows interleaved
+            if (hwx2 && cat_heads) {
+                const bool v0 = a0 < net.Sv, v1 = a0 + 16 < net.Sv;
+                const float lv0 = head_logit<TV>(fv, v0 ? a0 : 0, e), lv1 = head_logit<TV>(fv, v1 ? a0 + 16 : 0, e);
+                rew = rew_x[e];
+                val = row2_logits_to_scalar(lv0, lv1, v0, v1, net.Sv, a0);
+            } else if (cat_heads) {  // (every single-player configuration): the two rows interleaved
                 const bool hr0 = a0 < net.Sr, hr1 = a0 + 16 < net.Sr, hv0 = a0 < net.Sv, hv1 = a0 + 16 < net.Sv;
                 const float l0[2] = {head_logit<TR>(fr, hr0 ? a0 : 0, e), head_logit<TV>(fv, hv0 ? a0 : 0, e)};
                 const float l1[2] = {head_logit<TR>(fr, hr1 ? a0 + 16 : 0, e), head_logit<TV>(fv, hv1 ? a0 + 16 : 0, e)};
@@ -499,9 +570,24 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         MZ_STAMP(9);  // expand + backup
     }
-    if (env_ok) tree2_finish_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
-    if constexpr (FUSE)
-        if (env_ok) env_step_group(Pm.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
+    bool stepped = false;
+    if constexpr (FUSE && TWO) {
+        if (Pm.fenv.env.kind == ENV_CARTPOLE) {  // the step's inputs are requested before the play policy, see mz_env.h
+            CartPolePre pre;
+            const bool stepper = env_ok && a0 == 0;
+            if (stepper) cartpole_prefetch(Pm.fenv, env_g, pre);
+            int action = 0;
+            double rootv = 0.0;
+            if (env_ok) tree2_finish_group(smem, Pm, e, a0, env_g, &action, &rootv);
+            if (stepper) cartpole_step_prefetched(Pm.fenv, env_g, pre, action, rootv, reinterpret_cast<const double*>(smem + Pm.t_tmp) + e * 2);
+            stepped = true;
+        }
+    }
+    if (!stepped) {
+        if (env_ok) tree2_finish_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
+        if constexpr (FUSE)
+            if (env_ok) env_step_group(Pm.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
+    }
     MZ_STAMP(10);  // play policy + action
     MZ_STAMP_FLUSH(Pm);
 }

@@ -568,7 +568,10 @@ __device__ __forceinline__ void tree2_finish(unsigned char* smem, const SearchPa
 // twenty float64 divisions in a row (TicTacToe: 20 k cycles per move).  The sums keep the reference's orders: numpy's pairwise
 // np.sum over the A powers (every lane adds them itself), left-to-right prefix sums for np.cumsum.  Results identical to
 // play_from_visits; all 16 lanes of the env must call it.
-__device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g) {
+// `out_action` / `out_root`: the sampled action and the root value, segment-uniform, for a caller that goes on to step the env;
+// the policy stays in the env's t_tmp row (float64).
+__device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g, int* out_action = nullptr,
+                                                   double* out_root = nullptr) {
     const int A = P.A;
     const bool mine = a0 < A;
     const int a = mine ? a0 : 0;
@@ -624,10 +627,13 @@ __device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const Se
         const int idx = le ? 32 - __clz((int)le) : 0;  // one past the last action whose cdf value is <= u
         action = idx >= A ? A - 1 : idx;
     }
+    const double rootv = root.N > 0 ? root.W / (double)root.N : 0.0;
     if (a0 == 0) {
         P.out_action[env_g] = action;
-        P.out_root[env_g] = root.N > 0 ? root.W / (double)root.N : 0.0;
+        P.out_root[env_g] = rootv;
     }
+    if (out_action) *out_action = action;
+    if (out_root) *out_root = rootv;
 }
 
 // root_prior (mz_search.h) by the env's 16 lanes, A <= 16: lane a owns action a's mask byte, mix and divisions; the sums are

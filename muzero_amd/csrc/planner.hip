@@ -68,6 +68,7 @@ struct mz_planner {
     bool tree_old = false;       // MZ_TREE_OLD=1: evaluate every level on every descent (A/B measurements, tests)
     bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
     bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
+    int hwx = -1;  // k_search_fast helper-wave work split (MZ_HWX=0..3 overrides the default: A/B measurements)
     float* d_stream[1] = {};
     float* d_bias_all = nullptr;
     double *d_dbg_noise = nullptr, *d_dbg_utie = nullptr, *d_dbg_ufinal = nullptr;  // mz_debug_capture_rng
@@ -285,9 +286,13 @@ static int planner_init(mz_planner* p, bool conv) {
         const char* fg = getenv("MZ_FORCE_GENERIC");
         p->force_generic = fg && fg[0] == '1';
         const char* fe = getenv("MZ_FUSE_ENV");
-        // default: fuse for short moves, where three extra launches are >= 4 % of a move (C3: 0.45 ms); for long moves the kernels
-        // stay separate (the env work would run single-lane at the search kernel's tail and gain nothing)
-        p->fuse_env = fe ? fe[0] != '0' : cfg->num_simulations <= 30;
+        // default: fused -- one launch per lock-step move instead of four (temperature kernel, record copy, search, env step).  Round 1
+        // kept the kernels separate for long moves because the env step ran single-lane behind four dependent global round trips at the
+        // search kernel's tail; with its inputs requested before the play-policy phase (mz_env.h, cartpole_prefetch) the fused C2 move
+        // is 727.7 us against 734.6 us (same box, same build)
+        p->fuse_env = fe ? fe[0] != '0' : true;
+        const char* hx = getenv("MZ_HWX");
+        if (hx) p->hwx = atoi(hx);
         const char* to = getenv("MZ_TREE_OLD");
         p->tree_old = to && to[0] == '1';
     }
@@ -385,9 +390,13 @@ static int planner_init(mz_planner* p, bool conv) {
     if (c.hidden_dim == 64 && (c.num_planes == 256 || c.num_planes == 512) && c.num_actions <= 16 && c.value_support_size <= 32 &&
         c.reward_support_size <= 32 && (c.value_support_size + 15) / 16 == (c.reward_support_size + 15) / 16) {
         p->fast_planes = c.num_planes;
-#define MZ_FAST_LDS(PL, T, F, W) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<PL, T, T, F, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
+#define MZ_FAST_LDS(PL, T, F, W) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<PL, T, T, F, W, kFastHW>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
 #define MZ_FAST_LDS4(PL, T) MZ_FAST_LDS(PL, T, false, false); MZ_FAST_LDS(PL, T, false, true); MZ_FAST_LDS(PL, T, true, false); MZ_FAST_LDS(PL, T, true, true)
+#ifdef MZ_DEV_SHAPES  // development builds: only the C2 / C3 shapes of the tuned kernel (a third of the compile time)
+        MZ_FAST_LDS4(256, 1); MZ_FAST_LDS4(512, 2);
+#else
         MZ_FAST_LDS4(256, 1); MZ_FAST_LDS4(256, 2); MZ_FAST_LDS4(512, 1); MZ_FAST_LDS4(512, 2);
+#endif
 #undef MZ_FAST_LDS4
 #undef MZ_FAST_LDS
     }
@@ -654,6 +663,8 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     s.seed = c.seed; s.move_counter = p->move_counter++; s.env_offset = 0; s.stamps = p->d_stamps;
     s.dbg_noise = p->d_dbg_noise; s.dbg_utie = p->d_dbg_utie; s.dbg_ufinal = p->d_dbg_ufinal;
     s.fuse_env = fenv ? 1 : 0;
+    // both where both heads are categorical (classic control: -2.3 % on C2); neither for the MSE heads of the board games (C3: +1 %), measured
+    s.hwx = p->hwx >= 0 ? p->hwx : ((c.reward_support_size > 1 && c.value_support_size > 1) ? 3 : 0);
     if (fenv) s.fenv = *fenv;
     const dim3 grid((batch + TILE_E - 1) / TILE_E), block(WG_THREADS);
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -719,13 +730,19 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
     else if (p->fast_planes && !p->force_generic && s.tree_mode == 2) {  // (k_search_fast is written for the tree_mode 2 layout)
         const int two = p->net.L[L_VAL1].n_tiles == 2;
-#define MZ_FAST4(PL, T, F, W) hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W>), grid, block, s.lds_bytes, p->stream, s, p->fw)
+#define MZ_FAST4(PL, T, F, W) hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W, kFastHW>), grid, dim3(kFastHW ? 2 * WG_THREADS : WG_THREADS), s.lds_bytes, p->stream, s, p->fw)
 #define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, true); else MZ_FAST4(PL, T, true, false); } \
                             else { if (two_act) MZ_FAST4(PL, T, false, true); else MZ_FAST4(PL, T, false, false); } } while (0)
         // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
         const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
+#ifdef MZ_DEV_SHAPES
+        if (p->fast_planes == 512 && two) MZ_FAST(512, 2);
+        else if (p->fast_planes == 256 && !two) MZ_FAST(256, 1);
+        else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
+#else
         if (p->fast_planes == 512) { if (two) MZ_FAST(512, 2); else MZ_FAST(512, 1); }
         else { if (two) MZ_FAST(256, 2); else MZ_FAST(256, 1); }
+#endif
 #undef MZ_FAST4
 #undef MZ_FAST
     }
