@@ -570,23 +570,31 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         }
         MZ_STAMP(9);  // expand + backup
     }
+    // The tail reads its parameters (output pointers, mask, temperatures; FUSE: the env's two dozen pointers) through a pointer to the
+    // kernel-argument segment that is made opaque HERE: left to itself hipcc merges these loads with the ones at the top of the kernel
+    // and carries ~100 scalars across the simulation loop -- 200+ SGPR spills in the FUSE instantiations, every reload a v_readlane
+    // plus wait states on a wave that runs alone (1.6-2 k v_readlane in the kernel against 40-70 without the env, counted in the ISA).
+    typedef const __attribute__((address_space(4))) SearchParams* late_params_t;
+    late_params_t late = (late_params_t)__builtin_amdgcn_kernarg_segment_ptr();  // (SearchParams is the kernel's first argument)
+    asm volatile("" : "+s"(late));
+    const SearchParams& Pt = *(const SearchParams*)late;
     bool stepped = false;
     if constexpr (FUSE && TWO) {
-        if (Pm.fenv.env.kind == ENV_CARTPOLE) {  // the step's inputs are requested before the play policy, see mz_env.h
+        if (Pt.fenv.env.kind == ENV_CARTPOLE) {  // the step's inputs are requested before the play policy, see mz_env.h
             CartPolePre pre;
             const bool stepper = env_ok && a0 == 0;
-            if (stepper) cartpole_prefetch(Pm.fenv, env_g, pre);
+            if (stepper) cartpole_prefetch(Pt.fenv, env_g, pre);
             int action = 0;
             double rootv = 0.0;
-            if (env_ok) tree2_finish_group(smem, Pm, e, a0, env_g, &action, &rootv);
-            if (stepper) cartpole_step_prefetched(Pm.fenv, env_g, pre, action, rootv, reinterpret_cast<const double*>(smem + Pm.t_tmp) + e * 2);
+            if (env_ok) tree2_finish_group(smem, Pt, e, a0, env_g, action, rootv);
+            if (stepper) cartpole_step_prefetched(Pt.fenv, env_g, pre, action, rootv, reinterpret_cast<const double*>(smem + Pt.t_tmp) + e * 2);
             stepped = true;
         }
     }
     if (!stepped) {
-        if (env_ok) tree2_finish_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
+        if (env_ok) tree2_finish_group(smem, Pt, e, a0, env_g);  // (A <= 16 in this kernel)
         if constexpr (FUSE)
-            if (env_ok) env_step_group(Pm.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
+            if (env_ok) env_step_group(Pt.fenv, env_g, a0);  // env.step + record + auto-reset with the action lane 0 just sampled
     }
     MZ_STAMP(10);  // play policy + action
     MZ_STAMP_FLUSH(Pm);

@@ -570,8 +570,7 @@ __device__ __forceinline__ void tree2_finish(unsigned char* smem, const SearchPa
 // play_from_visits; all 16 lanes of the env must call it.
 // `out_action` / `out_root`: the sampled action and the root value, segment-uniform, for a caller that goes on to step the env;
 // the policy stays in the env's t_tmp row (float64).
-__device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g, int* out_action = nullptr,
-                                                   double* out_root = nullptr) {
+__device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g, int& out_action, double& out_root) {
     const int A = P.A;
     const bool mine = a0 < A;
     const int a = mine ? a0 : 0;
@@ -632,8 +631,13 @@ __device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const Se
         P.out_action[env_g] = action;
         P.out_root[env_g] = rootv;
     }
-    if (out_action) *out_action = action;
-    if (out_root) *out_root = rootv;
+    out_action = action;
+    out_root = rootv;
+}
+__device__ __forceinline__ void tree2_finish_group(unsigned char* smem, const SearchParams& P, int e, int a0, int env_g) {
+    int action;
+    double rootv;
+    tree2_finish_group(smem, P, e, a0, env_g, action, rootv);
 }
 
 // root_prior (mz_search.h) by the env's 16 lanes, A <= 16: lane a owns action a's mask byte, mix and divisions; the sums are
