@@ -268,8 +268,11 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
 // s_set_gpr_idx from one inline-asm loop, 8 more nodes in the LDS the root buffers leave free, no HBM node store at all.  Correct,
 // but the publish -> barrier -> indexed read -> LDS -> barrier chain costs what the MALL round trip of the HBM gather costs:
 // 746.8 vs 744.7 us per C2 move.)
-template <int P, int TR, int TV, bool FUSE = false, bool TWO = false, bool HW = false>
+template <int P, int TR, int TV, bool FUSE = false, int AC = 0, bool HW = false>
 __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((amdgpu_waves_per_eu(HW ? 2 : 1, HW ? 2 : 1))) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
+    // AC: what the launcher knows about the action count -- 2: exactly two actions, single player, categorical heads (classic control);
+    // 10: exactly ten actions (TicTacToe: the backup's best-child refresh fully unrolled); 0: anything up to 16
+    constexpr bool TWO = AC == 2;
     constexpr int RD = kFastRD;
     using C = FastCfg<P, TR, TV, RD>;
     constexpr int NT = C::NT;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             }
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            resume = tree2_backup<TWO ? 2 : 0>(smem, Pm, tid, env_ok, s, rew, val, T);  // backup and the next select of an env run on the same 16 lanes: no barrier
+            resume = tree2_backup<TWO ? 2 : 0, (AC > 2 ? AC : 0)>(smem, Pm, tid, env_ok, s, rew, val, T);  // backup and the next select of an env run on the same 16 lanes: no barrier
         }
         MZ_STAMP(9);  // expand + backup
     }

@@ -337,7 +337,10 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
 // expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
 // the path row as written by tree2_select of the same simulation
 // returns the resume point of the next descent (see header)
-template <int AM = -1>
+// ACT: the action count when the caller knows it at compile time (0: not known): pass 2 fully unrolled, all LDS reads of a node's
+// refresh in two batches (the generic loop's rounds of four paid two exposed LDS round trips and two wave-level branches each:
+// 4.7 k cycles per backup at ten actions)
+template <int AM = -1, int ACT = 0>
 __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
                                             Tree2Env& T) {
     const int e = tid >> 4, a0 = tid & 15;
@@ -413,8 +416,10 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         const double nxt = (board && same) ? (-rw + g * val) : (rw + g * val);
         val_in = __shfl(nxt, (tid & 48) | 15, 64);
     }
-    // min-max over the env's lanes (MinMaxStats.update, mcts.py:40-42)
-    {
+    // min-max over the env's lanes (MinMaxStats.update, mcts.py:40-42).  Most backups move neither bound (known bounds: almost none
+    // does; without them the range settles after the first simulations): one wave-level test skips the two float64 butterflies --
+    // every lane then still holds the old pair
+    if (__builtin_amdgcn_ballot_w64((mx > mx0) | (mn < mn0)) != 0) {
         double o;
         o = row_ror<8>(mn); mn = o < mn ? o : mn;  o = row_ror<8>(mx); mx = o > mx ? o : mx;
         o = row_ror<4>(mn); mn = o < mn ? o : mn;  o = row_ror<4>(mx); mx = o > mx ? o : mx;
@@ -527,7 +532,29 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 *cache_at(smem, P, e, p) = cc;
                 decided = norm & (fabsf(d10) > kCacheSlack);  // == what the next descent's test computes from cc (negation is exact)
             } else {
-                rank_actions(std::integral_constant<int, 4>{});
+                if constexpr (ACT > 0) {
+                    Entry2 en[ACT];
+                    double f[ACT], pr[ACT];
+#pragma unroll
+                    for (int j = 0; j < ACT; j++) en[j] = er[j];
+#pragma unroll
+                    for (int j = 0; j < ACT; j++) { f[j] = frow[en[j].cn]; pr[j] = prior[j]; }
+#pragma unroll
+                    for (int j = 0; j < ACT; j++) {  // the same statements as rank_actions, action j
+                        const float ua = child_u(pr[j], f[j], prior_f32);
+                        er[j].U = ua;
+                        const float qn = norm ? (float)((en[j].vq - mn) * st.rinv) : (float)en[j].vq;
+                        const float u = (en[j].cn > 0 ? qn : 0.0f) + ua;
+                        const bool gt = u > best, eq = u == best;
+                        second = gt ? best : ((!eq & (u > second)) ? u : second);
+                        cnt = gt ? 1 : (eq ? cnt + 1 : cnt);
+                        besta = gt ? j : besta;
+                        bestc = gt ? (int)en[j].c : bestc;
+                        best = gt ? u : best;
+                    }
+                } else {
+                    rank_actions(std::integral_constant<int, 4>{});
+                }
                 MZ_TS(5);  // [5] backup pass 2: per-action loop
                 SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
                 cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);

@@ -391,7 +391,8 @@ static int planner_init(mz_planner* p, bool conv) {
         c.reward_support_size <= 32 && (c.value_support_size + 15) / 16 == (c.reward_support_size + 15) / 16) {
         p->fast_planes = c.num_planes;
 #define MZ_FAST_LDS(PL, T, F, W) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<PL, T, T, F, W, kFastHW>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
-#define MZ_FAST_LDS4(PL, T) MZ_FAST_LDS(PL, T, false, false); MZ_FAST_LDS(PL, T, false, true); MZ_FAST_LDS(PL, T, true, false); MZ_FAST_LDS(PL, T, true, true)
+#define MZ_FAST_LDS4(PL, T) MZ_FAST_LDS(PL, T, false, 0); MZ_FAST_LDS(PL, T, false, 2); MZ_FAST_LDS(PL, T, true, 0); MZ_FAST_LDS(PL, T, true, 2)
+        MZ_FAST_LDS(256, 1, false, 10); MZ_FAST_LDS(256, 1, true, 10);  // ten actions (TicTacToe)
 #ifdef MZ_DEV_SHAPES  // development builds: only the C2 / C3 shapes of the tuned kernel (a third of the compile time)
         MZ_FAST_LDS4(256, 1); MZ_FAST_LDS4(512, 2);
 #else
@@ -731,10 +732,13 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     else if (p->fast_planes && !p->force_generic && s.tree_mode == 2) {  // (k_search_fast is written for the tree_mode 2 layout)
         const int two = p->net.L[L_VAL1].n_tiles == 2;
 #define MZ_FAST4(PL, T, F, W) hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W, kFastHW>), grid, dim3(kFastHW ? 2 * WG_THREADS : WG_THREADS), s.lds_bytes, p->stream, s, p->fw)
-#define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, true); else MZ_FAST4(PL, T, true, false); } \
-                            else { if (two_act) MZ_FAST4(PL, T, false, true); else MZ_FAST4(PL, T, false, false); } } while (0)
+#define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, 2); else MZ_FAST4(PL, T, true, 0); } \
+                            else { if (two_act) MZ_FAST4(PL, T, false, 2); else MZ_FAST4(PL, T, false, 0); } } while (0)
         // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
         const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
+        if (p->fast_planes == 256 && !two && c.num_actions == 10) {  // (TicTacToe: ten actions)
+            if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
+        } else
 #ifdef MZ_DEV_SHAPES
         if (p->fast_planes == 512 && two) MZ_FAST(512, 2);
         else if (p->fast_planes == 256 && !two) MZ_FAST(256, 1);

@@ -1,0 +1,3 @@
+out=gpurun_out/r3h; mkdir -p $out
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_soak.py tests/test_gpu_selfplay.py tests/test_gpu_rng.py -x -q -m gpu > $out/tests.txt 2>&1; tail -2 $out/tests.txt
+timeout 300 python tools/ab_env.py "MZ_LIB=muzero_amd/lib/libmz_nohw.so" "" 2>&1 | grep -v amdgpu.ids | tee $out/ab.txt
