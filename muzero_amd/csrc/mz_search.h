@@ -123,10 +123,13 @@ __device__ __forceinline__ long long ts_now() {
 #define MZ_SUBX_START() do {} while (0)
 #define MZ_SUBX(i) do {} while (0)
 #define MZ_SUBX_COUNT(i) do {} while (0)
-#define MZ_STAMP_DECL long long _t0 = 0; long long _acc[16] = {0};
+// (phase sums accumulate in global memory with return-less atomics, not in registers: 16 64-bit accumulators per thread pushed the
+// 8-wave kernels -- 256 registers per wave -- into VGPR spills that distorted exactly the phases being timed)
+__device__ long long g_stamp_acc[16];
+#define MZ_STAMP_DECL long long _t0 = 0;
 #define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
-#define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); _acc[i] += _t1 - _t0; _t0 = _t1; } } while (0)
-#define MZ_STAMP_FLUSH(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = _acc[_i]; } while (0)
+#define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); atomicAdd(reinterpret_cast<unsigned long long*>(&g_stamp_acc[i]), (unsigned long long)(_t1 - _t0)); _t0 = _t1; } } while (0)
+#define MZ_STAMP_FLUSH(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) { __threadfence(); for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = (long long)atomicExch(reinterpret_cast<unsigned long long*>(&g_stamp_acc[_i]), 0ULL); } } while (0)
 #else
 #define MZ_COUNT(i, v) do {} while (0)
 #define MZ_SUB_DECL

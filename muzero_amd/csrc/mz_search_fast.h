@@ -33,7 +33,13 @@ namespace mz {
 #ifndef MZ_FAST_RD
 #define MZ_FAST_RD 3
 #endif
-constexpr int kFastRD = MZ_FAST_RD;  // depth of the weight ring: the stream runs kFastRD - 1 slots ahead of the MFMAs
+#ifndef MZ_FAST_RD256
+#define MZ_FAST_RD256 3
+#endif
+// depth of the weight ring: the stream runs RD - 1 slots ahead of the MFMAs (a slot is 4 NT MFMAs = 128 NT cycles).  Measured at
+// num_planes 256 (NT = 4, C3): 3, 4 and 5 deep run within 0.3 % of each other, like 3 / 4 / 6 at 512 in round 2 -- the loads are
+// not late; the MFMA phases' overhead is barriers, partial-tile exchange and bias / ReLU epilogues
+constexpr int fast_rd(int planes) { return planes == 256 ? MZ_FAST_RD256 : MZ_FAST_RD; }
 #ifndef MZ_FAST_HW
 #define MZ_FAST_HW 1
 #endif
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     // AC: what the launcher knows about the action count -- 2: exactly two actions, single player, categorical heads (classic control);
     // 10: exactly ten actions (TicTacToe: the backup's best-child refresh fully unrolled); 0: anything up to 16
     constexpr bool TWO = AC == 2;
-    constexpr int RD = kFastRD;
+    constexpr int RD = fast_rd(P);
     using C = FastCfg<P, TR, TV, RD>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -528,6 +534,10 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             for (int t = 0; t < TV; t++) PBv[(wave * TV + t) * 64 + lane] = make_float4(accv[t][0], accv[t][1], accv[t][2], accv[t][3]);
             PadSlots<C, RD, C::I_END>::run(ring, ws, voff);
         }
+        // the backup's tree reads that do not depend on this simulation's reward / value: issued ahead of the barrier and the softmax
+        // (two-action searches: -0.9 % on C2; with ten actions the backup is dominated by its refresh loop and the move was +0.6 %)
+        Backup2Pre bpre;
+        if constexpr (TWO) bpre = tree2_backup_prefetch(smem, Pm, tid, env_ok, s, T);
         __syncthreads();
         MZ_STAMP(7);  // value head
         // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             }
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            resume = tree2_backup<TWO ? 2 : 0, (AC > 2 ? AC : 0)>(smem, Pm, tid, env_ok, s, rew, val, T);  // backup and the next select of an env run on the same 16 lanes: no barrier
+            resume = tree2_backup<TWO ? 2 : 0, (AC > 2 ? AC : 0), TWO>(smem, Pm, tid, env_ok, s, rew, val, T, &bpre);  // backup and the next select of an env run on the same 16 lanes: no barrier
         }
         MZ_STAMP(9);  // expand + backup
     }

@@ -334,15 +334,34 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     MZ_TS_FLUSH(0);
 }
 
+// What the backup needs of the tree BEFORE the network's outputs exist: this lane's path node (first chunk of 16 path positions)
+// and that node's record.  The path is known since the select, nothing writes the tree during the network evaluation, so the two
+// dependent LDS reads (path row -> node) can be issued ahead of the last barrier of the evaluation and of the value row's softmax
+// instead of in front of the value recurrence (round 2's stamps: "expand + loads" ~1 k cycles per backup).
+struct Backup2Pre {
+    int p;      // node at path position L - 1 - a0 (the new node for a0 == 0; 0 for lanes beyond the path)
+    Node2 xn;   // its record (the new node's is built by the backup itself)
+};
+__device__ __forceinline__ Backup2Pre tree2_backup_prefetch(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, const Tree2Env& T) {
+    const int e = tid >> 4, a0 = tid & 15;
+    const short* path = path_row(smem, P, e);
+    const int L = env_ok ? T.depth + 1 : 0, idx = L - 1 - a0;
+    const int from_row = (int)path[idx >= 0 ? idx : 0];
+    Backup2Pre pre;
+    pre.p = idx < 0 ? 0 : (idx == L - 1 ? s + 1 : from_row);
+    pre.xn = *node2_at(smem, P, e, idx == L - 1 ? 0 : pre.p);  // (the new node's slot holds nothing yet: any valid address)
+    return pre;
+}
+
 // expand + backup + cache refresh; executed by ALL threads (16 lanes per env cooperate); r32 / v32 segment-uniform;
 // the path row as written by tree2_select of the same simulation
 // returns the resume point of the next descent (see header)
 // ACT: the action count when the caller knows it at compile time (0: not known): pass 2 fully unrolled, all LDS reads of a node's
 // refresh in two batches (the generic loop's rounds of four paid two exposed LDS round trips and two wave-level branches each:
 // 4.7 k cycles per backup at ten actions)
-template <int AM = -1, int ACT = 0>
+template <int AM = -1, int ACT = 0, bool PRE = false>
 __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, float r32, float v32,
-                                            Tree2Env& T) {
+                                            Tree2Env& T, const Backup2Pre* pre = nullptr) {
     const int e = tid >> 4, a0 = tid & 15;
     const bool two = AM < 0 ? P.A == 2 : AM == 2;
     const short* path = path_row(smem, P, e);
@@ -354,6 +373,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     const bool board = AM == 2 ? false : P.board != 0;  // (the launcher picks AM == 2 for single-player searches only)
     Tree2Env& st = T;
     int n_after = 0;          // this lane's node's visit count after pass 1 (single-chunk paths: pass 2 need not re-read it)
+    int p_first = 0;          // this lane's node in the first chunk of 16 path positions (pass 2 need not re-read the path row)
     MZ_TS_DECL
     MZ_TS_START();
     if (a0 == 0 && env_ok) {  // expand (mcts.py:386); LDS operations of one wave execute in order: later reads see this
@@ -369,10 +389,19 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         const bool valid = idx >= 0;
         // node at path position idx: the new node, or the LDS path row (unconditional loads, selects afterwards: a load
         // under a lane predicate becomes a branch with its own LDS round trip)
-        const int from_row = (int)path[idx >= 0 ? idx : 0];
-        const int p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
+        int p;
+        Node2 xn;
+        if (PRE && base == 0) {  // (compile-time + wave-uniform) prefetched before the network's outputs existed
+            p = pre->p;
+            xn = pre->xn;
+            if (idx == L - 1) { xn.W = 0.0; xn.N = 0; xn.reward = r32; xn.link = node_link(lp, la, cp); }  // the node expanded above
+        } else {
+            const int from_row = (int)path[idx >= 0 ? idx : 0];
+            p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
+            xn = *node2_at(smem, P, e, p);
+        }
+        if (base == 0) p_first = p;
         Node2* x = node2_at(smem, P, e, p);
-        const Node2 xn = *x;
         const float rwf = xn.reward;
         const double W0 = xn.W;
         const int N0 = xn.N;
@@ -465,8 +494,11 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     for (int base = 0; __any(base < L); base += 16) {
         const int idx = L - 1 - (base + a0);
         const bool valid = idx >= 0;
-        const int from_row = (int)path[idx >= 0 ? idx : 0];
-        const int p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
+        int p = p_first;  // (the path row is read again only for paths deeper than 16: the load sat in front of the whole pass)
+        if (base > 0) {   // wave-uniform
+            const int from_row = (int)path[idx >= 0 ? idx : 0];
+            p = !valid ? 0 : (idx == L - 1 ? nw : from_row);
+        }
         bool decided = false;  // the refreshed cache entry will let the next descent pass through p without evaluating it
         int bestc = -1;
         if (valid) {

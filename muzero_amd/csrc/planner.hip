@@ -527,7 +527,7 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
     p->ip.net = p->net;
     if (p->fast_planes) {
         // ONE per-wave weight stream in consumption order (layout: mz_search_fast.h header)
-        const int NT = p->fast_planes / 64, TR = p->net.L[L_REW1].n_tiles, TV = p->net.L[L_VAL1].n_tiles, RD = kFastRD;
+        const int NT = p->fast_planes / 64, TR = p->net.L[L_REW1].n_tiles, TV = p->net.L[L_VAL1].n_tiles, RD = fast_rd(p->fast_planes);
         const int I_D1 = 0, I_D2 = I_D1 + 5, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
         const int SL = (I_END + RD - 1) / RD * RD;
         std::vector<float> st((size_t)WG_WAVES * SL * NT * 256, 0.0f);

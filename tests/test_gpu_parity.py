@@ -212,6 +212,28 @@ def test_generic_and_tuned_kernels_agree(monkeypatch):
             np.testing.assert_array_equal(fast[k], fast_old[k])
 
 
+def test_helper_wave_work_split_does_not_change_results(monkeypatch):
+    """k_search_fast runs 8 waves: waves 4-7 may take the new state's normalisation (bit 0 of MZ_HWX) and the reward row's
+    softmax (bit 1) off the MFMA waves.  Every split computes the same values: identical outputs for 0, 1, 2, 3 (and the default)."""
+    for g, S, board in (('cartpole', 50, False), ('lunar', 50, False), ('tictactoe', 25, True)):
+        case = mlp_case(g)
+        net = build_mlp(case)
+        A, B = case[2], 52
+        kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+        rs = np.random.RandomState(23)
+        obs = rs.uniform(-1, 1, size=(B,) + tuple(case[1])).astype(np.float32)
+        args = (obs, np.ones((B, A), bool), 1, 2 if board else 1, 1.0, False)
+        rng = dict(noise=rs.dirichlet(np.full(A, 0.25), size=B), u_tie=rs.rand(B, 4 * S + 8), u_final=rs.rand(B))
+        monkeypatch.delenv('MZ_HWX', raising=False)
+        ref = _planner(net, B, **kw).search(*args, **rng)
+        for split in ('0', '1', '2', '3'):
+            monkeypatch.setenv('MZ_HWX', split)
+            r = _planner(net, B, **kw).search(*args, **rng)
+            for k in ('visits', 'pi', 'action', 'root_value'):
+                np.testing.assert_array_equal(ref[k], r[k], err_msg=f'{g}: MZ_HWX={split}: {k}')
+        monkeypatch.delenv('MZ_HWX', raising=False)
+
+
 def test_production_rng_properties():
     """On-device Philox mode at the BASELINE size (4096 envs): size-independent properties -- visit counts sum to
     num_simulations, policy is a distribution supported on legal actions, runs are reproducible for a fixed seed."""
