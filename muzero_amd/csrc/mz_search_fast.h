@@ -537,7 +537,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         // the backup's tree reads that do not depend on this simulation's reward / value: issued ahead of the barrier and the softmax
         // (two-action searches: -0.9 % on C2; with ten actions the backup is dominated by its refresh loop and the move was +0.6 %)
         Backup2Pre bpre;
-        if constexpr (TWO) bpre = tree2_backup_prefetch(smem, Pm, tid, env_ok, s, T);
+        if constexpr (TWO) bpre = tree2_backup_prefetch<2>(smem, Pm, tid, env_ok, s, T);
         __syncthreads();
         MZ_STAMP(7);  // value head
         // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;

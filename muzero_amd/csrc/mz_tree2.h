@@ -341,7 +341,18 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
 struct Backup2Pre {
     int p;      // node at path position L - 1 - a0 (the new node for a0 == 0; 0 for lanes beyond the path)
     Node2 xn;   // its record (the new node's is built by the backup itself)
+    // two-action searches: the node's refreshed child_U pair and what pass 2 needs of its two entries.  child_U depends on visit
+    // counts only -- known before the simulation's value is: the node's own N + 1, its path child's N + 1 (from the neighbour lane),
+    // the sibling's as stored -- so the factor-table / prior reads, the two products and the U stores are done here too; of the
+    // entries only the path child's value changes later, and that arrives in pass 2 from the neighbour lane's registers (DPP),
+    // not through an LDS write -> read round trip.
+    float ua0, ua1;
+    double vq0, vq1;  // entries' Q terms as stored (the path child's is replaced in pass 2)
+    int cn0, cn1;     // visit counts AFTER this backup
+    int c0, c1;       // child node indices as stored (the path child's slot of a fresh expansion is filled in pass 2)
+    int mvc;          // action of this node's path child (lane a0 - 1), -1: none (the new node; lanes beyond the path)
 };
+template <int AM>
 __device__ __forceinline__ Backup2Pre tree2_backup_prefetch(unsigned char* smem, const SearchParams& P, int tid, bool env_ok, int s, const Tree2Env& T) {
     const int e = tid >> 4, a0 = tid & 15;
     const short* path = path_row(smem, P, e);
@@ -350,6 +361,26 @@ __device__ __forceinline__ Backup2Pre tree2_backup_prefetch(unsigned char* smem,
     Backup2Pre pre;
     pre.p = idx < 0 ? 0 : (idx == L - 1 ? s + 1 : from_row);
     pre.xn = *node2_at(smem, P, e, idx == L - 1 ? 0 : pre.p);  // (the new node's slot holds nothing yet: any valid address)
+    if constexpr (AM == 2) {
+        const bool is_new = idx == L - 1;
+        const int mv_self = is_new ? T.la : ((pre.xn.link >> 8) & 15), n_after = (is_new ? 0 : (int)pre.xn.N) + 1;
+        const int mvn = dpp_i<DPP_SHR1>(mv_self), cnn = dpp_i<DPP_SHR1>(n_after);  // the neighbour lane's node is this node's path child
+        const bool has_child = (a0 >= 1) & (idx >= 0);
+        pre.mvc = has_child ? mvn : -1;
+        Entry2* er = entry2_row(smem, P, e, pre.p);
+        const Entry2 e0 = er[0], e1 = er[1];
+        pre.cn0 = pre.mvc == 0 ? cnn : (int)e0.cn;
+        pre.cn1 = pre.mvc == 1 ? cnn : (int)e1.cn;
+        const double* frow = reinterpret_cast<const double*>(smem + P.t2_ftab) + tri(n_after);
+        const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
+        const double f0 = frow[pre.cn0], f1 = frow[pre.cn1], p0 = prior[0], p1 = prior[1];
+        const bool prior_f32 = (P.noise_mode == 0);
+        pre.ua0 = child_u(p0, f0, prior_f32);
+        pre.ua1 = child_u(p1, f1, prior_f32);
+        if (idx >= 0) { er[0].U = pre.ua0; er[1].U = pre.ua1; }
+        pre.vq0 = e0.vq; pre.vq1 = e1.vq;
+        pre.c0 = e0.c; pre.c1 = e1.c;
+    }
     return pre;
 }
 
@@ -372,6 +403,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     const double g = P.discount;
     const bool board = AM == 2 ? false : P.board != 0;  // (the launcher picks AM == 2 for single-player searches only)
     Tree2Env& st = T;
+    double v_first = 0.0;     // this lane's node's refreshed Q term (first chunk), for the parent lane's pass 2 (PRE)
     int n_after = 0;          // this lane's node's visit count after pass 1 (single-chunk paths: pass 2 need not re-read it)
     int p_first = 0;          // this lane's node in the first chunk of 16 path positions (pass 2 need not re-read the path row)
     MZ_TS_DECL
@@ -433,6 +465,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             const double v = board ? (rw + g * -Q) : (rw + g * Q);
             x->W = W; x->N = (short)N;
             n_after = N;
+            if (base == 0) v_first = v;
             if (par >= 0) {
                 Entry2* en = entry2_row(smem, P, e, par) + mv;
                 en->vq = v; en->cn = (short)N; en->c = (short)p;
@@ -501,6 +534,33 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         }
         bool decided = false;  // the refreshed cache entry will let the next descent pass through p without evaluating it
         int bestc = -1;
+        if (PRE && AM == 2 && base == 0) {
+            // two actions, first chunk: everything but the path child's new value was prepared by tree2_backup_prefetch; that value
+            // and the child's node index come from the neighbour lane's registers.  No LDS read in this pass.
+            const double vc = dpp_d<DPP_SHR1>(v_first);
+            const int pc = dpp_i<DPP_SHR1>(p);
+            const int mvc = pre->mvc;
+            const double vq0 = mvc == 0 ? vc : pre->vq0, vq1 = mvc == 1 ? vc : pre->vq1;
+            const int c0 = mvc == 0 ? pc : pre->c0, c1 = mvc == 1 ? pc : pre->c1;
+            const float ua0 = pre->ua0, ua1 = pre->ua1;
+            const bool v0 = pre->cn0 > 0, v1 = pre->cn1 > 0;
+            const float r32n = lead_r32(mn, mx), dmpn = (float)(st.qref - mn);
+            const double x0 = v0 ? vq0 : st.qref, x1 = v1 ? vq1 : st.qref;
+            const float a10 = (float)(x1 - x0), k10 = (float)((v1 ? 1 : 0) - (v0 ? 1 : 0)), ud10 = ua1 - ua0;
+            const float d10 = fmaf(fmaf(k10, dmpn, a10), r32n, ud10);
+            const bool b1 = d10 > 0.0f;
+            bestc = b1 ? c1 : c0;
+            MZ_TS(5);  // [5] backup pass 2: per-action loop
+            if (valid) {
+                SelCache cc;
+                cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+                cc.t = b1 ? ud10 : -ud10;
+                cc.a = norm ? (b1 ? a10 : -a10) : __uint_as_float(0xff800000u);
+                cc.k = b1 ? k10 : -k10;
+                *cache_at(smem, P, e, p) = cc;
+                decided = norm & (fabsf(d10) > kCacheSlack);
+            }
+        } else
         if (valid) {
             const int Np = L <= 16 ? n_after : (int)node2_at(smem, P, e, p)->N;
             const double* frow = ftab + tri(Np);
