@@ -306,7 +306,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     // ---- tables, tree, root (identical to k_search) ----
     if (main_w) {
         stage_biases(net, lds, tid);
-        tree2_init(smem, Pm, tid, env_ok, env_g);  // (this kernel is tree_mode 2 only: the launcher sends other layouts to k_search)
+        if (!HW) tree2_init(smem, Pm, tid, env_ok, env_g);  // (this kernel is tree_mode 2 only: the launcher sends other layouts to k_search)
         if (a0 == 0) {
             src[e] = env_ok ? Pm.obs + (size_t)env_g * net.in_dim : nullptr;
             dst[e] = env_ok ? Pm.hidden + (size_t)env_g * Pm.NN * net.H : nullptr;
@@ -314,13 +314,16 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     }
     __syncthreads();
     MZ_STAMP(2);  // root: bias staging + tree tables
-    // HW: the helpers draw the Dirichlet noise (into the t_tmp rows, read by the root prior after the inference's barriers) while
-    // waves 0-3 load the observation and run the root inference
+    // HW: the helpers draw the Dirichlet noise (into the t_tmp rows, read by the root prior after the inference's barriers) and fill
+    // the tree's tables while waves 0-3 load the observation and run the root inference
     if (!HW) root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
     if (main_w) load_obs(net, lds + o.X, src, tid);
     __syncthreads();
     MZ_STAMP(15);  // root: Dirichlet draws + observation load
-    if (HW && !main_w) root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
+    if (HW && !main_w) {  // HW: the tree's tables (50 KiB of LDS writes) and the noise are the helpers' job, under the root inference
+        tree2_init(smem, Pm, tid, env_ok, env_g);
+        root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
+    }
     mlp_initial_tile(net, o, lds, dst, pi0, (int)threadIdx.x, main_w, false);  // the root's value is discarded (mcts.py:356-367)
     if (Pm.S < 0) Pm.hidden[0] = warm;  // never true: keeps the prefetch loads alive
     __syncthreads();
