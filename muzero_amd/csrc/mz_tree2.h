@@ -107,7 +107,11 @@ __device__ __forceinline__ float norm_q(double v, double mn, double mx, double r
 // child_U of one action (mcts.py:189-200): float64 product rounded once in self-play; float32 * float32 when the root
 // prior stayed float32 (deterministic search under numpy 2)
 __device__ __forceinline__ float child_u(double prior_a, double f, bool prior_f32) {
-    return prior_f32 ? ((float)prior_a * (float)f) : (float)(prior_a * f);
+    // both forms are computed and SELECTED: written as a conditional expression hipcc turns the (wave-uniform) choice into a branch
+    // around each form -- one wave-level branch per action in the backup's refresh loops, ~40 cycles each for a wave that runs alone
+    float u32 = (float)prior_a * (float)f, u64 = (float)(prior_a * f);
+    asm("" : "+v"(u32), "+v"(u64));
+    return prior_f32 ? u32 : u64;
 }
 // two-action lead test (header, "TWO ACTIONS"): the float32 reciprocal of the range; select and backup must use this very
 // expression -- the backup's resume point promises what the next descent's test will say
@@ -375,8 +379,13 @@ __device__ __forceinline__ Backup2Pre tree2_backup_prefetch(unsigned char* smem,
         const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
         const double f0 = frow[pre.cn0], f1 = frow[pre.cn1], p0 = prior[0], p1 = prior[1];
         const bool prior_f32 = (P.noise_mode == 0);
-        pre.ua0 = child_u(p0, f0, prior_f32);
-        pre.ua1 = child_u(p1, f1, prior_f32);
+        if (prior_f32) {  // (one wave-uniform branch for the pair, not two forms per product)
+            pre.ua0 = (float)p0 * (float)f0;
+            pre.ua1 = (float)p1 * (float)f1;
+        } else {
+            pre.ua0 = (float)(p0 * f0);
+            pre.ua1 = (float)(p1 * f1);
+        }
         if (idx >= 0) { er[0].U = pre.ua0; er[1].U = pre.ua1; }
         pre.vq0 = e0.vq; pre.vq1 = e1.vq;
         pre.c0 = e0.c; pre.c1 = e1.c;
@@ -567,6 +576,9 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             Entry2* er = entry2_row(smem, P, e, p);
             float best = __uint_as_float(0xff800000u), second = __uint_as_float(0xff800000u);
             int besta = 0, cnt = 0;
+            // the cached ranking's Q term (vq - min) * rinv, or vq itself while normalisation is off, as ONE expression: (vq - 0) * 1 is vq
+            // exactly, and a per-action select between the two forms compiles to a lane-level branch per action
+            const double q_sub = norm ? mn : 0.0, q_mul = norm ? st.rinv : 1.0;
             // CH actions per round (their LDS reads overlap)
             auto rank_actions = [&](auto ch_tag) {
                 constexpr int CH = decltype(ch_tag)::value;
@@ -586,7 +598,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                             // the cached ranking may use the un-checked product: its error (1 ulp of float32) is far inside
                             // the cache's slack, and a choice that is not decided by more than the slack is re-evaluated
                             // exactly at visit time anyway
-                            const float qn = norm ? (float)((en[j].vq - mn) * st.rinv) : (float)en[j].vq;
+                            const float qn = (float)((en[j].vq - q_sub) * q_mul);
                             const float u = (en[j].cn > 0 ? qn : 0.0f) + ua;
                             // first maximum, number of actions tied with it, runner-up -- as selects (branches on lane
                             // predicates cost a wave that runs alone on its SIMD far more than the selects do)
@@ -631,19 +643,28 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                     for (int j = 0; j < ACT; j++) en[j] = er[j];
 #pragma unroll
                     for (int j = 0; j < ACT; j++) { f[j] = frow[en[j].cn]; pr[j] = prior[j]; }
+                    // the same ranking as rank_actions with two simplifications that change no result: the form of child_U is chosen once
+                    // per backup, not per action (two copies of the loop), and ties are not counted -- an action that ties with the best
+                    // one becomes the runner-up, margin 0, which the next descent's test (thr < t) can never pass: the level is then
+                    // evaluated (and its draw consumed) at visit time exactly as with the explicit tie mark
+                    auto refresh = [&](auto f32_tag) {
+                        constexpr bool F32 = decltype(f32_tag)::value;
 #pragma unroll
-                    for (int j = 0; j < ACT; j++) {  // the same statements as rank_actions, action j
-                        const float ua = child_u(pr[j], f[j], prior_f32);
-                        er[j].U = ua;
-                        const float qn = norm ? (float)((en[j].vq - mn) * st.rinv) : (float)en[j].vq;
-                        const float u = (en[j].cn > 0 ? qn : 0.0f) + ua;
-                        const bool gt = u > best, eq = u == best;
-                        second = gt ? best : ((!eq & (u > second)) ? u : second);
-                        cnt = gt ? 1 : (eq ? cnt + 1 : cnt);
-                        besta = gt ? j : besta;
-                        bestc = gt ? (int)en[j].c : bestc;
-                        best = gt ? u : best;
-                    }
+                        for (int j = 0; j < ACT; j++) {
+                            const float ua = F32 ? ((float)pr[j] * (float)f[j]) : (float)(pr[j] * f[j]);  // child_u
+                            er[j].U = ua;
+                            const float qn = (float)((en[j].vq - q_sub) * q_mul);
+                            const float u = (en[j].cn > 0 ? qn : 0.0f) + ua;
+                            const bool gt = u > best;
+                            second = gt ? best : (u > second ? u : second);
+                            besta = gt ? j : besta;
+                            bestc = gt ? (int)en[j].c : bestc;
+                            best = gt ? u : best;
+                        }
+                    };
+                    if (prior_f32) refresh(std::true_type{});
+                    else refresh(std::false_type{});
+                    cnt = 1;  // (ties: see above)
                 } else {
                     rank_actions(std::integral_constant<int, 4>{});
                 }
