@@ -268,8 +268,9 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
 // ALUs (matrix fp32 peak == packed vector fp32 peak), so neither a lone wave (tools/micro/mfma_valu.hip: one independent v_fma_f32
 // between two MFMAs costs +13 cycles, every further one +5; only LDS reads ride for free) nor a second wave of the SIMD (measured
 // here: the reward head slows down by about the issue cycles of the normalisation that runs beside it) hides VALU ISSUE under
-// MFMAs -- but the DPP / LDS / division latencies of those side jobs, which a lone wave sits through, overlap.  C2: -2.3 % with
-// both jobs moved; the MSE heads of C3 have no softmax and its normalisation alone is +1 %: the launcher picks (SearchParams::hwx).
+// MFMAs -- but the DPP / LDS / division latencies of those side jobs, which a lone wave sits through, overlap.  C2: -3.8 % with
+// both jobs moved (731.0 -> 702.9 us); C3 (MSE heads: no softmax row) -1.2 % with the normalisation: the launcher picks
+// (SearchParams::hwx).
 // (Tried on top and measured, not kept: the hidden states of all nodes in the helper waves' REGISTERS -- v[64:239] indexed with
 // s_set_gpr_idx from one inline-asm loop, 8 more nodes in the LDS the root buffers leave free, no HBM node store at all.  Correct,
 // but the publish -> barrier -> indexed read -> LDS -> barrier chain costs what the MALL round trip of the HBM gather costs:
