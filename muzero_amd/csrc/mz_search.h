@@ -530,11 +530,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_search(const SearchParams P) {
         else if (a0 == 0 && env_ok) tree_expand_backup(smem, P, e, s, r32, v32);
         __syncthreads();
     }
+    // the tail reads its parameters through an opaque pointer to the kernel-argument segment (see k_search_fast: merged with the loads
+    // at the top of the kernel they are carried across the simulation loop as spilled scalars)
+    typedef const __attribute__((address_space(4))) SearchParams* late_params_t;
+    late_params_t late = (late_params_t)__builtin_amdgcn_kernarg_segment_ptr();  // (SearchParams is the kernel's only argument)
+    asm volatile("" : "+s"(late));
+    const SearchParams& Pt = *(const SearchParams*)late;
     if (a0 == 0 && env_ok) {
-        if (P.tree_mode == 2) tree2_finish(smem, P, e, env_g);
-        else tree_finish(smem, P, e, env_g);
+        if (Pt.tree_mode == 2) tree2_finish(smem, Pt, e, env_g);
+        else tree_finish(smem, Pt, e, env_g);
     }
-    if (!SCRIPTED && P.fuse_env && env_ok) env_step_group(P.fenv, env_g, a0);
+    if (!SCRIPTED && Pt.fuse_env && env_ok) env_step_group(Pt.fenv, env_g, a0);
 }
 
 // ---- stand-alone batched inference (network.py:62-111) on the same tile pipeline ----
