@@ -577,6 +577,124 @@ __global__ __launch_bounds__(256) void k_gtree_select(const GTreeLaunch G) {
     }
 }
 
+// ---- select with ONE WAVE PER ENV (HBM trees, many actions) ----
+// k_gtree_select gives an env 16 lanes and a workgroup 16 envs: at C5 (256 envs, 226 actions) that is 16 workgroups on 256 CUs, each
+// lane walking 15 action chunks per level through dependent global loads -- 98 us per simulation, 2 % of a move.  Here a wave owns
+// an env (64 lanes -> 4 chunks per level at 226 actions) and a 256-thread workgroup four envs: 4x fewer dependent chunks per level,
+// 4x as many workgroups.  Same per-action arithmetic as select_level (child_Q + child_U, mcts.py:159-200), same tie set in
+// ascending action order, same draw protocol: identical results.
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = butterfly16_max(v);
+    const float a = __shfl_xor(v, 16, 64);
+    v = a > v ? a : v;
+    const float b = __shfl_xor(v, 32, 64);
+    return b > v ? b : v;
+}
+__device__ __forceinline__ int nth_set_bit64(unsigned long long m, int idx) {
+    for (int i = 0; i < idx; i++) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+constexpr int MAX_CH64 = 4;  // action chunks of 64 lanes: A <= 256
+
+__global__ __launch_bounds__(256) void k_gtree_select_wave(const GTreeLaunch G) {
+    const SearchParams& P = G.P;
+    const int lane = threadIdx.x & 63, env_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env_g >= P.B) return;  // (whole waves leave: no barrier in this kernel)
+    unsigned char* smem = G.regions + (size_t)(env_g / TILE_E) * P.lds_bytes;
+    const int e = env_g % TILE_E;
+    double* mm = reinterpret_cast<double*>(smem + P.t_mm) + e * 2;
+    int* sel = reinterpret_cast<int*>(smem + P.t_sel) + e * 4;
+    const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
+    const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
+    const double mn = mm[0], mx = mm[1];
+    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0);
+    const int nch = (P.A + 63) >> 6;
+    int n = 0, cp = P.cur[env_g], op = P.opp[env_g], ties = sel[3];
+    int lp = 0, la = 0, lpl = 0, depth = 0;
+    for (;;) {
+        // ---- best_child of node n (mcts.py:104-127) ----
+        const int Nn = node_at(smem, P, e, n)->N;
+        const double* frow = ftab + Nn * (P.S + 1);
+        const short* crow = child_row(smem, P, e, n);
+        float u[MAX_CH64];
+        float best = __uint_as_float(0xff800000u);
+#pragma unroll
+        for (int ch = 0; ch < MAX_CH64; ch++) {
+            u[ch] = __uint_as_float(0xff800000u);
+            const int a = ch * 64 + lane;
+            if (ch < nch && a < P.A) {
+                const int c = crow[a];
+                int cn = 0;
+                float qa = 0.0f;  // child_Q, mcts.py:159-178
+                if (c >= 0) {
+                    const TreeNode* cd = node_at(smem, P, e, c);
+                    cn = cd->N;
+                    if (cn > 0) {
+                        double v = cd->vq;
+                        if (norm) v = (v - mn) / (mx - mn);
+                        qa = (float)v;
+                    }
+                }
+                const double f = frow[cn];  // child_U, mcts.py:180-200
+                const float ua = prior_f32 ? ((float)prior[a] * (float)f) : (float)(prior[a] * f);
+                u[ch] = qa + ua;
+                best = u[ch] > best ? u[ch] : best;
+            }
+        }
+        best = wave_max_f32(best);
+        unsigned long long msk[MAX_CH64];  // tie set in ascending action order (np.where(ucb == max), mcts.py:124)
+        int total = 0;
+#pragma unroll
+        for (int ch = 0; ch < MAX_CH64; ch++) {
+            const int a = ch * 64 + lane;
+            msk[ch] = __ballot((ch < nch) && (a < P.A) && (u[ch] == best));
+            total += __popcll(msk[ch]);
+        }
+        int pick = 0;
+        if (total > 1) {  // np.random.choice consumes randomness only when there is a real tie (wave-uniform)
+            double uu;
+            if (P.rng_mode == 0) {
+                if (ties < P.max_ties) uu = P.u_tie[(size_t)env_g * P.max_ties + ties];
+                else { uu = 0.5; if (lane == 0) atomicExch(P.err, 4); }
+            } else {
+                Philox g(P.seed, P.env_offset + (unsigned)env_g, P.move_counter, 0x10000000u + (unsigned)ties);
+                uu = g.uniform();
+                if (P.dbg_utie && lane == 0 && ties < P.max_ties) P.dbg_utie[(size_t)env_g * P.max_ties + ties] = uu;
+            }
+            ties++;
+            pick = (int)floor(uu * (double)total);
+            pick = pick >= total ? total - 1 : pick;
+        }
+        int a_sel = 0, cum = 0;
+        bool found = false;
+#pragma unroll
+        for (int ch = 0; ch < MAX_CH64; ch++) {
+            const int c = __popcll(msk[ch]);
+            if (!found && pick < cum + c) {
+                a_sel = ch * 64 + nth_set_bit64(msk[ch], pick - cum);
+                found = true;
+            }
+            cum += c;
+        }
+        const int t = cp; cp = op; op = t;  // mcts.py:379
+        const int c = crow[a_sel];
+        depth++;
+        if (c < 0 || depth > P.NN) { lp = n; la = a_sel; lpl = cp; break; }
+        n = c;
+    }
+    if (lane == 0) {
+        sel[0] = lp; sel[1] = la; sel[2] = lpl; sel[3] = ties;
+        float* base = P.hidden + (size_t)env_g * P.NN * G.hidden_size;
+        G.src_ptrs[env_g] = base + (size_t)lp * G.hidden_size;
+        G.dst_ptrs[env_g] = base + (size_t)(G.sim + 1) * G.hidden_size;
+        G.actions[env_g] = la;
+        if (P.trace_parent) {
+            P.trace_parent[(size_t)env_g * P.S + G.sim] = lp;
+            P.trace_action[(size_t)env_g * P.S + G.sim] = la;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gtree_backup(const GTreeLaunch G) {
     const SearchParams& P = G.P;
     unsigned char* smem = G.regions + (size_t)blockIdx.x * P.lds_bytes;
