@@ -69,7 +69,7 @@ struct mz_planner {
     bool force_generic = false;  // MZ_FORCE_GENERIC=1: run the shape-generic kernel (A/B measurements, tests)
     bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
     int hwx = -1;  // k_search_fast helper-wave work split (MZ_HWX=0..3 overrides the default: A/B measurements)
-    bool gtree_wave = false;  // HBM trees: select with one wave per env (set when num_actions > 32)
+    bool gtree_wave = true;   // HBM trees: select with one wave per env
     float* d_stream[1] = {};
     float* d_bias_all = nullptr;
     double *d_dbg_noise = nullptr, *d_dbg_utie = nullptr, *d_dbg_ufinal = nullptr;  // mz_debug_capture_rng
@@ -293,7 +293,7 @@ static int planner_init(mz_planner* p, bool conv) {
         // is 727.7 us against 734.6 us (same box, same build)
         p->fuse_env = fe ? fe[0] != '0' : true;
         const char* gw = getenv("MZ_GTREE_WAVE");
-        p->gtree_wave = gw ? gw[0] != '0' : (cfg->num_actions > 32 && cfg->num_actions <= 64 * MAX_CH64);
+        p->gtree_wave = gw ? gw[0] != '0' : cfg->num_actions <= 64 * MAX_CH64;  // (C5: +4.3 %; C4, six actions: +0.5 %)
         const char* hx = getenv("MZ_HWX");
         if (hx) p->hwx = atoi(hx);
         const char* to = getenv("MZ_TREE_OLD");
@@ -715,7 +715,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         hipLaunchKernelGGL(k_gtree_init, grid, block, 0, p->stream, G);
         for (int sim = 0; sim < c.num_simulations; sim++) {
             G.sim = sim;
-            // many actions: one wave per env (see k_gtree_select_wave); MZ_GTREE_WAVE=0/1 overrides (A/B measurements, tests)
+            // one wave per env (see k_gtree_select_wave); MZ_GTREE_WAVE=0/1 overrides (A/B measurements, tests)
             if (p->gtree_wave) hipLaunchKernelGGL(k_gtree_select_wave, dim3((batch + 3) / 4), block, 0, p->stream, G);
             else hipLaunchKernelGGL(k_gtree_select, grid, block, 0, p->stream, G);
             if (scripted) {
