@@ -1,4 +1,7 @@
-out=gpurun_out/r3j; mkdir -p $out
+#!/bin/bash
+# Round checkpoint on the GPU box (run through gpurun): the whole GPU test suite, the default bench line, rocprofv3 profiles of all
+# four workloads (tools/profile_all.sh -> gpurun_out/profiles/, then tools/stamp_profiles.py here) and the phase stamps of C2 / C3.
+out=gpurun_out/checkpoint; mkdir -p $out
 timeout 900 python -m pytest tests -m gpu -x -q > $out/tests.txt 2>&1; tail -3 $out/tests.txt
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; tail -2 $out/bench_default.err
 python - <<PY
@@ -9,3 +12,5 @@ for k, v in (d.get("configs") or {}).items(): print(k, "%.1f k sims/s" % (v["val
 print(d["e2e"]["fraction_of_planner_rate"], d["sustained"]["frac"], d["cpu_baseline"]["value"])
 PY
 bash tools/profile_all.sh c2 c3 c4 c5 > $out/profile_all.log 2>&1; tail -3 $out/profile_all.log
+python tools/phase_profile.py cartpole 2>&1 | grep -v amdgpu.ids > $out/phase_c2.txt; tail -14 $out/phase_c2.txt
+python tools/phase_profile.py tictactoe 2>&1 | grep -v amdgpu.ids > $out/phase_c3.txt; tail -14 $out/phase_c3.txt
