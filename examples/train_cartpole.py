@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--eval-episodes', type=int, default=3)
     ap.add_argument('--out', default='')
     ap.add_argument('--host-assembly', action='store_true', help='assemble (Transition, priority) items on the host instead of the device epilogue')
+    ap.add_argument('--eager-learner', action='store_true', help='learner.train_step per update instead of the HIP-graph step (learner.GraphedTrainStep)')
     args = ap.parse_args()
 
     from muzero_amd import learner
@@ -49,7 +50,8 @@ def main():
     cfg = make_classic_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
     cfg.num_envs = args.envs
     net = MuZeroMLPNet((4, 5), 2, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    opt = (torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay) if args.eager_learner
+           else learner.make_capturable_adam(net, cfg, dev))
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
     replay = PrioritizedReplay(50000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
 
@@ -62,6 +64,7 @@ def main():
     asm = EpisodeAssembler(cfg, args.envs, (4, 5))
 
     steps, t0, last = 0, time.time(), dict(episodes=0, episode_steps=0)
+    graphed = None
     log = []
     while steps < args.train_steps:
         T = float(cfg.visit_softmax_temperature_fn(0, steps))
@@ -74,15 +77,21 @@ def main():
         net.train()
         for _ in range(args.updates_per_iter):
             batch, idx, w = replay.sample_tensors(cfg.batch_size)
-            loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
-            replay.update_priorities(idx, prio)
+            if args.eager_learner:
+                loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
+                replay.update_priorities(idx, prio)
+            else:  # the whole update as one HIP graph; uniform replay (the launchers' default) ignores priorities: no host read-back
+                if graphed is None:
+                    graphed = learner.GraphedTrainStep(cfg, net, opt, dev, cfg.batch_size, (4, 5), cfg.unroll_steps, 2)
+                loss, prio = graphed(batch, w)
+                sched.step()
             steps += 1
             if steps % args.report_every == 0:
                 c = p.selfplay_counters()
                 de, ds = c['episodes'] - last['episodes'], c['episode_steps'] - last['episode_steps']
                 last = dict(episodes=c['episodes'], episode_steps=c['episode_steps'])
                 rec = dict(train_steps=steps, env_steps=c['env_steps'], episodes_finished=de, mean_episode_length=(ds / de) if de else None,
-                           loss=loss, replay=replay.size, seconds=round(time.time() - t0, 1))
+                           loss=float(loss), replay=replay.size, seconds=round(time.time() - t0, 1))
                 log.append(rec)
                 print(json.dumps(rec), flush=True)
         net.eval()

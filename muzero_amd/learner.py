@@ -100,6 +100,29 @@ def unroll(network: MuZeroNet, state: torch.Tensor, action: torch.Tensor):
     return torch.stack(pis, dim=1), torch.stack(values, dim=1), torch.stack(rewards, dim=1)
 
 
+def loss_tensors(network: MuZeroNet, state, action, value_scalar, reward_scalar, pi_target, weights) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`calc_loss` on tensors that already live on the network's device, returning TENSORS (loss, priorities [B]): no host
+    synchronisation anywhere, so the whole update can be captured into a HIP graph (`GraphedTrainStep`)."""
+    K = action.shape[1]
+    mse_v, mse_r = network.mse_loss_for_value, network.mse_loss_for_reward
+    pi_logits, value_out, reward_out = unroll(network, state, action)
+    value_target = value_scalar.unsqueeze(-1) if mse_v else scalar_to_categorical_probabilities(value_scalar, network.value_support_size)
+    reward_target = reward_scalar.unsqueeze(-1) if mse_r else scalar_to_categorical_probabilities(reward_scalar, network.reward_support_size)
+    v_loss = loss_func(value_out, value_target, mse_v)
+    r_loss = loss_func(reward_out, reward_target, mse_r)
+    if mse_v:
+        v_loss = v_loss.squeeze(-1)
+    if mse_r:
+        r_loss = r_loss.squeeze(-1)
+    per_sample = (r_loss + v_loss + loss_func(pi_logits, pi_target)).sum(dim=1)  # [B]
+    loss = scale_gradient((per_sample * weights.detach()).mean(), 1.0 / K)
+    with torch.no_grad():
+        v0 = value_out[:, 0]
+        v0_scalar = v0.squeeze(-1) if mse_v else logits_to_transformed_expected_value(v0, network.value_support_size).squeeze(-1)
+        priorities = (v0_scalar - value_scalar[:, 0]).abs()
+    return loss, priorities
+
+
 def calc_loss(network: MuZeroNet, device: torch.device, transitions: Transition, weights: torch.Tensor) -> Tuple[torch.Tensor, np.ndarray]:
     """The MuZero loss of one batch and the new replay priorities (pipeline.py:541-612).  `transitions` fields may be numpy
     arrays (reference form) or tensors already on `device` (`PrioritizedReplay.sample_tensors`).
@@ -113,26 +136,8 @@ def calc_loss(network: MuZeroNet, device: torch.device, transitions: Transition,
     value_scalar = _as_tensor(transitions.value, device, torch.float32)    # [B, K]
     reward_scalar = _as_tensor(transitions.reward, device, torch.float32)  # [B, K]
     pi_target = _as_tensor(transitions.pi_prob, device, torch.float32)     # [B, K, A]
-    K = action.shape[1]
-    mse_v, mse_r = network.mse_loss_for_value, network.mse_loss_for_reward
-
-    pi_logits, value_out, reward_out = unroll(network, state, action)
-    value_target = value_scalar.unsqueeze(-1) if mse_v else scalar_to_categorical_probabilities(value_scalar, network.value_support_size)
-    reward_target = reward_scalar.unsqueeze(-1) if mse_r else scalar_to_categorical_probabilities(reward_scalar, network.reward_support_size)
-    v_loss = loss_func(value_out, value_target, mse_v)
-    r_loss = loss_func(reward_out, reward_target, mse_r)
-    if mse_v:
-        v_loss = v_loss.squeeze(-1)
-    if mse_r:
-        r_loss = r_loss.squeeze(-1)
-    per_sample = (r_loss + v_loss + loss_func(pi_logits, pi_target)).sum(dim=1)  # [B]
-    loss = scale_gradient((per_sample * weights.detach()).mean(), 1.0 / K)
-
-    with torch.no_grad():
-        v0 = value_out[:, 0]
-        v0_scalar = v0.squeeze(-1) if mse_v else logits_to_transformed_expected_value(v0, network.value_support_size).squeeze(-1)
-        priorities = (v0_scalar - value_scalar[:, 0]).abs().cpu().numpy()
-    return loss, priorities
+    loss, priorities = loss_tensors(network, state, action, value_scalar, reward_scalar, pi_target, weights)
+    return loss, priorities.cpu().numpy()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -188,6 +193,82 @@ def train_step(config, network, optimizer, lr_scheduler, device, transitions, we
     return float(loss.detach()), priorities
 
 
+class GraphedTrainStep:
+    """The whole learner update of `train_step` -- unroll forward, loss, backward, gradient clipping, Adam -- captured ONCE as a HIP
+    graph and replayed per step.  The MLP learner step is launch-bound: ~400 small kernels for a 128-sample batch, each a few
+    microseconds of GPU work behind a Python / dispatcher round trip; replayed as one graph the GPU runs them back to back
+    (`tools/learner_bench.py`: ms per step eager vs graphed, and the parity of the two).  Same arithmetic as the eager step: the same
+    autograd graph, `torch.optim.Adam(..., capturable=True)` (step count and bias corrections as device tensors), the learning rate a
+    device tensor that `MultiStepLR` fills in place, so the schedule is not baked into the capture.
+
+    Requirements: one learner rank (a gradient all-reduce would have to be captured too: the eager `train_step` remains the
+    multi-rank path), fixed batch shapes, an optimizer built by `make_capturable_adam`.  `__call__` returns device tensors (loss,
+    priorities): nothing synchronises with the host unless the caller reads them."""
+
+    def __init__(self, config, network, optimizer, device, batch_size: int, state_shape, unroll_steps: int, num_actions: int):
+        if not all(g.get('capturable', False) for g in optimizer.param_groups):
+            raise ValueError('GraphedTrainStep needs an optimizer with capturable=True (learner.make_capturable_adam)')
+        self.config, self.network, self.optimizer = config, network, optimizer
+        B, K, A = batch_size, unroll_steps, num_actions
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=device)  # noqa: E731
+        self.state, self.action = z(B, *state_shape), z(B, K, dtype=torch.long)
+        self.value, self.reward, self.pi, self.weights = z(B, K), z(B, K), torch.full((B, K, A), 1.0 / A, device=device), torch.ones(B, device=device)
+        # warm-up on a side stream (allocator pools, lazy optimizer state), then restore weights and optimizer state: the warm-up
+        # steps must not count as training
+        import copy
+
+        net_state = copy.deepcopy(network.state_dict())
+        fresh = len(optimizer.state) == 0
+        opt_state = None if fresh else copy.deepcopy(optimizer.state_dict())
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._step_body()
+        torch.cuda.current_stream(device).wait_stream(side)
+        network.load_state_dict(net_state)
+        if fresh:
+            # a fresh optimizer goes back to zero moments and step IN PLACE: restoring an empty state would make Adam allocate and
+            # zero its state inside the capture, and every replay would then reset the moments
+            for st in optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        else:
+            optimizer.load_state_dict(opt_state)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss, self.priorities = self._step_body()
+
+    def _step_body(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, priorities = loss_tensors(self.network, self.state, self.action, self.value, self.reward, self.pi, self.weights)
+        loss.backward()
+        if self.config.clip_grad:
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.config.max_grad_norm)
+        self.optimizer.step()
+        return loss.detach(), priorities
+
+    def __call__(self, transitions: Transition, weights) -> Tuple[torch.Tensor, torch.Tensor]:
+        dev = self.state.device
+        self.state.copy_(_as_tensor(transitions.state, dev, torch.float32))
+        self.action.copy_(_as_tensor(transitions.action, dev, torch.long))
+        self.value.copy_(_as_tensor(transitions.value, dev, torch.float32))
+        self.reward.copy_(_as_tensor(transitions.reward, dev, torch.float32))
+        self.pi.copy_(_as_tensor(transitions.pi_prob, dev, torch.float32))
+        self.weights.copy_(_as_tensor(weights, dev, torch.float32))
+        self.graph.replay()
+        return self.loss, self.priorities
+
+
+def make_capturable_adam(network, config, device):
+    """`torch.optim.Adam` as the reference builds it (lr_init, weight_decay: classic/run_training.py:94-95) in the form a HIP graph can
+    hold: capturable, learning rate as a device tensor (LR schedulers fill it in place)."""
+    return torch.optim.Adam(network.parameters(), lr=torch.tensor(float(config.lr_init), device=device), weight_decay=config.weight_decay,
+                            capturable=True)
+
+
 def _all_ranks(flag_any: bool, device) -> bool:
     """True if `flag_any` is set on ANY learner rank (a tiny MAX all-reduce); the local value without a process group."""
     import torch.distributed as dist
@@ -229,6 +310,7 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
     from muzero_amd import metrics as mzm
 
     metrics = mzm.LearnerMetrics(mzm.run_file(config, 'learner', tag) if rank == 0 else None)
+    graphed = None
 
     def snapshot():
         return {'network': network.state_dict(), 'optimizer': optimizer.state_dict(), 'lr_scheduler': lr_scheduler.state_dict(),
@@ -254,7 +336,16 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
         if _all_ranks(train_steps_counter.value >= config.num_training_steps, device):
             break
         transitions, indices, weights = replay.sample_tensors(config.batch_size)
-        loss, priorities = train_step(config, network, optimizer, lr_scheduler, device, transitions, weights)
+        if graphed is None and not multi and torch.device(device).type == 'cuda' and all(g.get('capturable', False) for g in optimizer.param_groups):
+            # an optimizer built by make_capturable_adam on one learner rank: the update runs as one HIP graph (GraphedTrainStep)
+            graphed = GraphedTrainStep(config, network, optimizer, device, config.batch_size, tuple(transitions.state.shape[1:]),
+                                       int(transitions.action.shape[1]), int(transitions.pi_prob.shape[2]))
+        if graphed is not None:
+            loss_t, prio_t = graphed(transitions, weights)
+            lr_scheduler.step()
+            loss, priorities = float(loss_t), prio_t.cpu().numpy()
+        else:
+            loss, priorities = train_step(config, network, optimizer, lr_scheduler, device, transitions, weights)
         if priorities is not None:
             if priorities.shape != (config.batch_size,):
                 raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {priorities.shape}')

@@ -132,3 +132,44 @@ def test_classic_evaluator_runs_cartpole_checkpoints(tmp_path):
     assert len(res) == 1 and res[0][2] == 7 and len(res[0][0]) == 2
     for ret, steps in zip(res[0][0], res[0][1]):
         assert ret == float(steps) and 8 <= steps <= 500  # reward 1 per step; an untrained net drops the pole quickly
+
+
+def test_graphed_train_step_matches_eager_step():
+    """learner.GraphedTrainStep -- the whole update (unroll forward, loss, backward, clipping, Adam) replayed as ONE HIP graph -- against
+    learner.train_step from the same start: losses, priorities, the learning-rate schedule across a milestone, and the weights
+    after six updates (capturable Adam orders a few float32 operations differently: 5e-4 absolute on weights that move by lr per step)."""
+    import copy
+
+    import torch
+    from muzero_amd import learner
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.network import MuZeroMLPNet
+    from muzero_amd.replay import Transition
+
+    dev = torch.device('cuda', 0)
+    cfg = make_classic_config(use_tensorboard=False)
+    B, K, A = 64, cfg.unroll_steps, 2
+    torch.manual_seed(0)
+    net_a = MuZeroMLPNet((4, 5), A, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+    net_b = copy.deepcopy(net_a)
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    sch_a = torch.optim.lr_scheduler.MultiStepLR(opt_a, milestones=[3], gamma=0.1)
+    opt_b = learner.make_capturable_adam(net_b, cfg, dev)
+    sch_b = torch.optim.lr_scheduler.MultiStepLR(opt_b, milestones=[3], gamma=0.1)
+    before = copy.deepcopy(net_b.state_dict())
+    graphed = learner.GraphedTrainStep(cfg, net_b, opt_b, dev, B, (4, 5), K, A)
+    for k, v in net_b.state_dict().items():  # building the graph (three warm-up updates + the capture) must not train
+        assert torch.equal(v, before[k]), k
+    rs = np.random.RandomState(0)
+    for step in range(6):
+        tr = Transition(rs.uniform(-1, 1, (B, 4, 5)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
+                        rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), rs.uniform(0, 50, (B, K)).astype(np.float32), np.ones((B, K), np.float32))
+        w = rs.uniform(0.5, 1, B).astype(np.float32)
+        la, pa = learner.train_step(cfg, net_a, opt_a, sch_a, dev, tr, w)
+        lb, pb = graphed(tr, w)
+        sch_b.step()
+        assert abs(la - float(lb)) <= 1e-4 * max(1.0, abs(la)), step
+        np.testing.assert_allclose(pb.cpu().numpy(), pa, rtol=1e-3, atol=2e-3)
+        assert abs(sch_a.get_last_lr()[0] - float(opt_b.param_groups[0]['lr'])) < 1e-9
+    for (n, x), (_, y) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert float((x - y).abs().max()) < 1e-3, n
