@@ -86,3 +86,27 @@ def test_run_training_writes_learner_metrics(tmp_path):
     steps, lr = mzm.read_scalars(str(tmp_path / 'm' / 't_learner.jsonl'), 'learner(train_steps)/learning_rate')
     np.testing.assert_array_equal(steps, [1, 2, 3, 4])
     np.testing.assert_allclose(lr, [1e-3, 1e-3, 1e-4, 1e-4])
+
+
+def test_bench_reports_profiled_traffic_only_for_matching_kernel_sources(monkeypatch):
+    """roofline.traffic comes from a committed rocprofv3 PMC summary; it must belong to the kernel sources the run is built
+    from.  bench.profiled_traffic compares the summary's `_source_fingerprint` with muzero_amd.build.source_fingerprint() and returns
+    None -- with the reason -- for a stale profile."""
+    import json
+    import os
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    from muzero_amd import build as mz_build
+
+    path = os.path.join(repo, 'profiles', bench.PROFILE_ROUND, 'c2', 'pmc_summary.json')
+    doc = json.load(open(path))
+    assert doc.get('_source_fingerprint') and doc.get('_git_head'), 'committed summaries carry the build they were measured on'
+    monkeypatch.setattr(mz_build, 'source_fingerprint', lambda: doc['_source_fingerprint'])
+    traffic, src = bench.profiled_traffic('c2', 'k_search_fast<512')
+    assert traffic and traffic > 5e7 and doc['_source_fingerprint'] in src
+    monkeypatch.setattr(mz_build, 'source_fingerprint', lambda: 'ffffffffffffffff')
+    traffic, src = bench.profiled_traffic('c2', 'k_search_fast<512')
+    assert traffic is None and 'stale' in src
