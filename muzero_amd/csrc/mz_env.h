@@ -490,6 +490,106 @@ __device__ __forceinline__ void cartpole_step_prefetched(const EnvLaunch& L, int
     }
 }
 
+// ---- small boards (TicTacToe) inside the search kernel: as for CartPole, everything the step reads except the action is requested
+// BEFORE the play-policy phase -- lane i's point of the board and of all eight history planes (both players: whose move it is comes
+// back with the same batch), player, step count -- and action / policy / root value arrive in registers.  board_step_small paid
+// four dependent global round trips (action, player -> planes, record read-back) at the kernel's tail.
+struct BoardSmallPre {
+    signed char b, pl[8];
+    int me, st;
+};
+__device__ __forceinline__ void board_small_prefetch(const EnvLaunch& L, int e, int lane, BoardSmallPre& pre) {
+    const int nn = L.env.nn, i = lane < nn ? lane : 0;
+    pre.b = L.env.board[(size_t)e * nn + i];
+    const signed char* pl = L.env.planes + (size_t)e * 8 * nn;
+#pragma unroll
+    for (int t = 0; t < 8; t++) pre.pl[t] = pl[t * nn + i];
+    pre.me = L.env.player[e];
+    pre.st = L.env.steps[e];
+}
+// == board_step_small + env_record on prefetched state; `pi`: the env's policy row (float64 [A]); all 16 lanes of the env call it
+__device__ __forceinline__ void board_step_small_prefetched(const EnvLaunch& L, int e, int lane, const BoardSmallPre& pre, int a, double root, const double* pi) {
+    const int n = L.env.bn, nn = L.env.nn, A = L.env.A;
+    signed char* b = L.env.board + (size_t)e * nn;
+    signed char* pl = L.env.planes + (size_t)e * 8 * nn;
+    const int me = pre.me, opp = 3 - me, st = pre.st;
+    signed char* mine = pl + (me - 1) * 4 * nn;
+    const bool cell = lane < nn;
+    const int i = cell ? lane : 0;
+    const signed char bi = pre.b;
+    const bool black = me == 1;  // planes 0-3: black's history, 4-7: white's
+    const signed char m0 = black ? pre.pl[0] : pre.pl[4], m1 = black ? pre.pl[1] : pre.pl[5], m2 = black ? pre.pl[2] : pre.pl[6];
+    const signed char t0 = black ? pre.pl[4] : pre.pl[0], t1 = black ? pre.pl[5] : pre.pl[1], t2 = black ? pre.pl[6] : pre.pl[2],
+                      t3 = black ? pre.pl[7] : pre.pl[3];
+    const int base = (int)(__lane_id() & 48u);
+    const unsigned int my_stones = (unsigned int)(__ballot(cell && bi == me) >> base) & 0xffffu;
+    const unsigned int open = (unsigned int)(__ballot(cell && bi == 0 && i != a) >> base) & 0xffffu;  // empty points other than the one just played
+    int winner = 0;
+    float reward = 0.0f;
+    if (a == nn) {  // resign (games/env.py:134-136)
+        reward = -1.0f;
+        winner = opp;
+    } else if (st >= (L.env.win - 1) * 2) {  // games/tictactoe.py:37-38 with the pre-increment step count
+        const int r = a / n, c = a % n;
+        const int dirs[4][2] = {{0, 1}, {1, 0}, {1, 1}, {-1, 1}};
+        for (int d = 0; d < 4; d++)
+            if (1 + board_line_bits(my_stones, n, r, c, dirs[d][0], dirs[d][1]) + board_line_bits(my_stones, n, r, c, -dirs[d][0], -dirs[d][1]) >= L.env.win) winner = me;
+        if (winner) reward = 1.0f;
+    }
+    const bool done = winner != 0 || open == 0;
+    float* o = L.obs + (size_t)e * 9 * nn;
+    if (!done) {
+        const signed char nm0 = (signed char)((bi == me || i == a) ? 1 : 0);  // the mover's history after this move: [stones now, m0, m1, m2]
+        if (cell) {
+            mine[i] = nm0; mine[nn + i] = m0; mine[2 * nn + i] = m1; mine[3 * nn + i] = m2;
+            // observation of the next side to move (games/env.py:242-271): its own history, the mover's, the colour plane
+            o[0 * nn + i] = (float)t0; o[1 * nn + i] = (float)nm0;
+            o[2 * nn + i] = (float)t1; o[3 * nn + i] = (float)m0;
+            o[4 * nn + i] = (float)t2; o[5 * nn + i] = (float)m1;
+            o[6 * nn + i] = (float)t3; o[7 * nn + i] = (float)m2;
+            o[8 * nn + i] = opp == 1 ? 1.0f : 0.0f;
+            if (i == a) { b[i] = (signed char)me; L.mask[(size_t)e * (nn + 1) + a] = 0; }
+        }
+        if (lane == 0) {
+            L.env.player[e] = opp;
+            L.env.steps[e] = st + 1;
+            L.cur[e] = opp;
+            L.opp[e] = me;
+        }
+    } else {  // auto-reset (pipeline.py:111-113)
+        if (cell) {
+            b[i] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) { pl[t * nn + i] = 0; o[t * nn + i] = 0.0f; }
+            o[8 * nn + i] = 1.0f;
+            L.mask[(size_t)e * (nn + 1) + i] = 1;
+        }
+        if (lane == 0) {
+            L.mask[(size_t)e * (nn + 1) + nn] = 1;
+            atomicAdd(&L.env.counters[2], 1ULL);
+            atomicAdd(&L.env.counters[3], (unsigned long long)(st + 1));
+            L.env.steps[e] = 0;
+            L.env.episode[e] += 1;
+            L.env.player[e] = 1;
+            L.cur[e] = 1;
+            L.opp[e] = 2;
+        }
+    }
+    // the move's record (env_record), from registers / the policy's LDS row: lane j stores policy entry j
+    const size_t rec = (size_t)L.slot * L.B + e;
+    if (lane < A) L.env.r_pi[rec * A + lane] = pi[lane];
+    if (lane == 0) {
+        L.env.r_action[rec] = a;
+        L.env.r_reward[rec] = reward;
+        L.env.r_root[rec] = root;
+        L.env.r_done[rec] = done ? 1 : 0;
+        if (e == 0) {
+            atomicAdd(&L.env.counters[0], (unsigned long long)L.B);
+            atomicAdd(&L.env.counters[1], (unsigned long long)L.B * (unsigned long long)L.sims);
+        }
+    }
+}
+
 // env.step of one env by its 16-lane group (`lane` 0..15; all 16 lanes call this)
 __device__ inline void env_step_group(const EnvLaunch& L, int e, int lane) {
     if (L.env.kind != ENV_TICTACTOE && L.env.kind != ENV_GOMOKU) {

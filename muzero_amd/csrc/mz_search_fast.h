@@ -608,6 +608,19 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             stepped = true;
         }
     }
+    if constexpr (FUSE && AC == 10) {
+        if (Pt.fenv.env.kind == ENV_TICTACTOE && Pt.fenv.env.nn <= 16 && Pt.A <= 16) {  // small board: the same idea, see mz_env.h
+            BoardSmallPre pre;
+            if (env_ok) board_small_prefetch(Pt.fenv, env_g, a0, pre);
+            int action = 0;
+            double rootv = 0.0;
+            if (env_ok) {
+                tree2_finish_group(smem, Pt, e, a0, env_g, action, rootv);
+                board_step_small_prefetched(Pt.fenv, env_g, a0, pre, action, rootv, reinterpret_cast<const double*>(smem + Pt.t_tmp) + e * Pt.A);
+            }
+            stepped = true;
+        }
+    }
     if (!stepped) {
         if (env_ok) tree2_finish_group(smem, Pt, e, a0, env_g);  // (A <= 16 in this kernel)
         if constexpr (FUSE)
