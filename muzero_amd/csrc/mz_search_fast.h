@@ -258,6 +258,161 @@ __device__ __forceinline__ float head_logit(const float* PB, int n, int e) {
     return ((c0 + c1) + c2) + c3;
 }
 
+// ROOT INFERENCE, register-resident (representation + policy head; the search discards the root's value, mcts.py:356-367): the same
+// two ideas as the simulations' network -- wave w keeps its quarter of every num_planes-wide layer in accumulators, which ARE the B
+// operands of the K-split layer behind it -- on the weights in their generic packed layout (mz_mlp.h), two blocks in flight.  The
+// generic mlp_initial_tile writes both 512 x 16 hidden layers to LDS and reads them back (7 barriers); this form has 4, and the
+// same summation order: blocks ascending, k-steps ascending, quarter chains ((c0 + c1) + c2) + c3.
+//   `scr`: LDS scratch for the partial tiles, [4 waves][4 tiles] float4[64]; `hid0`: this lane's MFMA-side row of node 0 in the node
+//   store (or null); every thread of the workgroup calls it (`active`: waves 0-3 of the 8-wave kernels), 4 barriers inside.
+template <int NT>
+__device__ __forceinline__ void root_inference_fast(const MlpNet& net, const MlpLds& o, float* lds, float4* scr, float* hid0, float* pi0, int tid, int wave,
+                                                    int lane, bool active) {
+    const int q = lane >> 4;
+    const float* bias = lds;
+    MZ_ROOT_TS_START();
+    f32x4 h1[NT];
+    if (active) {
+        // ---- representation layer 1: X (observation, packed in LDS) -> this wave's NT tiles ----
+        const MlpLayer& L0 = net.L[L_REP0];
+        const float4* wp = reinterpret_cast<const float4*>(L0.w) + (size_t)(NT * wave) * L0.kg * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + L0.b_lds + (NT * wave + j) * 16 + q * 4);
+            h1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
+        float4 w0[NT], w1[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) w0[j] = ldg4(&wp[(size_t)j * L0.kg * 64]);
+        for (int g = 0; g < L0.kg; g += 2) {  // two blocks per iteration: the second one's weights are in flight while the first multiplies
+            const int g1 = g + 1 < L0.kg ? g + 1 : g, g2 = g + 2 < L0.kg ? g + 2 : g;
+#pragma unroll
+            for (int j = 0; j < NT; j++) w1[j] = ldg4(&wp[((size_t)j * L0.kg + g1) * 64]);
+            mma_block<NT>(h1, w0, reinterpret_cast<const float4*>(lds + o.X)[g * 64 + lane], g + 1 < L0.kg ? 4 : L0.last_steps);
+#pragma unroll
+            for (int j = 0; j < NT; j++) w0[j] = ldg4(&wp[((size_t)j * L0.kg + g2) * 64]);
+            if (g + 1 < L0.kg) mma_block<NT>(h1, w1, reinterpret_cast<const float4*>(lds + o.X)[(g + 1) * 64 + lane], g + 2 < L0.kg ? 4 : L0.last_steps);
+        }
+        relu_tiles<NT>(h1);
+        MZ_ROOT_TS(0);
+        // ---- representation layer 2, K-split: this wave's quarter (blocks NT w .. NT w + NT - 1) of all four output tiles ----
+        const MlpLayer& L1 = net.L[L_REP1];
+        const float4* wq = reinterpret_cast<const float4*>(L1.w) + lane;
+        f32x4 acc2[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + L1.b_lds + t * 16 + q * 4);
+            acc2[t] = wave == 0 ? f32x4{bv.x, bv.y, bv.z, bv.w} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        float4 wa[4], wb[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) wa[t] = ldg4(&wq[((size_t)t * L1.kg + NT * wave) * 64]);
+#pragma unroll
+        for (int kk = 0; kk < NT; kk += 2) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) wb[t] = ldg4(&wq[((size_t)t * L1.kg + NT * wave + (kk + 1 < NT ? kk + 1 : kk)) * 64]);
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(wa[t], st), h1[kk][st], acc2[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) wa[t] = ldg4(&wq[((size_t)t * L1.kg + NT * wave + (kk + 2 < NT ? kk + 2 : kk)) * 64]);
+            if (kk + 1 < NT) {
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(wb[t], st), h1[kk + 1][st], acc2[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) scr[(wave * 4 + t) * 64 + lane] = make_float4(acc2[t][0], acc2[t][1], acc2[t][2], acc2[t][3]);
+    }
+    __syncthreads();
+    MZ_ROOT_TS(1);
+    if (active) {
+        // ---- un-normalised state from the partials, min / max, this wave's tile normalised -> HS (LDS) and node 0 of the node store ----
+        // (four named tiles, not an array: `hw = h[wave]` on an array becomes a load through a selected address, i.e. scratch memory)
+        auto tile = [&](int t) {
+            const float4 c0 = scr[(0 * 4 + t) * 64 + lane], c1 = scr[(1 * 4 + t) * 64 + lane], c2 = scr[(2 * 4 + t) * 64 + lane], c3 = scr[(3 * 4 + t) * 64 + lane];
+            return f32x4{((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z, ((c0.w + c1.w) + c2.w) + c3.w};
+        };
+        const f32x4 h0 = tile(0), h1_ = tile(1), h2 = tile(2), h3 = tile(3);
+        float mn = h0[0], mx = h0[0];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { mn = fmin2(h0[r], mn); mx = fmax2(h0[r], mx); }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { mn = fmin2(h1_[r], mn); mx = fmax2(h1_[r], mx); }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { mn = fmin2(h2[r], mn); mx = fmax2(h2[r], mx); }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { mn = fmin2(h3[r], mn); mx = fmax2(h3[r], mx); }
+        mn = rows_min(mn);
+        mx = rows_max(mx);
+        const float d = (mx - mn) + 1e-8f;
+        f32x4 hw = h0;
+        if (wave == 1) hw = h1_;
+        if (wave == 2) hw = h2;
+        if (wave == 3) hw = h3;
+        const float4 hs = make_float4((hw[0] - mn) / d, (hw[1] - mn) / d, (hw[2] - mn) / d, (hw[3] - mn) / d);
+        reinterpret_cast<float4*>(lds + o.HS)[wave * 64 + lane] = hs;
+        if (hid0) *reinterpret_cast<float4*>(hid0 + wave * 16 + q * 4) = hs;
+    }
+    __syncthreads();
+    MZ_ROOT_TS(2);
+    if (active) {
+        // ---- policy head layer 1 (normalised state from LDS) and layer 2 (K-split, one output tile: A <= 16) ----
+        const MlpLayer& L2 = net.L[L_POL0];
+        const float4* wp = reinterpret_cast<const float4*>(L2.w) + (size_t)(NT * wave) * L2.kg * 64 + lane;
+        f32x4 p1[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + L2.b_lds + (NT * wave + j) * 16 + q * 4);
+            p1[j] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
+        float4 w0[NT], w1[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) w0[j] = ldg4(&wp[(size_t)j * L2.kg * 64]);
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {  // hidden_dim 64: four full blocks
+#pragma unroll
+            for (int j = 0; j < NT; j++) w1[j] = ldg4(&wp[((size_t)j * L2.kg + g + 1) * 64]);
+            mma_block_full<NT>(p1, w0, reinterpret_cast<const float4*>(lds + o.HS)[g * 64 + lane]);
+#pragma unroll
+            for (int j = 0; j < NT; j++) w0[j] = ldg4(&wp[((size_t)j * L2.kg + (g + 2 < 4 ? g + 2 : g)) * 64]);
+            mma_block_full<NT>(p1, w1, reinterpret_cast<const float4*>(lds + o.HS)[(g + 1) * 64 + lane]);
+        }
+        relu_tiles<NT>(p1);
+        MZ_ROOT_TS(3);
+        const MlpLayer& L3 = net.L[L_POL1];
+        const float4* wq = reinterpret_cast<const float4*>(L3.w) + (size_t)(NT * wave) * 64 + lane;  // tile 0, blocks NT w ..
+        const float4 bv = *reinterpret_cast<const float4*>(bias + L3.b_lds + q * 4);
+        f32x4 accp = wave == 0 ? f32x4{bv.x, bv.y, bv.z, bv.w} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float4 wv[NT];
+#pragma unroll
+        for (int kk = 0; kk < NT; kk++) wv[kk] = ldg4(&wq[kk * 64]);
+#pragma unroll
+        for (int kk = 0; kk < NT; kk++) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) accp = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(wv[kk], st), p1[kk][st], accp, 0, 0, 0);
+        }
+        scr[wave * 64 + lane] = make_float4(accp[0], accp[1], accp[2], accp[3]);
+    }
+    __syncthreads();
+    MZ_ROOT_TS(4);
+    if (active && wave == 0) {  // the four quarter chains -> logits LG[e][n]
+        const float4 c0 = scr[lane], c1 = scr[64 + lane], c2 = scr[128 + lane], c3 = scr[192 + lane];
+        float* pl = lds + o.LG + (lane & 15) * o.lg_stride + q * 4;
+        pl[0] = ((c0.x + c1.x) + c2.x) + c3.x; pl[1] = ((c0.y + c1.y) + c2.y) + c3.y;
+        pl[2] = ((c0.z + c1.z) + c2.z) + c3.z; pl[3] = ((c0.w + c1.w) + c2.w) + c3.w;
+    }
+    __syncthreads();
+    if (active) row_softmax(lds + o.LG + (tid >> 4) * o.lg_stride, pi0 + (tid >> 4) * net.A, net.A, tid & 15);
+    __syncthreads();
+    MZ_ROOT_TS(5);
+}
+
 // P = num_planes (256 or 512); TR / TV: tiles of the reward / value support (1 or 2)
 // FUSE: device self-play with the environment inside this kernel (mz_selfplay_step on short moves)
 // HW: HELPER WAVES.  The workgroup has 8 waves (two per SIMD; the kernel stays under 256 registers, so both fit): waves 0-3 are the
@@ -325,7 +480,12 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         tree2_init(smem, Pm, tid, env_ok, env_g);
         root_noise_lanes(smem, Pm, e, a0, env_g, env_ok);
     }
-    mlp_initial_tile(net, o, lds, dst, pi0, (int)threadIdx.x, main_w, false);  // the root's value is discarded (mcts.py:356-367)
+    {
+        // (root_inference_fast needs a policy head of one tile and full hidden blocks: every shape this kernel is launched for)
+        const int e2r = lane & 15, env2r = blockIdx.x * TILE_E + e2r;
+        float* hid0 = (main_w && env2r < Pm.B) ? Pm.hidden + (size_t)env2r * Pm.NN * 64 : nullptr;
+        root_inference_fast<NT>(net, o, lds, reinterpret_cast<float4*>(lds + o.H1), hid0, pi0, tid, wave, lane, main_w);  // the root's value is discarded (mcts.py:356-367)
+    }
     if (Pm.S < 0) Pm.hidden[0] = warm;  // never true: keeps the prefetch loads alive
     __syncthreads();
     {
