@@ -62,7 +62,9 @@ struct __attribute__((aligned(16))) Entry2 {  // 16 bytes
     short c;    // child's node index, -1 if unexpanded
 };
 struct __attribute__((aligned(16))) SelCache {  // 16 bytes: one ds_read_b128
-    int packed;  // bits 0-7 best action (0xff: evaluate at visit time), bits 8-15 env epoch when computed (mod 256,
+    int packed;  // bits 16-31: where a descent that follows this entry goes next -- the best child's node, or the SENTINEL slot (index NN)
+                 // if that child is not expanded yet (the descent stops there: one select per level instead of two in the chase);
+                 // bits 0-7 best action (0xff: evaluate at visit time), bits 8-15 env epoch when computed (mod 256,
                  // bumped when normalisation switches on), bits 16-31 best child node (signed, -1 unexpanded)
     float t;     // A > 2: margin + 2 * drift at compute time, rounded down: valid while 2 * drift_now + slack < t
                  // A == 2: ud = child_U(best) - child_U(other)
@@ -199,7 +201,11 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;
     const double mn = T.mn, mx = T.mx;
     const bool norm = mx > mn, lane_ok = a0 < P.A, two = AM < 0 ? P.A == 2 : AM == 2;
-    const float dmp = (float)(st.qref - mn), r32 = lead_r32(mn, mx);  // two actions: exact lead test (header)
+    float r32 = lead_r32(mn, mx);  // two actions: exact lead test (header)
+    // (kept a VALUE: left alone hipcc splits lead_r32's `range > 1e-30 ? rcp : NaN` into a mask that it ANDs with every level's
+    // compare -- a VALU -> SALU -> VALU hop per level of the chase; as a NaN the compare alone says no)
+    asm volatile("" : "+v"(r32));
+    const float dmp = (float)(st.qref - mn);
     const int SENT = P.NN;  // cache slot NN of every env: margin -inf, never advances
     int n = env_ok ? (resume & 0xffff) : SENT, ties = T.ties;
     int lp = 0, la = 0, k = resume >> 16;  // k: levels descended so far
@@ -215,9 +221,9 @@ __device__ __forceinline__ void tree2_select(unsigned char* smem, const SearchPa
                 MZ_TS_COUNT(1);  // [1] phase-A iterations
                 // (while normalisation is off r32 is NaN, and entries stored then carry a = -inf: the test fails)
                 const bool adv = TWO ? (fmaf(fmaf(cc.k, dmp, cc.a), r32, cc.t) > kCacheSlack) : (thr < cc.t);
-                const int c = cc.packed >> 16;
-                const bool stop = adv & (c < 0);
-                const int nxt = adv ? (c < 0 ? SENT : c) : n;
+                const int c = cc.packed >> 16;  // the best child, or SENT if it is unexpanded (the writers substitute it)
+                const bool stop = adv & (c == SENT);
+                const int nxt = adv ? c : n;
                 const SelCache nc = cb[nxt];
                 if (a0 == 0) path[k] = (short)n;  // node at depth k (parked segments re-write their spare slot)
                 lp = stop ? n : lp;
@@ -562,7 +568,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
             MZ_TS(5);  // [5] backup pass 2: per-action loop
             if (valid) {
                 SelCache cc;
-                cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+                cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | ((bestc < 0 ? P.NN : bestc) << 16);
                 cc.t = b1 ? ud10 : -ud10;
                 cc.a = norm ? (b1 ? a10 : -a10) : __uint_as_float(0xff800000u);
                 cc.k = b1 ? k10 : -k10;
@@ -629,7 +635,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 bestc = b1 ? (int)e1.c : (int)e0.c;
                 MZ_TS(5);  // [5] backup pass 2: per-action loop
                 SelCache cc;
-                cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+                cc.packed = (b1 ? 1 : 0) | ((st.epoch & 0xff) << 8) | ((bestc < 0 ? P.NN : bestc) << 16);
                 cc.t = b1 ? ud10 : -ud10;
                 cc.a = norm ? (b1 ? a10 : -a10) : __uint_as_float(0xff800000u);  // raw-Q levels (before normalisation switches on) are evaluated at visit time
                 cc.k = b1 ? k10 : -k10;
@@ -670,7 +676,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 }
                 MZ_TS(5);  // [5] backup pass 2: per-action loop
                 SelCache cc;  // real tie: action 0xff = evaluate (and draw) at visit time; single action: +inf margin
-                cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | (bestc << 16);
+                cc.packed = ((cnt == 1) ? besta : 0xff) | ((st.epoch & 0xff) << 8) | ((bestc < 0 ? P.NN : bestc) << 16);
                 cc.t = (cnt == 1) ? __double2float_rd(((double)best - (double)second) + 2.0 * st.drift) : __uint_as_float(0xff800000u);
                 cc.a = 0.0f; cc.k = 0.0f;
                 *cache_at(smem, P, e, p) = cc;
