@@ -44,10 +44,21 @@ constexpr int fast_rd(int planes) { return planes == 256 ? MZ_FAST_RD256 : MZ_FA
 #define MZ_FAST_HW 1
 #endif
 constexpr bool kFastHW = MZ_FAST_HW != 0;  // helper waves (see k_search_fast); 0: the 4-wave kernel (A/B measurements)
+#ifndef MZ_FAST_SC
+#define MZ_FAST_SC 0
+#endif
+#ifndef MZ_FAST_AX
+#define MZ_FAST_AX 1
+#endif
+// the ten-action instantiation (TicTacToe MLP net: MSE heads, reward / value support 1):
+//   SC  the two scalar heads' second layers (num_planes -> 1) as VALU chains instead of one 16-row MFMA tile with 15 idle rows each
+//   AX  the dynamics net's one-hot action block as ONE addition of the action's weight column instead of 3 k-steps of MFMAs
+constexpr bool kFastSC = MZ_FAST_SC != 0, kFastAX = MZ_FAST_AX != 0;
 
 struct FastWeights {
     const float4* stream;
     unsigned bytes;  // whole stream (4 waves)
+    const float* wact;  // AX: the dynamics net's action columns, [A][num_planes] (row-contiguous per action), or null
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -77,10 +88,10 @@ __device__ __forceinline__ float4 bload(const WSrc& w, int voff, int block) {
 __device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 // P = num_planes; TR / TV = 16-neuron tiles of the reward / value support; RD = ring depth
-template <int P, int TR, int TV, int RD>
+template <int P, int TR, int TV, int RD, int XG_ = 5>
 struct FastCfg {
     static constexpr int NT = P / 64;
-    static constexpr int XG = 5;  // input blocks of the dynamics net: hidden 64 + one action block (A <= 16)
+    static constexpr int XG = XG_;  // input blocks of the dynamics net: hidden 64 + one action block (A <= 16); AX: 4, no action block
     static constexpr int I_D1 = 0, I_D2 = I_D1 + XG, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
     static constexpr int SL = (I_END + RD - 1) / RD * RD;  // slots per simulation incl. padding
 };
@@ -436,7 +447,8 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     // 10: exactly ten actions (TicTacToe: the backup's best-child refresh fully unrolled); 0: anything up to 16
     constexpr bool TWO = AC == 2;
     constexpr int RD = fast_rd(P);
-    using C = FastCfg<P, TR, TV, RD>;
+    constexpr bool SC = AC == 10 && kFastSC, AX = AC == 10 && kFastAX;  // (the launcher sends only MSE-head nets to the SC build of AC == 10)
+    using C = FastCfg<P, SC ? 0 : TR, SC ? 0 : TV, RD, AX ? 4 : 5>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lds = reinterpret_cast<float*>(smem);
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             for (int j = 0; j < NT; j++) ring[i][j] = bload(ws, voff, i * NT + j);
         }
     }
-    const int x_last = TWO ? 1 : net.L[L_DYN0].last_steps;  // k-steps of the action block (1..4)
+    const int x_last = AX ? 4 : (TWO ? 1 : net.L[L_DYN0].last_steps);  // k-steps of the action block (1..4); AX: the last block is a hidden block
     // MFMA-side env of this lane (D column) and its hidden-state rows in the HBM node store
     const int e2 = lane & 15, q = lane >> 4;
     const int env2 = blockIdx.x * TILE_E + e2;
@@ -514,6 +526,37 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     float* const hid_sel = Pm.hidden + (size_t)(env_ok ? env_g : 0) * Pm.NN * 64;   // select-side env (tid >> 4)
     float* const hid_mma = Pm.hidden + (size_t)(env2_ok ? env2 : 0) * Pm.NN * 64;  // MFMA-side env (lane & 15)
     const float* bias = lds;  // biases live in LDS (stage_biases)
+    // SC: this lane's 4 NT weights of each scalar head -- row 0 of the packed second layer, input neurons 16 (NT w + j) + 4 q + i --
+    // stay in registers for the whole move
+    float4 w_sr[NT], w_sv[NT];
+    if constexpr (SC) {
+        if (main_w) {
+            const float4* wr = reinterpret_cast<const float4*>(net.L[L_REW1].w);
+            const float4* wv = reinterpret_cast<const float4*>(net.L[L_VAL1].w);
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                w_sr[j] = ldg4(&wr[(NT * wave + j) * 64 + q * 16]);
+                w_sv[j] = ldg4(&wv[(NT * wave + j) * 64 + q * 16]);
+            }
+        }
+    }
+    // a scalar head's second layer on this wave's quarter (SC): lane (e, q) runs ONE fmaf chain over its own 4 NT neurons (tiles
+    // ascending, registers ascending; the chain of wave 0, q 0 starts from the bias), the four q meet as (p0 + p1) + (p2 + p3)
+    // -- two row-swap butterflies, the same sum in every lane -- and the waves' sums meet in LDS like any K-split tile,
+    // ((c0 + c1) + c2) + c3 (EXPERIMENT, off: the CPU restatement of the summation order does not know this form)
+    auto scalar_head = [&](const f32x4 (&x)[NT], const float4 (&w)[NT], float b0, float* part /* [4 waves][256] floats, head_logit<1> layout */) {
+        float pacc = (wave == 0 && q == 0) ? b0 : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            pacc = fmaf(x[j][0], w[j].x, pacc); pacc = fmaf(x[j][1], w[j].y, pacc);
+            pacc = fmaf(x[j][2], w[j].z, pacc); pacc = fmaf(x[j][3], w[j].w, pacc);
+        }
+        u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(pacc), __float_as_uint(pacc), false, false);
+        pacc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        r = __builtin_amdgcn_permlane32_swap(__float_as_uint(pacc), __float_as_uint(pacc), false, false);
+        pacc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        if (q == 0) part[wave * 256 + e2 * 4] = pacc;
+    };
     // K-split partial tiles (LDS, aliased onto the H1 / V1 buffers that only the root inference uses):
     // PB [4 waves][4 tiles] dynamics layer 2, PBr [4][TR] reward layer 2, PBv [4][TV] value layer 2, float4[64] each
     float4* const PB = reinterpret_cast<float4*>(lds + o.H1);
@@ -537,16 +580,6 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     const int cp0 = env_ok ? Pm.cur[env_g] : 0, op0 = env_ok ? Pm.opp[env_g] : 0;  // the root's players: read once per move, not per descent
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
     tree2_env_init(T, Pm);
-    // un-normalised state h (64 x 16) from the four waves' partial tiles, ((c0 + c1) + c2) + c3
-    auto rebuild_h = [&](f32x4 (&h)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const float4 c0 = PB[(0 * 4 + t) * 64 + lane], c1 = PB[(1 * 4 + t) * 64 + lane], c2 = PB[(2 * 4 + t) * 64 + lane],
-                         c3 = PB[(3 * 4 + t) * 64 + lane];
-            h[t] = f32x4{((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
-                         ((c0.w + c1.w) + c2.w) + c3.w};
-        }
-    };
     // normalisation (util.py:31-36) of this wave's tile of h -> LDS (value head input) and the HBM node store
     // (the four tiles by value: through a reference to the array the `hw = h[wave]` selects below become ONE load through a selected
     // address, which pins the array in scratch memory -- a round trip per simulation, measured in the ISA)
@@ -580,15 +613,34 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         reinterpret_cast<float4*>(lds + o.HS)[wave * 64 + lane] = hs;
         if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = hs;
     };
-    const bool cat_heads = TWO || (net.Sr != 1 && net.Sv != 1);  // both heads categorical (TWO: guaranteed by the launcher)
+    constexpr bool MSE = AC == 10;  // the launcher sends only nets with MSE heads (reward / value support 1: TicTacToe's) to the ten-action build
+    // un-normalised state h (64 x 16) from the four waves' partial tiles, ((c0 + c1) + c2) + c3, in two stages: wave w sums tile w
+    // and publishes it (HN block), one more barrier, every wave reads the four finished tiles -- 8 tile reads per wave (4 per
+    // helper wave) instead of 16: the one-stage form moved 128 KiB through the LDS port right behind the barrier (C2 -0.6 %, C3 -0.5 %)
+    float4* const HT = reinterpret_cast<float4*>(lds + o.HN);
+    auto reduce_tile = [&]() {
+        const float4 c0 = PB[(0 * 4 + wave) * 64 + lane], c1 = PB[(1 * 4 + wave) * 64 + lane], c2 = PB[(2 * 4 + wave) * 64 + lane],
+                     c3 = PB[(3 * 4 + wave) * 64 + lane];
+        HT[wave * 64 + lane] = make_float4(((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
+                                           ((c0.w + c1.w) + c2.w) + c3.w);
+    };
+    auto read_h = [&](f32x4 (&h)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 v = HT[t * 64 + lane];
+            h[t] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    };
+    const bool cat_heads = !MSE && (TWO || (net.Sr != 1 && net.Sv != 1));  // both heads categorical (TWO: guaranteed by the launcher)
     if (HW && !main_w) {
         // ================= helper waves: the same barriers per simulation as waves 0-3 =================
         for (int s = 0; s < Pm.S; s++) {
             __syncthreads();  // B0 (X ready)
             __syncthreads();  // B1 (dynamics partial tiles ready)
+            __syncthreads();  // B1b (summed tiles ready)
             if (hwx) {
                 f32x4 h[4];
-                rebuild_h(h);
+                read_h(h);
                 normalise_store(h[0], h[1], h[2], h[3], s);
             }
             __syncthreads();  // B2 (reward partial tiles ready; HS written)
@@ -613,7 +665,8 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (env_ok) hv = *reinterpret_cast<const float4*>(hid_sel + (size_t)lp * 64 + a0 * 4);
             reinterpret_cast<float4*>(X)[(a0 >> 2) * 64 + (a0 & 3) * 16 + e] = hv;  // pk(4 a0 .. 4 a0 + 3, e)
-            X[pk_act(a0, e, 4)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;
+            if constexpr (AX) { if (a0 == 0) reinterpret_cast<int*>(smem + Pm.t_sel)[e * 4 + 1] = env_ok ? la : 0; }
+            else X[pk_act(a0, e, 4)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;
         }
         __syncthreads();
         MZ_STAMP(1);  // select + gather
@@ -629,7 +682,18 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             float4 xs[5];
 #pragma unroll
             for (int g = 0; g < C::XG; g++) xs[g] = reinterpret_cast<const float4*>(lds + o.X)[g * 64 + lane];
+            float4 wa4[NT];
+            if constexpr (AX) {  // the action's weight column for this lane's 4 NT neurons (requested here, added behind the MFMAs)
+                const int la2 = reinterpret_cast<const int*>(smem + Pm.t_sel)[e2 * 4 + 1];
+                const float4* wc = reinterpret_cast<const float4*>(FW.wact + la2 * P + wave * NT * 16 + q * 4);
+#pragma unroll
+                for (int j = 0; j < NT; j++) wa4[j] = wc[j * 4];
+            }
             WideSlots<C, RD, C::I_D1, 0, C::XG, true>::run(ring, ws, voff, xs, h, x_last, h1, nohook);
+            if constexpr (AX) {  // x = one-hot: the chain's last A steps are fmaf(0, w, acc) = acc and one fmaf(1, w, acc) = acc + w
+#pragma unroll
+                for (int j = 0; j < NT; j++) { h1[j][0] += wa4[j].x; h1[j][1] += wa4[j].y; h1[j][2] += wa4[j].z; h1[j][3] += wa4[j].w; }
+            }
             relu_tiles<NT>(h1);
             MZ_STAMP(3);  // dynamics layer 1
             f32x4 acc2[4];
@@ -644,9 +708,11 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         }
         __syncthreads();
         MZ_STAMP(4);  // dynamics layer 2 (partials)
-        // ---- every wave rebuilds the whole un-normalised state h (64 x 16) from the partials; normalisation
+        // ---- every wave needs the whole un-normalised state h (64 x 16): two-stage exchange (above); normalisation
         // (util.py:31-36) of its own tile goes to LDS (value head input) and to the HBM node store (HW: by the helpers) ----
-        rebuild_h(h);
+        reduce_tile();
+        __syncthreads();
+        read_h(h);
         if (!hwx) normalise_store(h[0], h[1], h[2], h[3], s);
         MZ_STAMP(5);  // reduce + normalise + hidden store
         // ---- reward head on the UN-normalised state (network.py:195-196): layer 1 from registers, layer 2 K-split ----
@@ -660,6 +726,9 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             }
             WideSlots<C, RD, C::I_R1, 0, 4, false>::run(ring, ws, voff, xs0, h, 4, r1, nohook);
             relu_tiles<NT>(r1);
+            if constexpr (SC) {
+                scalar_head(r1, w_sr, bias[net.L[L_REW1].b_lds], reinterpret_cast<float*>(PBr));
+            } else {
             f32x4 accr[TR];
 #pragma unroll
             for (int t = 0; t < TR; t++) {
@@ -669,6 +738,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             SplitSlots<C, RD, C::I_R2, 0, TR>::run(ring, ws, voff, r1, accr, nohook);
 #pragma unroll
             for (int t = 0; t < TR; t++) PBr[(wave * TR + t) * 64 + lane] = make_float4(accr[t][0], accr[t][1], accr[t][2], accr[t][3]);
+            }
         }
         __syncthreads();
         MZ_STAMP(6);  // reward head
@@ -687,6 +757,9 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             xs[4] = zero4;
             WideSlots<C, RD, C::I_V1, 0, 4, true>::run(ring, ws, voff, xs, h, 4, v1, nohook);
             relu_tiles<NT>(v1);
+            if constexpr (SC) {
+                scalar_head(v1, w_sv, bias[net.L[L_VAL1].b_lds], reinterpret_cast<float*>(PBv));
+            } else {
             f32x4 accv[TV];
 #pragma unroll
             for (int t = 0; t < TV; t++) {
@@ -696,6 +769,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             SplitSlots<C, RD, C::I_V2, 0, TV>::run(ring, ws, voff, v1, accv, nohook);
 #pragma unroll
             for (int t = 0; t < TV; t++) PBv[(wave * TV + t) * 64 + lane] = make_float4(accv[t][0], accv[t][1], accv[t][2], accv[t][3]);
+            }
             PadSlots<C, RD, C::I_END>::run(ring, ws, voff);
         }
         // the backup's tree reads that do not depend on this simulation's reward / value: issued ahead of the barrier and the softmax
@@ -711,6 +785,10 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             const float* fr = reinterpret_cast<const float*>(PBr);
             const float* fv = reinterpret_cast<const float*>(PBv);
             float rew, val;
+            if constexpr (MSE) {
+                rew = head_logit<TR>(fr, 0, e);
+                val = head_logit<TV>(fv, 0, e);
+            } else
             if (hwx2 && cat_heads) {
                 const bool v0 = a0 < net.Sv, v1 = a0 + 16 < net.Sv;
                 const float lv0 = head_logit<TV>(fv, v0 ? a0 : 0, e), lv1 = head_logit<TV>(fv, v1 ? a0 + 16 : 0, e);

@@ -653,6 +653,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                     // per backup, not per action (two copies of the loop), and ties are not counted -- an action that ties with the best
                     // one becomes the runner-up, margin 0, which the next descent's test (thr < t) can never pass: the level is then
                     // evaluated (and its draw consumed) at visit time exactly as with the explicit tie mark
+                    int bestcw = -1;  // {visits, node} word of the best child's entry (node -1: unexpanded)
                     auto refresh = [&](auto f32_tag) {
                         constexpr bool F32 = decltype(f32_tag)::value;
 #pragma unroll
@@ -661,15 +662,20 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                             er[j].U = ua;
                             const float qn = (float)((en[j].vq - q_sub) * q_mul);
                             const float u = (en[j].cn > 0 ? qn : 0.0f) + ua;
+                            // runner-up = the median of {best, runner-up, u} (best >= runner-up throughout): one v_med3_f32 for a compare
+                            // and two selects; the best child's node travels as the entry's {visits, node} word and is unpacked once
                             const bool gt = u > best;
-                            second = gt ? best : (u > second ? u : second);
+                            int cw;
+                            __builtin_memcpy(&cw, &en[j].cn, 4);
+                            second = __builtin_amdgcn_fmed3f(best, second, u);
                             besta = gt ? j : besta;
-                            bestc = gt ? (int)en[j].c : bestc;
+                            bestcw = gt ? cw : bestcw;
                             best = gt ? u : best;
                         }
                     };
                     if (prior_f32) refresh(std::true_type{});
                     else refresh(std::false_type{});
+                    bestc = bestcw >> 16;
                     cnt = 1;  // (ties: see above)
                 } else {
                     rank_actions(std::integral_constant<int, 4>{});

@@ -467,6 +467,12 @@ static int packed_k(const MlpNet& n, int l, int g, int q, int s) {
     return k < L.k ? k : -1;
 }
 
+// the ten-action instantiation of the tuned kernel: ten actions AND MSE heads (TicTacToe's MLP net, config.py:106-136)
+static bool fast_ac10(const mz_planner* p) {
+    const mz_config& c = p->cfg;
+    return p->fast_planes == 256 && c.num_actions == 10 && c.value_support_size == 1 && c.reward_support_size == 1;
+}
+
 extern "C" int mz_planner_commit_params(mz_planner* p) {
     if (!p) return fail(MZ_E_INVALID, "null planner");
     HIPCHK(hipSetDevice(p->device));
@@ -530,10 +536,13 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
     p->ip.net = p->net;
     if (p->fast_planes) {
         // ONE per-wave weight stream in consumption order (layout: mz_search_fast.h header)
-        const int NT = p->fast_planes / 64, TR = p->net.L[L_REW1].n_tiles, TV = p->net.L[L_VAL1].n_tiles, RD = fast_rd(p->fast_planes);
-        const int I_D1 = 0, I_D2 = I_D1 + 5, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
+        const bool sc = kFastSC && fast_ac10(p), ax = kFastAX && fast_ac10(p);  // (mz_search_fast.h: scalar heads / action column outside the stream)
+        const int NT = p->fast_planes / 64, TR = sc ? 0 : p->net.L[L_REW1].n_tiles, TV = sc ? 0 : p->net.L[L_VAL1].n_tiles, RD = fast_rd(p->fast_planes);
+        const int XG = ax ? 4 : 5;
+        const int I_D1 = 0, I_D2 = I_D1 + XG, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
         const int SL = (I_END + RD - 1) / RD * RD;
-        std::vector<float> st((size_t)WG_WAVES * SL * NT * 256, 0.0f);
+        const size_t stream_floats = (size_t)WG_WAVES * SL * NT * 256;
+        std::vector<float> st(stream_floats + (ax ? (size_t)p->cfg.num_actions * p->fast_planes : 0), 0.0f);
         auto put = [&](int w, int slot, int j, int l, int row_tile, int g) {
             const MlpLayer& L = p->net.L[l];
             const HostTensor& W = p->params.find(std::string(kMlpNames[l]) + ".weight")->second;
@@ -545,7 +554,7 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
                 }
         };
         for (int w = 0; w < WG_WAVES; w++) {
-            for (int g = 0; g < 5; g++)
+            for (int g = 0; g < XG; g++)
                 for (int j = 0; j < NT; j++) put(w, I_D1 + g, j, L_DYN0, NT * w + j, g);
             for (int idx = 0; idx < 4 * NT; idx++) put(w, I_D2 + idx / NT, idx % NT, L_DYN1, idx % 4, NT * w + idx / 4);
             for (int g = 0; g < 4; g++)
@@ -555,10 +564,17 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
                 for (int j = 0; j < NT; j++) put(w, I_V1 + g, j, L_VAL0, NT * w + j, g);
             for (int idx = 0; idx < TV * NT; idx++) put(w, I_V2 + idx / NT, idx % NT, L_VAL1, idx % TV, NT * w + idx / TV);
         }
+        if (ax) {  // the action columns of the dynamics net's first layer, one row per action
+            const HostTensor& W = p->params.find(std::string(kMlpNames[L_DYN0]) + ".weight")->second;
+            const MlpLayer& L = p->net.L[L_DYN0];
+            for (int a = 0; a < p->cfg.num_actions; a++)
+                for (int r = 0; r < L.n; r++) st[stream_floats + (size_t)a * p->fast_planes + r] = W.data[(size_t)r * L.k + p->net.H + a];
+        }
         if (!p->d_stream[0]) HIPCHK(hipMalloc(&p->d_stream[0], st.size() * sizeof(float)));
         HIPCHK(hipMemcpy(p->d_stream[0], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
         p->fw.stream = reinterpret_cast<const float4*>(p->d_stream[0]);
-        p->fw.bytes = (unsigned)(st.size() * sizeof(float));
+        p->fw.bytes = (unsigned)(stream_floats * sizeof(float));
+        p->fw.wact = ax ? p->d_stream[0] + stream_floats : nullptr;
     }
     p->committed = true;
     return MZ_OK;
@@ -742,7 +758,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
                             else { if (two_act) MZ_FAST4(PL, T, false, 2); else MZ_FAST4(PL, T, false, 0); } } while (0)
         // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
         const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
-        if (p->fast_planes == 256 && !two && c.num_actions == 10) {  // (TicTacToe: ten actions)
+        if (fast_ac10(p)) {  // (TicTacToe: ten actions)
             if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
         } else
 #ifdef MZ_DEV_SHAPES
