@@ -452,6 +452,30 @@ __device__ __forceinline__ void heads_to_scalars(const MlpNet& net, const MlpLds
     }
 }
 
+// ONE-neuron K-split layer (the second layer of an MSE head: value / reward support size 1, network.py:172-182,212-222) on the
+// vector ALUs -- a 16-row MFMA tile would carry 15 idle rows.  Thread (e, c, q) of the tile's 256 runs the chain of lane group q of
+// quarter c for env e: k = 16g + 4q + i over the quarter's blocks g (ascending), i = 0..3; the chain of (c, q) = (0, 0) starts from
+// the bias.  The groups meet as (p0 + p1) + (p2 + p3), the quarters as ((s0 + s1) + s2) + s3 -- the order the CPU restatement
+// states for this layer and k_search_fast reproduces from its registers.  Xs: the packed input (pk layout, padding rows zero);
+// the packed weights of row 0 sit in lane group q of tile 0: float4 (g * 64 + 16 q).  Writes out[e * stride].
+__device__ __forceinline__ void scalar_head_tile(const MlpLayer& L, const float* __restrict__ lds, const float* __restrict__ Xs, float* out, int stride,
+                                                 int tid) {
+    const int e = tid >> 4, c = (tid >> 2) & 3, q = tid & 3;
+    const float4* X4 = reinterpret_cast<const float4*>(Xs);
+    const float4* W4 = reinterpret_cast<const float4*>(L.w);
+    float p = (c == 0 && q == 0) ? lds[L.b_lds] : 0.0f;
+    const int g1 = (c + 1) * L.kq < L.kg ? (c + 1) * L.kq : L.kg;
+    for (int g = c * L.kq; g < g1; g++) {
+        const float4 x = X4[g * 64 + q * 16 + e], w = ldg4(&W4[g * 64 + q * 16]);
+        p = fmaf(x.x, w.x, p); p = fmaf(x.y, w.y, p); p = fmaf(x.z, w.z, p); p = fmaf(x.w, w.w, p);
+    }
+    float sum = p + __shfl_xor(p, 1, 64);    // p0 + p1 | p2 + p3 (float addition commutes: both lanes of a pair hold the same sum)
+    sum = sum + __shfl_xor(sum, 2, 64);      // (p0 + p1) + (p2 + p3)
+    const int base = (tid & 63) & ~15;
+    const float s0 = __shfl(sum, base, 64), s1 = __shfl(sum, base + 4, 64), s2 = __shfl(sum, base + 8, 64), s3 = __shfl(sum, base + 12, 64);
+    if ((tid & 15) == 0) out[e * stride] = ((s0 + s1) + s2) + s3;
+}
+
 // dynamics + reward + value for the 16 envs of this tile (network.py:86-111 without the dead policy head unless
 // want_policy).  Expects X (packed hidden+onehot) ready in LDS and a barrier already passed.
 //   out: lds OUT[e][0] = reward, OUT[e][1] = value ; HS = normalised next hidden ; grow[e] (optional) global rows.
@@ -468,8 +492,10 @@ __device__ __forceinline__ void mlp_recurrent_tile(const MlpNet& net, const MlpL
     gemm_layer(net.L[L_REW0], lds, lds + o.HN, wave, lane, EpiReluPacked{lds + o.H1, lane});
     gemm_layer(net.L[L_VAL0], lds, lds + o.HS, wave, lane, EpiReluPacked{lds + o.V1, lane});
     __syncthreads();
-    gemm_layer(net.L[L_REW1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-    gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+    if (net.L[L_REW1].n == 1) scalar_head_tile(net.L[L_REW1], lds, lds + o.H1, lds + o.LG, o.lg_stride, tid);
+    else gemm_layer(net.L[L_REW1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
+    if (net.L[L_VAL1].n == 1) scalar_head_tile(net.L[L_VAL1], lds, lds + o.V1, lds + o.LG + 16 * o.lg_stride, o.lg_stride, tid);
+    else gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
     __syncthreads();
     heads_to_scalars(net, o, lds, tid, true);
     if (want_policy) {
@@ -530,7 +556,10 @@ __device__ __forceinline__ void mlp_initial_tile(const MlpNet& net, const MlpLds
     if (want_value || !gemm_one_tile_across_waves(net.L[L_POL1], lds, lds + o.H1, lds + o.V1, wave, lane, active, EpiLogits{lds + o.LG, o.lg_stride, lane})) {
         if (active) {
             gemm_layer(net.L[L_POL1], lds, lds + o.H1, wave, lane, EpiLogits{lds + o.LG, o.lg_stride, lane});
-            if (want_value) gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+            if (want_value) {
+                if (net.L[L_VAL1].n == 1) scalar_head_tile(net.L[L_VAL1], lds, lds + o.V1, lds + o.LG + 16 * o.lg_stride, o.lg_stride, tid);
+                else gemm_layer(net.L[L_VAL1], lds, lds + o.V1, (wave + 2) & 3, lane, EpiLogits{lds + o.LG + 16 * o.lg_stride, o.lg_stride, lane});
+            }
         }
     }
     __syncthreads();

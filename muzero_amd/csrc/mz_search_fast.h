@@ -45,7 +45,7 @@ constexpr int fast_rd(int planes) { return planes == 256 ? MZ_FAST_RD256 : MZ_FA
 #endif
 constexpr bool kFastHW = MZ_FAST_HW != 0;  // helper waves (see k_search_fast); 0: the 4-wave kernel (A/B measurements)
 #ifndef MZ_FAST_SC
-#define MZ_FAST_SC 0
+#define MZ_FAST_SC 1
 #endif
 #ifndef MZ_FAST_AX
 #define MZ_FAST_AX 1
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     // a scalar head's second layer on this wave's quarter (SC): lane (e, q) runs ONE fmaf chain over its own 4 NT neurons (tiles
     // ascending, registers ascending; the chain of wave 0, q 0 starts from the bias), the four q meet as (p0 + p1) + (p2 + p3)
     // -- two row-swap butterflies, the same sum in every lane -- and the waves' sums meet in LDS like any K-split tile,
-    // ((c0 + c1) + c2) + c3 (EXPERIMENT, off: the CPU restatement of the summation order does not know this form)
+    // ((c0 + c1) + c2) + c3: the order of mz_mlp.h's scalar_head_tile (C3: -2.9 %)
     auto scalar_head = [&](const f32x4 (&x)[NT], const float4 (&w)[NT], float b0, float* part /* [4 waves][256] floats, head_logit<1> layout */) {
         float pacc = (wave == 0 && q == 0) ? b0 : 0.0f;
 #pragma unroll

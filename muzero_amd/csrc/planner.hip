@@ -761,6 +761,11 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         if (fast_ac10(p)) {  // (TicTacToe: ten actions)
             if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
         } else
+        if (c.value_support_size == 1 || c.reward_support_size == 1) {
+            // an MSE head's one-neuron layer runs on the vector ALUs in its own summation order (mz_mlp.h, scalar_head_tile): of the
+            // tuned kernel's builds only the ten-action one has that form
+            hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
+        } else
 #ifdef MZ_DEV_SHAPES
         if (p->fast_planes == 512 && two) MZ_FAST(512, 2);
         else if (p->fast_planes == 256 && !two) MZ_FAST(256, 1);

@@ -148,11 +148,36 @@ static void linear(const float* x, int K, const float* W, const float* b, int N,
  * dynamics net (network.py:191-193) follow the Kh hidden inputs in natural order.  `split` (the second layer of every
  * two-layer net, K = num_planes): the blocks are dealt to 4 contiguous quarters, one chain each -- quarter 0 starts
  * from the bias, the others from +0 -- and the result is ((c0 + c1) + c2) + c3: the four waves of a workgroup each own
- * one quarter of the hidden layer in registers and never exchange it. */
+ * one quarter of the hidden layer in registers and never exchange it.
+ * `split` == 2 (the ONE-neuron second layer of an MSE head, value / reward support size 1, network.py:172-182,212-222): a
+ * 16-row MFMA tile would carry 15 idle rows, so the kernels run this layer on the vector ALUs, and each quarter is dealt
+ * once more to the 4 lane groups that hold its inputs: group q owns k = 16g + 4q + i of every block g of the quarter
+ * and runs ONE chain over them (g ascending, i ascending; the chain of quarter 0, group 0 starts from the bias, the
+ * others from +0); the groups meet as (p0 + p1) + (p2 + p3), the quarters as before. */
 static void linear_mlp(const float* x, int Kh, int Ka, const float* W, const float* b, int N, float* y, int relu, int split) {
     const int NB = (Kh + 15) / 16;
     const int NBq = split ? (NB + 3) / 4 : NB;
     const int chains = split ? 4 : 1;
+    if (split == 2) {
+        float sc[4];
+        for (int c = 0; c < 4; c++) {
+            float pq[4];
+            const int g1 = (c + 1) * NBq < NB ? (c + 1) * NBq : NB;
+            for (int q = 0; q < 4; q++) {
+                float acc = (c == 0 && q == 0) ? b[0] : 0.0f;
+                for (int g = c * NBq; g < g1; g++)
+                    for (int i = 0; i < 4; i++) {
+                        const int k = 16 * g + 4 * q + i;
+                        if (k < Kh) acc = fmaf(x[k], W[k], acc);
+                    }
+                pq[q] = acc;
+            }
+            sc[c] = (pq[0] + pq[1]) + (pq[2] + pq[3]);
+        }
+        const float total = ((sc[0] + sc[1]) + sc[2]) + sc[3];
+        y[0] = (relu && !(total > 0.0f)) ? 0.0f : total;
+        return;
+    }
     for (int n = 0; n < N; n++) {
         const float* w = W + (size_t)n * (Kh + Ka);
         float total = 0.0f;
@@ -427,7 +452,7 @@ static void mlp_prediction(mzo_net* n, const float* hidden, float* pi_out, float
         softmax_f32(lg, n->A, pi_out);
     }
     linear_mlp(hidden, n->H, 0, n->mp[16], n->mp[17], n->P, t, 1, 0);
-    linear_mlp(t, n->P, 0, n->mp[18], n->mp[19], n->Sv, lg, 0, 1);
+    linear_mlp(t, n->P, 0, n->mp[18], n->mp[19], n->Sv, lg, 0, n->Sv == 1 ? 2 : 1);
     *value_out = scalar_from_logits(lg, n->Sv);
 }
 
@@ -518,7 +543,7 @@ void mzo_recurrent_inference(mzo_net* n, const float* hidden_in, int32_t action,
         linear_mlp(t, n->P, 0, n->mp[6], n->mp[7], n->H, hidden_out, 0, 1);
         /* reward head reads the UN-normalised hidden state (network.py:195-196); normalisation follows (:263) */
         linear_mlp(hidden_out, n->H, 0, n->mp[8], n->mp[9], n->P, t, 1, 0);
-        linear_mlp(t, n->P, 0, n->mp[10], n->mp[11], n->Sr, lg, 0, 1);
+        linear_mlp(t, n->P, 0, n->mp[10], n->mp[11], n->Sr, lg, 0, n->Sr == 1 ? 2 : 1);
         *reward_out = scalar_from_logits(lg, n->Sr);
         mzo_normalize_hidden(hidden_out, n->H, 1);
         mlp_prediction(n, hidden_out, pi_out, value_out);
