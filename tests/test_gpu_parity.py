@@ -186,6 +186,41 @@ def test_batched_search_bit_exact_vs_oracle(oracle, g, B):
     np.testing.assert_array_equal(rd['root_value'], od['root_value'])
 
 
+@pytest.mark.parametrize('ishape,A,P,vs,rs_,board', [
+    ((4, 5), 4, 256, 1, 1, False),      # MSE heads on a tuned shape that is not the ten-action build: shape-generic kernel (scalar_head_tile)
+    ((4, 5), 2, 512, 10, 1, False),     # one categorical, one MSE head (same tile count: a tuned shape)
+    ((3, 3, 3), 10, 256, 1, 1, False),  # the ten-action build outside TicTacToe's settings: single player, no known bounds
+    ((3, 3, 3), 10, 256, 1, 1, True),
+], ids=['mse-a4-p256', 'mixed-a2-p512', 'mse-a10-single', 'mse-a10-board'])
+def test_mse_heads_on_tuned_shapes_bit_exact_vs_oracle(oracle, ishape, A, P, vs, rs_, board):
+    """The one-neuron second layer of an MSE head has its own summation order (oracle: linear_mlp split == 2; kernels:
+    scalar_head_tile / the ten-action tuned kernel's register chains): every kernel a tuned shape can be routed to agrees with the oracle."""
+    case = ('mse', ishape, A, P, vs, rs_, 64, 31)
+    net = build_mlp(case)
+    onet = _oracle_net(oracle, net, 'mlp')
+    S, B = 25, 80
+    kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None,
+              root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    ocfg = oracle.make_config(A, S, kw['discount'], board, kw['known_bounds'], 0.25, 0.25)
+    p = _planner(net, B, **kw)
+    rs = np.random.RandomState(77)
+    obs = rs.uniform(-1, 1, size=(B,) + tuple(ishape)).astype(np.float32)
+    mask = np.ones((B, A), bool)
+    cur = rs.randint(1, 3, B).astype(np.int32) if board else np.ones(B, np.int32)
+    opp = (3 - cur).astype(np.int32) if board else np.ones(B, np.int32)
+    temp = rs.choice([1.0, 0.5, 0.0], size=B)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    r = p.search(obs, mask, cur, opp, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    np.testing.assert_array_equal(r['visits'], o['visits'])
+    np.testing.assert_array_equal(r['pi'], o['pi'])
+    np.testing.assert_array_equal(r['action'], o['action'])
+    np.testing.assert_array_equal(r['root_value'], o['root_value'])
+    p.close()
+
+
 def test_generic_and_tuned_kernels_agree(monkeypatch):
     """k_search (shape-generic) and k_search_fast (benchmark shapes) are the same algorithm: identical outputs."""
     for g, S, board in (('cartpole', 50, False), ('tictactoe', 25, True)):
