@@ -34,11 +34,11 @@ namespace mz {
 #define MZ_FAST_RD 3
 #endif
 #ifndef MZ_FAST_RD256
-#define MZ_FAST_RD256 3
+#define MZ_FAST_RD256 4
 #endif
-// depth of the weight ring: the stream runs RD - 1 slots ahead of the MFMAs (a slot is 4 NT MFMAs = 128 NT cycles).  Measured at
-// num_planes 256 (NT = 4, C3): 3, 4 and 5 deep run within 0.3 % of each other, like 3 / 4 / 6 at 512 in round 2 -- the loads are
-// not late; the MFMA phases' overhead is barriers, partial-tile exchange and bias / ReLU epilogues
+// depth of the weight ring: the stream runs RD - 1 slots ahead of the MFMAs (a slot is 4 NT MFMAs = 128 NT cycles).  The loads are
+// not late at any depth tried (num_planes 512: 3 / 4 / 6 within 0.3 %); at num_planes 256 the ten-action build's 16 slots per
+// simulation divide by 4 -- no padding slots -- and 4 deep measures 0.4 % under 3 deep (2 deep: +1.2 %)
 constexpr int fast_rd(int planes) { return planes == 256 ? MZ_FAST_RD256 : MZ_FAST_RD; }
 #ifndef MZ_FAST_HW
 #define MZ_FAST_HW 1
