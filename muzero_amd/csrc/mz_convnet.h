@@ -281,7 +281,21 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
     ConvGeom g{};
     const bool whole = stride == 1 && oh * ow <= 240 && (oh + 2) * (ow + 2) <= 384;
     const int QP = (oh * ow + 3) / 4;  // pixel quads per image: one lane each
-    g.th = whole ? oh : 8; g.tw = whole ? ow : 8;
+    // tiled images: 8x8 output tiles (4 pixel tiles, a 10x10 slab), or, where the image divides and the stride-1 slab fits, 12x16 /
+    // 12x12 (12 / 9 pixel tiles: 1.31 / 1.36 staged positions per output pixel instead of 1.56, and 3x / 2.25x the MFMAs behind every
+    // barrier; C4 +0.6 %).  MZ_CONV_TILE = th * 100 + tw overrides (diagnostics).
+    int tth = 8, ttw = 8;
+    if (!whole && stride == 1) {
+        const int forced = env_int("MZ_CONV_TILE", 0);
+        const int cand[3][2] = {{forced / 100, forced % 100}, {12, 16}, {12, 12}};
+        for (int i = forced ? 0 : 1; i < 3; i++) {
+            const int wh = cand[i][0], ww = cand[i][1];
+            if (wh < 1 || ww < 1 || oh % wh || ow % ww || wh * ww > 240 || (wh + 2) * (ww + 2) > 384) continue;
+            const int n = round_npt((wh * ww + 15) / 16);
+            if (n && (n <= 4 || n >= 9)) { tth = wh; ttw = ww; break; }  // (the tiled kernel is instantiated for 1-4, 9, 12 and 15 pixel tiles)
+        }
+    }
+    g.th = whole ? oh : tth; g.tw = whole ? ow : ttw;
     const int plane = ((g.th - 1) * stride + 3) * ((g.tw - 1) * stride + 3), TP = g.th * g.tw;
     const int zs1 = (cout + 63) / 64;  // channel slices with NCT = 1
     g.G = 1;
@@ -327,7 +341,10 @@ inline void conv_launch_npt(int npt, dim3 grid, size_t lds, hipStream_t st, cons
                     default: hipLaunchKernelGGL((k_conv3x3<15, NCT, true>), grid, block, lds, st, L); break;
                 }
             }
-            break;  // tiled images use 8x8 tiles: npt == 4
+            else if (npt == 9) hipLaunchKernelGGL((k_conv3x3<9, NCT, false>), grid, block, lds, st, L);  // 12x12 tiles
+            else if (npt == 12) hipLaunchKernelGGL((k_conv3x3<12, NCT, false>), grid, block, lds, st, L);
+            else if (npt == 15) hipLaunchKernelGGL((k_conv3x3<15, NCT, false>), grid, block, lds, st, L);
+            break;  // tiled images use 8x8 tiles (npt == 4) or 12x12 (npt == 9)
     }
 }
 
