@@ -578,6 +578,13 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
 
     int resume = 0;
     const int cp0 = env_ok ? Pm.cur[env_g] : 0, op0 = env_ok ? Pm.opp[env_g] : 0;  // the root's players: read once per move, not per descent
+    // The tree phases' copy of the parameters, with what the build knows made a constant: the action count has 17 uses in mz_tree2.h
+    // (row strides of the entry table, loop bounds, lane predicates), each a scalar load + multiply from the kernel argument otherwise
+    // (C3 -1.2 %; pinning the LDS table offsets and the node count in registers on top of it -- hipcc re-loads ~30 kernel arguments at
+    // the top of every simulation's select -- measured the same)
+    SearchParams Pl = Pm;
+    if constexpr (AC == 10) Pl.A = 10;
+    if constexpr (TWO) Pl.A = 2;
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
     tree2_env_init(T, Pm);
     // normalisation (util.py:31-36) of this wave's tile of h -> LDS (value head input) and the HBM node store
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         return;
     }
     for (int s = 0; s < Pm.S; s++) {
-        tree2_select<false, TWO ? 2 : 0>(smem, Pm, tid, env_ok, env_g, T, cp0, op0, resume);
+        tree2_select<false, TWO ? 2 : 0>(smem, Pl, tid, env_ok, env_g, T, cp0, op0, resume);
         const int lp = T.lp, la = T.la;
         // gather: the env's 16 lanes fetch the parent's hidden state (64 floats = one float4 per lane) straight after
         // their descent and store it, with the one-hot action (network.py:191-193), into the packed B-operand buffer
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         // the backup's tree reads that do not depend on this simulation's reward / value: issued ahead of the barrier and the softmax
         // (two-action searches: -0.9 % on C2; with ten actions the backup is dominated by its refresh loop and the move was +0.6 %)
         Backup2Pre bpre;
-        if constexpr (TWO) bpre = tree2_backup_prefetch<2>(smem, Pm, tid, env_ok, s, T);
+        if constexpr (TWO) bpre = tree2_backup_prefetch<2>(smem, Pl, tid, env_ok, s, T);
         __syncthreads();
         MZ_STAMP(7);  // value head
         // softmax -> expectation -> signed_parabolic (util.py:70-93) in registers: 16 lanes per row, 2 logits per lane;
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             }
             }
             MZ_STAMP(8);  // softmax + expectation + transform
-            resume = tree2_backup<TWO ? 2 : 0, (AC > 2 ? AC : 0), TWO>(smem, Pm, tid, env_ok, s, rew, val, T, &bpre);  // backup and the next select of an env run on the same 16 lanes: no barrier
+            resume = tree2_backup<TWO ? 2 : 0, (AC > 2 ? AC : 0), TWO>(smem, Pl, tid, env_ok, s, rew, val, T, &bpre);  // backup and the next select of an env run on the same 16 lanes: no barrier
         }
         MZ_STAMP(9);  // expand + backup
     }
