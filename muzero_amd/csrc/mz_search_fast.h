@@ -441,7 +441,7 @@ __device__ __forceinline__ void root_inference_fast(const MlpNet& net, const Mlp
 // s_set_gpr_idx from one inline-asm loop, 8 more nodes in the LDS the root buffers leave free, no HBM node store at all.  Correct,
 // but the publish -> barrier -> indexed read -> LDS -> barrier chain costs what the MALL round trip of the HBM gather costs:
 // 746.8 vs 744.7 us per C2 move.)
-template <int P, int TR, int TV, bool FUSE = false, int AC = 0, bool HW = false>
+template <int P, int TR, int TV, bool FUSE = false, int AC = 0, bool HW = false, bool SPB = false>
 __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((amdgpu_waves_per_eu(HW ? 2 : 1, HW ? 2 : 1))) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
     // AC: what the launcher knows about the action count -- 2: exactly two actions, single player, categorical heads (classic control);
     // 10: exactly ten actions (TicTacToe: the backup's best-child refresh fully unrolled); 0: anything up to 16
@@ -585,8 +585,12 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     SearchParams Pl = Pm;
     if constexpr (AC == 10) Pl.A = 10;
     if constexpr (TWO) Pl.A = 2;
+    // SPB: the board games' self-play settings as constants too -- two players, known bounds, discount 1 (its products fold away),
+    // Dirichlet noise and tie draws from the device streams: the runtime forms of these cost the ten-action build 2.4 % (the launcher
+    // checks every one of them and falls back to the build without the constants)
+    if constexpr (SPB) { Pl.board = 1; Pl.has_bounds = 1; Pl.noise_mode = 2; Pl.rng_mode = 1; Pl.discount = 1.0; }
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
-    tree2_env_init(T, Pm);
+    tree2_env_init(T, Pl);
     // normalisation (util.py:31-36) of this wave's tile of h -> LDS (value head input) and the HBM node store
     // (the four tiles by value: through a reference to the array the `hw = h[wave]` selects below become ONE load through a selected
     // address, which pins the array in scratch memory -- a round trip per simulation, measured in the ISA)

@@ -396,6 +396,8 @@ static int planner_init(mz_planner* p, bool conv) {
 #define MZ_FAST_LDS(PL, T, F, W) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<PL, T, T, F, W, kFastHW>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
 #define MZ_FAST_LDS4(PL, T) MZ_FAST_LDS(PL, T, false, 0); MZ_FAST_LDS(PL, T, false, 2); MZ_FAST_LDS(PL, T, true, 0); MZ_FAST_LDS(PL, T, true, 2)
         MZ_FAST_LDS(256, 1, false, 10); MZ_FAST_LDS(256, 1, true, 10);  // ten actions (TicTacToe)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1, false, 10, kFastHW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1, true, 10, kFastHW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
 #ifdef MZ_DEV_SHAPES  // development builds: only the C2 / C3 shapes of the tuned kernel (a third of the compile time)
         MZ_FAST_LDS4(256, 1); MZ_FAST_LDS4(512, 2);
 #else
@@ -759,7 +761,13 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
         const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
         if (fast_ac10(p)) {  // (TicTacToe: ten actions)
-            if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
+            // SPB: the build with the board games' self-play settings as compile-time constants (mz_search_fast.h)
+            const bool spb = s.board && s.has_bounds && s.discount == 1.0 && s.noise_mode == 2 && s.rng_mode == 1;
+            const dim3 fblock(kFastHW ? 2 * WG_THREADS : WG_THREADS);
+            if (spb) {
+                if (fenv) hipLaunchKernelGGL((k_search_fast<256, 1, 1, true, 10, kFastHW, true>), grid, fblock, s.lds_bytes, p->stream, s, p->fw);
+                else hipLaunchKernelGGL((k_search_fast<256, 1, 1, false, 10, kFastHW, true>), grid, fblock, s.lds_bytes, p->stream, s, p->fw);
+            } else if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
         } else
         if (c.value_support_size == 1 || c.reward_support_size == 1) {
             // an MSE head's one-neuron layer runs on the vector ALUs in its own summation order (mz_mlp.h, scalar_head_tile): of the
