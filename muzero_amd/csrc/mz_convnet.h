@@ -366,6 +366,19 @@ inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
     const size_t lds = (size_t)2 * g.cstride * sizeof(float);
     const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));
+    // shape-specialised builds (mz_conv.h, SIDE): a whole 15x15 image per workgroup, 128 output channels (Gomoku's towers)
+    static const bool spec_ok = env_int("MZ_CONV_SPEC", 1) != 0;
+    if (spec_ok && g.whole && g.nct == 1 && g.npt == 15 && g.G == 1 && L.stride == 1 && L.ih == 15 && L.iw == 15 && L.oh == 15 && L.ow == 15 &&
+        Lr.cout == 128 && L.tiles_x == 1 && L.tiles_y == 1 && g.qstride == (((15 + 2) * (15 + 2) * 4 + 63) & ~63) && g.cstride == 4 * g.qstride) {
+        hipLaunchKernelGGL((k_conv3x3<15, 1, true, 15>), grid, dim3(256), lds, st, L);
+        return;
+    }
+    if (spec_ok && !g.whole && g.nct == 2 && g.G == 1 && L.stride == 1 && Lr.cout == 128 && L.ih == L.oh && L.iw == L.ow && L.oh == L.ow && g.th == 12 &&
+        L.tiles_x == L.ow / g.tw && L.tiles_y == L.oh / 12 && g.qstride == ((14 * (g.tw + 2) * 4 + 63) & ~63) && g.cstride == 4 * g.qstride) {
+        // the Atari representation's 48 x 48 (12 x 16 tiles) and 24 x 24 (12 x 12 tiles) layers
+        if (L.oh == 48 && g.tw == 16 && g.npt == 12) { hipLaunchKernelGGL((k_conv3x3<12, 2, false, 48>), grid, dim3(256), lds, st, L); return; }
+        if (L.oh == 24 && g.tw == 12 && g.npt == 9) { hipLaunchKernelGGL((k_conv3x3<9, 2, false, 24>), grid, dim3(256), lds, st, L); return; }
+    }
     if (g.whole) {
         if (g.nct == 2) conv_launch_npt<2, true>(g.npt, grid, lds, st, L);
         else conv_launch_npt<1, true>(g.npt, grid, lds, st, L);

@@ -29,6 +29,9 @@ struct TowerLaunch {
     long long* stamps;
 };
 
+// (Tried: the Atari tower's geometry -- 128 planes, two 6 x 6 images, 80 positions per plane -- as compile-time constants, the
+// way k_conv3x3's SIDE builds have it: C4 -2.1 %.  This kernel's offsets already live in VGPRs; the constants only changed the
+// schedule for the worse.)
 template <int NPT>
 __global__ __launch_bounds__(512, 1) void k_res_tower(const TowerLaunch L) {
     MZC_T_DECL
