@@ -440,7 +440,16 @@ inline float* tower_run(hipStream_t st, const std::vector<ResBlockDev>& blocks, 
                 case 2: tower_launch_npt<2>(st, L, wgs, g.lds); break;
                 case 3: tower_launch_npt<3>(st, L, wgs, g.lds); break;
                 case 4: tower_launch_npt<4>(st, L, wgs, g.lds); break;
-                case 5: tower_launch_npt<5>(st, L, wgs, g.lds); break;
+                case 5:
+                    if (env_int("MZ_CONV_SPEC", 1) != 0 && Pc == 128 && h == 6 && w == 6 && g.G == 2) {  // (mz_tower.h, SPEC == 1)
+                        static bool attr1 = false;
+                        if (!attr1) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res_tower<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            attr1 = true;
+                        }
+                        hipLaunchKernelGGL((k_res_tower<5, 1>), dim3(wgs), dim3(512), g.lds, st, L);
+                    } else tower_launch_npt<5>(st, L, wgs, g.lds);
+                    break;
                 default: tower_launch_npt<6>(st, L, wgs, g.lds); break;
             }
             return t1;

@@ -29,11 +29,13 @@ struct TowerLaunch {
     long long* stamps;
 };
 
-// (Tried: the Atari tower's geometry -- 128 planes, two 6 x 6 images, 80 positions per plane -- as compile-time constants, the
-// way k_conv3x3's SIDE builds have it: C4 -2.1 %.  This kernel's offsets already live in VGPRs; the constants only changed the
-// schedule for the worse.)
-template <int NPT>
-__global__ __launch_bounds__(512, 1) void k_res_tower(const TowerLaunch L) {
+// SPEC == 1: the Atari nets' tower -- 128 planes, two 6 x 6 images per workgroup -- with those numbers as compile-time constants (the
+// launcher checks them): C4 +0.4 %.  (Positions per plane, `nposp`, stays a kernel argument: as a constant too it costs 2.5 % --
+// this kernel's operand offsets already live in VGPRs, and the constant plane stride only changed the schedule for the worse.)
+template <int NPT, int SPEC = 0>
+__global__ __launch_bounds__(512, 1) void k_res_tower(const TowerLaunch L_) {
+    TowerLaunch L = L_;
+    if constexpr (SPEC == 1) { L.P = 128; L.h = 6; L.w_img = 6; L.G = 2; }
     MZC_T_DECL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lds = reinterpret_cast<float*>(smem);
