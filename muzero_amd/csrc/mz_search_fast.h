@@ -502,7 +502,11 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     __syncthreads();
     {
         MZ_ROOT_TS_START();
-        if (main_w && env_ok) root_prior_group(smem, Pm, e, a0, env_g);  // (A <= 16 in this kernel)
+        SearchParams Pr = Pm;  // (the action count as a constant where the build knows it, as in the simulation loop)
+        if constexpr (AC == 10) Pr.A = 10;
+        if constexpr (TWO) Pr.A = 2;
+        if constexpr (SPB) { Pr.noise_mode = 2; Pr.has_mask = 1; }  // (self-play settings as constants, see the simulation loop)
+        if (main_w && env_ok) root_prior_group(smem, Pr, e, a0, env_g);  // (A <= 16 in this kernel)
         MZ_ROOT_TS(6);
     }
 
@@ -586,9 +590,12 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     if constexpr (AC == 10) Pl.A = 10;
     if constexpr (TWO) Pl.A = 2;
     // SPB: the board games' self-play settings as constants too -- two players, known bounds, discount 1 (its products fold away),
-    // Dirichlet noise and tie draws from the device streams: the runtime forms of these cost the ten-action build 2.4 % (the launcher
+    // Dirichlet noise, tie and action draws from the device streams, sampled play over a legal-move mask: the runtime forms of these cost
+    // the ten-action build 2.4 % (the launcher
     // checks every one of them and falls back to the build without the constants)
     if constexpr (SPB) { Pl.board = 1; Pl.has_bounds = 1; Pl.noise_mode = 2; Pl.rng_mode = 1; Pl.discount = 1.0; }
+    // (the two-action build's counterpart -- classic control's self-play: no known bounds, device streams, sampled play -- measured
+    // +0.5 % on C2, i.e. worse: that build is register-bound and the constants only moved its schedule)
     Tree2Env T;  // tree_mode 2: the env's search state lives in its lanes' registers
     tree2_env_init(T, Pl);
     // normalisation (util.py:31-36) of this wave's tile of h -> LDS (value head input) and the HBM node store
@@ -852,7 +859,11 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             if (stepper) cartpole_prefetch(Pt.fenv, env_g, pre);
             int action = 0;
             double rootv = 0.0;
-            if (env_ok) tree2_finish_group(smem, Pt, e, a0, env_g, action, rootv);
+            if (env_ok) {
+                SearchParams Pf = Pt;
+                Pf.A = 2;
+                tree2_finish_group(smem, Pf, e, a0, env_g, action, rootv);
+            }
             if (stepper) cartpole_step_prefetched(Pt.fenv, env_g, pre, action, rootv, reinterpret_cast<const double*>(smem + Pt.t_tmp) + e * 2);
             stepped = true;
         }
@@ -864,8 +875,11 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             int action = 0;
             double rootv = 0.0;
             if (env_ok) {
-                tree2_finish_group(smem, Pt, e, a0, env_g, action, rootv);
-                board_step_small_prefetched(Pt.fenv, env_g, a0, pre, action, rootv, reinterpret_cast<const double*>(smem + Pt.t_tmp) + e * Pt.A);
+                SearchParams Pf = Pt;
+                Pf.A = 10;
+                if constexpr (SPB) { Pf.deterministic = 0; Pf.has_mask = 1; Pf.rng_mode = 1; }
+                tree2_finish_group(smem, Pf, e, a0, env_g, action, rootv);
+                board_step_small_prefetched(Pt.fenv, env_g, a0, pre, action, rootv, reinterpret_cast<const double*>(smem + Pt.t_tmp) + e * 10);
             }
             stepped = true;
         }

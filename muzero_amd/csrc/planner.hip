@@ -762,7 +762,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
         if (fast_ac10(p)) {  // (TicTacToe: ten actions)
             // SPB: the build with the board games' self-play settings as compile-time constants (mz_search_fast.h)
-            const bool spb = s.board && s.has_bounds && s.discount == 1.0 && s.noise_mode == 2 && s.rng_mode == 1;
+            const bool spb = s.board && s.has_bounds && s.discount == 1.0 && s.noise_mode == 2 && s.rng_mode == 1 && !s.deterministic && s.has_mask;
             const dim3 fblock(kFastHW ? 2 * WG_THREADS : WG_THREADS);
             if (spb) {
                 if (fenv) hipLaunchKernelGGL((k_search_fast<256, 1, 1, true, 10, kFastHW, true>), grid, fblock, s.lds_bytes, p->stream, s, p->fw);
