@@ -234,7 +234,9 @@ def test_selfplay_search_outputs_equal_oracle_search(oracle, game):
     board = game == 'tictactoe'
     case = mlp_case(game)
     net = build_mlp(case)
-    A, S, B, M = case[2], (25 if board else 50), 256, 40
+    import os
+    A, S = case[2], (25 if board else 50)
+    B, M = int(os.environ.get('MZ_SELFPLAY_B', '256')), int(os.environ.get('MZ_SELFPLAY_M', '40'))  # (soak runs: 4096 x 100)
     kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None,
               root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
     p = _planner(net, B, seed=77, **kw)
