@@ -7,7 +7,9 @@
  * Floating-point conventions (the oracle DEFINES the summation order that the HIP kernels reproduce):
  *   - tree statistics are IEEE float64 exactly as the reference's Python floats (mcts.py:129-200);
  *   - network arithmetic is float32; every dot product is one k-ordered fmaf chain whose initial
- *     accumulator is the bias (this is what v_mfma_f32_*_f32 computes, so GPU == oracle bit for bit);
+ *     accumulator is the bias (this is what v_mfma_f32_*_f32 computes, so GPU == oracle bit for bit),
+ *     or a fixed tree of such chains where the kernels split a layer (linear_mlp: K-split second layers,
+ *     and the one-neuron second layer of an MSE head, which the kernels run on the vector ALUs);
  *   - exp() is mzo_expf below (own polynomial, identical code on the GPU), sqrt and division are IEEE.
  *   The reference (torch CPU kernels) differs from this only by summation order / libm exp, i.e. at
  *   the 1e-6 relative level; tests/test_oracle_nets.py pins that against recorded reference outputs.
