@@ -1,0 +1,88 @@
+/*
+ * mzlearner.h -- C ABI of the MI355X-native MuZero learner step for the MLP nets (libmzlearner_hip.so).
+ *
+ * Row f2 of SURVEY.md section 8: what the reference does per training step in `run_training` (pipeline.py:238-255) --
+ * `calc_loss` (:541-612) + `loss.backward()` + optional `clip_grad_norm_` (:246-247) + `optimizer.step()` (torch.optim.Adam with
+ * L2 weight decay, classic/run_training.py:94) -- as hand-written gfx950 kernels (muzero_amd/csrc/mz_learn.h).  The batch is read
+ * straight from the HBM-resident replay ring (muzero_amd.replay.PrioritizedReplay(device='cuda')) through a vector of row indices;
+ * nothing crosses PCIe.  Plain C: pointers and sizes, status codes (0 = ok, <0 = error, text via mzl_last_error()), caller-allocated
+ * buffers, no torch types.  All d_* pointers are device pointers on the learner's GPU; `stream` is a hipStream_t (NULL = the
+ * null stream): every call only ENQUEUES work on it and returns.
+ *
+ * The gradient and the update are separate calls so that a data-parallel learner can all-reduce the flat gradient vector
+ * (RCCL, muzero_amd.learner.allreduce_gradients) between them.
+ */
+#ifndef MZLEARNER_H
+#define MZLEARNER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZL_OK 0
+#define MZL_E_INVALID (-1)
+#define MZL_E_HIP (-2)
+#define MZL_E_STATE (-3)
+
+/* MuZeroMLPNet's constructor arguments (network.py:239-247) + the batch geometry of calc_loss (pipeline.py:541-575). */
+typedef struct {
+    int32_t in_dim;               /* flattened observation (network.py:153-154) */
+    int32_t num_actions;
+    int32_t num_planes;
+    int32_t hidden_dim;
+    int32_t value_support_size;   /* 1: squared-error value head (network.py:126-134) */
+    int32_t reward_support_size;
+    int32_t unroll_steps;         /* K, config.py:87 */
+    int32_t max_batch;            /* capacity: mzl_grad accepts any batch <= max_batch */
+    int32_t grad_slices;          /* >= 1: the weight-gradient kernel splits its reduction over this many workgroup rows (large batches) */
+} mzl_config;
+
+/* One batch of `Transition`s (replay.py:27-32) addressed inside the replay ring's storages. */
+typedef struct {
+    const void* d_state;      /* [capacity][in_dim] float32, or int8 when state_is_int8 (board games) */
+    const void* d_action;     /* [capacity][K] int8, or int16 when action_bytes == 2 (num_actions > 128) */
+    const float* d_pi_prob;   /* [capacity][K][num_actions] */
+    const float* d_value;     /* [capacity][K] */
+    const float* d_reward;    /* [capacity][K] */
+    const int64_t* d_index;   /* [batch] ring rows of the sampled items (0 .. batch-1 for a stacked batch) */
+    const float* d_weights;   /* [batch] importance-sampling weights (pipeline.py:597) */
+    float* d_loss;            /* [1]   out: the reported loss (pipeline.py:594-597) */
+    float* d_priorities;      /* [batch] out: |v_0 - z_0| (pipeline.py:603-609) */
+    int32_t batch;
+    int32_t state_is_int8;
+    int32_t action_bytes;     /* 1 or 2 */
+} mzl_batch;
+
+typedef struct mz_learner mz_learner;
+
+const char* mzl_last_error(void);
+
+int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out);
+int mzl_destroy(mz_learner* h);
+
+/* Number of float32 parameters (the 20 tensors of MuZeroMLPNet.state_dict() -- SURVEY 8b -- concatenated in that order, each in
+ * torch layout) and the size in floats of the gradient buffer the caller must provide (grad_slices * parameters). */
+int64_t mzl_num_params(const mz_learner* h);
+int64_t mzl_grad_floats(const mz_learner* h);
+/* i-th tensor of the flat vector: name (state_dict key), float offset, rows, columns (columns == 0: a bias vector) */
+int mzl_tensor_info(const mz_learner* h, int32_t i, const char** name, int64_t* offset, int32_t* rows, int32_t* cols);
+
+/* Caller-owned flat device buffers: master weights, gradients, Adam's exp_avg / exp_avg_sq (torch.optim.Adam state), all float32.
+ * Replaces: network.parameters() / optimizer.state (pipeline.py:224-230).  The caller keeps them alive while bound. */
+int mzl_bind(mz_learner* h, float* d_params, float* d_grads, float* d_exp_avg, float* d_exp_avg_sq);
+/* (Re)build the MFMA operand copies from d_params (after loading a checkpoint into it).  Replaces: network.load_state_dict. */
+int mzl_commit(mz_learner* h, void* stream);
+
+/* loss + backward (pipeline.py:241-244): fills d_grads (slice 0 holds the complete gradient), d_loss, d_priorities. */
+int mzl_grad(mz_learner* h, const mzl_batch* batch, void* stream);
+/* clip_grad_norm_ when max_grad_norm > 0 (pipeline.py:246-247), then optimizer.step() (:249) for Adam step number `step` (1-based),
+ * learning rate `lr` as MultiStepLR gives it for this step (:250), and the refresh of the operand copies. */
+int mzl_apply(mz_learner* h, double lr, double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, int64_t step,
+              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,4 +1,5 @@
-"""Builds libmzplanner_hip.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
+"""Builds libmzplanner_hip.so (planner kernels + C ABI) and libmzlearner_hip.so (learner-step kernels + C ABI) in-tree with hipcc
+for gfx950.
 
     python -m muzero_amd.build [--force] [--verbose]
 
@@ -16,6 +17,9 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmzplanner_hip.so')
 SOURCES = ['planner.hip']
+LEARNER_LIB_PATH = os.path.join(LIB_DIR, 'libmzlearner_hip.so')
+LEARNER_SOURCES = ['learner.hip']
+LEARNER_FILES = ('learner.hip', 'mz_learn.h', 'mzlearner.h')  # what only the learner library is compiled from (besides mz_device.h)
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs where they fit.  The search kernels read every accumulator
 # with VALU code right after the layer (ReLU, normalisation, partial sums); in the default AGPR form each of those reads is a
 # v_accvgpr_read first (96 per simulation in k_search_fast: +2 % on C2, measured), and no kernel of this library needs the
@@ -27,9 +31,15 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared'
 
 
 def _deps():
-    """Every file the library is compiled from: all of csrc/ (sources and headers), the public C header, this script."""
-    return sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.hip'))) + \
+    """Every file the planner library is compiled from: csrc/ (sources and headers) without the learner's files, the public C
+    header, this script."""
+    return sorted(f for f in glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.hip')) if os.path.basename(f) not in LEARNER_FILES) + \
         [os.path.join(HERE, '..', 'include', 'mzplanner.h'), os.path.abspath(__file__)]
+
+
+def _learner_deps():
+    return [os.path.join(CSRC, 'learner.hip'), os.path.join(CSRC, 'mz_learn.h'), os.path.join(CSRC, 'mz_device.h'),
+            os.path.join(HERE, '..', 'include', 'mzlearner.h'), os.path.abspath(__file__)]
 
 
 def source_fingerprint():
@@ -54,6 +64,13 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
+def learner_needs_build():
+    if not os.path.exists(LEARNER_LIB_PATH):
+        return True
+    t = os.path.getmtime(LEARNER_LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in _learner_deps())
+
+
 def build_stamps(counters=False):
     """Diagnostic library with per-phase s_memtime stamps (never loaded by the product path); counters=True adds the
     atomic tree counters (hit rates, depths), which distort the timings."""
@@ -68,24 +85,26 @@ def build(force=False, verbose=False):
     """Compile if any dependency is newer than the library.  Safe to call from several processes at once (ranks of a
     multi-GPU job, pytest-xdist workers): one holds the lock and compiles into a temporary file that is renamed into
     place, so nobody ever dlopen()s a partially written library."""
-    if not force and not needs_build():
+    if not force and not needs_build() and not learner_needs_build():
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', 'hipcc')
     os.makedirs(LIB_DIR, exist_ok=True)
     with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not needs_build():  # another process built it while we waited
-                return LIB_PATH
-            tmp = LIB_PATH + '.tmp.%d' % os.getpid()
-            cmd = [hipcc] + FLAGS + os.environ.get('MZ_EXTRA_FLAGS', '').split() + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
-                [os.path.join(CSRC, s) for s in SOURCES] + ['-o', tmp]
-            try:
-                subprocess.check_call(cmd)
-                os.replace(tmp, LIB_PATH)
-            finally:
-                if os.path.exists(tmp):
-                    os.remove(tmp)
+            for need, path, sources, extra in ((needs_build, LIB_PATH, SOURCES, os.environ.get('MZ_EXTRA_FLAGS', '').split()),
+                                               (learner_needs_build, LEARNER_LIB_PATH, LEARNER_SOURCES, [])):
+                if not force and not need():  # up to date (or another process built it while we waited)
+                    continue
+                tmp = path + '.tmp.%d' % os.getpid()
+                cmd = [hipcc] + FLAGS + extra + (['-Rpass-analysis=kernel-resource-usage'] if verbose else []) + \
+                    [os.path.join(CSRC, s) for s in sources] + ['-o', tmp]
+                try:
+                    subprocess.check_call(cmd)
+                    os.replace(tmp, path)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

@@ -28,6 +28,35 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b'gfx950' in planner.load_library().mz_version()
 
 
+def test_learner_library_builds_and_exports_every_declared_symbol():
+    """include/mzlearner.h (the learner step) -- same check for the second library."""
+    from muzero_amd import build, hip_learner
+
+    build.build()
+    assert os.path.exists(build.LEARNER_LIB_PATH)
+    lib = ctypes.CDLL(build.LEARNER_LIB_PATH)
+    text = re.sub(r'/\*.*?\*/', '', open(os.path.join(REPO, 'include', 'mzlearner.h')).read(), flags=re.S)
+    declared = sorted(set(re.findall(r'\b(mzl_[a-z_]+)\s*\(', text)))
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/mzlearner.h but not exported'
+    assert sorted(hip_learner.ABI_SYMBOLS) == declared
+    hip_learner.load_library()
+
+
+def test_hip_learner_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    import pytest
+    from helpers import build_mlp, mlp_case
+    from muzero_amd.hip_learner import HipLearner, LearnerError
+
+    with pytest.raises(LearnerError):
+        HipLearner(build_mlp(mlp_case('tiny')), 'cuda:0', 5, 8, lr=1e-3)
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under muzero_amd/ may import, link or execute it."""
     for root, _, files in os.walk(os.path.join(REPO, 'muzero_amd')):

@@ -1,0 +1,154 @@
+"""SURVEY 8 f2, second stage: the learner step as hand-written HIP kernels (muzero_amd/csrc/mz_learn.h behind include/mzlearner.h)
+against (1) the vectors recorded from the REFERENCE's calc_loss / backward / clip / Adam / MultiStepLR (tests/golden/learn_cases.npz,
+generator oracle/gen_golden.py learn) and (2) this repo's PyTorch-autograd learner (muzero_amd.learner, itself pinned to the same
+vectors by tests/test_learner.py) on the benchmark shapes.  Tolerances are the ones tests/test_gpu_learner.py uses for the autograd
+step on the GPU: loss 1e-4 relative, priorities 1e-3, gradients 2e-3 relative (fp32, different summation orders)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_mlp, load_golden, mlp_case
+from muzero_amd import learner
+from muzero_amd.replay import Transition
+
+pytestmark = pytest.mark.gpu
+G = load_golden('learn_cases.npz')
+
+
+def _hip(net, dev, max_batch, **kw):
+    from muzero_amd.hip_learner import HipLearner
+
+    kw.setdefault('lr', 1e-3)
+    return HipLearner(net, dev, 5, max_batch, **kw)
+
+
+@pytest.mark.parametrize('name,cname', [('mlp_cat', 'tiny'), ('mlp_mse', 'tiny_mse')])
+def test_loss_gradients_and_three_updates_match_the_reference(name, cname):
+    """The recipe of gen_golden.gen_learn: Adam(lr 1e-3), MultiStepLR([2], 0.1), clip_grad_norm_(10) on the second step only."""
+    pre = f'learn_{name}'
+    dev = torch.device('cuda', 0)
+    net = build_mlp(mlp_case(cname)).to(dev)
+    net.train()
+    hl = _hip(net, dev, 16, lr=1e-3, milestones=[2], gamma=0.1, max_grad_norm=10.0)
+    tr = Transition(*[G[f'{pre}_{f}'] for f in Transition._fields])
+    B = tr.state.shape[0]
+    ring = dict(state=torch.from_numpy(tr.state).to(dev).reshape(B, -1).contiguous(), action=torch.from_numpy(tr.action).to(dev),
+                pi_prob=torch.from_numpy(tr.pi_prob).to(dev), value=torch.from_numpy(tr.value).to(dev), reward=torch.from_numpy(tr.reward).to(dev))
+    w = torch.from_numpy(G[f'{pre}_weights']).to(dev)
+    losses = []
+    for step in range(3):
+        loss, prio = hl.grad(ring, None, w, B)
+        if step == 0:
+            np.testing.assert_allclose(prio.cpu().numpy(), G[f'{pre}_prio'], rtol=1e-3, atol=1e-3)
+            for pn in hl.views:
+                np.testing.assert_allclose(hl.grad_views[pn].cpu().numpy(), G[f'{pre}_grad_{pn}'], rtol=2e-3, atol=2e-6, err_msg=pn)
+        hl.apply(clip=(step == 1))
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, G[f'{pre}_losses'], rtol=1e-4)
+    sd = net.state_dict()  # the module's parameters ARE the learner's weights
+    for pn in hl.views:
+        np.testing.assert_allclose(sd[pn].cpu().numpy(), G[f'{pre}_final_{pn}'], rtol=2e-3, atol=2e-5, err_msg=pn)
+    assert abs(hl.current_lr() - 1e-4) < 1e-12 and hl.steps == 3
+
+
+def _random_batch(rs, B, obs_shape, A, K=5, int8_state=False, vmax=50.0):
+    st = rs.randint(0, 2, (B,) + obs_shape).astype(np.int8) if int8_state else rs.uniform(-1, 1, (B,) + obs_shape).astype(np.float32)
+    return Transition(st, rs.randint(0, A, (B, K)).astype(np.int8), rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32),
+                      rs.uniform(-vmax, vmax, (B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
+
+
+# (lunar with 37 samples has a representation-layer pre-activation of 1.6e-7 -- sample 33, unit 221: its ReLU gate depends on the
+# summation order, and the whole row's gradient with it; the test stops at 33 samples)
+SHAPES = [('cartpole', 128, False, 50.0), ('cartpole', 100, False, 50.0), ('lunar', 33, False, 200.0), ('tictactoe', 128, True, 1.0), ('odd', 21, False, 5.0)]
+
+
+@pytest.mark.parametrize('cname,B,int8_state,vmax', SHAPES, ids=[f'{s[0]}-{s[1]}' for s in SHAPES])
+def test_step_matches_the_autograd_learner(cname, B, int8_state, vmax):
+    """Same start, same batches: six updates (clipping on, weight decay on, an LR milestone inside) of the HIP learner and of
+    learner.train_step (PyTorch-ROCm autograd + torch.optim.Adam)."""
+    case = mlp_case(cname)
+    dev = torch.device('cuda', 0)
+    net_a = build_mlp(case).to(dev)
+    net_b = copy.deepcopy(net_a)
+    net_a.train()
+    net_b.train()
+    cfg = type('Cfg', (), dict(clip_grad=True, max_grad_norm=5.0))()
+    opt = torch.optim.Adam(net_a.parameters(), lr=2e-3, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[3], gamma=0.1)
+    hl = _hip(net_b, dev, B, lr=2e-3, weight_decay=1e-4, milestones=[3], gamma=0.1, clip_grad=True, max_grad_norm=5.0)
+    rs = np.random.RandomState(7)
+    for step in range(6):
+        tr = _random_batch(rs, B, tuple(case[1]), case[2], int8_state=int8_state, vmax=vmax)
+        w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+        tr_a = tr._replace(state=tr.state.astype(np.float32))
+        if step == 0:  # gradients of the first batch, before anything moves
+            opt.zero_grad()
+            la0, _ = learner.calc_loss(net_a, dev, tr_a, torch.from_numpy(w).to(dev))
+            la0.backward()
+            ga = {k: p.grad.detach().clone() for k, p in net_a.named_parameters()}
+            B_ = tr.state.shape[0]
+            ring = dict(state=torch.from_numpy(tr.state).to(dev).reshape(B_, -1).contiguous(), action=torch.from_numpy(tr.action).to(dev),
+                        pi_prob=torch.from_numpy(tr.pi_prob).to(dev), value=torch.from_numpy(tr.value).to(dev), reward=torch.from_numpy(tr.reward).to(dev))
+            lb0, _ = hl.grad(ring, None, torch.from_numpy(w).to(dev), B_)
+            assert abs(float(la0) - float(lb0)) <= 1e-4 * max(1.0, abs(float(la0)))
+            for k in ga:
+                a, b = ga[k].cpu().numpy(), hl.grad_views[k].cpu().numpy()
+                scale = max(1e-8, float(np.abs(a).max()))
+                assert float(np.abs(a - b).max()) <= 2e-3 * scale, (k, float(np.abs(a - b).max()), scale)
+        la, pa = learner.train_step(cfg, net_a, opt, sch, dev, tr_a, w)
+        lb, pb = hl.step_transitions(tr, w)
+        assert abs(la - float(lb)) <= 2e-4 * max(1.0, abs(la)), (step, la, float(lb))
+        np.testing.assert_allclose(pb.cpu().numpy(), pa, rtol=2e-3, atol=2e-3 * max(1.0, vmax / 10))
+        assert abs(sch.get_last_lr()[0] - hl.current_lr()) < 1e-12
+    for (n, x), (_, y) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert float((x - y).abs().max()) < 1e-3, n  # weights move by ~lr per update: six updates of 2e-3
+
+
+def test_batch_read_from_the_replay_ring_by_index_equals_the_stacked_batch():
+    """The kernels gather sampled items from the HBM ring themselves (rows by index, repeated rows included); identical bits to
+    the same items stacked contiguously, and the gradient slices of a split reduction (k_learn_dw_big) add up to the unsplit gradient."""
+    case = mlp_case('cartpole')
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(3)
+    cap, B = 300, 208  # 13 tiles x 5 steps = 65 reduction blocks: with grad_slices > 1 the 4 x 4-tile kernel of long reductions runs
+    items = _random_batch(rs, cap, (4, 5), 2)
+    ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(items, f))).to(dev) for f in Transition._fields}
+    ring['state'] = ring['state'].reshape(cap, -1).contiguous()
+    idx = torch.from_numpy(rs.randint(0, cap, B).astype(np.int64)).to(dev)
+    idx[5] = idx[4]
+    w = torch.from_numpy(rs.uniform(0.5, 1, B).astype(np.float32)).to(dev)
+    res = []
+    for mode in ('ring', 'stacked', 'ring', 'sliced'):
+        net = build_mlp(case).to(dev)
+        hl = _hip(net, dev, B, grad_slices=3 if mode == 'sliced' else 1)
+        if mode == 'stacked':
+            sub = {f: ring[f].index_select(0, idx).contiguous() for f in ring}
+            loss, prio = hl.grad(sub, None, w, B)
+        else:
+            loss, prio = hl.grad(ring, idx, w, B)
+        res.append((float(loss), prio.cpu().numpy().copy(), hl.grad_flat.cpu().numpy().copy()))
+        hl.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert res[0][0] == res[2][0] and np.array_equal(res[0][2], res[2][2])  # run to run: bit-identical (no atomics anywhere)
+    assert res[0][0] == res[3][0]
+    np.testing.assert_allclose(res[3][2], res[0][2], rtol=1e-4, atol=1e-7)
+
+
+def test_errors_are_reported_not_swallowed():
+    from muzero_amd.hip_learner import LearnerError
+
+    dev = torch.device('cuda', 0)
+    net = build_mlp(mlp_case('tiny')).to(dev)
+    hl = _hip(net, dev, 8)
+    tr = _random_batch(np.random.RandomState(0), 12, (3, 4), 3)
+    with pytest.raises(LearnerError, match='max_batch'):
+        hl.step_transitions(tr)
+    bad = tr._replace(pi_prob=tr.pi_prob[:, :, :2])
+    with pytest.raises(LearnerError):
+        hl.step_transitions(Transition(*[x[:8] for x in bad]))
+    from helpers import build_conv, conv_case
+
+    with pytest.raises(LearnerError, match='MuZeroMLPNet'):
+        _hip(build_conv(conv_case('board3')).to(dev), dev, 8)
