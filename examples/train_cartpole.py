@@ -35,8 +35,15 @@ def main():
     ap.add_argument('--eval-episodes', type=int, default=3)
     ap.add_argument('--out', default='')
     ap.add_argument('--host-assembly', action='store_true', help='assemble (Transition, priority) items on the host instead of the device epilogue')
-    ap.add_argument('--eager-learner', action='store_true', help='learner.train_step per update instead of the HIP-graph step (learner.GraphedTrainStep)')
+    ap.add_argument('--learner', choices=('hip', 'graphed', 'eager'), default='hip',
+                    help='hip: hand-written gfx950 kernels (hip_learner.HipLearner, batch gathered from the HBM ring by index); graphed: the PyTorch '
+                         'update as one HIP graph (learner.GraphedTrainStep); eager: learner.train_step')
+    ap.add_argument('--overlap', action='store_true',
+                    help='let self-play (planner stream) and updates (learner stream) overlap: faster, but how many items the replay holds when a '
+                         'batch is drawn then depends on timing -- without it every draw happens after the moves before it have been committed '
+                         '(event order), and a seed gives ONE learning curve')
     args = ap.parse_args()
+    args.eager_learner = args.learner == 'eager'
 
     from muzero_amd import learner
     from muzero_amd import planner as pl
@@ -50,9 +57,14 @@ def main():
     cfg = make_classic_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
     cfg.num_envs = args.envs
     net = MuZeroMLPNet((4, 5), 2, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
-    opt = (torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay) if args.eager_learner
-           else learner.make_capturable_adam(net, cfg, dev))
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    hl = None
+    if args.learner == 'hip':
+        hl = learner.make_hip_learner(cfg, net, dev)
+        opt, sched = hl.optimizer, hl.lr_scheduler
+    else:
+        opt = (torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay) if args.eager_learner
+               else learner.make_capturable_adam(net, cfg, dev))
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
     replay = PrioritizedReplay(50000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
 
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
@@ -72,10 +84,25 @@ def main():
         if args.host_assembly:
             for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
                 replay.add(tr, prio)
+        if not args.overlap:
+            p.synchronize()  # event order: the moves above are committed to the replay before anything is drawn from it
         if replay.size < cfg.min_replay_size:
             continue
         net.train()
         for _ in range(args.updates_per_iter):
+            if hl is not None:  # indices drawn on the host (the reference's RandomState stream), items gathered by the kernels
+                idx, _, ring = replay.sample_indices(cfg.batch_size)
+                loss, prio = hl.step(ring, torch.from_numpy(idx).to(dev), None, cfg.batch_size)
+                steps += 1
+                if steps % args.report_every == 0:
+                    c = p.selfplay_counters()
+                    de, ds = c['episodes'] - last['episodes'], c['episode_steps'] - last['episode_steps']
+                    last = dict(episodes=c['episodes'], episode_steps=c['episode_steps'])
+                    rec = dict(train_steps=steps, env_steps=c['env_steps'], episodes_finished=de, mean_episode_length=(ds / de) if de else None,
+                               loss=float(loss), replay=replay.size, seconds=round(time.time() - t0, 1))
+                    log.append(rec)
+                    print(json.dumps(rec), flush=True)
+                continue
             batch, idx, w = replay.sample_tensors(cfg.batch_size)
             if args.eager_learner:
                 loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)

@@ -137,14 +137,16 @@ int mz_selfplay_counters(mz_planner* p, int64_t out[4]);
  * mid-episode flush every acc_seq_length steps (:118-142), then data_queue.put -> PrioritizedReplay.add (replay.py:67-75)
  * -- done on the GPU after every lock-step move, written straight into a caller-owned replay ring in device memory.
  * All pointers are DEVICE pointers (e.g. the storages of muzero_amd.replay.PrioritizedReplay(device='cuda')); the caller
- * keeps them alive while attached.  Items of one environment appear in step order; environments interleave (the
+ * keeps them alive while attached.  SINGLE WRITER: a ring may be attached to ONE planner at a time -- the planner reserves slots from
+ * its own cursor (seeded from *num_added at attach) and publishes *num_added by overwriting it; give each planner its own ring.  Items of one environment appear in step order; environments interleave (the
  * reference's actors are independent processes).  Call BEFORE mz_selfplay_reset (the record ring is sized to hold an open
  * trajectory); ring == NULL detaches.  Attach and detach drain the planner's stream, so after a detach the counter and the
  * priorities are final.  mz_selfplay_read then returns at most the moves the record ring holds. */
 typedef struct {
     int64_t capacity;     /* ring slots; slot of the i-th item ever added = i % capacity */
     float* state;         /* [capacity, obs_c*obs_h*obs_w] */
-    int8_t* action;       /* [capacity, unroll_steps] (num_actions <= 128) */
+    void* action;         /* [capacity, unroll_steps] int8 when num_actions <= 128, int16 otherwise (the reference's int8, pipeline.py:753,
+                           * cannot hold Gomoku 15x15's 226 actions: numpy 2 raises OverflowError there) */
     float* pi_prob;       /* [capacity, unroll_steps, num_actions] */
     float* value;         /* [capacity, unroll_steps] */
     float* reward;        /* [capacity, unroll_steps] */

@@ -624,13 +624,15 @@ __global__ void k_env_step(const EnvLaunch L) {  // 16 threads per env
 struct ReplayRing {
     long long capacity;
     float* state;         // [capacity][D]
-    signed char* action;  // [capacity][K]
+    signed char* action;  // [capacity][K] int8 -- or, when action16 is set (num_actions > 128), the same buffer as int16
+    int action16;
     float* pi_prob;       // [capacity][K][A]
     float* value;         // [capacity][K]
     float* reward;        // [capacity][K]
     float* priority;      // [capacity]
     long long* num_added; // COMMITTED items: published by k_epi_publish after every k_epilogue launch, when all slots below it are filled
-    long long* ctr;       // planner-owned: reserved write cursor (atomicAdd in k_epilogue)
+    long long* ctr;       // planner-owned: [0] reserved write cursor, [1] items of the move being written (k_epi_scan)
+    int* off;             // planner-owned [B]: first slot of env e's items of this move, relative to ctr[0] (k_epi_scan: prefix sum in env order)
     int* origin;          // optional [capacity]: env that produced the item (tests), or null
     int acc, K, td, board;
     double pw[34];        // discount ** i, i = 0..td (host libm pow == Python float pow)
@@ -645,7 +647,7 @@ struct EpiLaunch {
 
 // z[t], t in [0, T): target value of every step of the open trajectory (compute_n_step_target :632-673 /
 // compute_mc_return_target :676-707); rec(i) = record index of trajectory position i
-__device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int T, int n, double* z, int lane) {
+__device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int T, int n, long long base, double* z, int lane) {
     const EnvState& V = E.env;
     const ReplayRing& R = E.ring;
     const int B = E.B, A = V.A, D = V.D, K = R.K;
@@ -662,11 +664,9 @@ __device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int 
         }
     }
     __syncthreads();
-    __shared__ long long base_s;
-    // slots are RESERVED here and published (R.num_added) only when the whole launch has filled its slots: see k_epi_publish
-    if (lane == 0) base_s = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(R.ctr), (unsigned long long)n);
-    __syncthreads();
-    const long long base = base_s;
+    // `base`: this env's slots, reserved by k_epi_scan in ENV ORDER (round 3 reserved with one atomicAdd per env: which env got which
+    // slot then depended on workgroup scheduling, and with it every later replay draw -- the same seed gave different runs); the
+    // count is published (R.num_added) only when the whole launch has filled its slots: see k_epi_publish
     // the n items are written with the wave's lanes spread over (item, element) pairs: a flush emits acc_seq_length items at once
     for (int j = lane; j < n * D; j += 64) {
         const int t = j / D, i = j - t * D;
@@ -676,7 +676,8 @@ __device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int 
         const int t = j / K, k = j - t * K, idx = t + k;
         const size_t o = (size_t)((base + t) % R.capacity) * K + k;
         const bool real = idx < T;  // past the end: absorbing step (action 0, reward 0, value 0, uniform policy)
-        R.action[o] = real ? (signed char)V.r_action[rec(idx)] : (signed char)0;
+        if (R.action16) reinterpret_cast<short*>(R.action)[o] = real ? (short)V.r_action[rec(idx)] : (short)0;
+        else R.action[o] = real ? (signed char)V.r_action[rec(idx)] : (signed char)0;
         R.reward[o] = real ? V.r_reward[rec(idx)] : 0.0f;
         R.value[o] = real ? (float)z[idx] : 0.0f;
     }
@@ -703,26 +704,61 @@ __global__ __launch_bounds__(64) void k_epilogue(const EpiLaunch E) {
     const bool done = V.r_done[(size_t)(E.move_abs % V.ring_len) * E.B + e] != 0;
     const bool flush = !R.board && len == R.acc + R.K + R.td;
     if (flush || done) {
+        long long base = R.ctr[0] + (long long)R.off[e];
         if (flush) {
-            epi_emit(E, e, start, len, R.acc, z, lane);
+            epi_emit(E, e, start, len, R.acc, base, z, lane);
             start += R.acc;
             len -= R.acc;
+            base += R.acc;
         }
         if (done) {
-            epi_emit(E, e, start, len, len, z, lane);
+            epi_emit(E, e, start, len, len, base, z, lane);
             start = E.move_abs + 1;
         }
         if (lane == 0) V.ep_start[e] = start;
     }
 }
 
+// How many items every env emits after this move (the same tests as k_epilogue), as an exclusive prefix sum in env order: off[e],
+// and the move's total in ctr[1].  One workgroup: thread t owns a contiguous run of envs, the thread totals meet in an LDS scan.
+__global__ __launch_bounds__(1024) void k_epi_scan(const EpiLaunch E) {
+    __shared__ int part[1024];
+    const EnvState& V = E.env;
+    const ReplayRing& R = E.ring;
+    const int t = threadIdx.x, per = (E.B + 1023) / 1024, e0 = t * per, e1 = e0 + per < E.B ? e0 + per : E.B;
+    int sum = 0;
+    for (int e = e0; e < e1; e++) {
+        int len = (int)(E.move_abs + 1 - V.ep_start[e]);
+        const bool done = V.r_done[(size_t)(E.move_abs % V.ring_len) * E.B + e] != 0;
+        const bool flush = !R.board && len == R.acc + R.K + R.td;
+        int n = 0;
+        if (flush) { n += R.acc; len -= R.acc; }
+        if (done) n += len;
+        R.off[e] = sum;  // (relative to this thread's run; the run's base is added below)
+        sum += n;
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan of the thread totals
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int base = part[t] - sum;
+    for (int e = e0; e < e1; e++) R.off[e] += base;
+    if (t == 1023) R.ctr[1] = (long long)part[1023];
+}
+
 // Publish: the host (replay.num_added / sample on another stream) may only see a count whose slots are all filled.  Slots are
-// reserved inside k_epilogue (R.ctr[0]); this one-thread kernel, next on the same stream -- i.e. after every workgroup of the
+// reserved by k_epi_scan (R.off, R.ctr[1]); this one-thread kernel, next on the same stream -- i.e. after every workgroup of the
 // epilogue has finished and its writes are visible -- copies the reserved cursor to the committed counter the host reads.
 // (A last-workgroup-done counter inside k_epilogue did the same with 4096 same-address atomics per move: -9 % on the C2
 // env-steps-into-replay rate, measured.)
 __global__ void k_epi_publish(const ReplayRing R) {
-    *reinterpret_cast<volatile long long*>(R.num_added) = *reinterpret_cast<volatile long long*>(R.ctr);
+    const long long c = R.ctr[0] + R.ctr[1];
+    R.ctr[0] = c;
+    *reinterpret_cast<volatile long long*>(R.num_added) = c;
 }
 
 }  // namespace mz

@@ -117,6 +117,7 @@ struct mz_planner {
     int ring_len = 0, ring_pos = 0, ring_count = 0;
     bool has_replay = false;
     ReplayRing replay{};
+    int* d_epi_off = nullptr;        // per-env slot offsets of the move being written (k_epi_scan)
     long long* d_epi_ctr = nullptr;  // reserved write cursor of the attached replay ring (k_epilogue reserves, k_epi_publish commits)
     long long selfplay_moves = 0;  // moves since mz_selfplay_reset
 
@@ -426,6 +427,7 @@ extern "C" int mz_planner_destroy(mz_planner* p) {
     if (p->d_bias_all) (void)hipFree(p->d_bias_all);
     if (p->d_dbg_noise) { (void)hipFree(p->d_dbg_noise); (void)hipFree(p->d_dbg_utie); (void)hipFree(p->d_dbg_ufinal); }
     if (p->d_epi_ctr) (void)hipFree(p->d_epi_ctr);
+    if (p->d_epi_off) (void)hipFree(p->d_epi_off);
     void* cbufs[] = {p->d_pi_scratch, p->d_regions, p->d_pi0, p->d_sim_reward, p->d_sim_value, (void*)p->d_srcptrs, p->d_dstptrs, p->d_rootptrs, p->d_sim_action};
     for (void* b : cbufs)
         if (b) (void)hipFree(b);
@@ -929,6 +931,7 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
         if (p->has_replay) {
             EpiLaunch E{};
             E.env = p->env; E.ring = p->replay; E.B = c.num_envs; E.move_abs = p->selfplay_moves;
+            hipLaunchKernelGGL(k_epi_scan, dim3(1), dim3(1024), 0, p->stream, E);
             hipLaunchKernelGGL(k_epilogue, dim3(c.num_envs), dim3(64), (size_t)p->ring_len * sizeof(double), p->stream, E);
             hipLaunchKernelGGL(k_epi_publish, dim3(1), dim3(1), 0, p->stream, p->replay);
         }
@@ -939,7 +942,7 @@ extern "C" int mz_selfplay_step(mz_planner* p, double temperature, int32_t n_mov
         L.env = p->env; L.B = c.num_envs; L.seed = c.seed; L.temperature = temperature; L.move_counter = p->move_counter;
         L.obs = p->d_obs; L.mask = p->d_mask; L.cur = p->d_cur; L.opp = p->d_opp; L.temp_out = p->d_temp;
         L.action = p->d_action; L.pi = p->d_pi; L.root = p->d_root; L.slot = p->ring_pos; L.sims = c.num_simulations;
-        if (!p->conv && !p->hbm_tree && p->fuse_env) {
+        if (!p->conv && !p->hbm_tree && p->fuse_env && p->env_kind != MZ_ENV_SYNTHETIC) {  // (synthetic frames are redrawn by k_env_synth_obs below)
             // MLP nets: the whole move -- temperature / record, search, env.step, auto-reset -- is ONE kernel launch
             int rc = launch_search(p, c.num_envs, 0, true, false, false, &L);
             if (rc) return rc;
@@ -978,9 +981,8 @@ extern "C" int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ri
         return fail(MZ_E_INVALID, "mz_replay_ring: capacity and every array but `origin` are required");
     if (ring->unroll_steps < 1 || ring->td_steps < 0 || ring->td_steps > 32 || ring->acc_seq_length < 1)
         return fail(MZ_E_INVALID, "mz_replay_ring: unroll_steps >= 1, 0 <= td_steps <= 32, acc_seq_length >= 1");
-    if (c.num_actions > 128) return fail(MZ_E_INVALID, "device epilogue stores int8 actions: num_actions <= 128");
     ReplayRing& R = p->replay;
-    R.capacity = ring->capacity; R.state = ring->state; R.action = reinterpret_cast<signed char*>(ring->action); R.pi_prob = ring->pi_prob;
+    R.capacity = ring->capacity; R.state = ring->state; R.action = reinterpret_cast<signed char*>(ring->action); R.action16 = c.num_actions > 128 ? 1 : 0; R.pi_prob = ring->pi_prob;
     R.value = ring->value; R.reward = ring->reward; R.priority = ring->priority; R.num_added = reinterpret_cast<long long*>(ring->num_added);
     R.origin = ring->origin; R.acc = ring->acc_seq_length; R.K = ring->unroll_steps; R.td = ring->td_steps; R.board = c.is_board_game;
     for (int i = 0; i <= R.td; i++) R.pw[i] = std::pow(c.discount, (double)i);  // Python's discount ** i (pipeline.py:663-666)
@@ -990,6 +992,8 @@ extern "C" int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ri
     HIPCHK(hipMemcpyAsync(p->d_epi_ctr, R.num_added, sizeof(long long), hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     R.ctr = p->d_epi_ctr;
+    if (!p->d_epi_off) HIPCHK(hipMalloc(&p->d_epi_off, (size_t)c.num_envs * sizeof(int)));
+    R.off = p->d_epi_off;
     p->has_replay = true;
     p->env_kind = MZ_ENV_NONE;  // the record ring must be re-sized: mz_selfplay_reset next
     return MZ_OK;

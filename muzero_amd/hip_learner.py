@@ -69,6 +69,42 @@ def _check(rc):
         raise LearnerError(f'libmzlearner_hip: {load_library().mzl_last_error().decode()} (status {rc})')
 
 
+class _OptimizerView:
+    """What `run_training` (pipeline.py:170-286) holds as `optimizer`: the checkpoint's 'optimizer' entry in torch.optim.Adam's format."""
+
+    def __init__(self, hl):
+        self.hip_learner = hl
+
+    def state_dict(self):
+        return self.hip_learner.optimizer_state_dict()
+
+    def load_state_dict(self, sd):
+        self.hip_learner.load_optimizer_state_dict(sd)
+
+    @property
+    def param_groups(self):
+        return self.hip_learner.optimizer_state_dict()['param_groups']
+
+
+class _SchedulerView:
+    """... and as `lr_scheduler` (MultiStepLR): state for the checkpoint, `get_last_lr` for the metrics."""
+
+    def __init__(self, hl):
+        self.hip_learner = hl
+
+    def state_dict(self):
+        return self.hip_learner.lr_scheduler_state_dict()
+
+    def load_state_dict(self, sd):
+        self.hip_learner.steps = int(sd.get('last_epoch', self.hip_learner.steps))
+
+    def get_last_lr(self):
+        return [self.hip_learner.current_lr()]
+
+    def step(self):  # (the schedule advances inside HipLearner.apply)
+        pass
+
+
 class HipLearner:
     """The learner step of `run_training` (pipeline.py:238-255) for a `MuZeroMLPNet` on the GPU, as HIP kernels.
 
@@ -119,6 +155,7 @@ class HipLearner:
         self._ones = torch.ones(max_batch, dtype=torch.float32, device=self.device)
         self._iota = torch.arange(max_batch, dtype=torch.int64, device=self.device)
         self.network = network
+        self.optimizer, self.lr_scheduler = _OptimizerView(self), _SchedulerView(self)
         self.adopt(network)
 
     # ---- weights ----
@@ -224,6 +261,7 @@ class HipLearner:
         self.steps += 1
         _check(load_library().mzl_apply(self._h, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm if clip else 0.0,
                                         self.steps, self._stream()))
+        self.network._mz_weights_epoch = getattr(self.network, '_mz_weights_epoch', 0) + 1  # (torch's version counters do not see the kernels' writes)
 
     def step(self, ring, index, weights, batch: int, allreduce: bool = True):
         """One update.  With an initialised multi-rank process group the flat gradient is averaged over the ranks in ONE all-reduce

@@ -269,6 +269,16 @@ def make_capturable_adam(network, config, device):
                             capturable=True)
 
 
+def make_hip_learner(config, network, device, max_batch: Optional[int] = None):
+    """The learner step on hand-written gfx950 kernels (muzero_amd.hip_learner.HipLearner, MLP nets) with the optimizer the
+    reference's launchers build (classic/run_training.py:94-95: Adam(lr_init, weight_decay) + MultiStepLR(lr_milestones, lr_decay_rate)).
+    Hand `hl.optimizer` / `hl.lr_scheduler` to `run_training` in place of the torch objects."""
+    from muzero_amd.hip_learner import HipLearner
+
+    return HipLearner(network, device, config.unroll_steps, max_batch or config.batch_size, lr=config.lr_init, weight_decay=config.weight_decay,
+                      milestones=config.lr_milestones, gamma=config.lr_decay_rate, clip_grad=bool(config.clip_grad), max_grad_norm=config.max_grad_norm)
+
+
 def _all_ranks(flag_any: bool, device) -> bool:
     """True if `flag_any` is set on ANY learner rank (a tiny MAX all-reduce); the local value without a process group."""
     import torch.distributed as dist
@@ -311,6 +321,7 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
 
     metrics = mzm.LearnerMetrics(mzm.run_file(config, 'learner', tag) if rank == 0 else None)
     graphed = None
+    hip = getattr(optimizer, 'hip_learner', None)  # make_hip_learner(...).optimizer: the update runs on the HIP kernels
 
     def snapshot():
         return {'network': network.state_dict(), 'optimizer': optimizer.state_dict(), 'lr_scheduler': lr_scheduler.state_dict(),
@@ -335,23 +346,41 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
             continue
         if _all_ranks(train_steps_counter.value >= config.num_training_steps, device):
             break
-        transitions, indices, weights = replay.sample_tensors(config.batch_size)
-        if graphed is None and not multi and torch.device(device).type == 'cuda' and all(g.get('capturable', False) for g in optimizer.param_groups):
+        if hip is not None:
+            # the kernels gather the batch from the HBM ring by index; gradients of several learner ranks meet in one all-reduce inside step()
+            indices, is_w, ring = replay.sample_indices(config.batch_size)
+            idx_t = torch.from_numpy(indices).to(device)
+            w_t = None if replay._alpha == 0 else torch.from_numpy(np.asarray(is_w, np.float32)).to(device)
+            loss_t, prio_t = hip.step(ring, idx_t, w_t, config.batch_size)
+            if replay._alpha != 0:
+                replay.update_priorities(indices, prio_t.cpu().numpy())
+            train_steps_counter.value += 1
+            if train_steps_counter.value % 100 == 0 or train_steps_counter.value % config.checkpoint_interval == 0:
+                metrics.step(float(loss_t), lr_scheduler.get_last_lr()[0], train_steps_counter.value)  # (the only host read-backs of the loop)
+            transitions = weights = None
+        else:
+            transitions, indices, weights = replay.sample_tensors(config.batch_size)
+        if hip is not None:
+            pass
+        elif graphed is None and not multi and torch.device(device).type == 'cuda' and all(g.get('capturable', False) for g in optimizer.param_groups):
             # an optimizer built by make_capturable_adam on one learner rank: the update runs as one HIP graph (GraphedTrainStep)
             graphed = GraphedTrainStep(config, network, optimizer, device, config.batch_size, tuple(transitions.state.shape[1:]),
                                        int(transitions.action.shape[1]), int(transitions.pi_prob.shape[2]))
-        if graphed is not None:
+        if hip is not None:
+            pass
+        elif graphed is not None:
             loss_t, prio_t = graphed(transitions, weights)
             lr_scheduler.step()
             loss, priorities = float(loss_t), prio_t.cpu().numpy()
         else:
             loss, priorities = train_step(config, network, optimizer, lr_scheduler, device, transitions, weights)
-        if priorities is not None:
-            if priorities.shape != (config.batch_size,):
-                raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {priorities.shape}')
-            replay.update_priorities(indices, priorities)
-        train_steps_counter.value += 1
-        metrics.step(loss, lr_scheduler.get_last_lr()[0], train_steps_counter.value)
+        if hip is None:
+            if priorities is not None:
+                if priorities.shape != (config.batch_size,):
+                    raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {priorities.shape}')
+                replay.update_priorities(indices, priorities)
+            train_steps_counter.value += 1
+            metrics.step(loss, lr_scheduler.get_last_lr()[0], train_steps_counter.value)
         del transitions, indices, weights
         if train_steps_counter.value > 1 and train_steps_counter.value % config.checkpoint_interval == 0:
             path = save(f'{ckpt_prefix}_{train_steps_counter.value}')

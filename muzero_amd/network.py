@@ -247,7 +247,8 @@ class MuZeroNet(nn.Module):
         raise NotImplementedError
 
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        # (+ an epoch that writers outside torch bump: hip_learner.HipLearner updates the parameters' storage from its own kernels)
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()) + (getattr(self, '_mz_weights_epoch', 0),)
 
     def inference_engine(self, device=None):
         """The HIP inference engine bound to this module's current parameters (rebuilt when they change)."""

@@ -211,7 +211,7 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
     from muzero_amd.replay import PrioritizedReplay
 
     on_device = isinstance(data_queue, PrioritizedReplay)
-    if on_device:
+    if on_device:  # ONE device writer per replay (attach_device_writer raises on a second one): every actor rank its own shard
         p.attach_replay(data_queue, config, obs_shape=getattr(network, 'input_shape', None))
     p.selfplay_reset(kinds[name])
     asm = EpisodeAssembler(config, num_envs, getattr(network, 'input_shape', None))
@@ -240,6 +240,7 @@ def run_self_play(config, rank, network, device, env, data_queue, train_steps_co
                 data_queue.put(item)
         played += n
     tracker.close()
+    p.close()  # (detaches the device epilogue: the replay's write cursor and priorities go back to its host side)
     return played * num_envs
 
 

@@ -140,6 +140,11 @@ class Planner:
 
     def close(self):
         if getattr(self, 'h', None):
+            if getattr(self, '_replay_keepalive', None) is not None:
+                try:
+                    self.detach_replay()  # hand write cursor and priorities back: the replay outlives this planner
+                except Exception:
+                    pass
             self.lib.mz_planner_destroy(self.h)
             self.h = None
 
@@ -269,11 +274,12 @@ class Planner:
 
         K, A = int(config.unroll_steps), self.A
         shp = tuple(obs_shape) if obs_shape is not None else (self.obs_dim,)
+        adt = torch.int8 if A <= 128 else torch.int16  # (int16 where the reference's int8 field overflows: pipeline.py:753, Gomoku 15x15)
         if replay._ring is None:
-            replay.allocate(dict(state=shp, action=(K,), pi_prob=(K, A), value=(K,), reward=(K,)))
+            replay.allocate(dict(state=shp, action=(K,), pi_prob=(K, A), value=(K,), reward=(K,)), dict(action=adt))
         ring = replay._ring
-        if ring['state'].device.type != 'cuda' or ring['state'].dtype != torch.float32 or ring['action'].dtype != torch.int8:
-            raise PlannerError('attach_replay needs a replay on the GPU with float32 states and int8 actions')
+        if ring['state'].device.type != 'cuda' or ring['state'].dtype != torch.float32 or ring['action'].dtype != adt:
+            raise PlannerError(f'attach_replay needs a replay on the GPU with float32 states and {adt} actions ({A} actions)')
         if int(np.prod(ring['state'].shape[1:])) != self.obs_dim or tuple(ring['pi_prob'].shape[1:]) != (K, A):
             raise PlannerError('replay item shapes do not match the planner (observation size, unroll_steps, num_actions)')
         prio, count = replay.attach_device_writer()

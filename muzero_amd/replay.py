@@ -156,10 +156,14 @@ class PrioritizedReplay:
         nothing the GPU wrote in the meantime can be lost."""
         if self._ring is None:
             raise RuntimeError('allocate() the ring before attaching a device writer')
-        if self._attached is None:
-            prio = torch.from_numpy(self._prio.copy()).to(self._dev)
-            count = torch.tensor([self._count], dtype=torch.int64, device=self._dev)
-            self._attached = (prio, count)
+        if self._attached is not None:
+            # SINGLE WRITER: each planner reserves slots from its own cursor (seeded from this counter) and publishes the counter by
+            # overwriting it -- two planners on one ring would reserve the same slots and move the counter backwards
+            raise RuntimeError('PrioritizedReplay: a device writer is already attached; one planner epilogue per replay '
+                               '(give every actor GPU / planner its own replay shard, or detach the first writer)')
+        prio = torch.from_numpy(self._prio.copy()).to(self._dev)
+        count = torch.tensor([self._count], dtype=torch.int64, device=self._dev)
+        self._attached = (prio, count)
         return self._attached
 
     def detach_device_writer(self) -> None:
@@ -206,6 +210,17 @@ class PrioritizedReplay:
             batch[0] = batch[0].to(torch.float32)
         return Transition(*batch), picks, is_w
 
+    def sample_indices(self, batch_size: int):
+        """The draw of `sample` without the gather: (indices int64 [B], importance weights float32 [B], the ring's storages).  For a
+        learner that reads its batch out of the ring itself (hip_learner.HipLearner: the kernels gather by index)."""
+        with self._lock:
+            if self._attached is not None:
+                self._count = int(self._attached[1].item())
+                if self._alpha != 0:
+                    self._prio = self._attached[0].cpu().numpy()
+            picks, is_w = self._draw(batch_size)
+        return picks, is_w, self._ring
+
     def sample(self, batch_size: int) -> Tuple[Transition, np.ndarray, np.ndarray]:
         """A batch with replacement (replay.py:81-104): numpy arrays stacked on axis 0, the indices, the IS weights."""
         batch, picks, is_w = self.sample_tensors(batch_size)
@@ -219,6 +234,9 @@ class PrioritizedReplay:
         with self._lock:
             if self._attached is not None:
                 # the device owns the array: scatter only the touched entries (last value per repeated index), on the device
+                ia = np.asarray(indices, np.int64)
+                if ia.size and (ia.min() < 0 or ia.max() >= self._cap):
+                    raise IndexError(f'priority index outside [0, {self._cap})')
                 last = {int(i): float(v) for i, v in zip(indices, pr)}
                 if last:
                     idx = torch.tensor(list(last.keys()), dtype=torch.int64, device=self._dev)
@@ -249,6 +267,7 @@ class PrioritizedReplay:
         return {'num_added': self._count, 'storage': ring, 'priorities': self._prio}
 
     def set_state(self, state: Mapping[Text, Any]) -> None:
+        self._host_writer_only('set_state')  # (while attached the next read of the device counter would overwrite the restored state)
         self._count = state['num_added']
         self._ring = None if state['storage'] is None else {k: v.to(self._dev) for k, v in state['storage'].items()}
         self._prio = state['priorities']

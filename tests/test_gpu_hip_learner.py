@@ -152,3 +152,87 @@ def test_errors_are_reported_not_swallowed():
 
     with pytest.raises(LearnerError, match='MuZeroMLPNet'):
         _hip(build_conv(conv_case('board3')).to(dev), dev, 8)
+
+
+def _closed_loop(seed, iters=6, envs=64):
+    """device self-play -> device epilogue -> HBM replay -> HipLearner updates (batch gathered by index) -> planner reload, in event
+    order (the planner's stream is drained before a batch is drawn)."""
+    from muzero_amd import learner as L
+    from muzero_amd import planner as pl
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.network import MuZeroMLPNet
+    from muzero_amd.replay import PrioritizedReplay
+
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(seed)
+    cfg = make_classic_config(batch_size=64, min_replay_size=64, use_tensorboard=False)
+    cfg.num_simulations = 10
+    net = MuZeroMLPNet((4, 5), 2, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+    hl = L.make_hip_learner(cfg, net, dev)
+    replay = PrioritizedReplay(20000, 0.0, 0.0, np.random.RandomState(seed), device='cuda')
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=envs, seed=seed), 0)
+    p.load_state_dict(net.state_dict())
+    p.attach_replay(replay, cfg, obs_shape=(4, 5))
+    p.selfplay_reset(pl.ENV_CARTPOLE)
+    losses = []
+    for _ in range(iters):
+        p.selfplay_step(1.0, 24)
+        p.synchronize()
+        if replay.size < cfg.min_replay_size:
+            continue
+        for _ in range(4):
+            idx, _, ring = replay.sample_indices(cfg.batch_size)
+            loss, _ = hl.step(ring, torch.from_numpy(idx).to(dev), None, cfg.batch_size)
+            losses.append(loss.clone())
+        p.load_state_dict(net.state_dict())
+    out = ([float(x) for x in losses], {k: v.cpu().numpy().copy() for k, v in net.state_dict().items()}, replay.size)
+    p.close()
+    hl.close()
+    return out
+
+
+def test_closed_loop_is_reproducible_from_its_seed():
+    """the same seed must give the same run.  Philox self-play keyed by (seed, env, move), a replay draw after the
+    committed count is final, and a learner without atomics: losses and final weights are bit-identical; another seed differs."""
+    a, b, c = _closed_loop(5), _closed_loop(5), _closed_loop(6)
+    assert len(a[0]) >= 8 and np.isfinite(a[0]).all()
+    assert a[0] == b[0] and a[2] == b[2]
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    assert a[0] != c[0]
+
+
+def test_run_training_drives_the_hip_learner(tmp_path):
+    """learner.run_training (pipeline.py:170-286) with make_hip_learner's optimizer / scheduler views: checkpoints in the reference's
+    dict layout (optimizer state in torch.optim.Adam's format), actor refresh, stop protocol."""
+    import queue
+    import threading
+    import types
+
+    from muzero_amd.config import make_tictactoe_config
+    from muzero_amd.pipeline import load_checkpoint
+    from muzero_amd.replay import PrioritizedReplay
+
+    dev = torch.device('cuda', 0)
+    net, actor = build_mlp(mlp_case('tictactoe')).to(dev), build_mlp(mlp_case('tictactoe'))
+    cfg = make_tictactoe_config(num_training_steps=6, batch_size=32, min_replay_size=48, use_tensorboard=False)
+    cfg.checkpoint_interval = 3
+    hl = learner.make_hip_learner(cfg, net, dev)
+    rs = np.random.RandomState(0)
+    rp = PrioritizedReplay(256, 0.0, 0.0, np.random.RandomState(1), device='cuda')
+    items = _random_batch(rs, 64, (9, 3, 3), 10, vmax=1.0)
+    rp.add_batch(items._replace(state=items.state.reshape(64, 9, 3, 3)), np.ones(64))
+    counter, stop, files = types.SimpleNamespace(value=0), threading.Event(), []
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    learner.run_training(cfg, net, hl.optimizer, hl.lr_scheduler, dev, actor, rp, queue.SimpleQueue(), counter, str(tmp_path), files, stop, stop_grace_seconds=0.0)
+    assert stop.is_set() and counter.value == 6 and len(files) == 2 and hl.steps == 6
+    assert any(not torch.equal(before[k], v) for k, v in net.state_dict().items())
+    for k, v in actor.state_dict().items():
+        assert torch.equal(v.cpu(), net.state_dict()[k].cpu())
+    ck = load_checkpoint(str(tmp_path / 'train_steps_6_final'), torch.device('cpu'))
+    assert set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'} and ck['train_steps'] == 6
+    # the optimizer entry loads into a torch Adam built over the same parameters (the reference's resume path, pipeline.py:810-817)
+    ref = build_mlp(mlp_case('tictactoe'))
+    opt = torch.optim.Adam(ref.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    opt.load_state_dict(ck['optimizer'])
+    assert float(opt.state[next(iter(ref.parameters()))]['step']) == 6.0
