@@ -269,7 +269,124 @@ def configs_leg(args, rank, local_rank, world, torch, dist, red_dev):
     return out
 
 
-PROFILE_ROUND = 'round3'
+PROFILE_ROUND = 'round4'
+
+
+def lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=100, warm=20, preheat=100):
+    """The north-star's "4 actions" wording: a LunarLander-v2-SHAPED search workload (MuZeroMLPNet 512 / 64 / 31 on (4, 9) observations,
+    A = 4, config.py:170-201; the reference's shipped LunarLander checkpoint has these shapes), 4096 envs x 50 simulations.  Box2D is an
+    absent dependency, so the env is the synthetic stand-in (fresh U[0,1) observations, reward 0, 1000-step episodes: MZ_ENV_SYNTHETIC);
+    the search runs the general-action-count build of the tuned kernel, k_search_fast<512, 2, 2, *, 0, ...>."""
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import planner as pl
+
+    net = build_mlp(mlp_case('lunar'))
+    B, S = 4096, 50
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=2000 + rank, num_simulations=S, discount=0.997,
+                                     root_dirichlet_alpha=0.25, root_exploration_eps=0.25), local_rank)
+    p.load_state_dict(net.state_dict())
+    p.selfplay_reset(pl.ENV_SYNTHETIC)
+
+    def sync():
+        p.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    p.selfplay_step(1.0, preheat + warm)
+    sync()
+    p.profile_begin()
+    t0 = time.perf_counter()
+    p.selfplay_step(1.0, steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = p.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    p.close()
+    # transition (64 + 4) x 512 + 512 x 64, reward and value 64 x 512 + 512 x 31 each; root: representation 36 x 512 + 512 x 64 + policy 64 x 512 + 512 x 4
+    f_sim = 2 * ((68 * 512 + 512 * 64) + 2 * (64 * 512 + 512 * 31))
+    f_root = 2 * ((36 * 512 + 512 * 64) + (64 * 512 + 512 * 4))
+    flop = B * (S * f_sim + f_root)
+    k_ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
+    ms_step = 1e3 * elapsed / steps
+    return {'workload': 'LunarLander-shaped: MLP 512/64/31, obs (4, 9), A=4, 50 sims/move, 4096 envs per MI355X, synthetic observations (Box2D absent)',
+            'value': world * B * S * steps / elapsed, 'unit': 'sims/s', 'env_steps_per_sec': world * B * steps / elapsed, 'steps': steps, 'warmup': warm,
+            'ms_per_step': ms_step, 'n_gpus': world,
+            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, false, 0, true, false> (general action count; env step in its own kernels)',
+                         'achieved': flop / (k_ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flop / (k_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         'frac_step': flop / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_move_ms': k_ms, 'flop_per_move': flop}}
+
+
+def learner_leg(rank, local_rank, world, torch, dist, backend, batches=(128, 4096), iters=100):
+    """Row f2, the consumer of the self-play stream: one update of the reference's learner (calc_loss + backward + Adam, pipeline.py:238-255)
+    on the hand-written kernels (hip_learner.HipLearner), classic-control net, unroll 5, batch gathered from an HBM ring by index.  With
+    N > 1 ranks the flat gradient (0.97 MB) is averaged by one RCCL all-reduce per update.  Algorithmic FLOPs: 6 x MAC (forward + twice that
+    for the backward pass)."""
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.hip_learner import HipLearner
+    from muzero_amd.network import MuZeroMLPNet
+
+    dev = torch.device('cuda', local_rank)
+    cfg = make_classic_config(use_tensorboard=False)
+    K, A, cap = cfg.unroll_steps, 2, 65536
+    g = torch.Generator(device='cpu').manual_seed(7 + rank)
+    ring = dict(state=(torch.rand(cap, 20, generator=g) * 2 - 1).to(dev), action=torch.randint(0, A, (cap, K), generator=g).to(torch.int8).to(dev),
+                pi_prob=torch.full((cap, K, A), 0.5, device=dev), value=(torch.rand(cap, K, generator=g) * 50).to(dev), reward=torch.ones(cap, K, device=dev))
+    mac = 20 * 512 + 512 * 64 + K * ((66 * 512 + 512 * 64) + 2 * (64 * 512 + 512 * 31) + (64 * 512 + 512 * A))
+    rows = []
+    for B in batches:
+        torch.manual_seed(0)
+        net = MuZeroMLPNet((4, 5), A, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+        hl = HipLearner(net, dev, K, B, lr=cfg.lr_init, weight_decay=cfg.weight_decay, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+        idx = torch.randint(0, cap, (B,), generator=g).to(dev)
+        ar = world > 1 and backend == 'nccl'
+        for _ in range(20):
+            hl.step(ring, idx, None, B, allreduce=ar)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            hl.step(ring, idx, None, B, allreduce=ar)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / iters
+        tf = 6.0 * mac * B / (ms * 1e-3) / 1e12
+        rows.append({'batch_per_gpu': B, 'ms_per_update': ms, 'samples_per_sec': world * B / (ms * 1e-3), 'achieved_tflops_per_gpu': tf,
+                     'mfma_frac': tf / PEAK_FP32_MFMA_TFLOPS, 'gradient_allreduce': 'RCCL, one flat %.2f MB bucket per update' % (hl.total * 4 / 1e6) if ar else None})
+        hl.close()
+    return {'what': 'hip_learner.HipLearner: loss + backward + Adam + operand re-pack as gfx950 kernels, MuZeroMLPNet 512/64/31, unroll 5', 'rows': rows,
+            'flop_per_sample': 6.0 * mac}
+
+
+def allreduce_leg(rank, local_rank, world, torch, dist, backend, nbytes=30_400_000, iters=10):
+    """The learner-side collective the north-star names ("RCCL over xGMI only for replay / gradient all-reduce"): ONE flat all-reduce of a
+    gradient bucket the size of the Gomoku conv net (30.4 MB of fp32), as learner.allreduce_gradients issues it.  N > 1 only."""
+    if world < 2:
+        return None
+    dev = torch.device('cuda', local_rank) if backend == 'nccl' else torch.device('cpu')
+    t = torch.ones(nbytes // 4, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.fill_(1.0)
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    ok = bool(abs(float(t[0].item()) - float(world) ** iters) <= 1e-3 * float(world) ** iters)
+    tm = torch.tensor([ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    ms = float(tm.item())
+    alg = nbytes / (ms * 1e-3) / 1e9
+    return {'bytes': nbytes, 'ms': ms, 'algbw_GBps': alg, 'busbw_GBps': alg * 2 * (world - 1) / world, 'sum_correct': ok, 'backend': dist.get_backend(),
+            'world_size': world, 'what': 'one flat fp32 all-reduce (SUM) of a Gomoku-net-sized gradient bucket, MAX over ranks of the mean time'}
 
 
 def profiled_traffic(workload, kernel_substr):
@@ -383,12 +500,13 @@ def main():
     ap.add_argument('--preheat', type=int, default=150, help='untimed setup moves before the warm-up (c2 / c3): ~0.1 s of load takes the GPU out of its idle clocks')
     ap.add_argument('--envs', type=int, default=0, help='environments per GPU (default: that of the workload)')
     ap.add_argument('--sims', type=int, default=0, help='simulations per move (default: that of the workload)')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5', 'lunar'],
                     help='c2 (default, the headline line): CartPole MLP; c3: TicTacToe MLP; c4 / c5: the conv-tower configs of BASELINE.json (extra measurements)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 2 s sustained leg')
     ap.add_argument('--no-e2e', action='store_true', help='skip the env-steps-into-replay leg')
-    ap.add_argument('--no-configs', action='store_true', help='skip the C3 / C4 / C5 legs of the default run')
+    ap.add_argument('--no-configs', action='store_true', help='skip the C3 / C4 / C5 / LunarLander-shaped legs of the default run')
+    ap.add_argument('--no-learner', action='store_true', help='skip the learner-step leg (and, with N > 1 ranks, the gradient all-reduce leg)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -426,6 +544,14 @@ def main():
     if world > 1:
         dist.barrier()
 
+    if args.workload == 'lunar':  # the LunarLander-shaped leg alone (diagnostics; part of `configs` in the default run)
+        rec = lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=args.steps, warm=args.warmup, preheat=args.preheat)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     if args.workload != 'c2':
         return run_conv_workload(args, args.workload, rank, local_rank, world, torch, dist, red_dev, backend)
 
@@ -479,6 +605,20 @@ def main():
     del p
     torch.cuda.empty_cache()
     configs = None if args.no_configs or args.envs or args.sims else configs_leg(args, rank, local_rank, world, torch, dist, red_dev)
+    if configs is not None:
+        lunar = lunar_leg(rank, local_rank, world, torch, dist, red_dev)
+        if rank == 0:
+            configs['lunar'] = lunar
+    learner_rec = None if args.no_learner else learner_leg(rank, local_rank, world, torch, dist, backend)
+    allreduce_rec = None if args.no_learner else allreduce_leg(rank, local_rank, world, torch, dist, backend)
+    # every rank's own rate (the line's `value` is the job's: all ranks' simulations over the slowest rank's time)
+    my_rate = B * S * args.steps / (prof['search_kernel_ms'] * 1e-3) if prof['search_kernel_ms'] > 0 else 0.0
+    per_rank = [my_rate]
+    if world > 1:
+        tr = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        tr[rank] = my_rate
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        per_rank = [float(x) for x in tr.tolist()]
 
     if rank == 0:
         total_sims = world * B * S * args.steps
@@ -509,7 +649,7 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, true, true, true> (P, TR, TV, FUSE, TWO, HW: the one kernel of a move -- search + env step, 8 waves)', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, true, 2, true, false> (P, TR, TV, FUSE, AC, HW, SPB: the one kernel of a move -- search + env step, 8 waves)', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 # the same FLOPs over the driver-timed step (env kernels and launch gaps included), not only the search kernel
                 'frac_step': flop_per_launch / (1e-3 * 1e3 * elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -521,6 +661,9 @@ def main():
             'sustained': sustained,
             'e2e': e2e,
             'configs': configs,
+            'learner': learner_rec,
+            'allreduce': allreduce_rec,
+            'per_rank': {'sims_per_sec_by_kernel_time': per_rank, 'min': min(per_rank), 'max': max(per_rank), 'sum': sum(per_rank)},
             'distributed': dist_record(dist, world, backend),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -201,7 +201,7 @@ FULL = {
 
 
 @pytest.mark.parametrize('name', ['c4', 'c5'])
-def test_full_size_conv_search_properties(name):
+def test_full_size_conv_search_properties(oracle, name):
     """At BASELINE.json's full sizes the oracle is too slow to shadow every env; size-independent properties instead:
     visit counts sum to the simulation count (minus visits on illegal root children), the policy is visits / sum (T = 1),
     only legal actions are played, root values are finite, and the search is a pure function of (inputs, injected draws):
@@ -232,6 +232,24 @@ def test_full_size_conv_search_properties(name):
     np.testing.assert_array_equal(r1['pi'], v / v.sum(1, keepdims=True))
     assert mask[np.arange(B), r1['action']].all() and np.isfinite(r1['root_value']).all()
     assert len({tuple(x) for x in v[:B // 2]}) > 1  # different roots search differently
+    # ... and two envs taken from INSIDE the full-size batch against the oracle, bit for bit (VERDICT r3 missing #5: until now the oracle
+    # only saw 5-env batches of these nets).  C4: all 50 simulations; C5: the scalar oracle needs ~1 s per Gomoku simulation, so the
+    # full batch is searched once more with 64 simulations (200 with MZ_SLOW_TESTS=1) and that run is compared.
+    S_o = S if (name == 'c4' or os.environ.get('MZ_SLOW_TESTS') == '1') else 64
+    if S_o != S:
+        p.close()
+        p = _planner(net, B, num_simulations=S_o, root_exploration_eps=0.25, **kw)
+        r1 = p.search(*args, noise=noise, u_tie=u_tie[:, :4 * S_o + 8], u_final=u_final)
+    sel = [1, B // 2 - 1]
+    onet = _oracle_net(oracle, net, 'conv')
+    ocfg = oracle.make_config(A, S_o, kw['discount'], board, kw.get('known_bounds'), kw['root_dirichlet_alpha'], 0.25)
+    o = oracle.uct_search_batch(ocfg, onet, obs[sel], mask[sel].astype(np.uint8), 1, 2 if board else 1, 1.0, False, noise=noise[sel],
+                                u_tie=np.ascontiguousarray(u_tie[sel][:, :4 * S_o + 8]), u_final=u_final[sel], num_threads=2)
+    for i, b in enumerate(sel):
+        np.testing.assert_array_equal(r1['visits'][b], o['visits'][i])
+        np.testing.assert_array_equal(r1['pi'][b], o['pi'][i])
+        assert r1['action'][b] == o['action'][i] and r1['root_value'][b] == o['root_value'][i]
+    p.close()
 
 
 _SPOT = [('c4', 50, (1, 4)), ('c5', 64, (3,))]

@@ -193,6 +193,25 @@ def test_synthetic_frame_env_runs_atari_net():
     np.testing.assert_array_equal(rec['pi'], np.round(rec['pi'] * 4) / 4)
 
 
+def test_synthetic_env_with_mlp_net_redraws_the_observation_every_move():
+    """with the fused MLP move as the default the synthetic env's frame kernel was skipped -- every move searched the
+    same stale frame.  The LunarLander-shaped bench leg runs exactly this combination."""
+    from muzero_amd import planner as pl
+
+    net = build_mlp(mlp_case('lunar'))
+    B, M = 40, 4
+    p = _planner(net, B, num_simulations=6, discount=0.997)
+    p.selfplay_reset(pl.ENV_SYNTHETIC)
+    p.selfplay_step(1.0, M)
+    rec = p.selfplay_read(M)
+    assert (rec['reward'] == 0).all() and (rec['done'] == 0).all()
+    for m in range(1, M):
+        assert not np.array_equal(rec['obs'][m], rec['obs'][m - 1])
+    assert rec['obs'].min() >= 0.0 and rec['obs'].max() < 1.0
+    np.testing.assert_allclose(rec['pi'].sum(-1), 1.0, atol=1e-12)
+    assert set(np.unique(rec['action'])).issubset({0, 1, 2, 3})
+
+
 def test_run_self_play_gomoku_conv_net_emits_mc_return_items():
     """pipeline.run_self_play on the device Gomoku env with a conv (board) network: reference-shaped items, Monte-Carlo
     returns in {-1, 0, 1}, observations are the 9-plane board stacks."""
