@@ -57,6 +57,19 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
+def learner_fingerprint():
+    """The same for libmzlearner_hip.so (profiles/<round>/learner/)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in _learner_deps()[:-1]:
+        h.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True

@@ -13,6 +13,7 @@ from collections import defaultdict
 
 def main():
     d, targs, pargs = sys.argv[1], sys.argv[2], sys.argv[3]
+    prog = sys.argv[4] if len(sys.argv) > 4 else 'bench.py'
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, repo)
     from muzero_amd import build as mz_build
@@ -24,9 +25,9 @@ def main():
         head = subprocess.check_output(['git', '-C', repo, 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()[:12]
     except Exception:  # the GPU box gets a snapshot without .git: tools/stamp_profiles.py adds the commit when the summary is copied into profiles/
         pass
-    out = {'_source_fingerprint': mz_build.source_fingerprint(), '_git_head': head,
-           '_trace_command': f'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {targs}',
-           '_pmc_command': f'rocprofv3 --kernel-trace --output-format csv --pmc <group> -- python3 bench.py {pargs}  (one run per counter group)'}
+    out = {'_source_fingerprint': mz_build.source_fingerprint(), '_learner_fingerprint': mz_build.learner_fingerprint(), '_git_head': head,
+           '_trace_command': f'rocprofv3 --kernel-trace --stats --output-format csv -- python3 {prog} {targs}',
+           '_pmc_command': f'rocprofv3 --kernel-trace --output-format csv --pmc <group> -- python3 {prog} {pargs}  (one run per counter group)'}
     stats = glob.glob(os.path.join(d, 'trace', '**', '*_kernel_stats.csv'), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
@@ -39,7 +40,7 @@ def main():
             per[name][r['Counter_Name']].append(float(r['Counter_Value']))
     pm = {}
     for k, cs in per.items():
-        if not k.startswith(('void mz::', 'mz::')):
+        if not k.startswith(('void mz::', 'mz::', 'void mzl::', 'mzl::')):
             continue
         e = {c: dict(launches=len(v), mean_per_launch=sum(v) / len(v)) for c, v in cs.items()}
         if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:

@@ -26,7 +26,10 @@ def main():
     for w in workloads:
         src = os.path.join(REPO, 'gpurun_out', 'profiles', w)
         doc = json.load(open(os.path.join(src, 'summary.json')))
-        if doc.get('_source_fingerprint') != fp:
+        if w == 'learner':
+            if doc.get('_learner_fingerprint') != mz_build.learner_fingerprint():
+                sys.exit(f'learner: measured on other learner sources: re-run tools/profile_all.sh learner')
+        elif doc.get('_source_fingerprint') != fp:
             sys.exit(f'{w}: measured on kernel sources {doc.get("_source_fingerprint")}, the working tree is {fp}: re-run tools/profile_all.sh')
         doc['_git_head'] = head + (' + uncommitted kernel changes' if dirty else '')
         dst = os.path.join(REPO, 'profiles', rnd, w)
