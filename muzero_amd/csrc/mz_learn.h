@@ -135,17 +135,32 @@ __device__ __forceinline__ void wide_load(WideW& W, const float* __restrict__ wp
         for (int d = 0; d < KGM; d++) W.w[d][j] = ldg4(W4 + ((size_t)tc * kg + (d < kg ? d : kg - 1)) * 64);
     }
 }
-template <bool F, typename Epi>
+// MEASURED AND NOT KEPT (round 4): the next GEMM's operand loads issued BETWEEN this GEMM's MFMAs (one or two per group of four,
+// pinned with sched_barrier) instead of as a burst in front of them.  The burst holds a wave at the vector-memory issue for ~2 k
+// cycles (8 waves x 16 KiB through the CU's 64 B / clk L1 path), but spreading the loads is WORSE (first layer 8.5 k -> 10.8 k cycles,
+// the second layer's transpose 3.5 k -> 6.5 k): a wave issues in order, so a load waiting for the L1 path holds the MFMAs behind it.
+// The stage kernels are bound by weight bytes per MFMA (16 samples per weight load), not by where the requests sit.
+struct NoPf {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+constexpr int KSB = 16;  // reduction blocks per wave the register-resident form holds (512 planes, 4 output tiles: 16)
+struct KsW {
+    float4 w[KSB];
+    float bv;  // bias of the tile this wave finishes (waves 0 .. nt-1), requested with the weights
+    bool fast;
+};
+template <bool F, int KGM, typename Epi, typename Pf>
 __device__ __forceinline__ void wide_mma(const WideW& W, const float* __restrict__ wp, const float* __restrict__ bias, int nt, int kg, const float* Xs,
-                                         int wave, int lane, Epi epi) {
+                                         int wave, int lane, Epi epi, Pf) {
     const float4* X4 = reinterpret_cast<const float4*>(Xs) + lane;
     if (F || W.fast) {
         f32x4 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = f32x4{W.bv[j], W.bv[j], W.bv[j], W.bv[j]};
 #pragma unroll
-        for (int d = 0; d < WKG; d++)
-            if (d < kg) {
+        for (int d = 0; d < KGM; d++)
+            if (d < kg) {  // (ONE guarded block per reduction block: with a guard per accumulator the four MFMA chains end up in four
+                           // basic blocks and cannot be interleaved -- first layer 8.3 k -> 10.6 k cycles, measured)
                 const float4 x = X4[d * 64];
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[j] = mfma4(x, W.w[d][j], acc[j]);
@@ -197,12 +212,6 @@ __device__ __forceinline__ void wide_mma(const WideW& W, const float* __restrict
 // Few output tiles, long reduction (second layers, and the backward pass through a first layer): the reduction blocks of a tile
 // are split over LW / nt waves, the partial tiles meet in `red` (LW x 64 float4) and are added in part order.  Every thread of the
 // workgroup calls ks_mma (one barrier inside; the epilogue runs after it on waves 0 .. nt-1).
-constexpr int KSB = 16;  // reduction blocks per wave the register-resident form holds (512 planes, 4 output tiles: 16)
-struct KsW {
-    float4 w[KSB];
-    float bv;  // bias of the tile this wave finishes (waves 0 .. nt-1), requested with the weights
-    bool fast;
-};
 template <bool BIAS, bool F>
 __device__ __forceinline__ void ks_load(KsW& W, const float* __restrict__ wp, const float* __restrict__ bias, int nt, int kg, int wave, int lane) {
     W.fast = false;
@@ -218,9 +227,9 @@ __device__ __forceinline__ void ks_load(KsW& W, const float* __restrict__ wp, co
 #pragma unroll
     for (int d = 0; d < KSB; d++) W.w[d] = ldg4(wb + (g0 + d < g1 ? g0 + d : g1 - 1) * 64);  // (all KSB, clamped: see wide_load)
 }
-template <bool F, typename Epi>
+template <bool F, typename Epi, typename Pf>
 __device__ __forceinline__ void ks_mma(const KsW& W, const float* __restrict__ wp, const float* __restrict__ bias, int nt, int kg, const float* Xs,
-                                       float* red, int wave, int lane, Epi epi) {
+                                       float* red, int wave, int lane, Epi epi, Pf) {
     const float4* W4 = reinterpret_cast<const float4*>(wp);
     const float4* X4 = reinterpret_cast<const float4*>(Xs) + lane;
     if (!F && 2 * nt > LW) {  // enough tiles for every wave: whole reductions
@@ -308,18 +317,21 @@ __device__ __forceinline__ void copy_f4(float* dst, const float* src, int nfloat
 // ------------------------------------------------------------------------------------------------------------------
 // row phases: RPS = 32 threads per sample (e = tid >> 5, j = tid & 31); reductions stay inside a 32-lane half wave
 // ------------------------------------------------------------------------------------------------------------------
+// (four DPP row rotations + ONE ds_bpermute instead of five ds_bpermute round trips: the loss rows are a chain of such reductions on
+// waves that have nothing else to issue meanwhile)
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v = mz::butterfly16(v);
+    return v + __shfl_xor(v, 16, 64);
 }
 __device__ __forceinline__ float half_max(float v) {
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
-        const float o = __shfl_xor(v, m, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    v = mz::butterfly16_max(v);
+    const float o = __shfl_xor(v, 16, 64);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ float half_min(float v) {
+    v = mz::butterfly16_min(v);
+    const float o = __shfl_xor(v, 16, 64);
+    return o < v ? o : v;
 }
 
 // normalize_hidden_state, util.py:31-36, over the H real features of each sample; padding features stay zero
@@ -332,7 +344,7 @@ __device__ __forceinline__ void normalize_fwd(const float* HN, float* HS, int H,
         mx = v > mx ? v : mx;
     }
     mx = half_max(mx);
-    mn = -half_max(-mn);
+    mn = half_min(mn);
     const float d = (mx - mn) + 1e-8f;
     for (int k = j; k < h_t * 16; k += 32) HS[pk(k, e)] = k < H ? (HN[pk(k, e)] - mn) / d : 0.0f;
 }
@@ -342,19 +354,17 @@ __device__ __forceinline__ void normalize_fwd(const float* HN, float* HS, int H,
 __device__ __forceinline__ void normalize_bwd(const float* G, float gs, const float* U, const float* R, float* DU, int H, int h_t, int tid) {
     const int e = tid >> 5, j = tid & 31;
     float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
-    int imn = 0x7fffffff, imx = 0x7fffffff;
+    float imn = 1e9f, imx = 1e9f;  // first index that attains the bound, as a float (indices are small integers: exact)
     for (int k = j; k < H; k += 32) {
         const float v = U[pk(k, e)];
-        if (v < mn) { mn = v; imn = k; }
-        if (v > mx) { mx = v; imx = k; }
+        if (v < mn) { mn = v; imn = (float)k; }
+        if (v > mx) { mx = v; imx = (float)k; }
     }
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
-        const float omn = __shfl_xor(mn, m, 64), omx = __shfl_xor(mx, m, 64);
-        const int oimn = __shfl_xor(imn, m, 64), oimx = __shfl_xor(imx, m, 64);
-        if (omn < mn || (omn == mn && oimn < imn)) { mn = omn; imn = oimn; }
-        if (omx > mx || (omx == mx && oimx < imx)) { mx = omx; imx = oimx; }
-    }
+    const float gmn = half_min(mn), gmx = half_max(mx);
+    imn = half_min(mn == gmn ? imn : 1e9f);
+    imx = half_min(mx == gmx ? imx : 1e9f);
+    mn = gmn;
+    mx = gmx;
     const float d = (mx - mn) + 1e-8f;
     float s1 = 0.0f, s2 = 0.0f;
     for (int k = j; k < H; k += 32) {
@@ -369,8 +379,8 @@ __device__ __forceinline__ void normalize_bwd(const float* G, float gs, const fl
         float v = 0.0f;
         if (k < H) {
             v = G[pk(k, e)] * gs / d;
-            if (k == imn) v += dmn;
-            if (k == imx) v += dmx;
+            if ((float)k == imn) v += dmn;
+            if ((float)k == imx) v += dmx;
             if (R) v += R[pk(k, e)];
         }
         DU[pk(k, e)] = v;
@@ -456,8 +466,9 @@ __device__ __forceinline__ float head_loss_rows(const float* LG, int lgs, int S,
 
 // sum of `v` over the workgroup -> out (thread 0 writes); scratch: LW floats of LDS
 __device__ __forceinline__ void block_sum_store(float v, float* scratch, float* out, int tid) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    v = mz::butterfly16(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     if ((tid & 63) == 0) scratch[tid >> 6] = v;
     __syncthreads();
     if (tid == 0) {
@@ -523,14 +534,14 @@ __global__ __launch_bounds__(LT) void k_learn_repr(LNet net, LSave sv, LBatch bt
     ks_load<true, F>(w2, net.L[REP1].wp, net.L[REP1].b, net.h_t, net.p_t, wave, lane);
     save_T_from_pk(lds + o.X, net.in_t, sv.in_rep + blk(0, tiles, tile, net.in_t), tid);
     float* h1b = sv.h1_rep + blk(0, tiles, tile, net.p_t);
-    wide_mma<F>(w1, net.L[REP0].wp, net.L[REP0].b, net.p_t, net.in_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
+    wide_mma<F, 6>(w1, net.L[REP0].wp, net.L[REP0].b, net.p_t, net.in_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
         const f32x4 r = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f)};
         g_put_T(h1b, t, lane, r);
         lds_put_T(lds + o.H1, t, lane, r);
-    });
+    }, NoPf{});
     __syncthreads();
     ks_mma<F>(w2, net.L[REP1].wp, net.L[REP1].b, net.h_t, net.p_t, lds + o.H1, lds + o.RED, wave, lane,
-           [&](int t, f32x4 a) { lds_put_T(lds + o.HN, t, lane, a); });
+           [&](int t, f32x4 a) { lds_put_T(lds + o.HN, t, lane, a); }, NoPf{});
     __syncthreads();
     normalize_fwd(lds + o.HN, lds + o.HS, net.H, net.h_t, tid);
     __syncthreads();
@@ -563,15 +574,15 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
         ks_load<true, F>(w2, net.L[DYN1].wp, net.L[DYN1].b, net.h_t, net.p_t, wave, lane);
         save_T_from_pk(lds + o.X, net.h_t + net.a_t, sv.x + blk(k, tiles, tile, net.h_t + net.a_t), tid);
         float* h1b = sv.h1_dyn + blk(k, tiles, tile, net.p_t);
-        wide_mma<F>(w1, net.L[DYN0].wp, net.L[DYN0].b, net.p_t, net.h_t + net.a_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
+        wide_mma<F, 6>(w1, net.L[DYN0].wp, net.L[DYN0].b, net.p_t, net.h_t + net.a_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
             const f32x4 r = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f)};
             g_put_T(h1b, t, lane, r);
             lds_put_T(lds + o.H1, t, lane, r);
-        });
+        }, NoPf{});
         __syncthreads();
         MZL_STAMP(2);
         ks_mma<F>(w2, net.L[DYN1].wp, net.L[DYN1].b, net.h_t, net.p_t, lds + o.H1, lds + o.RED, wave, lane,
-               [&](int t, f32x4 a) { lds_put_T(lds + o.HN, t, lane, a); });
+               [&](int t, f32x4 a) { lds_put_T(lds + o.HN, t, lane, a); }, NoPf{});
         __syncthreads();
         MZL_STAMP(3);
         normalize_fwd(lds + o.HN, lds + o.HS, net.H, net.h_t, tid);
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
 #pragma unroll
     for (int i = 0; i < 4; i++) h1k[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const bool keep = F || w1.fast;
-    wide_mma<F>(w1, net.L[l0].wp, net.L[l0].b, net.p_t, net.h_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
+    wide_mma<F, 4>(w1, net.L[l0].wp, net.L[l0].b, net.p_t, net.h_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
         const f32x4 r = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f)};
         g_put_T(h1b, t, lane, r);
         lds_put_T(lds + o.H1, t, lane, r);
@@ -627,16 +638,16 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
             if (jj == 2) h1k[2] = r;
             if (jj == 3) h1k[3] = r;
         }
-    });
+    }, NoPf{});
     MZL_STAMP(sb + 10);
     __syncthreads();
     MZL_STAMP(sb + 2);
-    wide_load<2, false, F>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, wave, lane);  // the backward pass's operands, behind the forward layer's MFMAs
+    wide_load<2, false, F>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, wave, lane);  // the backward pass's operands, one phase ahead
     ks_mma<F>(w2, net.L[l1].wp, net.L[l1].b, s_t, net.p_t, lds + o.H1, lds + o.RED, wave, lane, [&](int t, f32x4 a) {
         const int f = lane & 15, sq = lane >> 4;
 #pragma unroll
         for (int i = 0; i < 4; i++) lds[o.LG + (4 * sq + i) * net.lgs + 16 * t + f] = a[i];
-    });
+    }, NoPf{});
     __syncthreads();
     MZL_STAMP(sb + 3);
     ks_load<false, F>(w2, net.L[l0].wtp, nullptr, net.h_t, net.p_t, wave, lane);
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
     save_T_from_pk(lds + o.DL, s_t, dz1_all + blk(step, tiles, tile, s_t), tid);
     float* dzb = dz0_all + blk(step, tiles, tile, net.p_t);
     const bool kept = F || (keep && w1.fast);
-    wide_mma<F>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, lds + o.DL, wave, lane, [&](int t, f32x4 a) {
+    wide_mma<F, 2>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, lds + o.DL, wave, lane, [&](int t, f32x4 a) {
         f32x4 h;
         if (kept) {
             const int jj = (t - wave) / LW;
@@ -663,11 +674,11 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
         const f32x4 r = {h[0] > 0.0f ? a[0] : 0.0f, h[1] > 0.0f ? a[1] : 0.0f, h[2] > 0.0f ? a[2] : 0.0f, h[3] > 0.0f ? a[3] : 0.0f};
         g_put_T(dzb, t, lane, r);
         lds_put_T(lds + o.DZ, t, lane, r);
-    });
+    }, NoPf{});
     __syncthreads();
     MZL_STAMP(sb + 5);
     ks_mma<F>(w2, net.L[l0].wtp, nullptr, net.h_t, net.p_t, lds + o.DZ, lds + o.RED, wave, lane,
-           [&](int t, f32x4 a) { lds_put_T(lds + o.G, t, lane, a); });
+           [&](int t, f32x4 a) { lds_put_T(lds + o.G, t, lane, a); }, NoPf{});
     __syncthreads();
     MZL_STAMP(sb + 6);
     copy_f4(dx_all + blk(step, tiles, tile, net.h_t), lds + o.G, hf, tid);
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(LT) void k_learn_back(LNet net, LSave sv, LBatch bt
     __syncthreads();
     save_T_from_pk(lds + o.HS, net.h_t, (k >= 0 ? sv.dz_dyn1 : sv.dz_rep1) + blk(st, tiles, tile, net.h_t), tid);
     float* dzb = (k >= 0 ? sv.dz_dyn0 : sv.dz_rep0) + blk(st, tiles, tile, net.p_t);
-    wide_mma<F>(w1, net.L[l1].wtp, nullptr, net.p_t, net.h_t, lds + o.HS, wave, lane, [&](int t, f32x4 a) {
+    wide_mma<F, 4>(w1, net.L[l1].wtp, nullptr, net.p_t, net.h_t, lds + o.HS, wave, lane, [&](int t, f32x4 a) {
         f32x4 h;
         if (pre) {
             const int jj = (t - wave) / LW;
@@ -735,11 +746,11 @@ __global__ __launch_bounds__(LT) void k_learn_back(LNet net, LSave sv, LBatch bt
         const f32x4 r = {h[0] > 0.0f ? a[0] : 0.0f, h[1] > 0.0f ? a[1] : 0.0f, h[2] > 0.0f ? a[2] : 0.0f, h[3] > 0.0f ? a[3] : 0.0f};
         g_put_T(dzb, t, lane, r);
         lds_put_T(lds + o.DZ, t, lane, r);
-    });
+    }, NoPf{});
     if (k < 0) return;  // the observation needs no gradient
     __syncthreads();
     ks_mma<F>(w2, net.L[DYN0].wtp, nullptr, net.h_t, net.p_t, lds + o.DZ, lds + o.RED, wave, lane,
-           [&](int t, f32x4 a) { lds_put_T(lds + o.G, t, lane, a); });
+           [&](int t, f32x4 a) { lds_put_T(lds + o.G, t, lane, a); }, NoPf{});
     __syncthreads();
     copy_f4(sv.dxd + blk(k, tiles, tile, net.h_t), lds + o.G, hf, tid);
 }
