@@ -61,6 +61,12 @@ struct mz_planner {
     SearchParams sp2{};  // tree_mode 2 layout (valid if tree2_ok)
     bool tree2_ok = false;
     int lds_mode0 = 0, lds_mode2 = 0;
+    // tree_mode 2 behind the TUNED kernel's own, smaller network carve-out (k_search_fast keeps the num_planes-wide layers in registers: of
+    // the generic H1 / V1 buffers it uses 16 KiB each, for its K-split partial tiles): lets four-action, 50-simulation searches at
+    // num_planes 512 (the LunarLander-shaped configuration) fit 160 KiB.  Only used when the generic carve-out does not fit.
+    SearchParams sp2f{};
+    bool tree2f_ok = false;
+    int lds_mode2f = 0, fast_delta = 0;
     double* d_ftab_tri = nullptr;
     InferParams ip{};
     // tuned kernel for the benchmark shapes (mz_search_fast.h): per-wave weight streams of the wide layers
@@ -209,6 +215,30 @@ static void compute_layout(mz_planner* p) {
             q.t2_nodes = n2; q.t2_entries = e2; q.t_prior = pr; q.t_tmp = tm; q.t_pi0 = p0; q.t_mm = mmo; q.t_sel = se; q.t_ptr = pt;
             q.t2_ftab = ft; q.t_cache = ca; q.t_path = pa; q.t_ver = ve;
             q.lds_bytes = total; q.tree_mode = 2;
+        }
+        constexpr int kFastPart = 4 * 4 * 256;  // floats of H1 / V1 the tuned kernel touches: [4 waves][<= 4 tiles] float4[64]
+        if (!p->tree2_ok && n.p_pad * 16 > kFastPart) {
+            const int delta = 2 * (n.p_pad * 16 - kFastPart);
+            MlpLds of = o;
+            of.V1 = o.H1 + kFastPart;
+            of.HN -= delta; of.HS -= delta; of.LG -= delta; of.OUT -= delta; of.BIAS -= delta; of.PM -= delta; of.total_floats -= delta;
+            b = of.total_floats * 4;
+            const int n2 = take(16 * s.NN * 16, 16), e2 = take(16 * s.NN * s.A * 16, 16), pr = take(16 * s.A * 8, 16), tm = take(16 * s.A * 8, 16),
+                      p0 = take(16 * s.A * 4, 16), mmo = take(16 * 2 * 8, 16), se = take(128 * 4, 16), pt = take(32 * 8, 16),
+                      ft = take(((s.S + 1) * (s.S + 2) / 2) * 8, 16), ca = take(16 * (s.NN + 1) * 16, 16), pa = take(16 * (s.NN + 3) * 2, 16),
+                      ve = take(16 * 32, 16);
+            const int total = (b + 15) & ~15;
+            if (total <= 160 * 1024) {
+                p->tree2f_ok = true;
+                p->lds_mode2f = total;
+                p->fast_delta = delta;
+                p->sp2f = s;
+                SearchParams& q = p->sp2f;
+                q.o = of;
+                q.t2_nodes = n2; q.t2_entries = e2; q.t_prior = pr; q.t_tmp = tm; q.t_pi0 = p0; q.t_mm = mmo; q.t_sel = se; q.t_ptr = pt;
+                q.t2_ftab = ft; q.t_cache = ca; q.t_path = pa; q.t_ver = ve;
+                q.lds_bytes = total; q.tree_mode = 2;
+            }
         }
     }
 
@@ -383,7 +413,7 @@ static int planner_init(mz_planner* p, bool conv) {
             return MZ_OK;
         }
     }
-    int max_lds = p->tree2_ok ? p->lds_mode2 : 0;
+    int max_lds = p->tree2_ok ? p->lds_mode2 : (p->tree2f_ok ? p->lds_mode2f : 0);
     if (p->lds_mode0 <= 160 * 1024 && p->lds_mode0 > max_lds) max_lds = p->lds_mode0;
     if (max_lds == 0) max_lds = p->ip.lds_bytes;  // hbm_tree: the LDS-resident search kernels are never launched
     if (p->lds_mode0 > 160 * 1024) p->tree_old = false;  // only the mode-2 layout fits
@@ -667,10 +697,18 @@ static int next_kernel_events(mz_planner* p, hipEvent_t* a, hipEvent_t* b) {
 // launches the fused search kernel over inputs that are already resident in the planner's device buffers
 static int launch_search(mz_planner* p, int batch, int deterministic, bool has_mask, bool injected_rng, bool scripted, const EnvLaunch* fenv = nullptr) {
     const mz_config& c = p->cfg;
-    const bool mode2 = p->tree2_ok && !p->tree_old;
-    SearchParams s = mode2 ? p->sp2 : p->sp;
+    // the tuned kernel with its own LDS carve-out (sp2f): only where the generic carve-out does not fit AND k_search_fast is the kernel
+    // the dispatch below picks (categorical heads; the ten-action MSE build is 256 planes wide and always fits the generic one)
+    const bool fastlayout = !p->tree2_ok && p->tree2f_ok && p->fast_planes && !p->force_generic && !p->tree_old && !scripted &&
+                            c.value_support_size > 1 && c.reward_support_size > 1 && !getenv("MZ_NO_FAST_LAYOUT");
+    const bool mode2 = (p->tree2_ok && !p->tree_old) || fastlayout;
+    SearchParams s = fastlayout ? p->sp2f : (mode2 ? p->sp2 : p->sp);
     s.tree_mode = mode2 ? 2 : 0;
     s.net = p->net;
+    if (fastlayout) {  // the bias block sits `fast_delta` floats lower in this carve-out
+        s.net.b_base -= p->fast_delta;
+        for (int l = 0; l < L_COUNT; l++) s.net.L[l].b_lds -= p->fast_delta;
+    }
     s.ftab_tri = p->d_ftab_tri;
     s.discount = c.discount; s.board = c.is_board_game; s.has_bounds = c.has_known_bounds;
     s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
