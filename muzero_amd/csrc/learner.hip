@@ -130,7 +130,14 @@ static void build_big_jobs(mz_learner* h) {
                 q.a_t0 = r0; q.na = row_tiles - r0 < 4 ? row_tiles - r0 : 4;
                 q.b_t0 = c0; q.nb = col_tiles - c0 < 4 ? col_tiles - c0 : 4;
                 q.R = first->R; q.n = first->n; q.k = first->k; q.kH = first->kH; q.kHpad = first->kHpad;
-                h->big.push_back(q);
+                // one unit per gradient slice for every job.  (Measured and not kept, round 4: units of about equal MFMA count -- fewer,
+                // longer units for the 4 x 1-tile jobs -- made the kernel SLOWER, 173 -> 234 us at batch 4096: a reduction block costs a
+                // unit its eight operand loads whatever its tile count, so the small jobs' units became the long ones.)
+                const int nj = h->cfg.grad_slices;
+                for (int k = 0; k < nj; k++) {
+                    q.slice = k; q.nslices = nj;
+                    h->big.push_back(q);
+                }
             }
     }
 }
@@ -185,7 +192,8 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     const int xt = (n.in_t > n.h_t + n.a_t ? n.in_t : n.h_t + n.a_t);
     o.X = f; f += xt * 256;
     o.H1 = f; f += n.p_t * 256;
-    o.DZ = f; f += n.p_t * 256;
+    o.DZ = o.H1;  // dL/dz1 takes the place of relu(z1): a head's forward layers are done with H1 before its backward pass writes DZ, the
+                  // dynamics role never writes DZ and the backward sweep never reads H1 -- 32 KB less LDS at 512 planes: two workgroups per CU fit
     o.HN = f; f += n.h_t * 256;
     o.HS = f; f += n.h_t * 256;
     o.G = f; f += n.h_t * 256;
@@ -265,6 +273,7 @@ extern "C" int mzl_bind(mz_learner* h, float* d_params, float* d_grads, float* d
     if (!h || !d_params || !d_grads || !d_exp_avg || !d_exp_avg_sq) return fail(MZL_E_INVALID, "null argument to mzl_bind");
     h->params = d_params; h->grads = d_grads; h->m = d_exp_avg; h->v = d_exp_avg_sq;
     h->committed = false;
+    h->jobs_tiles = -1;  // (the job tables are re-uploaded and the new gradient slices zeroed by the next mzl_grad)
     return MZL_OK;
 }
 
@@ -316,6 +325,8 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
         for (auto& j : bb) j.R *= tiles;
         HIPCHK(hipMemcpyAsync(h->d_jobs, jj.data(), jj.size() * sizeof(DwJob), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(h->d_big, bb.data(), bb.size() * sizeof(DwBig), hipMemcpyHostToDevice, st));
+        // (a job with fewer units than slices never writes its part of the upper slices: those stay the zeros written here)
+        HIPCHK(hipMemsetAsync(h->grads, 0, (size_t)h->P.total * h->cfg.grad_slices * sizeof(float), st));
         HIPCHK(hipStreamSynchronize(st));  // (temporaries; happens once per batch size)
         h->jobs_tiles = tiles;
     }
@@ -332,7 +343,7 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     // long reductions (grad_slices > 1 is the caller's statement that the batch is large): 4 x 4 tiles per wave, the slices carry the
     // parallelism; short ones: 1 x 4 tiles per workgroup, its eight waves split the reduction
     if (h->cfg.grad_slices > 1 && tiles * K >= 64)
-        hipLaunchKernelGGL(k_learn_dw_big, dim3(((unsigned)h->big.size() + DWB_WAVES - 1) / DWB_WAVES, h->cfg.grad_slices), dim3(DWB_WAVES * 64), 0, st,
+        hipLaunchKernelGGL(k_learn_dw_big, dim3(((unsigned)h->big.size() + DWB_WAVES - 1) / DWB_WAVES), dim3(DWB_WAVES * 64), 0, st,
                            h->d_big, (int)h->big.size(), h->grads, (size_t)h->P.total);
     else
         hipLaunchKernelGGL(k_learn_dw, dim3((unsigned)h->jobs.size(), h->cfg.grad_slices), dim3(LT), LW * 8 * 256 * 4, st, h->d_jobs, h->grads,

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(LT) void k_learn_dw(const DwJob* __restrict__ jobs,
 // The same gradients for LONG reductions (large batches).  There the small-block kernel above is bound by the CU's 64 B / clk of L1
 // bandwidth, not by the MFMA pipes: a wave that owns 1 x 4 tiles loads 5 operand blocks (5 KiB) per 16 MFMAs.  Here a wave owns up to
 // 4 x 4 tiles -- 8 KiB per 64 MFMAs -- runs its whole reduction slice alone (no LDS exchange; the slices of grid.y meet in
-// k_learn_gradsum), and requests the next reduction block's operands before multiplying the current one.  One job per WAVE.
+// k_learn_gradsum), and requests the next reduction block's operands before multiplying the current one.  One unit (job, slice) per WAVE.
 struct DwBig {
     const float* a;
     const float* b;
@@ -859,15 +859,19 @@ struct DwBig {
     int a_ft, b_ft;
     int a_t0, na, b_t0, nb;  // up to 4 x 4 tiles
     int R, n, k, kH, kHpad;
+    int slice, nslices;      // this unit's share of the reduction: blocks [slice R / nslices, (slice + 1) R / nslices), written to gradient
+                             // slice `slice` (one unit per job and slice)
 };
 constexpr int DWB_WAVES = 4;
 __global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __restrict__ jobs, int njobs, float* __restrict__ grads, size_t grad_stride) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int ji = blockIdx.x * DWB_WAVES + wave;
+    // units are listed layer by layer; a workgroup takes one from each quarter of the list, so that every workgroup -- all of them are
+    // resident at once, nothing re-balances later -- holds a mix of 4 x 4-tile and 4 x 1-tile units instead of four of a kind
+    const int ji = wave * gridDim.x + blockIdx.x;
     if (ji >= njobs) return;
     const DwBig J = jobs[ji];
-    const int r0 = (int)((long long)blockIdx.y * J.R / gridDim.y), r1 = (int)((long long)(blockIdx.y + 1) * J.R / gridDim.y);
-    float* G = grads + (size_t)blockIdx.y * grad_stride;
+    const int r0 = (int)((long long)J.slice * J.R / J.nslices), r1 = (int)((long long)(J.slice + 1) * J.R / J.nslices);
+    float* G = grads + (size_t)J.slice * grad_stride;
     const bool bias = J.gb >= 0;
     f32x4 acc[4][4], accb[4];
 #pragma unroll
