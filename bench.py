@@ -257,7 +257,10 @@ def configs_leg(args, rank, local_rank, world, torch, dist, red_dev):
     import types
 
     out = {}
+    only = os.environ.get('MZ_BENCH_CONFIGS')  # diagnostics: a comma list of the legs to run
     for name, (steps, warm) in CONFIG_LEGS.items():
+        if only and name not in only.split(','):
+            continue
         a = types.SimpleNamespace(envs=0, sims=0)
         r = measure_workload(a, name, rank, local_rank, world, torch, dist, red_dev, steps, warm, 0, False, False)
         if rank == 0:
@@ -605,7 +608,7 @@ def main():
     del p
     torch.cuda.empty_cache()
     configs = None if args.no_configs or args.envs or args.sims else configs_leg(args, rank, local_rank, world, torch, dist, red_dev)
-    if configs is not None:
+    if configs is not None and 'lunar' in os.environ.get('MZ_BENCH_CONFIGS', 'lunar').split(','):
         lunar = lunar_leg(rank, local_rank, world, torch, dist, red_dev)
         if rank == 0:
             configs['lunar'] = lunar

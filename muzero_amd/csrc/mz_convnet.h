@@ -537,10 +537,11 @@ inline void convnet_recurrent(hipStream_t st, ConvNetDev& n, int B, const float*
                               size_t store_floats = 0) {
     const int h = n.hh, w = n.hw, hw = h * w;
     if (n.dyn_inv_hw > 0) {  // board games: dense part over the real channels, then the <= 9 non-zero action-plane terms per output
-        conv_run(st, n.dyn_real, B, src_dense, src_ptrs, nullptr, 0, h, w, nullptr, n.bufA, false, store_base, store_floats);
+        static const int dbg = env_int("MZ_DBG_SPARSE", 0);
+        if (dbg != 2) conv_run(st, n.dyn_real, B, src_dense, src_ptrs, nullptr, 0, h, w, nullptr, n.bufA, false, store_base, store_floats);
         ActionSparseLaunch S{};
         S.x = n.bufA; S.action = action; S.w = n.dyn_act_w; S.B = B; S.cout = n.P; S.h = h; S.w_img = w; S.A = n.A; S.inv_hw = n.dyn_inv_hw;
-        hipLaunchKernelGGL(k_action_sparse, dim3((hw + 15) / 16, B), dim3(256), 0, st, S);
+        if (dbg != 1) hipLaunchKernelGGL(k_action_sparse, dim3((hw + 15) / 16, B), dim3(256), 0, st, S);
     } else {
         conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true, store_base, store_floats);
     }
