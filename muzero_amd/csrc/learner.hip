@@ -240,6 +240,7 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_learn_dw), hipFuncAttributeMaxDynamicSharedMemorySize, LW * 8 * 256 * 4);
     if (e != hipSuccess) return cleanup(fail(MZL_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)));
+    HIPCHK(hipDeviceSynchronize());  // (dalloc's fills run on the NULL stream; the caller's stream need not wait for it)
     *out = h;
     return MZL_OK;
 }

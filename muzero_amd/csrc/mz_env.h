@@ -94,7 +94,10 @@ inline hipError_t env_alloc(EnvState& e, int kind, int B, int A, int D, int ring
     MZ_ALLOC(e.counters, 4 * sizeof(unsigned long long));
     MZ_ALLOC(e.ep_start, (size_t)B * sizeof(long long));
 #undef MZ_ALLOC
-    return hipSuccess;
+    // hipMemset on device memory returns before the fill has run, and it runs on the NULL stream -- which the planner's non-blocking
+    // stream does not wait for: a late fill zeroed what k_env_reset had just written (player ids 0 -> the board step indexes the
+    // history planes out of range).  Seen as a memory fault when two processes share a GPU (round 4); a latent race everywhere.
+    return hipDeviceSynchronize();
 }
 
 // ---- CartPole ----

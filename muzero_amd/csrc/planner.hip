@@ -378,6 +378,7 @@ static int planner_init(mz_planner* p, bool conv) {
     HIPCHK(hipMalloc(&p->d_stamps, 16 * sizeof(long long)));
     HIPCHK(hipMemset(p->d_stamps, 0, 16 * sizeof(long long)));
     HIPCHK(hipMemset(p->d_mask, 1, B * A));
+    HIPCHK(hipDeviceSynchronize());  // (the fills above run on the NULL stream, which p->stream -- non-blocking -- never waits for)
     // child_U factor table: pb(N) / (n_child + 1) in float64 with the host libm, i.e. the very values math.log /
     // math.sqrt give the reference (mcts.py:193-195)
     std::vector<double> ft((S + 1) * (S + 1));
@@ -863,7 +864,8 @@ static int download_results(mz_planner* p, int batch, int32_t* h_action, double*
     HIPCHK(hipMemcpyAsync(&err, p->d_err, sizeof(int), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     if (err) {
-        HIPCHK(hipMemset(p->d_err, 0, sizeof(int)));
+        HIPCHK(hipMemsetAsync(p->d_err, 0, sizeof(int), p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
         if (err == 4) return fail(MZ_E_TIES, "injected tie-break stream exhausted (raise mz_config.max_ties)");
         return fail(MZ_E_INVALID, "search kernel reported error " + std::to_string(err));
     }
@@ -1127,6 +1129,7 @@ extern "C" int mz_debug_capture_rng(mz_planner* p, int32_t enable) {
         HIPCHK(hipMemcpy(p->d_dbg_utie, half.data(), B * T * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(p->d_dbg_ufinal, half.data(), B * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(p->d_dbg_noise, 0, B * A * sizeof(double)));
+        HIPCHK(hipDeviceSynchronize());
     }
     return MZ_OK;
 }
