@@ -387,6 +387,10 @@ def _search_case(net, cfg, obs, mask, players, T, det, seed, prefix, out, A):
         out_action=np.int32(action),
         out_pi=np.asarray(pi, np.float64),
         out_root_value=np.float64(root_value),
+        # the global numpy stream right after the search (seeded with `seed` before it): a literal "identical seeds" run must leave the
+        # generator in the same place -- same number of words consumed by the Dirichlet draw, every tie-break and the final sample
+        seed=np.int64(seed),
+        next_uniform=np.float64(np.random.random_sample()),
     )
     d.update(rec.as_dict(A, max_ties=4 * cfg.num_simulations + 8))
     for k, v in d.items():

