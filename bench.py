@@ -364,6 +364,61 @@ def learner_leg(rank, local_rank, world, torch, dist, backend, batches=(128, 409
             'flop_per_sample': 6.0 * mac}
 
 
+def train_leg(rank, local_rank, world, torch, dist, seconds=2.0, batch=4096, moves=8):
+    """The whole loop on one GPU at the headline workload's size -- run_self_play + run_training of the reference (pipeline.py:41-286) as the
+    planner (C2: 4096 CartPole envs, 50 sims, device epilogue into a 1 M-item HBM replay) and the HIP learner taking turns on the device, in
+    event order: `moves` lock-step moves, then one update per move of `batch` samples drawn from the replay (about one sampled item per env
+    step; the reference's classic run trains ~11 per env step at 340 env-steps/s), the planner re-fed with the learner's weights every 16
+    iterations.  Reports what the pair sustains together."""
+    import types
+
+    from muzero_amd import learner
+    from muzero_amd import planner as pl
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.network import MuZeroMLPNet
+    from muzero_amd.replay import PrioritizedReplay
+
+    dev = torch.device('cuda', local_rank)
+    cfg = make_classic_config(batch_size=batch, min_replay_size=batch, use_tensorboard=False)
+    torch.manual_seed(3 + rank)
+    net = MuZeroMLPNet((4, 5), 2, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+    hl = learner.make_hip_learner(cfg, net, dev)
+    B = 4096
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=B, seed=3000 + rank), local_rank)
+    net.eval()
+    p.load_state_dict(net.state_dict())
+    rp = PrioritizedReplay(1 << 20, 0.0, 0.0, np.random.RandomState(11 + rank), device='cuda')
+    p.attach_replay(rp, types.SimpleNamespace(is_board_game=False, acc_seq_length=200, unroll_steps=5, td_steps=10, discount=0.997), obs_shape=(4, 5))
+    p.selfplay_reset(pl.ENV_CARTPOLE)
+    p.selfplay_step(1.0, 240)  # past the first mid-episode flush: the replay is filling
+    p.synchronize()
+
+    def iteration():
+        p.selfplay_step(1.0, moves)
+        p.synchronize()
+        for _ in range(moves):
+            idx, _, ring = rp.sample_indices(batch)
+            hl.step(ring, torch.from_numpy(idx).to(dev), None, batch, allreduce=False)
+
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    it, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        iteration()
+        it += 1
+        if it % 16 == 0:
+            p.load_state_dict(net.state_dict())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = float(hl.loss)
+    p.close()
+    hl.close()
+    return {'what': 'C2 planner (4096 envs, 50 sims, device epilogue -> HBM replay) and the HIP learner (batch %d gathered from the replay) taking turns on one GPU, event order' % batch,
+            'seconds': dt, 'iterations': it, 'env_steps_per_sec': it * moves * B / dt, 'sims_per_sec': it * moves * B * 50 / dt, 'updates_per_sec': it * moves / dt,
+            'samples_per_sec': it * moves * batch / dt, 'samples_per_env_step': batch / B, 'last_loss': loss, 'replay_items': int(rp.size)}
+
+
 def allreduce_leg(rank, local_rank, world, torch, dist, backend, nbytes=30_400_000, iters=10):
     """The learner-side collective the north-star names ("RCCL over xGMI only for replay / gradient all-reduce"): ONE flat all-reduce of a
     gradient bucket the size of the Gomoku conv net (30.4 MB of fp32), as learner.allreduce_gradients issues it.  N > 1 only."""
@@ -613,6 +668,7 @@ def main():
         if rank == 0:
             configs['lunar'] = lunar
     learner_rec = None if args.no_learner else learner_leg(rank, local_rank, world, torch, dist, backend)
+    train_rec = None if args.no_learner else train_leg(rank, local_rank, world, torch, dist)
     allreduce_rec = None if args.no_learner else allreduce_leg(rank, local_rank, world, torch, dist, backend)
     # every rank's own rate (the line's `value` is the job's: all ranks' simulations over the slowest rank's time)
     my_rate = B * S * args.steps / (prof['search_kernel_ms'] * 1e-3) if prof['search_kernel_ms'] > 0 else 0.0
@@ -665,6 +721,7 @@ def main():
             'e2e': e2e,
             'configs': configs,
             'learner': learner_rec,
+            'train': train_rec,
             'allreduce': allreduce_rec,
             'per_rank': {'sims_per_sec_by_kernel_time': per_rank, 'min': min(per_rank), 'max': max(per_rank), 'sum': sum(per_rank)},
             'distributed': dist_record(dist, world, backend),

@@ -47,6 +47,9 @@ def main():
     ap.add_argument('--eval-games', type=int, default=50)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--out', default='')
+    ap.add_argument('--host-assembly', action='store_true',
+                    help="round 1's path: (Transition, priority) items assembled on the host and the PyTorch learner step; default: device epilogue "
+                         'into the HBM replay + the HIP learner kernels (hip_learner.HipLearner), in event order (a seed gives one run)')
     args = ap.parse_args()
 
     from muzero_amd import learner
@@ -61,12 +64,18 @@ def main():
     cfg = make_tictactoe_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
     cfg.num_envs = args.envs
     net = MuZeroMLPNet((9, 3, 3), 10, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    hl = None
+    if args.host_assembly:
+        opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    else:
+        hl = learner.make_hip_learner(cfg, net, dev)
     replay = PrioritizedReplay(20000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
     net.eval()
     p.load_state_dict(net.state_dict())
+    if hl is not None:
+        p.attach_replay(replay, cfg, obs_shape=(9, 3, 3))
     p.selfplay_reset(pl.ENV_TICTACTOE)
     asm = EpisodeAssembler(cfg, args.envs, (9, 3, 3))
     rs = np.random.RandomState(args.seed + 7)
@@ -76,19 +85,26 @@ def main():
     steps, t0 = 0, time.time()
     while steps < args.train_steps:
         p.selfplay_step(-1.0, args.moves_per_iter)  # per-env temperature schedule of the game (config.py:236-241)
-        for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
-            replay.add(tr, prio)
+        if hl is None:
+            for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
+                replay.add(tr, prio)
+        else:
+            p.synchronize()  # event order: the moves above are committed before a batch is drawn
         if replay.size < cfg.min_replay_size:
             continue
         net.train()
         for _ in range(args.updates_per_iter):
-            batch, idx, w = replay.sample_tensors(cfg.batch_size)
-            loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
-            replay.update_priorities(idx, prio)
+            if hl is not None:
+                idx, _, ring = replay.sample_indices(cfg.batch_size)
+                loss, prio = hl.step(ring, torch.from_numpy(idx).to(dev), None, cfg.batch_size)
+            else:
+                batch, idx, w = replay.sample_tensors(cfg.batch_size)
+                loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
+                replay.update_priorities(idx, prio)
             steps += 1
             if steps % args.report_every == 0:
                 net.eval()
-                rec = dict(train_steps=steps, loss=loss, seconds=round(time.time() - t0, 1), env_steps=p.selfplay_counters()['env_steps'],
+                rec = dict(train_steps=steps, loss=float(loss), seconds=round(time.time() - t0, 1), env_steps=p.selfplay_counters()['env_steps'],
                            black=play_vs_random(net, dev, cfg, 1, args.eval_games, rs), white=play_vs_random(net, dev, cfg, 2, args.eval_games, rs))
                 net.train()
                 log.append(rec)
