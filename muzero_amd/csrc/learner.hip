@@ -334,11 +334,13 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     const size_t lds = (size_t)h->lds_bytes;
     if (h->fast) {
         hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
-        for (int k = 0; k <= K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles, 4), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
+        for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
+        hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
         for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
     } else {
         hipLaunchKernelGGL(k_learn_repr<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
-        for (int k = 0; k <= K; k++) hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles, 4), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
+        for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
+        hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
         for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
     }
     // long reductions (grad_slices > 1 is the caller's statement that the batch is large): 4 x 4 tiles per wave, the slices carry the

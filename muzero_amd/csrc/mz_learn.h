@@ -8,9 +8,11 @@
 // (MI355X_MICROARCH.md, rows "boundary" / "barrier-xcd"), and every stage's workgroups depend only on workgroups of the SAME tile in
 // the previous stage:
 //   k_learn_repr            grid (tiles)        representation net forward -> h_0
-//   k_learn_unroll<k>       grid (tiles, 4)     role 0: dynamics_k forward (h_k, a_k -> u_{k+1}, h_{k+1});
-//                                               roles 1 / 2: policy_k / value_k forward + loss + backward to dL/dh_k;
-//                                               role 3: reward_{k-1} forward + loss + backward to dL/du_k           (k = 0 .. K)
+//   k_learn_unroll          K launches, grid (tiles): role 0, dynamics_k forward (h_k, a_k -> u_{k+1}, h_{k+1}) -- the only serial chain of
+//                                               the forward sweep;
+//                           then ONE launch, grid (tiles, 3, K): roles 1 / 2: policy_k / value_k forward + loss + backward to dL/dh_k;
+//                                               role 3: reward_k forward + loss + backward to dL/du_{k+1} -- every head of every step
+//                                               needs only h_k / u_{k+1}, so all 3 K of them run side by side (120 workgroups at batch 128)
 //   k_learn_back<k>         grid (tiles)        dL/dh_{k+1} (halved, pipeline.py:584) -> normalisation backward (+ reward's dL/du_{k+1})
 //                                               -> dynamics_k backward -> dL/dh_k                                    (k = K-1 .. 0, then repr)
 //   k_learn_dw              grid (jobs, split)  every weight / bias gradient: dW = sum over (step, sample) dZ x^T as MFMA tiles
@@ -552,9 +554,12 @@ __global__ __launch_bounds__(LT) void k_learn_repr(LNet net, LSave sv, LBatch bt
 
 // one unroll step of the forward sweep (pipeline.py:579-592); see the header for the roles
 template <bool F>
-__global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch bt, LLds o, int k) {
+__global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch bt, LLds o, int k0, int role0) {
     extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = blockIdx.x, tiles = bt.tiles, role = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = blockIdx.x, tiles = bt.tiles;
+    // grid (tiles, roles, steps): role = role0 + blockIdx.y; the launch's step index blockIdx.z addresses h_k for the dynamics / policy / value
+    // roles and u_k (reward of step k - 1) for the reward role, whose steps are therefore shifted by one
+    const int role = role0 + (int)blockIdx.y, k = k0 + (int)blockIdx.z + ((role == 3 && gridDim.z > 1) ? 1 : 0);
     const int K = net.K, hf = net.h_t * 64;
     const int e = tid >> 5, j = tid & 31, s = tile * TILE + e;
     WideW w1;
