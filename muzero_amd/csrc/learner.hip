@@ -52,6 +52,7 @@ struct mz_learner {
     int sq_blocks = 0;
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
     bool committed = false;
+    int back_parts = 1;  // plane slices of the backward stages at small batches (k_learn_back_sliced), 1: unsliced
     bool fast = false;  // every GEMM of the net fits the register-resident forms: the kernels without their generic paths
 };
 
@@ -218,7 +219,7 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     A(&s.h1_pol, T * K * n.p_t); A(&s.dz_pol0, T * K * n.p_t); A(&s.dz_pol1, T * K * n.a_t);
     A(&s.h1_val, T * K * n.p_t); A(&s.dz_val0, T * K * n.p_t); A(&s.dz_val1, T * K * n.sv_t);
     A(&s.hc, T * (K + 1) * n.h_t); A(&s.uc, T * (K + 1) * n.h_t);
-    A(&s.dxd, T * K * n.h_t); A(&s.dxp, T * K * n.h_t); A(&s.dxv, T * K * n.h_t); A(&s.dxr, T * K * n.h_t);
+    A(&s.dxd, T * K * n.h_t * DX_PARTS); A(&s.dxp, T * K * n.h_t); A(&s.dxv, T * K * n.h_t); A(&s.dxr, T * K * n.h_t);
     A(&s.lossp, (size_t)3 * K * tiles);
     if (getenv("MZL_STAMPS")) ok = ok && dalloc(h, &s.stamps, 64) == hipSuccess;
     ok = ok && dalloc(h, &s.actc, (size_t)K * tiles * 16) == hipSuccess;
@@ -230,12 +231,18 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
         h->fast = n.p_t <= 4 * LW && n.in_t <= 6 && n.h_t + n.a_t <= 6 && n.h_t <= 4 && n.a_t <= 2 && n.sv_t <= 2 && n.sr_t <= 2 && n.h_t * 64 <= LT &&
                   ks_ok(n.h_t, n.p_t) && ks_ok(n.a_t, n.p_t) && ks_ok(n.sv_t, n.p_t) && ks_ok(n.sr_t, n.p_t) && !getenv("MZL_GENERIC");
     }
+    {   // k_learn_back_sliced: four slices when the register forms fit them (p_t / 4 plane tiles per workgroup, one per wave)
+        const bool ok = h->fast && n.p_t % DX_PARTS == 0 && n.p_t / DX_PARTS <= LW && n.h_t <= 4 && LW % n.h_t == 0 && (n.p_t / DX_PARTS) % (LW / n.h_t) == 0 &&
+                        (n.p_t / DX_PARTS) / (LW / n.h_t) <= 4 && n.h_t * 64 <= LT && !getenv("MZL_NO_SLICE");
+        h->back_parts = ok ? DX_PARTS : 1;
+    }
     build_jobs(h);
     build_big_jobs(h);
     if (dalloc(h, &h->d_jobs, h->jobs.size()) != hipSuccess || dalloc(h, &h->d_big, h->big.size()) != hipSuccess) return cleanup(fail(MZL_E_HIP, "hipMalloc failed (jobs)"));
     hipError_t e = hipSuccess;
     const void* stage_kernels[] = {(const void*)&k_learn_repr<true>,   (const void*)&k_learn_repr<false>, (const void*)&k_learn_unroll<true>,
-                                   (const void*)&k_learn_unroll<false>, (const void*)&k_learn_back<true>,  (const void*)&k_learn_back<false>};
+                                   (const void*)&k_learn_unroll<false>, (const void*)&k_learn_back<true>,  (const void*)&k_learn_back<false>,
+                                   (const void*)&k_learn_back_sliced<true>};
     for (const void* f : stage_kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_learn_dw), hipFuncAttributeMaxDynamicSharedMemorySize, LW * 8 * 256 * 4);
@@ -336,7 +343,13 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
         hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
         for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
         hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
-        for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
+        // small batches: the backward chain cut four ways across the planes (32 instead of 8 workgroups per stage at batch 128)
+        LSave svb = h->sv;
+        svb.dx_parts = (h->back_parts > 1 && tiles * h->back_parts <= 512) ? h->back_parts : 1;
+        if (svb.dx_parts > 1)
+            for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back_sliced<true>, dim3(tiles, svb.dx_parts), dim3(LT), lds, st, n, svb, bt, h->o, k);
+        else
+            for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<true>, dim3(tiles), dim3(LT), lds, st, n, svb, bt, h->o, k);
     } else {
         hipLaunchKernelGGL(k_learn_repr<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
         for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);

@@ -41,6 +41,7 @@ constexpr int LW = 8;        // waves per workgroup
 constexpr int LT = LW * 64;  // threads per workgroup
 constexpr int TILE = 16;     // samples per tile
 constexpr int RPS = LT / TILE;  // threads per sample in the row phases (32)
+constexpr int DX_PARTS = 4;     // partial dL/dh tiles a backward stage may leave for the next one (k_learn_back_sliced)
 
 __device__ __forceinline__ int pk(int k, int e) { return (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + e) << 2) + (k & 3); }
 
@@ -71,6 +72,8 @@ struct LSave {
     // chain tensors handed from stage to stage in pk order: [K + 1][tiles][h_t * 256]
     float *hc, *uc;                  // h_k (normalised), u_k (before normalisation)
     float *dxd, *dxp, *dxv, *dxr;    // dL/dh_k from dynamics_k / policy_k / value_k ; dL/du_{k+1} from reward_k   [K][tiles][h_t * 256]
+                                     // (dxd: [K][tiles][DX_PARTS][h_t * 256] -- the sliced backward stage leaves one partial per slice)
+    int dx_parts;                    // partials the backward stages of this step write and read (1: unsliced)
     float* lossp;                    // [3 K][tiles] partial losses (sum over the tile of w * loss)
     long long* stamps;               // diagnostic (tools/dev/learn_stamps.py): cycle stamps of tile 0's workgroups, or nullptr
     int* actc;                       // [K][tiles][16] the batch's actions, gathered once by k_learn_repr (-1: no such sample)
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(LT) void k_learn_back(LNet net, LSave sv, LBatch bt
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const bool cons = j < K;  // consumers of h_j: dynamics_j, policy_j, value_j (none for j == K)
     const size_t cjc = cons ? cj : 0;
-    const float4 ga = reinterpret_cast<const float4*>(sv.dxd + cjc)[ci], gb = reinterpret_cast<const float4*>(sv.dxp + cjc)[ci],
+    const float4 ga = reinterpret_cast<const float4*>(sv.dxd + cjc * DX_PARTS)[ci], gb = reinterpret_cast<const float4*>(sv.dxp + cjc)[ci],
                  gc = reinterpret_cast<const float4*>(sv.dxv + cjc)[ci];
     const float4 uu = reinterpret_cast<const float4*>(sv.uc + cj)[ci];
     const float4 rr = reinterpret_cast<const float4*>(sv.dxr + blk(st, tiles, tile, net.h_t))[ci];
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(LT) void k_learn_back(LNet net, LSave sv, LBatch bt
     for (int i = tid + LT; !F && i < hf; i += LT) {  // (states wider than 128 features)
         float4 g = z4;
         if (cons) {
-            const float4 a = reinterpret_cast<const float4*>(sv.dxd + cj)[i], b = reinterpret_cast<const float4*>(sv.dxp + cj)[i],
+            const float4 a = reinterpret_cast<const float4*>(sv.dxd + cj * DX_PARTS)[i], b = reinterpret_cast<const float4*>(sv.dxp + cj)[i],
                          c = reinterpret_cast<const float4*>(sv.dxv + cj)[i];
             g = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
         }
@@ -757,7 +760,92 @@ __global__ __launch_bounds__(LT) void k_learn_back(LNet net, LSave sv, LBatch bt
     ks_mma<F>(w2, net.L[DYN0].wtp, nullptr, net.h_t, net.p_t, lds + o.DZ, lds + o.RED, wave, lane,
            [&](int t, f32x4 a) { lds_put_T(lds + o.G, t, lane, a); }, NoPf{});
     __syncthreads();
-    copy_f4(sv.dxd + blk(k, tiles, tile, net.h_t), lds + o.G, hf, tid);
+    copy_f4(sv.dxd + blk(k, tiles, tile, net.h_t) * DX_PARTS, lds + o.G, hf, tid);
+}
+
+// The same stage for SMALL batches, cut across the planes: workgroup (tile, part) owns the plane tiles [part p_t / np, (part + 1) p_t / np)
+// -- one per wave -- of dL/dz1 and leaves a PARTIAL dL/dh_k over its slice; the next stage adds the np partials when it loads them (a
+// kernel boundary is the cheapest grid-wide exchange on this part, and the consumer's sum costs np - 1 more 16-byte loads per lane).
+// At batch 128 the backward chain is 6 dependent stages on 8 workgroups; sliced four ways each stage does a quarter of the MFMAs on
+// 32 workgroups.  Register-resident forms only (the launcher checks: p_t / np <= LW, h_t <= 4, LW / h_t divides the slice).
+template <bool F>
+__global__ __launch_bounds__(LT) void k_learn_back_sliced(LNet net, LSave sv, LBatch bt, LLds o, int k) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = blockIdx.x, tiles = bt.tiles;
+    const int part = blockIdx.y, np = gridDim.y, K = net.K, j = k + 1, hf = net.h_t * 64;
+    const int l0 = k >= 0 ? DYN0 : REP0, l1 = l0 + 1, st = k >= 0 ? k : 0;
+    const int tb = part * net.p_t / np, te = (part + 1) * net.p_t / np;  // this workgroup's plane tiles
+    const size_t cj = blk(j, tiles, tile, net.h_t);
+    const int ci = tid < hf ? tid : hf - 1;
+    const bool cons = j < K;
+    const size_t cjc = cons ? cj : 0;
+    float4 ga = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int pp = 0; pp < DX_PARTS; pp++) {  // (clamped, never guarded: see LOAD ORDER)
+        const float4 v = reinterpret_cast<const float4*>(sv.dxd + (cjc * DX_PARTS) + (size_t)(pp < sv.dx_parts ? pp : 0) * net.h_t * 256)[ci];
+        const float m = pp < sv.dx_parts ? 1.0f : 0.0f;
+        ga = make_float4(ga.x + m * v.x, ga.y + m * v.y, ga.z + m * v.z, ga.w + m * v.w);
+    }
+    const float4 gb = reinterpret_cast<const float4*>(sv.dxp + cjc)[ci], gc = reinterpret_cast<const float4*>(sv.dxv + cjc)[ci];
+    const float4 uu = reinterpret_cast<const float4*>(sv.uc + cj)[ci];
+    const float4 rr = reinterpret_cast<const float4*>(sv.dxr + blk(st, tiles, tile, net.h_t))[ci];
+    // operands: this wave's plane tile of W2^T (h_t blocks), its relu gate, and its share of W1^T over the slice
+    const int t = tb + wave < te ? tb + wave : te - 1;
+    const bool t_ok = tb + wave < te;
+    const float4* W2T = reinterpret_cast<const float4*>(net.L[l1].wtp) + lane;
+    float4 w1[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) w1[d] = ldg4(W2T + ((size_t)t * net.h_t + (d < net.h_t ? d : net.h_t - 1)) * 64);
+    const float* h1b = (k >= 0 ? sv.h1_dyn : sv.h1_rep) + blk(st, tiles, tile, net.p_t);
+    const f32x4 gate = g_get_T(h1b, t, lane);
+    const int kparts = LW / net.h_t, ot = wave % net.h_t, kp = wave / net.h_t;  // output tile and reduction share of this wave in the second GEMM
+    const int nb = (te - tb) / kparts, g0 = tb + kp * nb;
+    const float4* W1T = reinterpret_cast<const float4*>(net.L[DYN0].wtp) + ((size_t)ot * net.p_t) * 64 + lane;
+    float4 w2[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) w2[d] = ldg4(W1T + (size_t)(g0 + (d < nb ? d : nb - 1)) * 64);
+    if (tid < hf) {
+        reinterpret_cast<float4*>(lds + o.G)[tid] = cons ? make_float4((ga.x + gb.x) + gc.x, (ga.y + gb.y) + gc.y, (ga.z + gb.z) + gc.z, (ga.w + gb.w) + gc.w)
+                                                         : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        reinterpret_cast<float4*>(lds + o.HN)[tid] = uu;
+        reinterpret_cast<float4*>(lds + o.R)[tid] = rr;
+    }
+    __syncthreads();
+    normalize_bwd(lds + o.G, k >= 0 ? 0.5f : 1.0f, lds + o.HN, k >= 0 ? lds + o.R : nullptr, lds + o.HS, net.H, net.h_t, tid);
+    __syncthreads();
+    if (part == 0) save_T_from_pk(lds + o.HS, net.h_t, (k >= 0 ? sv.dz_dyn1 : sv.dz_rep1) + blk(st, tiles, tile, net.h_t), tid);
+    float* dzb = (k >= 0 ? sv.dz_dyn0 : sv.dz_rep0) + blk(st, tiles, tile, net.p_t);
+    if (t_ok) {
+        const float4* X4 = reinterpret_cast<const float4*>(lds + o.HS) + lane;
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (d < net.h_t) a = mfma4(X4[d * 64], w1[d], a);
+        const f32x4 r = {gate[0] > 0.0f ? a[0] : 0.0f, gate[1] > 0.0f ? a[1] : 0.0f, gate[2] > 0.0f ? a[2] : 0.0f, gate[3] > 0.0f ? a[3] : 0.0f};
+        g_put_T(dzb, t, lane, r);
+        lds_put_T(lds + o.DZ, t, lane, r);
+    }
+    if (k < 0) return;
+    __syncthreads();
+    {
+        const float4* X4 = reinterpret_cast<const float4*>(lds + o.DZ) + lane;
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (d < nb) a = mfma4(X4[(g0 + d) * 64], w2[d], a);
+        reinterpret_cast<float4*>(lds + o.RED)[(kp * net.h_t + ot) * 64 + lane] = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    __syncthreads();
+    if (wave < net.h_t) {
+        f32x4 sacc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < kparts; q++) {
+            const float4 v = reinterpret_cast<const float4*>(lds + o.RED)[(q * net.h_t + wave) * 64 + lane];
+            sacc = sacc + f32x4{v.x, v.y, v.z, v.w};
+        }
+        lds_put_T(lds + o.G, wave, lane, sacc);
+    }
+    __syncthreads();
+    copy_f4(sv.dxd + blk(k, tiles, tile, net.h_t) * DX_PARTS + (size_t)part * net.h_t * 256, lds + o.G, hf, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
