@@ -219,6 +219,7 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     A(&s.h1_pol, T * K * n.p_t); A(&s.dz_pol0, T * K * n.p_t); A(&s.dz_pol1, T * K * n.a_t);
     A(&s.h1_val, T * K * n.p_t); A(&s.dz_val0, T * K * n.p_t); A(&s.dz_val1, T * K * n.sv_t);
     A(&s.hc, T * (K + 1) * n.h_t); A(&s.uc, T * (K + 1) * n.h_t);
+    A(&s.up, T * (K + 1) * n.h_t * DX_PARTS);
     A(&s.dxd, T * K * n.h_t * DX_PARTS); A(&s.dxp, T * K * n.h_t); A(&s.dxv, T * K * n.h_t); A(&s.dxr, T * K * n.h_t);
     A(&s.lossp, (size_t)3 * K * tiles);
     if (getenv("MZL_STAMPS")) ok = ok && dalloc(h, &s.stamps, 64) == hipSuccess;
@@ -242,7 +243,7 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     hipError_t e = hipSuccess;
     const void* stage_kernels[] = {(const void*)&k_learn_repr<true>,   (const void*)&k_learn_repr<false>, (const void*)&k_learn_unroll<true>,
                                    (const void*)&k_learn_unroll<false>, (const void*)&k_learn_back<true>,  (const void*)&k_learn_back<false>,
-                                   (const void*)&k_learn_back_sliced<true>};
+                                   (const void*)&k_learn_back_sliced<true>, (const void*)&k_learn_fwd_sliced<true>};
     for (const void* f : stage_kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_learn_dw), hipFuncAttributeMaxDynamicSharedMemorySize, LW * 8 * 256 * 4);
@@ -339,9 +340,15 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
         h->jobs_tiles = tiles;
     }
     const size_t lds = (size_t)h->lds_bytes;
+    const int fparts = (h->fast && h->back_parts > 1 && tiles * h->back_parts <= 512 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
     if (h->fast) {
-        hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
-        for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
+        if (fparts > 1) {  // small batches: the forward chain cut across the planes too (k = -1: representation; k = K: finishes u_K)
+            for (int k = -1; k < K; k++) hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, fparts), dim3(LT), lds, st, n, h->sv, bt, h->o, k, fparts);
+            hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, 1), dim3(LT), lds, st, n, h->sv, bt, h->o, K, fparts);
+        } else {
+            hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
+            for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
+        }
         hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
         // small batches: the backward chain cut four ways across the planes (32 instead of 8 workgroups per stage at batch 128)
         LSave svb = h->sv;

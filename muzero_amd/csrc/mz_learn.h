@@ -74,6 +74,7 @@ struct LSave {
     float *dxd, *dxp, *dxv, *dxr;    // dL/dh_k from dynamics_k / policy_k / value_k ; dL/du_{k+1} from reward_k   [K][tiles][h_t * 256]
                                      // (dxd: [K][tiles][DX_PARTS][h_t * 256] -- the sliced backward stage leaves one partial per slice)
     int dx_parts;                    // partials the backward stages of this step write and read (1: unsliced)
+    float* up;                       // [K + 1][tiles][DX_PARTS][h_t * 256]: partial u_k (no bias) left by the sliced forward stages
     float* lossp;                    // [3 K][tiles] partial losses (sum over the tile of w * loss)
     long long* stamps;               // diagnostic (tools/dev/learn_stamps.py): cycle stamps of tile 0's workgroups, or nullptr
     int* actc;                       // [K][tiles][16] the batch's actions, gathered once by k_learn_repr (-1: no such sample)
@@ -691,6 +692,113 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
     MZL_STAMP(sb + 6);
     copy_f4(dx_all + blk(step, tiles, tile, net.h_t), lds + o.G, hf, tid);
     MZL_STAMP(sb + 7);
+}
+
+// The forward chain for SMALL batches, cut across the planes like k_learn_back_sliced: workgroup (tile, part) computes its slice of the
+// first layer (one plane tile per wave) and a PARTIAL second layer over that slice; the consumer -- the next stage's workgroups, each
+// for itself -- adds the np partials and the bias, normalises, and goes on.  k == -1: representation net on the observations -> partial
+// u_0; 0 <= k < K: dynamics_k -> partial u_{k+1}; k == K (grid (tiles, 1)): only finishes u_K / h_K for the heads and the backward sweep.
+// Part 0 of every stage also writes the finished u_k / h_k (uc / hc) and the T blocks that are not sliced (x_k, the observation).
+template <bool F>
+__global__ __launch_bounds__(LT) void k_learn_fwd_sliced(LNet net, LSave sv, LBatch bt, LLds o, int k, int np) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = blockIdx.x, tiles = bt.tiles;
+    const int part = blockIdx.y, K = net.K, hf = net.h_t * 64;
+    const int e = tid >> 5, jr = tid & 31, smp = tile * TILE + e;
+    const int l0 = k < 0 ? REP0 : DYN0, l1 = l0 + 1, kg1 = k < 0 ? net.in_t : net.h_t + net.a_t;
+    const int tb = part * net.p_t / np, te = (part + 1) * net.p_t / np;
+    const int ci = tid < hf ? tid : hf - 1;
+    // ---- requests in order of use: the state's partials (+ bias), the action, then both layers' operands of this wave ----
+    float4 us = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int act = -1;
+    const int kk = k < 0 ? 0 : k;
+    {
+        const float* ub = sv.up + blk(kk, tiles, tile, net.h_t) * DX_PARTS;
+#pragma unroll
+        for (int pp = 0; pp < DX_PARTS; pp++) {
+            const float4 v = reinterpret_cast<const float4*>(ub + (size_t)(pp < np ? pp : 0) * net.h_t * 256)[ci];
+            const float m = pp < np ? 1.0f : 0.0f;
+            us = make_float4(us.x + m * v.x, us.y + m * v.y, us.z + m * v.z, us.w + m * v.w);
+        }
+        const float* bsrc = (k <= 0 ? net.L[REP1].b : net.L[DYN1].b) + (ci >> 6) * 16 + ((ci >> 4) & 3) * 4;  // the four features of this float4
+        const float4 bv = *reinterpret_cast<const float4*>(bsrc);
+        us = make_float4(us.x + bv.x, us.y + bv.y, us.z + bv.z, us.w + bv.w);
+        act = sv.actc[((kk < K ? kk : K - 1) * tiles + tile) * TILE + e];
+    }
+    const int row = sample_row(bt, smp);
+    const int t = tb + wave < te ? tb + wave : te - 1;
+    const bool t_ok = tb + wave < te && k < K;
+    const float4* W1 = reinterpret_cast<const float4*>(net.L[l0].wp) + lane;
+    float4 w1[WKG];
+#pragma unroll
+    for (int d = 0; d < WKG; d++) w1[d] = ldg4(W1 + ((size_t)t * kg1 + (d < kg1 ? d : kg1 - 1)) * 64);
+    const float b1 = net.L[l0].b[t * 16 + (lane & 15)];
+    const int kparts = LW / net.h_t, ot = wave % net.h_t, kp = wave / net.h_t;
+    const int nb = (te - tb) / kparts, g0 = tb + kp * nb;
+    const float4* W2 = reinterpret_cast<const float4*>(net.L[l1].wp) + ((size_t)ot * net.p_t) * 64 + lane;
+    float4 w2[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) w2[d] = ldg4(W2 + (size_t)(g0 + (d < nb ? d : nb - 1)) * 64);
+    // ---- the layer input ----
+    if (k < 0) {
+        const bool valid = smp < bt.B;
+        for (int f = jr; f < net.in_t * 16; f += 32) {
+            float v = 0.0f;
+            if (valid && f < net.in_dim)
+                v = bt.state_i8 ? (float)reinterpret_cast<const int8_t*>(bt.state)[(size_t)row * net.in_dim + f]
+                                : reinterpret_cast<const float*>(bt.state)[(size_t)row * net.in_dim + f];
+            lds[o.X + pk(f, e)] = v;
+        }
+        if (part == 0 && jr < K) sv.actc[(jr * tiles + tile) * TILE + e] = valid ? sample_action(bt, row, K, jr) : -1;
+        __syncthreads();
+        if (part == 0) save_T_from_pk(lds + o.X, net.in_t, sv.in_rep + blk(0, tiles, tile, net.in_t), tid);
+    } else {
+        if (tid < hf) reinterpret_cast<float4*>(lds + o.HN)[tid] = us;
+        __syncthreads();
+        normalize_fwd(lds + o.HN, lds + o.X, net.H, net.h_t, tid);  // h_k straight into the layer-input buffer
+        for (int a = jr; a < net.a_t * 16; a += 32) lds[o.X + pk(net.h_t * 16 + a, e)] = a == act ? 1.0f : 0.0f;
+        __syncthreads();
+        if (part == 0) {
+            const size_t cb = blk(k, tiles, tile, net.h_t);
+            copy_f4(sv.uc + cb, lds + o.HN, hf, tid);
+            copy_f4(sv.hc + cb, lds + o.X, hf, tid);
+            if (k < K) save_T_from_pk(lds + o.X, net.h_t + net.a_t, sv.x + blk(k, tiles, tile, net.h_t + net.a_t), tid);
+        }
+        if (k >= K) return;
+    }
+    // ---- first layer: this wave's plane tile ----
+    float* h1b = (k < 0 ? sv.h1_rep : sv.h1_dyn) + blk(kk, tiles, tile, net.p_t);
+    if (t_ok) {
+        const float4* X4 = reinterpret_cast<const float4*>(lds + o.X) + lane;
+        f32x4 a = {b1, b1, b1, b1};
+#pragma unroll
+        for (int d = 0; d < WKG; d++)
+            if (d < kg1) a = mfma4(X4[d * 64], w1[d], a);
+        const f32x4 r = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f)};
+        g_put_T(h1b, t, lane, r);
+        lds_put_T(lds + o.H1, t, lane, r);
+    }
+    __syncthreads();
+    // ---- second layer over the slice: partial u ----
+    {
+        const float4* X4 = reinterpret_cast<const float4*>(lds + o.H1) + lane;
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (d < nb) a = mfma4(X4[(g0 + d) * 64], w2[d], a);
+        reinterpret_cast<float4*>(lds + o.RED)[(kp * net.h_t + ot) * 64 + lane] = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    __syncthreads();
+    if (wave < net.h_t) {
+        f32x4 sacc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < kparts; q++) {
+            const float4 v = reinterpret_cast<const float4*>(lds + o.RED)[(q * net.h_t + wave) * 64 + lane];
+            sacc = sacc + f32x4{v.x, v.y, v.z, v.w};
+        }
+        lds_put_T(lds + o.G, wave, lane, sacc);
+    }
+    __syncthreads();
+    copy_f4(sv.up + blk(k + 1, tiles, tile, net.h_t) * DX_PARTS + (size_t)part * net.h_t * 256, lds + o.G, hf, tid);
 }
 
 // backward sweep, one step of the dynamics chain: k in [0, K) -> dynamics_k; k == -1 -> the representation net

@@ -236,3 +236,30 @@ def test_run_training_drives_the_hip_learner(tmp_path):
     opt = torch.optim.Adam(ref.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
     opt.load_state_dict(ck['optimizer'])
     assert float(opt.state[next(iter(ref.parameters()))]['step']) == 6.0
+
+
+def test_plane_sliced_chains_equal_the_unsliced_stages(monkeypatch):
+    """Small batches run the forward / backward chains cut four ways across the planes (k_learn_fwd_sliced / k_learn_back_sliced: partial
+    second-layer sums added by the consumer stage); MZL_NO_SLICE=1 keeps one workgroup per tile.  Same loss and gradients up to the
+    summation order of the partials."""
+    case = mlp_case('cartpole')
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(11)
+    B = 112
+    tr = _random_batch(rs, B, (4, 5), 2)
+    ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(tr, f))).to(dev) for f in Transition._fields}
+    ring['state'] = ring['state'].reshape(B, -1).contiguous()
+    w = torch.from_numpy(rs.uniform(0.5, 1, B).astype(np.float32)).to(dev)
+    out = []
+    for no_slice in ('0', '1'):
+        if no_slice == '1':
+            monkeypatch.setenv('MZL_NO_SLICE', '1')
+        hl = _hip(build_mlp(case).to(dev), dev, B)
+        loss, prio = hl.grad(ring, None, w, B)
+        out.append((float(loss), prio.cpu().numpy().copy(), hl.grad_flat.cpu().numpy().copy()))
+        hl.close()
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * abs(out[1][0])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-5, atol=1e-5)
+    scale = np.abs(out[1][2]).max()
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-5 * scale
+    assert not np.array_equal(out[0][2], out[1][2])  # (the two paths really are different kernels)
