@@ -340,8 +340,13 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
         h->jobs_tiles = tiles;
     }
     const size_t lds = (size_t)h->lds_bytes;
-    const int fparts = (h->fast && h->back_parts > 1 && tiles * h->back_parts <= 512 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
-    if (h->fast) {
+    // register-resident operands (230 VGPRs: one workgroup per CU) pay for latency-bound small batches; from ~2 k samples on the grid is
+    // several workgroups per CU deep and the streaming builds (60-72 VGPRs, 66 KB of LDS: TWO workgroups per CU, one's loss rows and
+    // barriers under the other's MFMAs) are faster: batch 4096 0.578 -> 0.532 ms, 16384 2.02 -> 1.71 ms (same box)
+    static const int fast_max_tiles = getenv("MZL_FAST_MAX_TILES") ? atoi(getenv("MZL_FAST_MAX_TILES")) : 128;
+    const bool use_fast = h->fast && tiles < fast_max_tiles;
+    const int fparts = (use_fast && h->back_parts > 1 && tiles * h->back_parts <= 512 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
+    if (use_fast) {
         if (fparts > 1) {  // small batches: the forward chain cut across the planes too (k = -1: representation; k = K: finishes u_K)
             for (int k = -1; k < K; k++) hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, fparts), dim3(LT), lds, st, n, h->sv, bt, h->o, k, fparts);
             hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, 1), dim3(LT), lds, st, n, h->sv, bt, h->o, K, fparts);

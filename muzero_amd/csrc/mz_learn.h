@@ -115,6 +115,9 @@ __device__ __forceinline__ f32x4 mfma4(const float4 x, const float4 w, f32x4 acc
 //
 // Many output tiles, short reduction (first layers, and the backward pass through a second layer): output tiles are dealt to the
 // waves round-robin, four per wave.  epi(t, acc): acc[i] = Y[16 t + (lane & 15)][sample 4 (lane >> 4) + i].
+#ifndef MZL_GW
+#define MZL_GW 2
+#endif
 constexpr int WKG = 6;  // reduction blocks the register-resident form holds (dynamics layer 1 of the benchmark nets: 5)
 struct WideW {
     float4 w[WKG][4];
@@ -129,7 +132,9 @@ struct WideW {
 template <int KGM, bool BIAS, bool F>
 __device__ __forceinline__ void wide_load(WideW& W, const float* __restrict__ wp, const float* __restrict__ bias, int nt, int kg, int wave, int lane) {
     static_assert(KGM <= WKG, "register-resident form holds WKG blocks");
-    W.fast = F || (nt <= 4 * LW && kg <= KGM);  // F: the launcher has checked every GEMM of the net (learn_fast_shapes): no generic code in the kernel
+    // F: the launcher has checked every GEMM of the net: register-resident operands, no generic code in the kernel; !F: the streaming
+    // forms (two workgroups per CU under 128 VGPRs), except first layers of at most MZL_GW blocks, which fit that budget too
+    W.fast = F || (KGM <= MZL_GW && nt <= 4 * LW && kg <= KGM);
     if (!W.fast) return;
     const float4* W4 = reinterpret_cast<const float4*>(wp) + lane;
 #pragma unroll
@@ -225,7 +230,7 @@ __device__ __forceinline__ void ks_load(KsW& W, const float* __restrict__ wp, co
     if (!F && 2 * nt > LW) return;
     const int parts = LW / nt;
     if constexpr (BIAS) W.bv = bias[(wave < nt ? wave : 0) * 16 + (lane & 15)];
-    W.fast = F || (kg + parts - 1) / parts <= KSB;  // (uniform over the workgroup: every wave takes the same path)
+    W.fast = F;
     if (!W.fast || wave >= nt * parts) return;
     const int t = wave % nt, part = wave / nt;
     const int g0 = part * kg / parts, g1 = (part + 1) * kg / parts;
