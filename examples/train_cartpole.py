@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--report-every', type=int, default=250)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--eval-episodes', type=int, default=3)
+    ap.add_argument('--eval-every', type=int, default=0, help='also evaluate every N training steps (deterministic episodes on the host env); 0: only at the end')
     ap.add_argument('--out', default='')
     ap.add_argument('--host-assembly', action='store_true', help='assemble (Transition, priority) items on the host instead of the device epilogue')
     ap.add_argument('--learner', choices=('hip', 'graphed', 'eager'), default='hip',
@@ -75,6 +76,23 @@ def main():
     p.selfplay_reset(pl.ENV_CARTPOLE)
     asm = EpisodeAssembler(cfg, args.envs, (4, 5))
 
+    from muzero_amd import mcts
+    from muzero_amd.games import CartPoleEnv
+
+    def evaluate():
+        # deterministic evaluation episodes (pipeline.py:400-488: argmax of the visit counts, no root noise) on the host env
+        net.eval()
+        lengths = []
+        for ep in range(args.eval_episodes):
+            env = CartPoleEnv(4, seed=1000 + ep)
+            obs, done = env.reset(), False
+            while not done:
+                action, *_ = mcts.uct_search(obs, net, dev, cfg, 0.0, env.actions_mask, 1, 1, deterministic=True)
+                obs, _, done, _ = env.step(action)
+            lengths.append(env.steps)
+        return lengths
+
+    evals = []
     steps, t0, last = 0, time.time(), dict(episodes=0, episode_steps=0)
     graphed = None
     log = []
@@ -123,22 +141,14 @@ def main():
                 print(json.dumps(rec), flush=True)
         net.eval()
         p.load_state_dict(net.state_dict())  # actor <- learner (the reference does this every checkpoint_interval steps)
-    # deterministic evaluation episodes (pipeline.py:400-488: argmax of the visit counts, no root noise) on the host env
-    from muzero_amd import mcts
-    from muzero_amd.games import CartPoleEnv
-
-    net.eval()
-    lengths = []
-    for ep in range(args.eval_episodes):
-        env = CartPoleEnv(4, seed=1000 + ep)
-        obs, done = env.reset(), False
-        while not done:
-            action, *_ = mcts.uct_search(obs, net, dev, cfg, 0.0, env.actions_mask, 1, 1, deterministic=True)
-            obs, _, done, _ = env.step(action)
-        lengths.append(env.steps)
+        if args.eval_every and steps < args.train_steps and steps // args.eval_every > (steps - args.updates_per_iter) // args.eval_every:
+            evals.append(dict(train_steps=steps, eval_episode_lengths=evaluate()))
+            print(json.dumps(evals[-1]), flush=True)
+    lengths = evaluate()
+    evals.append(dict(train_steps=steps, eval_episode_lengths=lengths))
     print(json.dumps(dict(eval_episode_lengths=lengths)), flush=True)
     if args.out:
-        json.dump(dict(args=vars(args), log=log, eval_episode_lengths=lengths), open(args.out, 'w'), indent=1)
+        json.dump(dict(args=vars(args), log=log, eval_episode_lengths=lengths, evals=evals), open(args.out, 'w'), indent=1)
 
 
 if __name__ == '__main__':

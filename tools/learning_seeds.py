@@ -17,7 +17,7 @@ def run(seed, steps, extra):
     with tempfile.NamedTemporaryFile(suffix='.json', delete=False) as f:
         out = f.name
     cmd = [sys.executable, os.path.join(REPO, 'examples', 'train_cartpole.py'), '--train-steps', str(steps), '--seed', str(seed), '--report-every', '500',
-           '--eval-episodes', '5', '--out', out] + extra
+           '--eval-episodes', '5', '--eval-every', '1000', '--out', out] + extra
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
     r = json.load(open(out))
     os.unlink(out)
@@ -37,8 +37,11 @@ def main():
         r = run(s, args.train_steps, args.extra)
         logs[s] = r
         to500 = next((x['train_steps'] for x in r['log'] if x['mean_episode_length'] and x['mean_episode_length'] >= 475), None)
+        ev = [(x['train_steps'], sum(x['eval_episode_lengths']) / len(x['eval_episode_lengths'])) for x in r.get('evals', [])]
+        first500 = next((st for st, m in ev if m >= 475), None)
         rows.append(dict(seed=s, eval_episode_lengths=r['eval_episode_lengths'], eval_mean=sum(r['eval_episode_lengths']) / len(r['eval_episode_lengths']),
-                         train_steps_to_selfplay_mean_475=to500, final_selfplay_mean=r['log'][-1]['mean_episode_length'], env_steps=r['log'][-1]['env_steps'],
+                         train_steps_to_selfplay_mean_475=to500, train_steps_to_eval_mean_475=first500, eval_means_every_1000=ev,
+                         evals_at_or_above_475_from_10k=sum(1 for st, m in ev if st >= 10000 and m >= 475), evals_from_10k=sum(1 for st, m in ev if st >= 10000), final_selfplay_mean=r['log'][-1]['mean_episode_length'], env_steps=r['log'][-1]['env_steps'],
                          seconds=r['log'][-1]['seconds'], final_loss=r['log'][-1]['loss']))
         print(json.dumps(rows[-1]), flush=True)
     again = run(seeds[0], args.train_steps, args.extra)
