@@ -318,7 +318,7 @@ def lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=100, warm=20,
     return {'workload': 'LunarLander-shaped: MLP 512/64/31, obs (4, 9), A=4, 50 sims/move, 4096 envs per MI355X, synthetic observations (Box2D absent)',
             'value': world * B * S * steps / elapsed, 'unit': 'sims/s', 'env_steps_per_sec': world * B * steps / elapsed, 'steps': steps, 'warmup': warm,
             'ms_per_step': ms_step, 'n_gpus': world,
-            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, false, 0, true, false> (general action count; env step in its own kernels)',
+            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, false, 4, true, false> (four-action build; env step in its own kernels)',
                          'achieved': flop / (k_ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flop / (k_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          'frac_step': flop / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_move_ms': k_ms, 'flop_per_move': flop}}
 

@@ -115,31 +115,38 @@ static void build_jobs(mz_learner* h) {
 
 static void build_big_jobs(mz_learner* h) {
     h->big.clear();
-    std::vector<DwJob> seen;
-    // the small jobs already enumerate (layer, operands): rebuild 4 x 4 groups from each layer's first job
+    // the small jobs already enumerate (layer, operands): rebuild 4 x 5 tile groups from each layer's first job.  Order: layer, slice, unit,
+    // each (layer, slice) padded to whole workgroups of DWB_WAVES units -- a workgroup's waves share one slice of one layer (mz_learn.h).
+    // A layer of `steps` reduction blocks per tile gets grad_slices * steps / K slices: every workgroup then runs about the same number
+    // of reduction blocks (the representation layers have 1 block per tile, the unrolled layers K).
     const LNet& n = h->net;
     for (int l = 0; l < NLAYER; l++) {
         const DwJob* first = nullptr;
         for (const auto& j : h->jobs)
             if (j.gw == h->P.t[2 * l].off) { first = &j; break; }
         const int row_tiles = n.L[l].nt, col_tiles = (l == DYN0) ? n.h_t + n.a_t : tiles16(n.L[l].k);
+        std::vector<DwBig> units;
         for (int r0 = 0; r0 < row_tiles; r0 += 4)
-            for (int c0 = 0; c0 < col_tiles; c0 += 4) {
+            for (int c0 = 0; c0 < col_tiles;) {
+                const int left = col_tiles - c0, nb = left <= DWB_NB ? left : 4;  // (a 5-tile row stays one unit; longer rows go in fours)
                 DwBig q{};
                 q.a = first->a; q.b = first->b; q.gw = first->gw; q.gb = c0 == 0 ? h->P.t[2 * l + 1].off : -1;
                 q.a_ft = first->a_ft; q.b_ft = first->b_ft;
                 q.a_t0 = r0; q.na = row_tiles - r0 < 4 ? row_tiles - r0 : 4;
-                q.b_t0 = c0; q.nb = col_tiles - c0 < 4 ? col_tiles - c0 : 4;
+                q.b_t0 = c0; q.nb = nb;
                 q.R = first->R; q.n = first->n; q.k = first->k; q.kH = first->kH; q.kHpad = first->kHpad;
-                // one unit per gradient slice for every job.  (Measured and not kept, round 4: units of about equal MFMA count -- fewer,
-                // longer units for the 4 x 1-tile jobs -- made the kernel SLOWER, 173 -> 234 us at batch 4096: a reduction block costs a
-                // unit its eight operand loads whatever its tile count, so the small jobs' units became the long ones.)
-                const int nj = h->cfg.grad_slices;
-                for (int k = 0; k < nj; k++) {
-                    q.slice = k; q.nslices = nj;
-                    h->big.push_back(q);
-                }
+                units.push_back(q);
+                c0 += nb;
             }
+        int nj = (h->cfg.grad_slices * first->R + n.K - 1) / n.K;  // first->R: the layer's reduction blocks per tile (1 or K)
+        nj = nj < 1 ? 1 : (nj > h->cfg.grad_slices ? h->cfg.grad_slices : nj);
+        for (int k = 0; k < nj; k++) {
+            for (auto q : units) {
+                q.slice = k; q.nslices = nj;
+                h->big.push_back(q);
+            }
+            while (h->big.size() % DWB_WAVES) h->big.push_back(DwBig{});  // (na == 0: the wave exits)
+        }
     }
 }
 
@@ -378,7 +385,7 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
                            (size_t)h->P.total);
     if (h->cfg.grad_slices > 1)  // slice 0 <- the complete gradient (what a data-parallel learner all-reduces)
         hipLaunchKernelGGL(k_learn_gradsum, dim3(h->sq_blocks), dim3(256), 0, st, h->grads, (size_t)h->P.total, h->cfg.grad_slices, h->P.total, h->d_sq);
-    hipLaunchKernelGGL(k_learn_finish, dim3(1), dim3(256), 0, st, h->sv.lossp, 3 * K * tiles, b->batch, b->d_loss);
+    hipLaunchKernelGGL(k_learn_finish, dim3(1), dim3(FIN_T), 0, st, h->sv.lossp, 3 * K * tiles, b->batch, b->d_loss);
     HIPCHK(hipGetLastError());
     return MZL_OK;
 }

@@ -1056,75 +1056,85 @@ __global__ __launch_bounds__(LT) void k_learn_dw(const DwJob* __restrict__ jobs,
 
 // The same gradients for LONG reductions (large batches).  There the small-block kernel above is bound by the CU's 64 B / clk of L1
 // bandwidth, not by the MFMA pipes: a wave that owns 1 x 4 tiles loads 5 operand blocks (5 KiB) per 16 MFMAs.  Here a wave owns up to
-// 4 x 4 tiles -- 8 KiB per 64 MFMAs -- runs its whole reduction slice alone (no LDS exchange; the slices of grid.y meet in
-// k_learn_gradsum), and requests the next reduction block's operands before multiplying the current one.  One unit (job, slice) per WAVE.
+// 4 x 5 tiles -- 9 KiB per 80 MFMAs -- runs its whole reduction slice alone (no LDS exchange; the slices meet in k_learn_gradsum), and
+// requests the next reduction block's operands before multiplying the current one.  One unit (tile group, slice) per WAVE, and the
+// eight waves of a workgroup hold the units of ONE layer and ONE slice: together they read every dz and every input block of that slice
+// exactly once from HBM (the operand the units share -- the 4 input tiles of a 512 x 64 layer, the 4 dz tiles of a 64 x 512 layer --
+// comes from L2 for seven of them).  With one unit per wave in layer-mixed workgroups (round 4's first form) the 245 MB of saved
+// activations of a 4096-sample batch crossed the fabric 2.7 times, 3.9 TB/s for the kernel's 166 us: it was memory-bound at 40 % MFMA
+// busy.  The bias gradient (row sums of dz) is accumulated on the vector ALUs under the MFMAs (it was a fifth MFMA column: +25 %).
 struct DwBig {
     const float* a;
     const float* b;
     int gw, gb;
     int a_ft, b_ft;
-    int a_t0, na, b_t0, nb;  // up to 4 x 4 tiles
+    int a_t0, na, b_t0, nb;  // up to 4 x 5 tiles; na == 0: padding unit (the workgroup's layer has fewer than DWB_WAVES units)
     int R, n, k, kH, kHpad;
     int slice, nslices;      // this unit's share of the reduction: blocks [slice R / nslices, (slice + 1) R / nslices), written to gradient
                              // slice `slice` (one unit per job and slice)
 };
-constexpr int DWB_WAVES = 4;
+constexpr int DWB_WAVES = 8, DWB_NB = 5;
 __global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __restrict__ jobs, int njobs, float* __restrict__ grads, size_t grad_stride) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    // units are listed layer by layer; a workgroup takes one from each quarter of the list, so that every workgroup -- all of them are
-    // resident at once, nothing re-balances later -- holds a mix of 4 x 4-tile and 4 x 1-tile units instead of four of a kind
-    const int ji = wave * gridDim.x + blockIdx.x;
+    const int ji = blockIdx.x * DWB_WAVES + wave;
     if (ji >= njobs) return;
     const DwBig J = jobs[ji];
+    if (J.na == 0) return;
     const int r0 = (int)((long long)J.slice * J.R / J.nslices), r1 = (int)((long long)(J.slice + 1) * J.R / J.nslices);
     float* G = grads + (size_t)J.slice * grad_stride;
     const bool bias = J.gb >= 0;
-    f32x4 acc[4][4], accb[4];
+    f32x4 acc[4][DWB_NB];
+    float accb[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        accb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        accb[i] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < DWB_NB; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    const float one = (lane & 15) == 0 ? 1.0f : 0.0f;
-    const float4 ones = make_float4(one, one, one, one);
     const float4* A4 = reinterpret_cast<const float4*>(J.a) + lane;
     const float4* B4 = reinterpret_cast<const float4*>(J.b) + lane;
     // tile offsets inside a block, clamped to the job's real tiles (a clamped tile is loaded, never multiplied)
-    int ao[4], bo[4];
+    int ao[4], bo[DWB_NB];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        ao[i] = (J.a_t0 + (i < J.na ? i : J.na - 1)) * 64;
-        bo[i] = (J.b_t0 + (i < J.nb ? i : J.nb - 1)) * 64;
-    }
-    float4 a[4], b[4], an[4], bn[4];
-    if (r0 < r1) {
+    for (int i = 0; i < 4; i++) ao[i] = (J.a_t0 + (i < J.na ? i : J.na - 1)) * 64;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            a[i] = ldg4(A4 + (size_t)r0 * J.a_ft * 64 + ao[i]);
-            b[i] = ldg4(B4 + (size_t)r0 * J.b_ft * 64 + bo[i]);
-        }
-    }
-    for (int r = r0; r < r1; r++) {
-        const int rn = r + 1 < r1 ? r + 1 : r;
+    for (int i = 0; i < DWB_NB; i++) bo[i] = (J.b_t0 + (i < J.nb ? i : J.nb - 1)) * 64;
+    // three operand sets in rotation: block r is multiplied while r + 1 is landing and r + 2 is requested -- the kernel streams the saved
+    // activations of the whole batch from HBM (0.4 GB at 4096 samples) with 16 waves per CU, and one block ahead left too few bytes in
+    // flight to keep the memory side busy
+    float4 a[3][4], b[3][DWB_NB];
+    auto request = [&](int set, int rr) {
+        const int rc = rr < r1 ? rr : r1 - 1;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            an[i] = ldg4(A4 + (size_t)rn * J.a_ft * 64 + ao[i]);
-            bn[i] = ldg4(B4 + (size_t)rn * J.b_ft * 64 + bo[i]);
-        }
+        for (int i = 0; i < 4; i++) a[set][i] = ldg4(A4 + (size_t)rc * J.a_ft * 64 + ao[i]);
+#pragma unroll
+        for (int i = 0; i < DWB_NB; i++) b[set][i] = ldg4(B4 + (size_t)rc * J.b_ft * 64 + bo[i]);
+    };
+    auto multiply = [&](int set) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (i < J.na) {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (j < J.nb) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
-                if (bias) accb[i] = mfma4(a[i], ones, accb[i]);
+                for (int j = 0; j < DWB_NB; j++)
+                    if (j < J.nb) acc[i][j] = mfma4(a[set][i], b[set][j], acc[i][j]);
+                if (bias) accb[i] = accb[i] + (((a[set][i].x + a[set][i].y) + a[set][i].z) + a[set][i].w);  // this lane's 4 samples of row (lane & 15)
             }
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            a[i] = an[i];
-            b[i] = bn[i];
+    };
+    if (r0 < r1) {
+        request(0, r0);
+        request(1, r0 + 1);
+    }
+    for (int r = r0; r < r1; r += 3) {
+        request(2, r + 2);
+        multiply(0);
+        if (r + 1 < r1) {
+            request(0, r + 3);
+            multiply(1);
+        }
+        if (r + 2 < r1) {
+            request(1, r + 4);
+            multiply(2);
         }
     }
     const int q = lane >> 4, c = lane & 15;
@@ -1132,7 +1142,7 @@ __global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __
     for (int i = 0; i < 4; i++) {
         if (i >= J.na) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < DWB_NB; j++) {
             if (j >= J.nb) continue;
             const int pc = 16 * (J.b_t0 + j) + c;
             const int col = pc < J.kH ? pc : (pc >= J.kHpad ? pc - J.kHpad + J.kH : -1);
@@ -1143,12 +1153,12 @@ __global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __
                 if (row < J.n) G[J.gw + (size_t)row * J.k + col] = acc[i][j][ii];
             }
         }
-        if (bias && c == 0) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ii++) {
-                const int row = 16 * (J.a_t0 + i) + 4 * q + ii;
-                if (row < J.n) G[J.gb + row] = accb[i][ii];
-            }
+        if (bias) {  // the four sample groups of a row sit 16 lanes apart: (g0 + g1) + (g2 + g3)
+            float t = accb[i];
+            t = t + __shfl_xor(t, 16, 64);
+            t = t + __shfl_xor(t, 32, 64);
+            const int row = 16 * (J.a_t0 + i) + c;
+            if (q == 0 && row < J.n) G[J.gb + row] = t;
         }
     }
 }
@@ -1167,15 +1177,21 @@ struct LParams {
     int total;
 };
 
-// loss = mean_i w_i sum_k (reward + value + policy loss) (pipeline.py:594-597); fixed summation order: 256 strided partial
-// sums, then a tree
-__global__ __launch_bounds__(256) void k_learn_finish(const float* __restrict__ lossp, int n, int B, float* __restrict__ loss_out) {
-    __shared__ float sc[256];
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) s += lossp[i];
-    sc[threadIdx.x] = s;
+// loss = mean_i w_i sum_k (reward + value + policy loss) (pipeline.py:594-597); fixed summation order: 1024 strided partial sums (four
+// independent chains per thread: the loads of a chain step are in flight together), then a tree
+constexpr int FIN_T = 1024;
+__global__ __launch_bounds__(FIN_T) void k_learn_finish(const float* __restrict__ lossp, int n, int B, float* __restrict__ loss_out) {
+    __shared__ float sc[FIN_T];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int i = threadIdx.x;
+    for (; i + 3 * FIN_T < n; i += 4 * FIN_T) {
+        const float a = lossp[i], b = lossp[i + FIN_T], c = lossp[i + 2 * FIN_T], d = lossp[i + 3 * FIN_T];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; i < n; i += FIN_T) s0 += lossp[i];
+    sc[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    for (int m = 128; m > 0; m >>= 1) {
+    for (int m = FIN_T / 2; m > 0; m >>= 1) {
         if ((int)threadIdx.x < m) sc[threadIdx.x] += sc[threadIdx.x + m];
         __syncthreads();
     }

@@ -39,7 +39,12 @@ namespace mz {
 // depth of the weight ring: the stream runs RD - 1 slots ahead of the MFMAs (a slot is 4 NT MFMAs = 128 NT cycles).  The loads are
 // not late at any depth tried (num_planes 512: 3 / 4 / 6 within 0.3 %); at num_planes 256 the ten-action build's 16 slots per
 // simulation divide by 4 -- no padding slots -- and 4 deep measures 0.4 % under 3 deep (2 deep: +1.2 %)
-constexpr int fast_rd(int planes) { return planes == 256 ? MZ_FAST_RD256 : MZ_FAST_RD; }
+// The builds that do not know "two actions" keep more of the tree phases' state live across the MFMA phases: at num_planes 512 a ring
+// of 3 x 8 float4 leaves them 6-10 spilled VGPRs (scratch round trips inside the simulation loop); 2 deep they fit.
+#ifndef MZ_FAST_RD_GEN
+#define MZ_FAST_RD_GEN 2
+#endif
+constexpr int fast_rd(int planes, int ac) { return planes == 256 ? MZ_FAST_RD256 : (ac == 2 ? MZ_FAST_RD : MZ_FAST_RD_GEN); }
 #ifndef MZ_FAST_HW
 #define MZ_FAST_HW 1
 #endif
@@ -444,9 +449,10 @@ __device__ __forceinline__ void root_inference_fast(const MlpNet& net, const Mlp
 template <int P, int TR, int TV, bool FUSE = false, int AC = 0, bool HW = false, bool SPB = false>
 __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((amdgpu_waves_per_eu(HW ? 2 : 1, HW ? 2 : 1))) void k_search_fast(const SearchParams Pm, const FastWeights FW) {
     // AC: what the launcher knows about the action count -- 2: exactly two actions, single player, categorical heads (classic control);
-    // 10: exactly ten actions (TicTacToe: the backup's best-child refresh fully unrolled); 0: anything up to 16
+    // 10: exactly ten actions (TicTacToe: the backup's best-child refresh fully unrolled); 4: exactly four actions, categorical heads
+    // (LunarLander's shape: the same unrolled refresh, the action count a constant in the tree phases); 0: anything up to 16
     constexpr bool TWO = AC == 2;
-    constexpr int RD = fast_rd(P);
+    constexpr int RD = fast_rd(P, AC);
     constexpr bool SC = AC == 10 && kFastSC, AX = AC == 10 && kFastAX;  // (the launcher sends only MSE-head nets to the SC build of AC == 10)
     using C = FastCfg<P, SC ? 0 : TR, SC ? 0 : TV, RD, AX ? 4 : 5>;
     constexpr int NT = C::NT;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     {
         MZ_ROOT_TS_START();
         SearchParams Pr = Pm;  // (the action count as a constant where the build knows it, as in the simulation loop)
-        if constexpr (AC == 10) Pr.A = 10;
+        if constexpr (AC == 10 || AC == 4) Pr.A = AC;
         if constexpr (TWO) Pr.A = 2;
         if constexpr (SPB) { Pr.noise_mode = 2; Pr.has_mask = 1; }  // (self-play settings as constants, see the simulation loop)
         if (main_w && env_ok) root_prior_group(smem, Pr, e, a0, env_g);  // (A <= 16 in this kernel)
@@ -527,8 +533,18 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     const int e2 = lane & 15, q = lane >> 4;
     const int env2 = blockIdx.x * TILE_E + e2;
     const bool env2_ok = env2 < Pm.B;
-    float* const hid_sel = Pm.hidden + (size_t)(env_ok ? env_g : 0) * Pm.NN * 64;   // select-side env (tid >> 4)
-    float* const hid_mma = Pm.hidden + (size_t)(env2_ok ? env2 : 0) * Pm.NN * 64;  // MFMA-side env (lane & 15)
+    // (32-bit byte offsets from the uniform base, not pointers: one VGPR each across the simulation loop instead of two -- the two-action
+    // FUSE build spilled the MFMA-side pointer and reloaded it behind a vmcnt(0) every simulation; the launcher checks that the node
+    // store is smaller than 4 GiB)
+#ifdef MZ_EXP_HID64  // (A/B: the pointer form)
+    char* const hid_base = nullptr;
+    const size_t hid_sel = (size_t)(Pm.hidden + (size_t)(env_ok ? env_g : 0) * Pm.NN * 64 + a0 * 4);
+    const size_t hid_mma = (size_t)(Pm.hidden + (size_t)(env2_ok ? env2 : 0) * Pm.NN * 64 + wave * 16 + q * 4);
+#else
+    const unsigned hid_sel = (unsigned)((env_ok ? env_g : 0) * Pm.NN * 64 + a0 * 4) * 4u;                  // select-side env (tid >> 4)
+    const unsigned hid_mma = (unsigned)((env2_ok ? env2 : 0) * Pm.NN * 64 + wave * 16 + q * 4) * 4u;       // MFMA-side env (lane & 15)
+    char* const hid_base = reinterpret_cast<char*>(Pm.hidden);
+#endif
     const float* bias = lds;  // biases live in LDS (stage_biases)
     // SC: this lane's 4 NT weights of each scalar head -- row 0 of the packed second layer, input neurons 16 (NT w + j) + 4 q + i --
     // stay in registers for the whole move
@@ -587,7 +603,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     // (C3 -1.2 %; pinning the LDS table offsets and the node count in registers on top of it -- hipcc re-loads ~30 kernel arguments at
     // the top of every simulation's select -- measured the same)
     SearchParams Pl = Pm;
-    if constexpr (AC == 10) Pl.A = 10;
+    if constexpr (AC == 10 || AC == 4) Pl.A = AC;
     if constexpr (TWO) Pl.A = 2;
     // SPB: the board games' self-play settings as constants too -- two players, known bounds, discount 1 (its products fold away),
     // Dirichlet noise, tie and action draws from the device streams, sampled play over a legal-move mask: the runtime forms of these cost
@@ -629,7 +645,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         if (wave == 3) hw = h3;
         const float4 hs = make_float4((hw[0] - mn) / d, (hw[1] - mn) / d, (hw[2] - mn) / d, (hw[3] - mn) / d);
         reinterpret_cast<float4*>(lds + o.HS)[wave * 64 + lane] = hs;
-        if (env2_ok) *reinterpret_cast<float4*>(hid_mma + (size_t)(s + 1) * 64 + wave * 16 + q * 4) = hs;
+        if (env2_ok) *reinterpret_cast<float4*>(hid_base + (size_t)(hid_mma + (unsigned)(s + 1) * 256u)) = hs;
     };
     constexpr bool MSE = AC == 10;  // the launcher sends only nets with MSE heads (reward / value support 1: TicTacToe's) to the ten-action build
     // un-normalised state h (64 x 16) from the four waves' partial tiles, ((c0 + c1) + c2) + c3, in two stages: wave w sums tile w
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
             h[t] = f32x4{v.x, v.y, v.z, v.w};
         }
     };
-    const bool cat_heads = !MSE && (TWO || (net.Sr != 1 && net.Sv != 1));  // both heads categorical (TWO: guaranteed by the launcher)
+    const bool cat_heads = !MSE && (TWO || AC == 4 || (net.Sr != 1 && net.Sv != 1));  // both heads categorical (TWO, AC == 4: guaranteed by the launcher)
     if (HW && !main_w) {
         // ================= helper waves: the same barriers per simulation as waves 0-3 =================
         for (int s = 0; s < Pm.S; s++) {
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
         {
             float* X = lds + o.X;
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (env_ok) hv = *reinterpret_cast<const float4*>(hid_sel + (size_t)lp * 64 + a0 * 4);
+            if (env_ok) hv = *reinterpret_cast<const float4*>(hid_base + (size_t)(hid_sel + (unsigned)lp * 256u));
             reinterpret_cast<float4*>(X)[(a0 >> 2) * 64 + (a0 & 3) * 16 + e] = hv;  // pk(4 a0 .. 4 a0 + 3, e)
             if constexpr (AX) { if (a0 == 0) reinterpret_cast<int*>(smem + Pm.t_sel)[e * 4 + 1] = env_ok ? la : 0; }
             else X[pk_act(a0, e, 4)] = (a0 == la && a0 < Pm.A) ? 1.0f : 0.0f;

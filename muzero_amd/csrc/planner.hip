@@ -423,11 +423,13 @@ static int planner_init(mz_planner* p, bool conv) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_infer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, p->ip.lds_bytes));
     if (c.hidden_dim == 64 && (c.num_planes == 256 || c.num_planes == 512) && c.num_actions <= 16 && c.value_support_size <= 32 &&
-        c.reward_support_size <= 32 && (c.value_support_size + 15) / 16 == (c.reward_support_size + 15) / 16) {
+        c.reward_support_size <= 32 && (c.value_support_size + 15) / 16 == (c.reward_support_size + 15) / 16 &&
+        (size_t)c.num_envs * (c.num_simulations + 1) * 256 < ((size_t)1 << 32)) {  // (the tuned kernel addresses the node store with 32-bit byte offsets)
         p->fast_planes = c.num_planes;
 #define MZ_FAST_LDS(PL, T, F, W) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<PL, T, T, F, W, kFastHW>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
 #define MZ_FAST_LDS4(PL, T) MZ_FAST_LDS(PL, T, false, 0); MZ_FAST_LDS(PL, T, false, 2); MZ_FAST_LDS(PL, T, true, 0); MZ_FAST_LDS(PL, T, true, 2)
         MZ_FAST_LDS(256, 1, false, 10); MZ_FAST_LDS(256, 1, true, 10);  // ten actions (TicTacToe)
+        MZ_FAST_LDS(512, 2, false, 4); MZ_FAST_LDS(512, 2, true, 4);    // four actions, the classic-control net (LunarLander's shape)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1, false, 10, kFastHW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fast<256, 1, 1, true, 10, kFastHW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
 #ifdef MZ_DEV_SHAPES  // development builds: only the C2 / C3 shapes of the tuned kernel (a third of the compile time)
@@ -508,6 +510,11 @@ static bool fast_ac10(const mz_planner* p) {
     return p->fast_planes == 256 && c.num_actions == 10 && c.value_support_size == 1 && c.reward_support_size == 1;
 }
 
+// the two-action instantiations: two actions, single player, categorical reward and value heads (classic control)
+static bool fast_two_act(const mz_config& c) {
+    return c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
+}
+
 extern "C" int mz_planner_commit_params(mz_planner* p) {
     if (!p) return fail(MZ_E_INVALID, "null planner");
     HIPCHK(hipSetDevice(p->device));
@@ -572,7 +579,7 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
     if (p->fast_planes) {
         // ONE per-wave weight stream in consumption order (layout: mz_search_fast.h header)
         const bool sc = kFastSC && fast_ac10(p), ax = kFastAX && fast_ac10(p);  // (mz_search_fast.h: scalar heads / action column outside the stream)
-        const int NT = p->fast_planes / 64, TR = sc ? 0 : p->net.L[L_REW1].n_tiles, TV = sc ? 0 : p->net.L[L_VAL1].n_tiles, RD = fast_rd(p->fast_planes);
+        const int NT = p->fast_planes / 64, TR = sc ? 0 : p->net.L[L_REW1].n_tiles, TV = sc ? 0 : p->net.L[L_VAL1].n_tiles, RD = fast_rd(p->fast_planes, fast_two_act(p->cfg) ? 2 : 0);
         const int XG = ax ? 4 : 5;
         const int I_D1 = 0, I_D2 = I_D1 + XG, I_R1 = I_D2 + 4, I_R2 = I_R1 + 4, I_V1 = I_R2 + TR, I_V2 = I_V1 + 4, I_END = I_V2 + TV;
         const int SL = (I_END + RD - 1) / RD * RD;
@@ -800,7 +807,10 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
 #define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, 2); else MZ_FAST4(PL, T, true, 0); } \
                             else { if (two_act) MZ_FAST4(PL, T, false, 2); else MZ_FAST4(PL, T, false, 0); } } while (0)
         // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
-        const bool two_act = c.num_actions == 2 && !c.is_board_game && c.reward_support_size > 1 && c.value_support_size > 1;
+        const bool two_act = fast_two_act(c);  // (also fixes the depth of the weight ring the stream is packed for: load_weights)
+        // four actions, categorical heads, the 512-plane net (mz_tree2.h, ACT: the backup's refresh unrolled, the action count a constant)
+        static const bool ac4_on = env_int("MZ_FAST_AC4", 1) != 0;
+        const bool four_act = ac4_on && c.num_actions == 4 && c.reward_support_size > 1 && c.value_support_size > 1 && p->fast_planes == 512 && two;
         if (fast_ac10(p)) {  // (TicTacToe: ten actions)
             // SPB: the build with the board games' self-play settings as compile-time constants (mz_search_fast.h)
             const bool spb = s.board && s.has_bounds && s.discount == 1.0 && s.noise_mode == 2 && s.rng_mode == 1 && !s.deterministic && s.has_mask;
@@ -810,7 +820,8 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
                 else hipLaunchKernelGGL((k_search_fast<256, 1, 1, false, 10, kFastHW, true>), grid, fblock, s.lds_bytes, p->stream, s, p->fw);
             } else if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
         } else
-        if (c.value_support_size == 1 || c.reward_support_size == 1) {
+        if (four_act) { if (fenv) MZ_FAST4(512, 2, true, 4); else MZ_FAST4(512, 2, false, 4); }
+        else if (c.value_support_size == 1 || c.reward_support_size == 1) {
             // an MSE head's one-neuron layer runs on the vector ALUs in its own summation order (mz_mlp.h, scalar_head_tile): of the
             // tuned kernel's builds only the ten-action one has that form
             hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);

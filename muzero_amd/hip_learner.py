@@ -124,8 +124,11 @@ class HipLearner:
         if spec['kind'] != 'mlp':
             raise LearnerError('HipLearner covers MuZeroMLPNet; the conv nets train through muzero_amd.learner.train_step')
         tiles = (max_batch + 15) // 16
-        if grad_slices is None:  # enough workgroup rows to fill the chip once the reduction is long (large batches)
-            grad_slices = 1 if tiles * unroll_steps < 256 else min(64, max(8, tiles * unroll_steps // 40))
+        if grad_slices is None:
+            # long reductions (large batches): the weight-gradient kernel runs one 8-wave workgroup per (layer, slice) -- 8 unrolled layers
+            # with grad_slices slices each, 2 representation layers with grad_slices / K -- and all of them should be resident at once
+            cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
+            grad_slices = 1 if tiles * unroll_steps < 256 else max(2, min(64, int(cus / (8.0 + 2.0 / unroll_steps)), tiles * unroll_steps // 8))
         in_dim = int(np.prod(spec['input_shape']))
         cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], spec['hidden_dim'], spec['value_support_size'], spec['reward_support_size'],
                         unroll_steps, max_batch, grad_slices)
