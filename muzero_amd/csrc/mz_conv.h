@@ -45,6 +45,10 @@ struct ConvLaunch {
     int qstride;                  // LDS floats per channel-slot plane (>= 4 * G * sih * siw, multiple of 64: see the slab layout)
     int B;
     long long* stamps;            // diagnostic builds (-DMZC_STAMPS) only
+    // SP builds (see k_action_sparse below): the <= 9 non-zero action-plane terms of the dynamics net's first conv, added in the epilogue
+    const float* sp_w;            // [A * 9 + 1][cout]: row c * 9 + tap = folded weights of action channel c, last row zeros
+    const int* sp_terms;          // [A][ih * iw][12]: byte offsets of the pixel's nine rows of sp_w in chain order (absent terms: the zero row)
+    const int* sp_action;         // [B]
 };
 
 constexpr int CONV_RK = 2;    // slab positions per thread: G * sih * siw <= 384
@@ -75,8 +79,9 @@ __device__ __forceinline__ int conv_idiv(int p, float rcp_d) { return (int)(((fl
 // per-lane byte offset (ONE VGPR, loop-invariant) + uniform byte offset (SGPR: channel or weight step).  With plain
 // pointers hipcc keeps one 64-bit VGPR address per unrolled load alive across the loop (or emits flat loads that also
 // tick lgkmcnt and serialise against the LDS reads).
-template <int NPT, int NCT, bool WHOLE, int SIDE = 0>
+template <int NPT, int NCT, bool WHOLE, int SIDE = 0, bool SP = false>
 __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const ConvLaunch L_) {
+    static_assert(!SP || WHOLE, "the sparse action terms are fused into whole-image builds only");
     // SIDE > 0: the launch geometry of a whole SIDE x SIDE image per workgroup, 128 output channels, as compile-time constants (the
     // launcher checks every one).  The kernel's index arithmetic is hoisted out of its loops, but with the geometry in kernel
     // arguments it is still ~4 % of a 140 us launch (prologue divisions, per-tap offsets, predicates): C5 0.757 -> 0.785 of the peak.
@@ -136,6 +141,16 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
             w_pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
         }
         for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers
+        if constexpr (SP) {
+            // this workgroup's term rows (12 ints per pixel, per image its action's table) -> LDS behind the slabs; read in the epilogue,
+            // many barriers from here
+            int4* s_term4 = reinterpret_cast<int4*>(slab + 2 * bufsz);
+            const float r_row = 1.0f / (float)(ihw * 3);
+            for (int i = tid; i < L.G * ihw * 3; i += 256) {
+                const int g = conv_idiv(i, r_row), rem = i - g * ihw * 3, cimg = img0 + g < L.B ? img0 + g : L.B - 1;
+                s_term4[i] = reinterpret_cast<const int4*>(L.sp_terms)[(size_t)L.sp_action[cimg] * ihw * 3 + rem];
+            }
+        }
         __syncthreads();
     }
     auto wfetch_real = [&](int cb, int i) {  // channel 4i + wave of block cb, clamped to a valid channel (branch-free)
@@ -365,6 +380,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
     const int ohw = L.oh * L.ow;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(L.out, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.residual ? L.residual : L.out), 0, -1, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_spw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SP ? L.sp_w : L.out), 0, -1, 0x00020000);
     constexpr int EC = NPT < 4 ? NPT : 4;
 #pragma unroll
     for (int c = 0; c < NCT; c++) {
@@ -377,6 +393,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
             unsigned vo[EC][4];
             bool ok[EC][4], vec[EC];
             f32x4 rv[EC];
+            [[maybe_unused]] int tr[EC][4];  // SP: LDS row (12 ints) of the slot's action terms
 #pragma unroll
             for (int e = 0; e < EC; e++) {
                 const int pt = p0 + e < NPT ? p0 + e : NPT - 1;
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
                 for (int r = 0; r < 4; r++) {
                     ok[e][r] = co_ok && (p0 + e < NPT) && (g < L.G) && (img0 + g < L.B) && (ty0 + py < L.oh) && (tx0 + px < L.ow);
                     vo[e][r] = (unsigned)((g * L.cout + co) * ohw + (ty0 + py) * L.ow + tx0 + px) * (unsigned)sizeof(float);
+                    if constexpr (SP) tr[e][r] = ok[e][r] ? (g * ohw + (ty0 + py) * L.ow + tx0 + px) * 12 : 0;
                     px++;
                     if (px == L.tw) { px = 0; py++; }
                     if (py == L.th) { py = 0; g++; }
@@ -405,9 +423,30 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
                 }
 #endif
             }
+            // SP: the nine weights of each of the lane's four pixels, requested one pixel tile ahead of the additions
+            [[maybe_unused]] float spw[2][4][9];
+            [[maybe_unused]] auto sp_request = [&](int e, int buf) {
+                if constexpr (SP) {
+                    const int* s_term = reinterpret_cast<const int*>(slab + 2 * bufsz);
+                    const unsigned cob = (unsigned)(co_ok ? co : 0) * (unsigned)sizeof(float);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int4 t0 = *reinterpret_cast<const int4*>(s_term + tr[e][r]), t1 = *reinterpret_cast<const int4*>(s_term + tr[e][r] + 4),
+                                   t2 = *reinterpret_cast<const int4*>(s_term + tr[e][r] + 8);
+                        const int ks[9] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
+#pragma unroll
+                        for (int t = 0; t < 9; t++)
+                            spw[buf][r][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_spw, (unsigned)ks[t] + cob, 0, 0));
+                    }
+                }
+            };
+            if constexpr (SP) sp_request(0, 0);
 #pragma unroll
             for (int e = 0; e < EC; e++) {
                 if (p0 + e >= NPT) continue;
+                if constexpr (SP) {
+                    if (e + 1 < EC && p0 + e + 1 < NPT) sp_request(e + 1, (e + 1) & 1);
+                }
                 f32x4 v = acc[c][p0 + e];
 #ifdef MZC_NO_EPI
                 if (v[0] != 123.456f) continue;
@@ -415,6 +454,10 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float t = v[r] + rv[e][r];  // (+ 0 without a residual: exact; -0 + 0 = +0 is clamped the same way)
+                    if constexpr (SP) {         // k_action_sparse's order: the stored pre-activation, then the nine terms, then the ReLU
+#pragma unroll
+                        for (int i = 0; i < 9; i++) t = t + spw[e & 1][r][i];
+                    }
                     if (L.relu && !(t > 0.0f)) t = 0.0f;
                     v[r] = t;
                 }

@@ -7,6 +7,7 @@
 // LDS-resident search (mz_search.h: tree_select / tree_expand_backup / root_prior / tree_finish) pointed at a per-block
 // global-memory region with the identical layout, so their parity with the reference carries over.
 #pragma once
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -49,6 +50,10 @@ struct ConvNetDev {
     ConvLayerDev dyn_real;
     float* dyn_act_w = nullptr;
     int dyn_inv_hw = 0;
+    // the same terms for the fused form (k_conv3x3's SP builds): weights transposed to [A * 9 + 1][cout] (last row zeros) and, per
+    // (action, pixel), the byte offsets of the pixel's nine rows in chain order, 12 ints per pixel
+    float* dyn_sp_w = nullptr;
+    int* dyn_sp_terms = nullptr;
     HeadDev reward, policy, value;
     std::vector<void*> allocs;
     // work buffers (dense activations), sized by ensure_buffers
@@ -69,11 +74,20 @@ inline hipError_t dev_upload(ConvNetDev& n, const std::vector<float>& h, float**
     return hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
 }
 
+inline hipError_t dev_upload(ConvNetDev& n, const std::vector<int>& h, int** d) {
+    float* f = nullptr;
+    hipError_t e = hipMalloc(&f, h.size() * sizeof(int));
+    if (e != hipSuccess) return e;
+    n.allocs.push_back(f);
+    *d = reinterpret_cast<int*>(f);
+    return hipMemcpy(f, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+}
+
 // Conv (bias-free) + optional eval-mode BatchNorm folded exactly like the oracle's conv_init: alpha = (1/sqrt(var+eps))*gamma,
 // w' = w*alpha, b' = beta - mean*alpha (float32 operations in that order); weights packed into the MFMA A-fragment order
 // [co_tile][cb][tap][lane][4]:  W'[16t + (lane&15)][cb*16 + 4s + (lane>>4)][tap]
 inline int build_conv(ConvNetDev& n, const ParamMap& pm, const std::string& conv_w, const std::string& bn, int cin, int cin_real, int cout,
-                      int k, int stride, ConvLayerDev* out, std::string* err, int pack_cin = -1, float** tail_w = nullptr) {
+                      int k, int stride, ConvLayerDev* out, std::string* err, int pack_cin = -1, float** tail_w = nullptr, float** tail_wT = nullptr) {
     auto wi = pm.find(conv_w);
     if (wi == pm.end()) { *err = "missing parameter " + conv_w; return -1; }
     const HostTensorRef& W = wi->second;
@@ -112,6 +126,13 @@ inline int build_conv(ConvNetDev& n, const ParamMap& pm, const std::string& conv
                     tw[((size_t)co * nt + c) * taps + tap] = v;
                 }
         if (dev_upload(n, tw, tail_w) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+        if (tail_wT) {  // [nt * taps + 1][cout], row c * taps + tap; the last row stays zero
+            std::vector<float> twt((size_t)(nt * taps + 1) * cout, 0.0f);
+            for (int co = 0; co < cout; co++)
+                for (int c = 0; c < nt; c++)
+                    for (int tap = 0; tap < taps; tap++) twt[((size_t)c * taps + tap) * cout + co] = tw[((size_t)co * nt + c) * taps + tap];
+            if (dev_upload(n, twt, tail_wT) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+        }
     }
     std::vector<float> pw((size_t)co_tiles * n_cb * taps * 256, 0.0f);
     for (int t = 0; t < co_tiles; t++)
@@ -203,11 +224,36 @@ inline int convnet_build(ConvNetDev& n, const ParamMap& pm, std::string* err) {
         n.dyn_inv_hw = 0;
         if ((P & 15) == 0 && gcd(hw, n.A) == 1 && env_int_early("MZ_ACTION_SPARSE", 1)) {
             if ((rc = build_conv(n, pm, "dynamics_net.conv_block.0.weight", "dynamics_net.conv_block.1", P + n.A, P, P, 3, 1, &n.dyn_real, err, P,
-                                 &n.dyn_act_w)))
+                                 &n.dyn_act_w, &n.dyn_sp_w)))
                 return rc;
             for (int i = 1; i < n.A; i++)
                 if ((long long)i * (hw % n.A) % n.A == 1) n.dyn_inv_hw = i;
             if (n.A == 1) n.dyn_inv_hw = 0;
+            if (n.dyn_inv_hw > 0) {
+                // k_action_sparse's term list (key = chain position: 16-channel block, tap, channel in block), for every (action, pixel)
+                std::vector<int> terms((size_t)n.A * hw * 12, 0);
+                const int zero_row = n.A * 9 * P * (int)sizeof(float);
+                for (int a = 0; a < n.A; a++)
+                    for (int p = 0; p < hw; p++) {
+                        int key[9], cnt = 0;
+                        for (int t = 0; t < 9; t++) {
+                            const int y = p / n.hw + t / 3 - 1, x = p % n.hw + t % 3 - 1;
+                            if (y < 0 || y >= n.hh || x < 0 || x >= n.hw) continue;
+                            int d = (a - (y * n.hw + x)) % n.A;
+                            d = d < 0 ? d + n.A : d;
+                            const int c = (int)(((long long)d * n.dyn_inv_hw) % n.A);
+                            key[cnt++] = ((c >> 4) * 9 + t) * 16 + (c & 15);
+                        }
+                        std::sort(key, key + cnt);
+                        int* row = &terms[((size_t)a * hw + p) * 12];
+                        for (int t = 0; t < 12; t++) row[t] = zero_row;
+                        for (int t = 0; t < cnt; t++) {
+                            const int k = key[t], c = (k / 144) * 16 + (k & 15), tap = (k % 144) / 16;
+                            row[t] = (c * 9 + tap) * P * (int)sizeof(float);
+                        }
+                    }
+                if (dev_upload(n, terms, &n.dyn_sp_terms) != hipSuccess) { *err = "hipMalloc/hipMemcpy failed"; return -2; }
+            }
         }
     }
     n.dyn_res.resize(R);
@@ -323,22 +369,22 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
     return g;
 }
 
-template <int NCT, bool WHOLE>
+template <int NCT, bool WHOLE, bool SP = false>
 inline void conv_launch_npt(int npt, dim3 grid, size_t lds, hipStream_t st, const ConvLaunch& L) {
     const dim3 block(256);
     switch (npt) {
-        case 1: hipLaunchKernelGGL((k_conv3x3<1, NCT, WHOLE>), grid, block, lds, st, L); break;
-        case 2: hipLaunchKernelGGL((k_conv3x3<2, NCT, WHOLE>), grid, block, lds, st, L); break;
-        case 3: hipLaunchKernelGGL((k_conv3x3<3, NCT, WHOLE>), grid, block, lds, st, L); break;
-        case 4: hipLaunchKernelGGL((k_conv3x3<4, NCT, WHOLE>), grid, block, lds, st, L); break;
+        case 1: hipLaunchKernelGGL((k_conv3x3<1, NCT, WHOLE, 0, SP>), grid, block, lds, st, L); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<2, NCT, WHOLE, 0, SP>), grid, block, lds, st, L); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<3, NCT, WHOLE, 0, SP>), grid, block, lds, st, L); break;
+        case 4: hipLaunchKernelGGL((k_conv3x3<4, NCT, WHOLE, 0, SP>), grid, block, lds, st, L); break;
         default:
             if constexpr (WHOLE) {
                 switch (npt) {
-                    case 5: hipLaunchKernelGGL((k_conv3x3<5, NCT, true>), grid, block, lds, st, L); break;
-                    case 6: hipLaunchKernelGGL((k_conv3x3<6, NCT, true>), grid, block, lds, st, L); break;
-                    case 9: hipLaunchKernelGGL((k_conv3x3<9, NCT, true>), grid, block, lds, st, L); break;
-                    case 12: hipLaunchKernelGGL((k_conv3x3<12, NCT, true>), grid, block, lds, st, L); break;
-                    default: hipLaunchKernelGGL((k_conv3x3<15, NCT, true>), grid, block, lds, st, L); break;
+                    case 5: hipLaunchKernelGGL((k_conv3x3<5, NCT, true, 0, SP>), grid, block, lds, st, L); break;
+                    case 6: hipLaunchKernelGGL((k_conv3x3<6, NCT, true, 0, SP>), grid, block, lds, st, L); break;
+                    case 9: hipLaunchKernelGGL((k_conv3x3<9, NCT, true, 0, SP>), grid, block, lds, st, L); break;
+                    case 12: hipLaunchKernelGGL((k_conv3x3<12, NCT, true, 0, SP>), grid, block, lds, st, L); break;
+                    default: hipLaunchKernelGGL((k_conv3x3<15, NCT, true, 0, SP>), grid, block, lds, st, L); break;
                 }
             }
             else if (npt == 9) hipLaunchKernelGGL((k_conv3x3<9, NCT, false>), grid, block, lds, st, L);  // 12x12 tiles
@@ -352,8 +398,16 @@ static long long* g_conv_stamps = nullptr;  // diagnostic builds only (tools/mic
 
 // one 3x3 conv launch; input either dense `in` or per-image `in_ptrs`
 // (gathered input: in_base / in_span_floats describe the store the row pointers point into)
-inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float* in, const float* const* in_ptrs, const int* action, int A, int ih,
-                     int iw, const float* residual, float* out, bool relu, const float* in_base = nullptr, size_t in_span_floats = 0) {
+// sparse action terms for the SP builds (null: none); conv_run returns whether it fused them (the caller runs k_action_sparse otherwise)
+struct ConvSparse {
+    const float* w;
+    const int* terms;
+    const int* action;
+};
+
+inline bool conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float* in, const float* const* in_ptrs, const int* action, int A, int ih,
+                     int iw, const float* residual, float* out, bool relu, const float* in_base = nullptr, size_t in_span_floats = 0,
+                     const ConvSparse* sp = nullptr) {
     ConvLaunch L{};
     L.in_ptrs = in_ptrs; L.in = in; L.in_base = in_base; L.action = action; L.num_actions = A > 0 ? A : 1;
     L.cin_real = Lr.cin_real; L.cin = Lr.cin; L.ih = ih; L.iw = iw; L.stride = Lr.stride;
@@ -364,28 +418,41 @@ inline void conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     const ConvGeom g = conv_geometry(B, L.oh, L.ow, Lr.stride, Lr.cout, group_ok);
     L.th = g.th; L.tw = g.tw; L.G = g.G; L.cstride = g.cstride; L.qstride = g.qstride; L.stamps = g_conv_stamps;
     L.tiles_x = (L.ow + L.tw - 1) / L.tw; L.tiles_y = (L.oh + L.th - 1) / L.th;
-    const size_t lds = (size_t)2 * g.cstride * sizeof(float);
+    size_t lds = (size_t)2 * g.cstride * sizeof(float);
     const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));
+    // SP: whole-image builds with one 64-channel slice per workgroup, stride 1; the term rows of the workgroup's images live behind the slabs
+    static const bool sp_on = env_int("MZ_ACTION_FUSE", 1) != 0;
+    const bool fuse = sp && sp_on && g.whole && g.nct == 1 && L.stride == 1 && L.oh == L.ih && L.ow == L.iw &&
+                      lds + (size_t)g.G * ih * iw * 48 <= 64 * 1024;
+    if (fuse) {
+        L.sp_w = sp->w; L.sp_terms = sp->terms; L.sp_action = sp->action;
+        lds += (size_t)g.G * ih * iw * 48;
+    } else if (sp) {
+        L.relu = 0;  // k_action_sparse reads the pre-activation and applies the ReLU after its additions
+    }
     // shape-specialised builds (mz_conv.h, SIDE): a whole 15x15 image per workgroup, 128 output channels (Gomoku's towers)
     static const bool spec_ok = env_int("MZ_CONV_SPEC", 1) != 0;
     if (spec_ok && g.whole && g.nct == 1 && g.npt == 15 && g.G == 1 && L.stride == 1 && L.ih == 15 && L.iw == 15 && L.oh == 15 && L.ow == 15 &&
         Lr.cout == 128 && L.tiles_x == 1 && L.tiles_y == 1 && g.qstride == (((15 + 2) * (15 + 2) * 4 + 63) & ~63) && g.cstride == 4 * g.qstride) {
-        hipLaunchKernelGGL((k_conv3x3<15, 1, true, 15>), grid, dim3(256), lds, st, L);
-        return;
+        if (fuse) hipLaunchKernelGGL((k_conv3x3<15, 1, true, 15, true>), grid, dim3(256), lds, st, L);
+        else hipLaunchKernelGGL((k_conv3x3<15, 1, true, 15>), grid, dim3(256), lds, st, L);
+        return fuse;
     }
     if (spec_ok && !g.whole && g.nct == 2 && g.G == 1 && L.stride == 1 && Lr.cout == 128 && L.ih == L.oh && L.iw == L.ow && L.oh == L.ow && g.th == 12 &&
         L.tiles_x == L.ow / g.tw && L.tiles_y == L.oh / 12 && g.qstride == ((14 * (g.tw + 2) * 4 + 63) & ~63) && g.cstride == 4 * g.qstride) {
         // the Atari representation's 48 x 48 (12 x 16 tiles) and 24 x 24 (12 x 12 tiles) layers
-        if (L.oh == 48 && g.tw == 16 && g.npt == 12) { hipLaunchKernelGGL((k_conv3x3<12, 2, false, 48>), grid, dim3(256), lds, st, L); return; }
-        if (L.oh == 24 && g.tw == 12 && g.npt == 9) { hipLaunchKernelGGL((k_conv3x3<9, 2, false, 24>), grid, dim3(256), lds, st, L); return; }
+        if (L.oh == 48 && g.tw == 16 && g.npt == 12) { hipLaunchKernelGGL((k_conv3x3<12, 2, false, 48>), grid, dim3(256), lds, st, L); return false; }
+        if (L.oh == 24 && g.tw == 12 && g.npt == 9) { hipLaunchKernelGGL((k_conv3x3<9, 2, false, 24>), grid, dim3(256), lds, st, L); return false; }
     }
     if (g.whole) {
-        if (g.nct == 2) conv_launch_npt<2, true>(g.npt, grid, lds, st, L);
+        if (fuse) conv_launch_npt<1, true, true>(g.npt, grid, lds, st, L);
+        else if (g.nct == 2) conv_launch_npt<2, true>(g.npt, grid, lds, st, L);
         else conv_launch_npt<1, true>(g.npt, grid, lds, st, L);
     } else {
         if (g.nct == 2) conv_launch_npt<2, false>(g.npt, grid, lds, st, L);
         else conv_launch_npt<1, false>(g.npt, grid, lds, st, L);
     }
+    return fuse;
 }
 
 // Geometry of the fused LDS-resident tower (mz_tower.h) for a P-channel tower on h x w images, or npt == 0 if it does not apply
@@ -537,11 +604,16 @@ inline void convnet_recurrent(hipStream_t st, ConvNetDev& n, int B, const float*
                               size_t store_floats = 0) {
     const int h = n.hh, w = n.hw, hw = h * w;
     if (n.dyn_inv_hw > 0) {  // board games: dense part over the real channels, then the <= 9 non-zero action-plane terms per output
-        static const int dbg = env_int("MZ_DBG_SPARSE", 0);
-        if (dbg != 2) conv_run(st, n.dyn_real, B, src_dense, src_ptrs, nullptr, 0, h, w, nullptr, n.bufA, false, store_base, store_floats);
-        ActionSparseLaunch S{};
-        S.x = n.bufA; S.action = action; S.w = n.dyn_act_w; S.B = B; S.cout = n.P; S.h = h; S.w_img = w; S.A = n.A; S.inv_hw = n.dyn_inv_hw;
-        if (dbg != 1) hipLaunchKernelGGL(k_action_sparse, dim3((hw + 15) / 16, B), dim3(256), 0, st, S);
+        // the action terms ride in the conv's epilogue where a build for the geometry exists (bit-identical: the same additions in the same
+        // order on the accumulator instead of on the stored value), else k_action_sparse adds them in place
+        const ConvSparse sp{n.dyn_sp_w, n.dyn_sp_terms, action};
+        const bool fused = conv_run(st, n.dyn_real, B, src_dense, src_ptrs, nullptr, 0, h, w, nullptr, n.bufA, true, store_base, store_floats,
+                                    n.dyn_sp_terms ? &sp : nullptr);
+        if (!fused) {
+            ActionSparseLaunch S{};
+            S.x = n.bufA; S.action = action; S.w = n.dyn_act_w; S.B = B; S.cout = n.P; S.h = h; S.w_img = w; S.A = n.A; S.inv_hw = n.dyn_inv_hw;
+            hipLaunchKernelGGL(k_action_sparse, dim3((hw + 15) / 16, B), dim3(256), 0, st, S);
+        }
     } else {
         conv_run(st, n.dyn_conv, B, src_dense, src_ptrs, action, n.A, h, w, nullptr, n.bufA, true, store_base, store_floats);
     }

@@ -524,7 +524,7 @@ extern "C" int mz_planner_commit_params(mz_planner* p) {
         fresh.allocs.clear(); fresh.rep_res.clear(); fresh.dyn_res.clear(); fresh.pred_res.clear();
         fresh.bufA = fresh.bufB = fresh.bufC = nullptr; fresh.buf_elems = 0;
         fresh.tw_rep = fresh.tb_rep = fresh.tw_dyn = fresh.tb_dyn = fresh.tw_pred = fresh.tb_pred = nullptr;
-        fresh.dyn_act_w = nullptr; fresh.dyn_inv_hw = 0;
+        fresh.dyn_act_w = nullptr; fresh.dyn_inv_hw = 0; fresh.dyn_sp_w = nullptr; fresh.dyn_sp_terms = nullptr;
         convnet_free(p->cnet);
         p->cnet = fresh;
         ParamMap pm;

@@ -144,10 +144,18 @@ def test_conv_search_matches_reference_fixture_and_oracle(oracle, g):
         assert abs(r['root_value'][0] - rv) <= 1e-4 * max(1.0, abs(rv))
 
 
-@pytest.mark.parametrize('g,B,S', [('board3', 40, 25), ('board5', 21, 20), ('board9', 18, 12), ('atari_s', 6, 8)])
+# board nets whose plane count is a multiple of 16 (like the full-size ones): the dynamics net's action planes then run as <= 9 sparse terms
+# per output, fused into the first conv's epilogue (mz_conv.h, SP builds) -- one image per workgroup (board11) and several (board7w, board3)
+EXTRA_BOARD = {
+    'board7w': ('board7w', 'board', (5, 7, 7), 50, 1, 16, 1, 1, 26),
+    'board11': ('board11', 'board', (3, 11, 11), 122, 1, 32, 1, 1, 27),
+}
+
+
+@pytest.mark.parametrize('g,B,S', [('board3', 40, 25), ('board5', 21, 20), ('board9', 18, 12), ('atari_s', 6, 8), ('board7w', 19, 10), ('board11', 9, 8)])
 def test_conv_batched_search_bit_exact_vs_oracle(oracle, g, B, S):
     """Lock-step envs with random injected draws: every env equals an independent oracle search."""
-    case = conv_case(g)
+    case = EXTRA_BOARD.get(g) or conv_case(g)
     net = build_conv(case)
     onet = _oracle_net(oracle, net, 'conv')
     A = case[3]
@@ -174,6 +182,20 @@ def test_conv_batched_search_bit_exact_vs_oracle(oracle, g, B, S):
         np.testing.assert_array_equal(r['pi'], o['pi'])
         np.testing.assert_array_equal(r['action'], o['action'])
         np.testing.assert_array_equal(r['root_value'], o['root_value'])
+
+
+def test_conv_parity_with_separate_action_kernel():
+    """The same oracle comparisons with the action terms added by their own kernel (MZ_ACTION_FUSE=0: the path for geometries without a
+    fused build) -- both forms are bit-identical to the oracle, hence to each other.  The switch is read once per process: child pytest."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MZ_ACTION_FUSE='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                        'batched_search_bit_exact and (board3 or board7w or board11)'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert '3 passed' in r.stdout, r.stdout[-1000:]
 
 
 def test_conv_network_api_runs_on_planner(oracle):
