@@ -42,6 +42,8 @@ struct mz_learner {
     std::string names[2 * NLAYER];
     int tiles_cap = 0;
     int lds_bytes = 0;
+    LLds o_heads{};   // LDS layout / bytes of the heads-only launch (streaming form)
+    int lds_heads = 0;
     std::vector<void*> allocs;
     DwJob* d_jobs = nullptr;
     DwBig* d_big = nullptr;     // one job per wave, up to 4 x 4 tiles: long reductions (k_learn_dw_big)
@@ -212,6 +214,22 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     o.MISC = f; f += 64;
     o.total = f;
     h->lds_bytes = f * 4;
+    {   // the heads' launch of the streaming form: only the blocks a head role touches (three workgroups per CU fit at 512 planes)
+        LLds& q = h->o_heads;
+        q = o;
+        int g = 0;
+        q.X = g; g += n.h_t * 256;
+        q.H1 = g; g += n.p_t * 256;
+        q.DZ = q.H1;
+        q.G = g; g += n.h_t * 256;
+        q.LG = g; g += (16 * n.lgs + 3) & ~3;
+        q.DL = g; g += smax * 256;
+        q.RED = g; g += LW * 256;
+        q.MISC = g; g += 64;
+        q.HN = q.HS = q.R = 0;  // (never addressed by a head role)
+        q.total = g;
+        h->lds_heads = g * 4;
+    }
     if (h->lds_bytes > 160 * 1024) return cleanup(fail(MZL_E_INVALID, "network needs " + std::to_string(h->lds_bytes) + " bytes of LDS per workgroup (> 160 KiB)"));
     // saved tensors and chain tensors
     const int tiles = tiles16(cfg->max_batch), K = n.K;
@@ -250,7 +268,8 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     hipError_t e = hipSuccess;
     const void* stage_kernels[] = {(const void*)&k_learn_repr<true>,   (const void*)&k_learn_repr<false>, (const void*)&k_learn_unroll<true>,
                                    (const void*)&k_learn_unroll<false>, (const void*)&k_learn_back<true>,  (const void*)&k_learn_back<false>,
-                                   (const void*)&k_learn_back_sliced<true>, (const void*)&k_learn_fwd_sliced<true>};
+                                   (const void*)&k_learn_back_sliced<true>, (const void*)&k_learn_fwd_sliced<true>,
+                                   (const void*)&k_learn_unroll<false, 3>};
     for (const void* f : stage_kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_learn_dw), hipFuncAttributeMaxDynamicSharedMemorySize, LW * 8 * 256 * 4);
@@ -372,7 +391,10 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     } else {
         hipLaunchKernelGGL(k_learn_repr<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
         for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
-        hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
+        static const bool heads3_on = !getenv("MZL_NO_HEADS3");
+        const bool heads3 = heads3_on && n.p_t <= 4 * LW && n.a_t <= 2 && n.sv_t <= 2 && n.sr_t <= 2 && 3 * (h->lds_heads + 512) <= 160 * 1024;
+        if (heads3) hipLaunchKernelGGL((k_learn_unroll<false, 3>), dim3(tiles, 3, K), dim3(LT), (size_t)h->lds_heads, st, n, h->sv, bt, h->o_heads, 0, 1);
+        else hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
         for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
     }
     // long reductions (grad_slices > 1 is the caller's statement that the batch is large): 4 x 4 tiles per wave, the slices carry the

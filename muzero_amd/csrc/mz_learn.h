@@ -31,6 +31,8 @@
 // Summation orders are this file's own (fp32 throughout); parity with the reference is by tolerance (tests/test_gpu_hip_learner.py:
 // loss 1e-4, gradients 2e-3 relative, three optimizer steps), not bit-exactness -- the reference's own CPU GEMM order is unpinned.
 #pragma once
+#include <type_traits>
+
 #include "mz_device.h"
 
 namespace mzl {
@@ -101,6 +103,15 @@ __device__ __forceinline__ float4 ldg4(const float4* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// the same load through a pointer that was itself LOADED from memory (the job tables of the weight-gradient kernels): the compiler
+// cannot tell its address space and emits flat_load, which ticks lgkmcnt as well and drains out of order -- every wait becomes
+// vmcnt(0) lgkmcnt(0).  An explicit global pointer keeps them counted vector-memory loads (k_learn_dw_big: -0.7 % at batch 16384).
+__device__ __forceinline__ float4 ldg4g(const float4* p) {
+    typedef const __attribute__((address_space(1))) f32x4* gptr_t;
+    const f32x4 v = *(gptr_t)(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ f32x4 mfma4(const float4 x, const float4 w, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc, 0, 0, 0);
@@ -160,7 +171,7 @@ struct KsW {
     float bv;  // bias of the tile this wave finishes (waves 0 .. nt-1), requested with the weights
     bool fast;
 };
-template <bool F, int KGM, typename Epi, typename Pf>
+template <bool F, int KGM, bool LEAN = false, typename Epi, typename Pf>
 __device__ __forceinline__ void wide_mma(const WideW& W, const float* __restrict__ wp, const float* __restrict__ bias, int nt, int kg, const float* Xs,
                                          int wave, int lane, Epi epi, Pf) {
     const float4* X4 = reinterpret_cast<const float4*>(Xs) + lane;
@@ -182,6 +193,31 @@ __device__ __forceinline__ void wide_mma(const WideW& W, const float* __restrict
         return;
     }
     const float4* W4 = reinterpret_cast<const float4*>(wp) + lane;
+    if constexpr (LEAN) {  // six waves per SIMD: the other waves cover the loads; one block of weights in registers, not two
+        for (int t0 = wave; t0 < nt; t0 += 4 * LW) {
+            f32x4 acc[4];
+            unsigned wo[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int t = t0 + j * LW, tc = t < nt ? t : nt - 1;
+                const float bv = bias ? bias[tc * 16 + (lane & 15)] : 0.0f;
+                acc[j] = f32x4{bv, bv, bv, bv};
+                wo[j] = (unsigned)(tc * kg * 64);
+            }
+            for (int g = 0; g < kg; g++) {
+                float4 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) w[j] = ldg4(W4 + wo[j] + g * 64);
+                const float4 x = X4[g * 64];
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = mfma4(x, w[j], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (t0 + j * LW < nt) epi(t0 + j * LW, acc[j]);
+        }
+        return;
+    }
     for (int t0 = wave; t0 < nt; t0 += 4 * LW) {  // any shape: groups of four tiles, weights one block ahead
         f32x4 acc[4];
         const float4* wb[4];
@@ -562,8 +598,10 @@ __global__ __launch_bounds__(LT) void k_learn_repr(LNet net, LSave sv, LBatch bt
 }
 
 // one unroll step of the forward sweep (pipeline.py:579-592); see the header for the roles
-template <bool F>
-__global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch bt, LLds o, int k0, int role0) {
+// OCC: workgroups per CU the build is compiled for (launch bound: OCC x LW / 4 waves per SIMD).  3 (streaming form, heads only): the heads need 53 KB of LDS (LLds without the
+// dynamics role's blocks, learner.hip) and 80 VGPRs -- a third co-resident workgroup's MFMAs under the others' barriers and loss rows
+template <bool F, int OCC = 1>
+__global__ __launch_bounds__(LT, OCC * LW / 4) void k_learn_unroll(LNet net, LSave sv, LBatch bt, LLds o, int k0, int role0) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = blockIdx.x, tiles = bt.tiles;
     // grid (tiles, roles, steps): role = role0 + blockIdx.y; the launch's step index blockIdx.z addresses h_k for the dynamics / policy / value
@@ -573,7 +611,7 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
     const int e = tid >> 5, j = tid & 31, s = tile * TILE + e;
     WideW w1;
     KsW w2;
-    if (role == 0) {
+    if (OCC != 3 && role == 0) {  // (the heads-only build carries no dynamics code)
         if (k >= K) return;
         MZL_STAMP(0);
         const float* hsrc = sv.hc + blk(k, tiles, tile, net.h_t);
@@ -641,7 +679,7 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
 #pragma unroll
     for (int i = 0; i < 4; i++) h1k[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const bool keep = F || w1.fast;
-    wide_mma<F, 4>(w1, net.L[l0].wp, net.L[l0].b, net.p_t, net.h_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
+    wide_mma<F, 4, OCC == 3>(w1, net.L[l0].wp, net.L[l0].b, net.p_t, net.h_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
         const f32x4 r = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f)};
         g_put_T(h1b, t, lane, r);
         lds_put_T(lds + o.H1, t, lane, r);
@@ -656,7 +694,7 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
     MZL_STAMP(sb + 10);
     __syncthreads();
     MZL_STAMP(sb + 2);
-    wide_load<2, false, F>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, wave, lane);  // the backward pass's operands, one phase ahead
+    if constexpr (OCC != 3) wide_load<2, false, F>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, wave, lane);  // the backward pass's operands, one phase ahead
     ks_mma<F>(w2, net.L[l1].wp, net.L[l1].b, s_t, net.p_t, lds + o.H1, lds + o.RED, wave, lane, [&](int t, f32x4 a) {
         const int f = lane & 15, sq = lane >> 4;
 #pragma unroll
@@ -664,6 +702,8 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
     }, NoPf{});
     __syncthreads();
     MZL_STAMP(sb + 3);
+    if constexpr (OCC == 3) wide_load<2, false, true>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, wave, lane);  // (80-VGPR build: behind the streamed GEMM, under the
+                                                                                                          // loss rows; register form: the launcher checks p_t <= 4 LW, s_t <= 2)
     ks_load<false, F>(w2, net.L[l0].wtp, nullptr, net.h_t, net.p_t, wave, lane);
     {
         const float scale = w / ((float)bt.B * (float)K);
@@ -677,7 +717,7 @@ __global__ __launch_bounds__(LT) void k_learn_unroll(LNet net, LSave sv, LBatch 
     save_T_from_pk(lds + o.DL, s_t, dz1_all + blk(step, tiles, tile, s_t), tid);
     float* dzb = dz0_all + blk(step, tiles, tile, net.p_t);
     const bool kept = F || (keep && w1.fast);
-    wide_mma<F, 2>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, lds + o.DL, wave, lane, [&](int t, f32x4 a) {
+    wide_mma<F || OCC == 3, 2>(w1, net.L[l1].wtp, nullptr, net.p_t, s_t, lds + o.DL, wave, lane, [&](int t, f32x4 a) {
         f32x4 h;
         if (kept) {
             const int jj = (t - wave) / LW;
@@ -1074,6 +1114,10 @@ struct DwBig {
                              // slice `slice` (one unit per job and slice)
 };
 constexpr int DWB_WAVES = 8, DWB_NB = 5;
+// (Measured and not kept, round 4: the reduction loop instantiated per tile-group shape (NA x NB compile-time, no clamped loads, no guards)
+// with the block's MFMAs issued component by component across the accumulators instead of four dependent k-steps per accumulator --
+// 130 -> 158 us at batch 4096 whichever way the MFMAs were ordered: twenty loop bodies in one kernel and the register moves of their
+// operand rotation cost more than the clamped loads and the 40-cycle dependent issue they remove.)
 __global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __restrict__ jobs, int njobs, float* __restrict__ grads, size_t grad_stride) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int ji = blockIdx.x * DWB_WAVES + wave;
@@ -1106,9 +1150,9 @@ __global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __
     auto request = [&](int set, int rr) {
         const int rc = rr < r1 ? rr : r1 - 1;
 #pragma unroll
-        for (int i = 0; i < 4; i++) a[set][i] = ldg4(A4 + (size_t)rc * J.a_ft * 64 + ao[i]);
+        for (int i = 0; i < 4; i++) a[set][i] = ldg4g(A4 + (size_t)rc * J.a_ft * 64 + ao[i]);
 #pragma unroll
-        for (int i = 0; i < DWB_NB; i++) b[set][i] = ldg4(B4 + (size_t)rc * J.b_ft * 64 + bo[i]);
+        for (int i = 0; i < DWB_NB; i++) b[set][i] = ldg4g(B4 + (size_t)rc * J.b_ft * 64 + bo[i]);
     };
     auto multiply = [&](int set) {
 #pragma unroll

@@ -43,10 +43,14 @@ def main():
     ap.add_argument('--batches', default='128,1024,4096,16384')
     ap.add_argument('--no-torch', action='store_true')
     ap.add_argument('--iters', type=int, default=200)
+    ap.add_argument('--lib', default=None, help='diagnostic A/B: another build of the learner library')
     args = ap.parse_args()
     from muzero_amd import learner
     from muzero_amd.config import make_classic_config
+    from muzero_amd import hip_learner
     from muzero_amd.hip_learner import HipLearner
+    if args.lib:
+        hip_learner.LIB_PATH = os.path.abspath(args.lib)
     from muzero_amd.network import MuZeroMLPNet
     from muzero_amd.replay import Transition
 
