@@ -366,13 +366,20 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
         h->jobs_tiles = tiles;
     }
     const size_t lds = (size_t)h->lds_bytes;
-    // register-resident operands (230 VGPRs: one workgroup per CU) pay for latency-bound small batches; from ~2 k samples on the grid is
-    // several workgroups per CU deep and the streaming builds (60-72 VGPRs, 66 KB of LDS: TWO workgroups per CU, one's loss rows and
-    // barriers under the other's MFMAs) are faster: batch 4096 0.578 -> 0.532 ms, 16384 2.02 -> 1.71 ms (same box)
-    static const int fast_max_tiles = getenv("MZL_FAST_MAX_TILES") ? atoi(getenv("MZL_FAST_MAX_TILES")) : 128;
-    const bool use_fast = h->fast && tiles < fast_max_tiles;
-    const int fparts = (use_fast && h->back_parts > 1 && tiles * h->back_parts <= 512 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
-    if (use_fast) {
+    // register-resident operands (230 VGPRs: one workgroup per CU) pay for latency-bound grids of at most one workgroup per CU; deeper
+    // grids run the streaming builds (60-94 VGPRs: two workgroups per CU, the heads-only build three -- one's loss rows and barriers under
+    // the others' MFMAs).  The heads' grid is 15 x tiles: with the three-per-CU build the streaming form wins from 16 tiles on
+    // (batch 512: 0.153 -> 0.146 ms, 1024: 0.202 -> 0.188, 2000: 0.317 -> 0.287; with two per CU it only won from ~2 k samples)
+    static const int fast_max_tiles = getenv("MZL_FAST_MAX_TILES") ? atoi(getenv("MZL_FAST_MAX_TILES")) : 16;
+    // The CHAIN stages (representation, dynamics_k, their backward stages) are grid (tiles): up to one workgroup per CU they are latency
+    // chains whatever the build, and the register-resident form is the shorter chain; the heads' grid is 15 x tiles deep, so they switch
+    // to the streaming builds (two or three workgroups per CU) much earlier.
+    static const int chain_max_tiles = getenv("MZL_CHAIN_FAST_MAX_TILES") ? atoi(getenv("MZL_CHAIN_FAST_MAX_TILES")) : 256;
+    const bool fast_heads = h->fast && tiles < fast_max_tiles;
+    const bool fast_chain = h->fast && (fast_heads || tiles <= chain_max_tiles);
+    const int fparts = (fast_chain && h->back_parts > 1 && tiles * h->back_parts <= 512 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
+    // forward chain
+    if (fast_chain) {
         if (fparts > 1) {  // small batches: the forward chain cut across the planes too (k = -1: representation; k = K: finishes u_K)
             for (int k = -1; k < K; k++) hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, fparts), dim3(LT), lds, st, n, h->sv, bt, h->o, k, fparts);
             hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, 1), dim3(LT), lds, st, n, h->sv, bt, h->o, K, fparts);
@@ -380,7 +387,21 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
             hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
             for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
         }
+    } else {
+        hipLaunchKernelGGL(k_learn_repr<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
+        for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
+    }
+    // heads: forward + loss + backward of the three heads of every step
+    if (fast_heads) {
         hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
+    } else {
+        static const bool heads3_on = !getenv("MZL_NO_HEADS3");
+        const bool heads3 = heads3_on && n.p_t <= 4 * LW && n.a_t <= 2 && n.sv_t <= 2 && n.sr_t <= 2 && 3 * (h->lds_heads + 512) <= 160 * 1024;
+        if (heads3) hipLaunchKernelGGL((k_learn_unroll<false, 3>), dim3(tiles, 3, K), dim3(LT), (size_t)h->lds_heads, st, n, h->sv, bt, h->o_heads, 0, 1);
+        else hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
+    }
+    // backward chain
+    if (fast_chain) {
         // small batches: the backward chain cut four ways across the planes (32 instead of 8 workgroups per stage at batch 128)
         LSave svb = h->sv;
         svb.dx_parts = (h->back_parts > 1 && tiles * h->back_parts <= 512) ? h->back_parts : 1;
@@ -389,12 +410,6 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
         else
             for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<true>, dim3(tiles), dim3(LT), lds, st, n, svb, bt, h->o, k);
     } else {
-        hipLaunchKernelGGL(k_learn_repr<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
-        for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
-        static const bool heads3_on = !getenv("MZL_NO_HEADS3");
-        const bool heads3 = heads3_on && n.p_t <= 4 * LW && n.a_t <= 2 && n.sv_t <= 2 && n.sr_t <= 2 && 3 * (h->lds_heads + 512) <= 160 * 1024;
-        if (heads3) hipLaunchKernelGGL((k_learn_unroll<false, 3>), dim3(tiles, 3, K), dim3(LT), (size_t)h->lds_heads, st, n, h->sv, bt, h->o_heads, 0, 1);
-        else hipLaunchKernelGGL(k_learn_unroll<false>, dim3(tiles, 3, K), dim3(LT), lds, st, n, h->sv, bt, h->o, 0, 1);
         for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
     }
     // long reductions (grad_slices > 1 is the caller's statement that the batch is large): 4 x 4 tiles per wave, the slices carry the
