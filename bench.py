@@ -143,7 +143,7 @@ def conv_cpu_baseline(name, case, net, kw, full_sims):
                        f'{t_root:.2f} s per root inference per thread; rate of whole {full_sims}-simulation moves')
 
 
-DOMINANT = {'c3': 'k_search_fast<256', 'c4': 'k_res_tower<', 'c5': 'k_conv3x3<15'}  # dominant kernel of each workload (substring of its rocprof name)
+DOMINANT = {'c3': 'k_search_fast<256', 'c4': 'k_res_tower<', 'c5': 'k_conv3x3<15, 1, true, 15, false>'}  # dominant kernel of each workload (substring of its rocprof name)
 
 
 def measure_workload(args, name, rank, local_rank, world, torch, dist, red_dev, steps, warmup, preheat, with_cpu, with_sustained):
@@ -315,12 +315,14 @@ def lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=100, warm=20,
     flop = B * (S * f_sim + f_root)
     k_ms = prof['search_kernel_ms'] / max(1, prof['search_kernel_launches'])
     ms_step = 1e3 * elapsed / steps
+    traffic, traffic_src = profiled_traffic('lunar', 'k_search_fast<512')
     return {'workload': 'LunarLander-shaped: MLP 512/64/31, obs (4, 9), A=4, 50 sims/move, 4096 envs per MI355X, synthetic observations (Box2D absent)',
             'value': world * B * S * steps / elapsed, 'unit': 'sims/s', 'env_steps_per_sec': world * B * steps / elapsed, 'steps': steps, 'warmup': warm,
             'ms_per_step': ms_step, 'n_gpus': world,
             'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, false, 4, true, false> (four-action build; env step in its own kernels)',
                          'achieved': flop / (k_ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flop / (k_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         'frac_step': flop / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'avg_move_ms': k_ms, 'flop_per_move': flop}}
+                         'frac_step': flop / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'avg_move_ms': k_ms, 'flop_per_move': flop}}
 
 
 def learner_leg(rank, local_rank, world, torch, dist, backend, batches=(128, 4096), iters=100):

@@ -534,17 +534,11 @@ __global__ __launch_bounds__(HW ? 2 * WG_THREADS : WG_THREADS) __attribute__((am
     const int env2 = blockIdx.x * TILE_E + e2;
     const bool env2_ok = env2 < Pm.B;
     // (32-bit byte offsets from the uniform base, not pointers: one VGPR each across the simulation loop instead of two -- the two-action
-    // FUSE build spilled the MFMA-side pointer and reloaded it behind a vmcnt(0) every simulation; the launcher checks that the node
-    // store is smaller than 4 GiB)
-#ifdef MZ_EXP_HID64  // (A/B: the pointer form)
-    char* const hid_base = nullptr;
-    const size_t hid_sel = (size_t)(Pm.hidden + (size_t)(env_ok ? env_g : 0) * Pm.NN * 64 + a0 * 4);
-    const size_t hid_mma = (size_t)(Pm.hidden + (size_t)(env2_ok ? env2 : 0) * Pm.NN * 64 + wave * 16 + q * 4);
-#else
+    // FUSE build spilled the MFMA-side pointer and reloaded it behind a vmcnt(0) every simulation: C2 696.5 -> 691.5 us per move, C3
+    // 228.7 -> 229.5, same box; the launcher checks that the node store is smaller than 4 GiB)
     const unsigned hid_sel = (unsigned)((env_ok ? env_g : 0) * Pm.NN * 64 + a0 * 4) * 4u;                  // select-side env (tid >> 4)
     const unsigned hid_mma = (unsigned)((env2_ok ? env2 : 0) * Pm.NN * 64 + wave * 16 + q * 4) * 4u;       // MFMA-side env (lane & 15)
     char* const hid_base = reinterpret_cast<char*>(Pm.hidden);
-#endif
     const float* bias = lds;  // biases live in LDS (stage_biases)
     // SC: this lane's 4 NT weights of each scalar head -- row 0 of the packed second layer, input neurons 16 (NT w + j) + 4 q + i --
     // stay in registers for the whole move
