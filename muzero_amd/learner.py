@@ -238,7 +238,11 @@ class GraphedTrainStep:
             optimizer.load_state_dict(opt_state)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # CAPTURE BEFORE ANY ACTOR THREAD STARTS (prepare_graphed_step below): a null-stream hipMemcpy / hipMalloc from another thread of
+        # the process (a planner's load_state_dict, selfplay_read) synchronises with every blocking stream and invalidates a capture in
+        # progress -- in thread-local mode too (measured: hipErrorStreamCaptureInvalidated, tests/test_gpu_learner.py); REPLAYING the
+        # graph beside such threads is fine
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.loss, self.priorities = self._step_body()
 
     def _step_body(self):
@@ -297,6 +301,17 @@ def _rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def prepare_graphed_step(config, network, optimizer, device, state_shape, num_actions, unroll_steps=None, batch_size=None):
+    """Build the one-graph update (GraphedTrainStep) for `run_training` AHEAD of the training loop -- in the launcher, before the actor
+    threads start: a capture cannot share the process with other threads' null-stream HIP calls (see GraphedTrainStep).  The step is
+    left on the optimizer (`optimizer.graphed_step`), where run_training finds it; without it run_training captures lazily at its first
+    update, which is only safe when no actor thread of the same process is running yet (the process-per-actor layout)."""
+    step = GraphedTrainStep(config, network, optimizer, device, batch_size or config.batch_size, tuple(state_shape),
+                            unroll_steps or config.unroll_steps, num_actions)
+    optimizer.graphed_step = step
+    return step
+
+
 def run_training(config, network, optimizer, lr_scheduler, device, actor_network, replay: PrioritizedReplay, data_queue, train_steps_counter,
                  checkpoint_dir: str, checkpoint_files: List, stop_event, tag: Optional[str] = None, stop_grace_seconds: float = 10.0) -> None:
     """pipeline.py:170-286: the learner loop that paces the pipeline.  Same arguments; the reference's tensorboard trackers are
@@ -320,7 +335,7 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
     from muzero_amd import metrics as mzm
 
     metrics = mzm.LearnerMetrics(mzm.run_file(config, 'learner', tag) if rank == 0 else None)
-    graphed = None
+    graphed = getattr(optimizer, 'graphed_step', None)  # prepare_graphed_step(...): captured by the launcher before the actors started
     hip = getattr(optimizer, 'hip_learner', None)  # make_hip_learner(...).optimizer: the update runs on the HIP kernels
 
     def snapshot():

@@ -173,3 +173,60 @@ def test_graphed_train_step_matches_eager_step():
         assert abs(sch_a.get_last_lr()[0] - float(opt_b.param_groups[0]['lr'])) < 1e-9
     for (n, x), (_, y) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
         assert float((x - y).abs().max()) < 1e-3, n
+
+
+def test_graphed_step_prepared_before_the_actors_replays_beside_them():
+    """The threaded layout (pipeline.py:170-286 beside actor threads): the launcher captures the one-graph update BEFORE the actors
+    start (learner.prepare_graphed_step -- a capture cannot share the process with another thread's null-stream hipMemcpy / hipMalloc),
+    run_training finds it on the optimizer, and REPLAYING it while a planner thread plays, reads and reloads weights matches the eager step."""
+    import copy
+    import threading
+
+    from muzero_amd import planner as pl
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.network import MuZeroMLPNet
+
+    dev = torch.device('cuda', 0)
+    cfg = make_classic_config(use_tensorboard=False)
+    B, K, A = 32, cfg.unroll_steps, 2
+    torch.manual_seed(0)
+    net_a = MuZeroMLPNet((4, 5), A, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size, cfg.hidden_dim).to(dev)
+    net_b = copy.deepcopy(net_a)
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    sch_a = torch.optim.lr_scheduler.MultiStepLR(opt_a, milestones=[10 ** 9], gamma=0.1)
+    opt_b = learner.make_capturable_adam(net_b, cfg, dev)
+    graphed = learner.prepare_graphed_step(cfg, net_b, opt_b, dev, (4, 5), A, batch_size=B)
+    assert opt_b.graphed_step is graphed
+    anet = build_mlp(mlp_case('cartpole'))
+    p = pl.Planner(pl.make_mz_config(anet.planner_spec(), None, num_envs=64, seed=3, num_simulations=10, discount=0.997), 0)
+    p.load_state_dict(anet.state_dict())
+    p.selfplay_reset(pl.ENV_CARTPOLE)
+    stop, errors, moves = threading.Event(), [], [0]
+
+    def actor():
+        try:
+            while not stop.is_set():
+                p.selfplay_step(1.0, 1)
+                p.selfplay_read(1)
+                p.load_state_dict(anet.state_dict())
+                moves[0] += 1
+        except Exception as e:  # noqa: BLE001 -- reported by the assertion below
+            errors.append(repr(e))
+
+    th = threading.Thread(target=actor)
+    th.start()
+    rs = np.random.RandomState(1)
+    try:
+        for step in range(20):
+            tr = Transition(rs.uniform(-1, 1, (B, 4, 5)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
+                            rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), rs.uniform(0, 50, (B, K)).astype(np.float32), np.ones((B, K), np.float32))
+            w = np.ones(B, np.float32)
+            la, _ = learner.train_step(cfg, net_a, opt_a, sch_a, dev, tr, w)
+            lb, _ = graphed(tr, w)
+            assert abs(la - float(lb)) <= 2e-4 * max(1.0, abs(la)), step
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    assert moves[0] > 0
+    p.close()
