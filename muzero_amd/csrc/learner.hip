@@ -52,6 +52,9 @@ struct mz_learner {
     int jobs_tiles = -1;       // tile count the device copy of the jobs was built for
     float* d_sq = nullptr;     // partial sums of squares of the gradient
     int sq_blocks = 0;
+    int num_cus = 256;
+    int fast_max_tiles = 16, stage_fast_max_tiles = 256;  // MZL_FAST_MAX_TILES / MZL_CHAIN_FAST_MAX_TILES at create (see mzl_grad)
+    int chain_min_tiles = 96, chain_max_tiles = 1 << 30;  // batch range of the persistent chain kernels (MZL_CHAIN_MIN_TILES / MZL_CHAIN_MAX_TILES at create)
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
     bool committed = false;
     int back_parts = 1;  // plane slices of the backward stages at small batches (k_learn_back_sliced), 1: unsliced
@@ -166,6 +169,14 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     mz_learner* h = new mz_learner();
     h->cfg = *cfg;
     h->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) h->num_cus = cus;
+        if (getenv("MZL_FAST_MAX_TILES")) h->fast_max_tiles = atoi(getenv("MZL_FAST_MAX_TILES"));
+        if (getenv("MZL_CHAIN_FAST_MAX_TILES")) h->stage_fast_max_tiles = atoi(getenv("MZL_CHAIN_FAST_MAX_TILES"));
+        if (getenv("MZL_CHAIN_MIN_TILES")) h->chain_min_tiles = atoi(getenv("MZL_CHAIN_MIN_TILES"));
+        if (getenv("MZL_CHAIN_MAX_TILES")) h->chain_max_tiles = atoi(getenv("MZL_CHAIN_MAX_TILES"));
+    }
     LNet& n = h->net;
     n.in_dim = cfg->in_dim; n.A = cfg->num_actions; n.P = cfg->num_planes; n.H = cfg->hidden_dim;
     n.Sv = cfg->value_support_size; n.Sr = cfg->reward_support_size; n.K = cfg->unroll_steps;
@@ -269,7 +280,7 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
     const void* stage_kernels[] = {(const void*)&k_learn_repr<true>,   (const void*)&k_learn_repr<false>, (const void*)&k_learn_unroll<true>,
                                    (const void*)&k_learn_unroll<false>, (const void*)&k_learn_back<true>,  (const void*)&k_learn_back<false>,
                                    (const void*)&k_learn_back_sliced<true>, (const void*)&k_learn_fwd_sliced<true>,
-                                   (const void*)&k_learn_unroll<false, 3>};
+                                   (const void*)&k_learn_unroll<false, 3>, (const void*)&k_learn_dyn_chain, (const void*)&k_learn_dyn_back_chain};
     for (const void* f : stage_kernels)
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_learn_dw), hipFuncAttributeMaxDynamicSharedMemorySize, LW * 8 * 256 * 4);
@@ -370,19 +381,29 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     // grids run the streaming builds (60-94 VGPRs: two workgroups per CU, the heads-only build three -- one's loss rows and barriers under
     // the others' MFMAs).  The heads' grid is 15 x tiles: with the three-per-CU build the streaming form wins from 16 tiles on
     // (batch 512: 0.153 -> 0.146 ms, 1024: 0.202 -> 0.188, 2000: 0.317 -> 0.287; with two per CU it only won from ~2 k samples)
-    static const int fast_max_tiles = getenv("MZL_FAST_MAX_TILES") ? atoi(getenv("MZL_FAST_MAX_TILES")) : 16;
+    const int fast_max_tiles = h->fast_max_tiles;
     // The CHAIN stages (representation, dynamics_k, their backward stages) are grid (tiles): up to one workgroup per CU they are latency
     // chains whatever the build, and the register-resident form is the shorter chain; the heads' grid is 15 x tiles deep, so they switch
     // to the streaming builds (two or three workgroups per CU) much earlier.
-    static const int chain_max_tiles = getenv("MZL_CHAIN_FAST_MAX_TILES") ? atoi(getenv("MZL_CHAIN_FAST_MAX_TILES")) : 256;
+    const int chain_max_tiles = h->stage_fast_max_tiles;
     const bool fast_heads = h->fast && tiles < fast_max_tiles;
-    const bool fast_chain = h->fast && (fast_heads || tiles <= chain_max_tiles);
-    const int fparts = (fast_chain && h->back_parts > 1 && tiles * h->back_parts <= 512 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
+    const bool fast_chain_base = h->fast && (fast_heads || tiles <= chain_max_tiles);
+    // the persistent chain kernels (register-resident, one workgroup per CU looping over its tiles) from `chain_min_tiles` on; below that the
+    // plane-sliced stage kernels spread a stage over more CUs than there are tiles
+    const bool chain = h->fast && n.h_t * 64 <= LT && tiles >= h->chain_min_tiles && tiles <= h->chain_max_tiles;
+    const int sliced_ok = (h->back_parts > 1 && tiles * h->back_parts <= 512) ? h->back_parts : 1;
+    const bool fast_chain = fast_chain_base || chain;
+    const int fparts = (!chain && fast_chain && sliced_ok > 1 && n.in_t <= WKG && n.h_t + n.a_t <= WKG) ? h->back_parts : 1;
     // forward chain
     if (fast_chain) {
         if (fparts > 1) {  // small batches: the forward chain cut across the planes too (k = -1: representation; k = K: finishes u_K)
             for (int k = -1; k < K; k++) hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, fparts), dim3(LT), lds, st, n, h->sv, bt, h->o, k, fparts);
             hipLaunchKernelGGL(k_learn_fwd_sliced<true>, dim3(tiles, 1), dim3(LT), lds, st, n, h->sv, bt, h->o, K, fparts);
+        } else if (chain) {  // one persistent workgroup per CU runs the whole dynamics chain of its tiles, operands loaded once (mz_learn.h)
+            // (the representation stage is a plain grid over the tiles: register form up to one workgroup per CU, streaming form beyond)
+            if (fast_chain_base) hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
+            else hipLaunchKernelGGL(k_learn_repr<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
+            hipLaunchKernelGGL(k_learn_dyn_chain, dim3(tiles < h->num_cus ? tiles : h->num_cus), dim3(LT), lds, st, n, h->sv, bt, h->o);
         } else {
             hipLaunchKernelGGL(k_learn_repr<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o);
             for (int k = 0; k < K; k++) hipLaunchKernelGGL(k_learn_unroll<true>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k, 0);
@@ -404,11 +425,16 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     if (fast_chain) {
         // small batches: the backward chain cut four ways across the planes (32 instead of 8 workgroups per stage at batch 128)
         LSave svb = h->sv;
-        svb.dx_parts = (h->back_parts > 1 && tiles * h->back_parts <= 512) ? h->back_parts : 1;
-        if (svb.dx_parts > 1)
+        svb.dx_parts = chain ? 1 : sliced_ok;
+        if (svb.dx_parts > 1) {
             for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back_sliced<true>, dim3(tiles, svb.dx_parts), dim3(LT), lds, st, n, svb, bt, h->o, k);
-        else
+        } else if (chain) {
+            hipLaunchKernelGGL(k_learn_dyn_back_chain, dim3(tiles < h->num_cus ? tiles : h->num_cus), dim3(LT), lds, st, n, svb, bt, h->o);
+            if (fast_chain_base) hipLaunchKernelGGL(k_learn_back<true>, dim3(tiles), dim3(LT), lds, st, n, svb, bt, h->o, -1);
+            else hipLaunchKernelGGL(k_learn_back<false>, dim3(tiles), dim3(LT), lds, st, n, svb, bt, h->o, -1);
+        } else {
             for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<true>, dim3(tiles), dim3(LT), lds, st, n, svb, bt, h->o, k);
+        }
     } else {
         for (int k = K - 1; k >= -1; k--) hipLaunchKernelGGL(k_learn_back<false>, dim3(tiles), dim3(LT), lds, st, n, h->sv, bt, h->o, k);
     }

@@ -916,6 +916,122 @@ __global__ __launch_bounds__(LT) void k_learn_back(LNet net, LSave sv, LBatch bt
     copy_f4(sv.dxd + blk(k, tiles, tile, net.h_t) * DX_PARTS, lds + o.G, hf, tid);
 }
 
+// PERSISTENT CHAINS (register-resident form only).  The dynamics chain of a tile depends on nothing but the tile itself, and every one
+// of its K stages multiplies the SAME two weight matrices (the dynamics net is shared by the unroll steps, pipeline.py:579-592).  A stage
+// kernel per step re-streams 288 KB of operands per workgroup and pays a launch boundary and a prologue per step -- with one workgroup
+// per CU nothing hides it: 13-15 us per stage at batch 4096 against 4 us of MFMA time.  Here a workgroup loads the operands ONCE and
+// runs the whole chain of its tile(s) -- grid = min(tiles, CUs), tiles strided over the workgroups -- h_{k+1} going to the next stage
+// through LDS.  Same arithmetic and summation orders as the stage kernels (bit-identical: tests/test_gpu_hip_learner.py).
+//   k_learn_dyn_chain:       h_0 (from k_learn_repr) -> dynamics_0 .. dynamics_{K-1}: x_k, h1_k, u_{k+1}, h_{k+1}
+//   k_learn_dyn_back_chain:  dL/dh_K .. dL/dh_1 (+ the heads' contributions) -> dynamics_{K-1} .. dynamics_0 backward -> dL/dh_0's
+//                            dynamics part (the representation stage, k == -1, stays k_learn_back)
+__global__ __launch_bounds__(LT) void k_learn_dyn_chain(LNet net, LSave sv, LBatch bt, LLds o) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tiles = bt.tiles;
+    const int K = net.K, hf = net.h_t * 64;
+    const int e = tid >> 5, j = tid & 31;
+    WideW w1;
+    KsW w2;
+    wide_load<6, true, true>(w1, net.L[DYN0].wp, net.L[DYN0].b, net.p_t, net.h_t + net.a_t, wave, lane);
+    ks_load<true, true>(w2, net.L[DYN1].wp, net.L[DYN1].b, net.h_t, net.p_t, wave, lane);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const float* hsrc = sv.hc + blk(0, tiles, tile, net.h_t);
+        const float4 xv = chain_ld(hsrc, hf, tid);
+        int act = sv.actc[tile * TILE + e];
+        __syncthreads();  // (the previous tile's last stage is done with X)
+        chain_st<true>(lds + o.X, hsrc, xv, hf, tid);
+        for (int k = 0; k < K; k++) {
+            // X <- [h_k | onehot(a_k)] (network.py:191-193); h_k is in place
+            for (int a = j; a < net.a_t * 16; a += 32) lds[o.X + pk(net.h_t * 16 + a, e)] = a == act ? 1.0f : 0.0f;
+            const int kn = k + 1 < K ? k + 1 : k;
+            act = sv.actc[(kn * tiles + tile) * TILE + e];  // the next stage's, requested a stage ahead
+            __syncthreads();
+            save_T_from_pk(lds + o.X, net.h_t + net.a_t, sv.x + blk(k, tiles, tile, net.h_t + net.a_t), tid);
+            float* h1b = sv.h1_dyn + blk(k, tiles, tile, net.p_t);
+            wide_mma<true, 6>(w1, net.L[DYN0].wp, net.L[DYN0].b, net.p_t, net.h_t + net.a_t, lds + o.X, wave, lane, [&](int t, f32x4 a) {
+                const f32x4 r = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f)};
+                g_put_T(h1b, t, lane, r);
+                lds_put_T(lds + o.H1, t, lane, r);
+            }, NoPf{});
+            __syncthreads();
+            ks_mma<true>(w2, net.L[DYN1].wp, net.L[DYN1].b, net.h_t, net.p_t, lds + o.H1, lds + o.RED, wave, lane,
+                         [&](int t, f32x4 a) { lds_put_T(lds + o.HN, t, lane, a); }, NoPf{});
+            __syncthreads();
+            normalize_fwd(lds + o.HN, lds + o.HS, net.H, net.h_t, tid);
+            __syncthreads();
+            const size_t cb = blk(k + 1, tiles, tile, net.h_t);
+            copy_f4(sv.uc + cb, lds + o.HN, hf, tid);
+            copy_f4(sv.hc + cb, lds + o.HS, hf, tid);
+            if (tid < hf) reinterpret_cast<float4*>(lds + o.X)[tid] = reinterpret_cast<const float4*>(lds + o.HS)[tid];  // the next stage's input
+        }
+    }
+}
+
+__global__ __launch_bounds__(LT) void k_learn_dyn_back_chain(LNet net, LSave sv, LBatch bt, LLds o) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tiles = bt.tiles;
+    const int K = net.K, hf = net.h_t * 64;
+    const int ci = tid < hf ? tid : hf - 1;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    WideW w1;
+    KsW w2;
+    wide_load<4, false, true>(w1, net.L[DYN1].wtp, nullptr, net.p_t, net.h_t, wave, lane);
+    ks_load<false, true>(w2, net.L[DYN0].wtp, nullptr, net.h_t, net.p_t, wave, lane);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        // stage inputs, requested one stage ahead: the heads' contributions to dL/dh_{k+1} (policy, value: none for k + 1 == K), u_{k+1},
+        // the reward head's dL/du_{k+1}, and the ReLU gate of this wave's tiles of dynamics_k's first layer
+        float4 gb = z4, gc = z4, uu, rr;
+        f32x4 gate[4];
+        auto request = [&](int k) {
+            const int jj = k + 1;
+            const size_t cj = blk(jj, tiles, tile, net.h_t), cjc = jj < K ? cj : 0;
+            gb = reinterpret_cast<const float4*>(sv.dxp + cjc)[ci];
+            gc = reinterpret_cast<const float4*>(sv.dxv + cjc)[ci];
+            uu = reinterpret_cast<const float4*>(sv.uc + cj)[ci];
+            rr = reinterpret_cast<const float4*>(sv.dxr + blk(k, tiles, tile, net.h_t))[ci];
+            const float* h1b = sv.h1_dyn + blk(k, tiles, tile, net.p_t);
+#pragma unroll
+            for (int i = 0; i < 4; i++) gate[i] = g_get_T(h1b, wave + i * LW < net.p_t ? wave + i * LW : net.p_t - 1, lane);
+        };
+        request(K - 1);
+        __syncthreads();  // (the previous tile's last stage is done with G)
+        if (tid < hf) reinterpret_cast<float4*>(lds + o.G)[tid] = z4;  // dL/dh_K: no consumer of h_K inside the loss
+        for (int k = K - 1; k >= 0; k--) {
+            const bool cons = k + 1 < K;
+            if (tid < hf) {
+                // G holds the dynamics part of dL/dh_{k+1} (the previous stage's result); add the heads' parts in the stage kernels' order
+                float4* G4 = reinterpret_cast<float4*>(lds + o.G);
+                const float4 ga = G4[tid];
+                G4[tid] = cons ? make_float4((ga.x + gb.x) + gc.x, (ga.y + gb.y) + gc.y, (ga.z + gb.z) + gc.z, (ga.w + gb.w) + gc.w) : z4;
+                reinterpret_cast<float4*>(lds + o.HN)[tid] = uu;
+                reinterpret_cast<float4*>(lds + o.R)[tid] = rr;
+            }
+            f32x4 gk[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) gk[i] = gate[i];
+            __syncthreads();
+            if (k > 0) request(k - 1);
+            normalize_bwd(lds + o.G, 0.5f, lds + o.HN, lds + o.R, lds + o.HS, net.H, net.h_t, tid);  // (halved: pipeline.py:584)
+            __syncthreads();
+            save_T_from_pk(lds + o.HS, net.h_t, sv.dz_dyn1 + blk(k, tiles, tile, net.h_t), tid);
+            float* dzb = sv.dz_dyn0 + blk(k, tiles, tile, net.p_t);
+            wide_mma<true, 4>(w1, net.L[DYN1].wtp, nullptr, net.p_t, net.h_t, lds + o.HS, wave, lane, [&](int t, f32x4 a) {
+                const int jj = (t - wave) / LW;
+                const f32x4 h = jj == 0 ? gk[0] : (jj == 1 ? gk[1] : (jj == 2 ? gk[2] : gk[3]));
+                const f32x4 r = {h[0] > 0.0f ? a[0] : 0.0f, h[1] > 0.0f ? a[1] : 0.0f, h[2] > 0.0f ? a[2] : 0.0f, h[3] > 0.0f ? a[3] : 0.0f};
+                g_put_T(dzb, t, lane, r);
+                lds_put_T(lds + o.DZ, t, lane, r);
+            }, NoPf{});
+            __syncthreads();
+            ks_mma<true>(w2, net.L[DYN0].wtp, nullptr, net.h_t, net.p_t, lds + o.DZ, lds + o.RED, wave, lane,
+                         [&](int t, f32x4 a) { lds_put_T(lds + o.G, t, lane, a); }, NoPf{});
+            __syncthreads();
+        }
+        // dL/dh_0's dynamics part for the representation stage (k_learn_back, k == -1)
+        copy_f4(sv.dxd + blk(0, tiles, tile, net.h_t) * DX_PARTS, lds + o.G, hf, tid);
+    }
+}
+
 // The same stage for SMALL batches, cut across the planes: workgroup (tile, part) owns the plane tiles [part p_t / np, (part + 1) p_t / np)
 // -- one per wave -- of dL/dz1 and leaves a PARTIAL dL/dh_k over its slice; the next stage adds the np partials when it loads them (a
 // kernel boundary is the cheapest grid-wide exchange on this part, and the consumer's sum costs np - 1 more 16-byte loads per lane).

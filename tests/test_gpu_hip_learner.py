@@ -263,3 +263,30 @@ def test_plane_sliced_chains_equal_the_unsliced_stages(monkeypatch):
     scale = np.abs(out[1][2]).max()
     assert np.abs(out[0][2] - out[1][2]).max() <= 1e-5 * scale
     assert not np.array_equal(out[0][2], out[1][2])  # (the two paths really are different kernels)
+
+
+def test_persistent_chain_kernels_equal_the_stage_kernels(monkeypatch):
+    """From 96 tiles on the dynamics chain runs in two persistent kernels (k_learn_dyn_chain / k_learn_dyn_back_chain: one workgroup per
+    CU keeps the dynamics net's operands in registers across the K stages of its tiles, h_k passing through LDS); below that, and with
+    MZL_CHAIN_MIN_TILES out of reach, one stage kernel per step.  Same arithmetic in the same order: bit-identical loss, priorities and
+    gradients -- also when a workgroup loops over several tiles (more tiles than CUs)."""
+    case = mlp_case('cartpole')
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(12)
+    for B in (1600, 4800):  # 100 tiles (one per workgroup) and 300 (256 CUs: some workgroups run two tiles)
+        tr = _random_batch(rs, B, (4, 5), 2)
+        ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(tr, f))).to(dev) for f in Transition._fields}
+        ring['state'] = ring['state'].reshape(B, -1).contiguous()
+        w = torch.from_numpy(rs.uniform(0.5, 1, B).astype(np.float32)).to(dev)
+        out = []
+        for chain in (True, False):
+            monkeypatch.setenv('MZL_NO_SLICE', '1')  # (the plane-sliced stages add their partials in another order)
+            monkeypatch.setenv('MZL_CHAIN_MIN_TILES', '96' if chain else '1000000')
+            monkeypatch.setenv('MZL_CHAIN_FAST_MAX_TILES', '1000000')  # the register-resident stage kernels at every size
+            hl = _hip(build_mlp(case).to(dev), dev, B, grad_slices=1)
+            loss, prio = hl.grad(ring, None, w, B)
+            out.append((float(loss), prio.cpu().numpy().copy(), hl.grad_flat.cpu().numpy().copy()))
+            hl.close()
+        assert out[0][0] == out[1][0]
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+        np.testing.assert_array_equal(out[0][2], out[1][2])
