@@ -17,6 +17,10 @@
 //                                               -> dynamics_k backward -> dL/dh_k                                    (k = K-1 .. 0, then repr)
 //   k_learn_dw              grid (jobs, split)  every weight / bias gradient: dW = sum over (step, sample) dZ x^T as MFMA tiles
 //   k_learn_finish          1 block             loss, gradient norm partials
+// By batch size (the launcher, learner.hip mzl_grad): up to ~64 tiles both chains are cut across the planes (k_learn_fwd_sliced /
+// k_learn_back_sliced: more workgroups than tiles); from 96 tiles on the K dynamics stages of a tile run inside two PERSISTENT kernels
+// (k_learn_dyn_chain / k_learn_dyn_back_chain: operands loaded once per workgroup); the heads take a three-per-CU streaming build from
+// 16 tiles on; long reductions use k_learn_dw_big + k_learn_gradsum.
 //   k_learn_adam            grid (blocks, 20)   clip + Adam (L2 weight decay in the gradient) + re-pack of the MFMA operand copies
 // Every head's loss gradient is known as soon as its logits are (dL/dz = (softmax - target) w / (B K)), so the heads run forward AND
 // backward inside the forward sweep; the backward sweep is the dynamics chain alone.
