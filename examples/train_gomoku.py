@@ -5,7 +5,12 @@ loop as examples/train_tictactoe.py.  The reference's gomoku hyper-parameters (c
 (32 planes, 2 blocks) and 32 simulations so that a few minutes show learning.  Evaluation: deterministic games against a uniformly
 random opponent as black and as white (win = five in a row before the opponent; the random player never resigns).
 
-    python examples/train_gomoku.py --train-steps 2000 --envs 128"""
+By default the trajectories never leave the GPU: the device epilogue writes (Transition, priority) items into an HBM replay ring
+(`Planner.attach_replay`; int16 action fields where num_actions > 128, e.g. --board 15), batches are gathered on the device, and the
+update -- PyTorch-ROCm autograd for the conv nets -- can run as ONE HIP graph (--graphed, learner.GraphedTrainStep, captured before the
+loop).  --host-assembly keeps the reference's host-side assembler (pipeline.py:118-165).
+
+    python examples/train_gomoku.py --train-steps 2000 --envs 128 [--graphed] [--board 9]"""
 import argparse
 import json
 import os
@@ -19,19 +24,19 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def play_vs_random(net, dev, cfg, agent_player, games, rs):
+def play_vs_random(net, dev, cfg, agent_player, games, rs, board=9):
     from muzero_amd import mcts
     from muzero_amd.games import GomokuEnv
 
     res = dict(win=0, draw=0, loss=0)
     for _ in range(games):
-        env = GomokuEnv(board_size=9)
+        env = GomokuEnv(board_size=board)
         obs, done = env.reset(), False
         while not done:
             if env.current_player == agent_player:
                 action, *_ = mcts.uct_search(obs, net, dev, cfg, 0.0, env.actions_mask, env.current_player, env.opponent_player, deterministic=True)
             else:
-                legal = np.flatnonzero(env.actions_mask[:81])  # the random opponent never resigns
+                legal = np.flatnonzero(env.actions_mask[:board * board])  # the random opponent never resigns
                 action = int(rs.choice(legal))
             obs, _, done, _ = env.step(action)
         res['draw' if env.winner is None else ('win' if env.winner == agent_player else 'loss')] += 1
@@ -47,6 +52,9 @@ def main():
     ap.add_argument('--report-every', type=int, default=500)
     ap.add_argument('--eval-games', type=int, default=10)
     ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--board', type=int, default=9)
+    ap.add_argument('--host-assembly', action='store_true', help='trajectories through selfplay_read + the host EpisodeAssembler instead of the device epilogue')
+    ap.add_argument('--graphed', action='store_true', help='the update as one HIP graph (learner.GraphedTrainStep)')
     ap.add_argument('--out', default='')
     args = ap.parse_args()
 
@@ -61,36 +69,58 @@ def main():
     dev = torch.device('cuda', 0)
     cfg = make_gomoku_config(num_training_steps=args.train_steps, batch_size=128, min_replay_size=5000, use_tensorboard=False)
     cfg.num_envs, cfg.num_simulations, cfg.num_planes, cfg.num_res_blocks = args.envs, 32, 32, 2
-    net = MuZeroBoardGameNet((9, 9, 9), 82, cfg.num_res_blocks, cfg.num_planes).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    N = args.board
+    A, obs_shape = N * N + 1, (9, N, N)
+    net = MuZeroBoardGameNet(obs_shape, A, cfg.num_res_blocks, cfg.num_planes).to(dev)
+    graphed = None
+    if args.graphed:  # captured here, before anything else drives the GPU (learner.prepare_graphed_step)
+        import warnings
+
+        warnings.filterwarnings('ignore', message='Detected call of `lr_scheduler.step\\(\\)` before')  # (optimizer.step() runs inside the graph)
+        opt = learner.make_capturable_adam(net, cfg, dev)
+        graphed = learner.prepare_graphed_step(cfg, net, opt, dev, obs_shape, A)
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
     replay = PrioritizedReplay(20000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
     net.eval()
     p.load_state_dict(net.state_dict())
+    if not args.host_assembly:
+        p.attach_replay(replay, cfg, obs_shape=obs_shape)
     p.selfplay_reset(pl.ENV_GOMOKU)
-    asm = EpisodeAssembler(cfg, args.envs, (9, 9, 9))
+    asm = EpisodeAssembler(cfg, args.envs, obs_shape)
     rs = np.random.RandomState(args.seed + 7)
 
-    log = [dict(train_steps=0, black=play_vs_random(net, dev, cfg, 1, args.eval_games, rs), white=play_vs_random(net, dev, cfg, 2, args.eval_games, rs))]
+    def evaluate(player):
+        return play_vs_random(net, dev, cfg, player, args.eval_games, rs, N)
+
+    log = [dict(train_steps=0, black=evaluate(1), white=evaluate(2))]
     print(json.dumps(log[0]), flush=True)
     steps, t0 = 0, time.time()
     while steps < args.train_steps:
         p.selfplay_step(-1.0, args.moves_per_iter)  # per-env temperature schedule of the game (config.py:244-249)
-        for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
-            replay.add(tr, prio)
+        if args.host_assembly:
+            for tr, prio in asm.feed(p.selfplay_read(args.moves_per_iter)):
+                replay.add(tr, prio)
+        else:
+            p.synchronize()  # event order: the moves above are committed to the ring before a batch is drawn
         if replay.size < cfg.min_replay_size:
             continue
         net.train()
         for _ in range(args.updates_per_iter):
             batch, idx, w = replay.sample_tensors(cfg.batch_size)
-            loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
-            replay.update_priorities(idx, prio)
+            if graphed is not None:  # uniform replay (the launchers' default) ignores priorities: no host read-back per update
+                loss, prio = graphed(batch, w)
+                sched.step()
+            else:
+                loss, prio = learner.train_step(cfg, net, opt, sched, dev, batch, w)
+                replay.update_priorities(idx, prio)
             steps += 1
             if steps % args.report_every == 0:
                 net.eval()
-                rec = dict(train_steps=steps, loss=loss, seconds=round(time.time() - t0, 1), env_steps=p.selfplay_counters()['env_steps'],
-                           black=play_vs_random(net, dev, cfg, 1, args.eval_games, rs), white=play_vs_random(net, dev, cfg, 2, args.eval_games, rs))
+                rec = dict(train_steps=steps, loss=float(loss), seconds=round(time.time() - t0, 1), env_steps=p.selfplay_counters()['env_steps'],
+                           black=evaluate(1), white=evaluate(2))
                 net.train()
                 log.append(rec)
                 print(json.dumps(rec), flush=True)

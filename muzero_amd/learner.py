@@ -263,6 +263,9 @@ class GraphedTrainStep:
         self.pi.copy_(_as_tensor(transitions.pi_prob, dev, torch.float32))
         self.weights.copy_(_as_tensor(weights, dev, torch.float32))
         self.graph.replay()
+        # a graph replay rewrites the parameters without touching their torch version counters: tell the module's HIP inference engine
+        # (network.inference_engine compares versions) that the weights changed, as hip_learner.HipLearner.apply does
+        self.network._mz_weights_epoch = getattr(self.network, '_mz_weights_epoch', 0) + 1
         return self.loss, self.priorities
 
 

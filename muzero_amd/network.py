@@ -246,6 +246,14 @@ class MuZeroNet(nn.Module):
     def planner_spec(self) -> dict:
         raise NotImplementedError
 
+    def __getstate__(self):
+        # the bound engine is a handle into libmzplanner_hip.so: it does not travel with a pickled / deep-copied module (the reference's
+        # launchers hand `actor_network` to spawned actor processes, */run_training.py); the copy binds its own engine on first use
+        state = dict(super().__getstate__())
+        state['_engine'] = None
+        state['_engine_version'] = None
+        return state
+
     def _weights_version(self):
         # (+ an epoch that writers outside torch bump: hip_learner.HipLearner updates the parameters' storage from its own kernels)
         return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()) + (getattr(self, '_mz_weights_epoch', 0),)

@@ -230,3 +230,52 @@ def test_graphed_step_prepared_before_the_actors_replays_beside_them():
     assert not errors, errors
     assert moves[0] > 0
     p.close()
+
+
+def test_graphed_train_step_on_a_conv_net_matches_the_eager_step():
+    """The one-graph update for the board-game conv nets (BatchNorm in train mode, running statistics updated inside the graph; int16
+    action fields as the device replay of a 15 x 15 board holds them): losses, priorities and weights after three updates equal the
+    eager `train_step` within float32 tolerance."""
+    import copy
+
+    from muzero_amd.config import make_gomoku_config
+    from muzero_amd.network import MuZeroBoardGameNet
+
+    dev = torch.device('cuda', 0)
+    cfg = make_gomoku_config(use_tensorboard=False)
+    N, B, K = 7, 16, cfg.unroll_steps
+    A, shape = N * N + 1, (9, N, N)
+    torch.manual_seed(0)
+    net_a = MuZeroBoardGameNet(shape, A, 1, 16).to(dev)
+    net_b = copy.deepcopy(net_a)
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    sch_a = torch.optim.lr_scheduler.MultiStepLR(opt_a, milestones=[10 ** 9], gamma=0.1)
+    opt_b = learner.make_capturable_adam(net_b, cfg, dev)
+    graphed = learner.prepare_graphed_step(cfg, net_b, opt_b, dev, shape, A, batch_size=B)
+    for (k, x), (_, y) in zip(net_a.state_dict().items(), net_b.state_dict().items()):  # warm-up + capture trained nothing, BN buffers included
+        assert torch.equal(x, y), k
+    rs = np.random.RandomState(0)
+    net_b.eval()
+    net_b.initial_inference(torch.zeros((1,) + shape, device=dev))  # binds the module's HIP engine to the INITIAL weights
+    net_a.train(); net_b.train()
+    for step in range(3):
+        tr = Transition(torch.from_numpy(rs.randint(0, 2, (B,) + shape).astype(np.float32)).to(dev),
+                        torch.from_numpy(rs.randint(0, A, (B, K)).astype(np.int16)).to(dev),
+                        torch.from_numpy(rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32)).to(dev),
+                        torch.from_numpy(rs.uniform(-1, 1, (B, K)).astype(np.float32)).to(dev),
+                        torch.from_numpy(rs.uniform(-1, 1, (B, K)).astype(np.float32)).to(dev))
+        w = np.ones(B, np.float32)
+        la, pa = learner.train_step(cfg, net_a, opt_a, sch_a, dev, tr, w)
+        lb, pb = graphed(tr, w)
+        assert abs(la - float(lb)) <= 2e-4 * max(1.0, abs(la)), step
+        np.testing.assert_allclose(pb.cpu().numpy(), pa, rtol=2e-3, atol=2e-3)
+    for (k, x), (_, y) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert float((x.float() - y.float()).abs().max()) < 2e-3, k
+    # the module's own inference API (network.py:62-84, served by the HIP engine) must see the weights the graph replays wrote -- they
+    # change without bumping torch's version counters: an engine bound BEFORE the updates answers like one bound after them
+    net_c = copy.deepcopy(net_b).eval()
+    obs = torch.from_numpy(rs.randint(0, 2, (1,) + shape).astype(np.float32)).to(dev)
+    net_b.eval()
+    out_b, out_c = net_b.initial_inference(obs), net_c.initial_inference(obs)
+    np.testing.assert_array_equal(out_b.pi_probs, out_c.pi_probs)
+    assert out_b.value == out_c.value

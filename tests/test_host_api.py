@@ -183,3 +183,20 @@ def test_episode_assembler_matches_reference_episode():
         np.testing.assert_array_equal(np.stack([t.value for t, _ in items]), P[f'ep{ep}_tr_value'])
         np.testing.assert_array_equal(np.stack([t.pi_prob for t, _ in items]), P[f'ep{ep}_tr_pi'])
         np.testing.assert_array_equal(np.array([p for _, p in items]), P[f'ep{ep}_tr_priority'])
+
+
+def test_network_modules_pickle_and_deepcopy_without_their_engine():
+    """The reference's launchers hand `actor_network` to spawned actor processes (classic/run_training.py:100,168-186): a module whose HIP
+    inference engine is already bound (a ctypes handle) must still pickle and deep-copy -- the copy binds its own engine on first use."""
+    import copy
+    import pickle
+
+    import torch
+
+    net = build_mlp(MLP_CASES[0])
+    net._engine, net._engine_version = object(), ('stale',)  # (stand-in for a bound engine: no GPU here)
+    for clone in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+        assert clone._engine is None and clone._engine_version is None
+        for (k, x), (_, y) in zip(net.state_dict().items(), clone.state_dict().items()):
+            assert torch.equal(x, y), k
+    assert net._engine is not None  # (the original keeps its engine)
