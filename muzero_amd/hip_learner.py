@@ -120,6 +120,8 @@ class HipLearner:
             raise LearnerError('HipLearner needs a GPU (no CPU fallback)')
         L = load_library()
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
         spec = network.planner_spec()
         if spec['kind'] != 'mlp':
             raise LearnerError('HipLearner covers MuZeroMLPNet; the conv nets train through muzero_amd.learner.train_step')
@@ -245,6 +247,13 @@ class HipLearner:
                 raise LearnerError(f'{f} storage must be contiguous float32')
         if index is None:
             index = self._iota[:batch]
+        # every pointer handed to the kernels must be memory of the learner's GPU: a host-resident replay (PrioritizedReplay's default
+        # device) would be read as a device address
+        for name, t in (('state', st), ('action', ac), ('pi_prob', ring['pi_prob']), ('value', ring['value']), ('reward', ring['reward']),
+                        ('index', index), ('weights', self._ones if weights is None else weights)):
+            if t.device != self.device:
+                raise LearnerError(f'{name} lives on {t.device}, the learner on {self.device}: build the replay with device=\'cuda\' '
+                                   f'(muzero_amd.replay.PrioritizedReplay(..., device=\'cuda\')) and pass device tensors')
         if index.dtype != torch.int64 or index.numel() != batch:
             raise LearnerError('index must be an int64 tensor of `batch` rows')
         w = self._ones if weights is None else weights

@@ -148,6 +148,12 @@ def test_errors_are_reported_not_swallowed():
     bad = tr._replace(pi_prob=tr.pi_prob[:, :, :2])
     with pytest.raises(LearnerError):
         hl.step_transitions(Transition(*[x[:8] for x in bad]))
+    # a host-resident replay ring (PrioritizedReplay's default device) must be refused, not read as device addresses
+    ok = Transition(*[x[:8] for x in tr])
+    host_ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(ok, f))) for f in Transition._fields}
+    host_ring['state'] = host_ring['state'].reshape(8, -1).contiguous()
+    with pytest.raises(LearnerError, match="device='cuda'"):
+        hl.grad(host_ring, None, None, 8)
     from helpers import build_conv, conv_case
 
     with pytest.raises(LearnerError, match='MuZeroMLPNet'):

@@ -1,0 +1,69 @@
+"""The reference's process topology (classic/run_training.py:59-194) driven through this package's drop-in functions on one GPU: a SPAWNED
+actor process (`run_self_play` on a shared-memory `actor_network`, its own planner on the GPU), a data collector thread
+(`run_data_collector`: queue -> replay) and the learner (`run_training`, update on the HIP learner kernels) in the launching process."""
+import multiprocessing as mp
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _actor_main(cfg, actor_network, data_queue, counter, stop_event, out):
+    sys.path.insert(0, REPO)
+    import torch
+
+    from muzero_amd import pipeline
+
+    try:
+        steps = pipeline.run_self_play(cfg, 0, actor_network, torch.device('cuda', 0), 'CartPole-v1', data_queue, counter, stop_event, moves_per_drain=4)
+        out.put(('ok', steps))
+    except Exception as e:  # noqa: BLE001 -- reported to the parent
+        out.put(('error', repr(e)))
+
+
+def test_spawned_actor_collector_and_hip_learner_train_together(tmp_path):
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch
+
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import learner
+    from muzero_amd.config import make_classic_config
+    from muzero_amd.pipeline import load_checkpoint
+    from muzero_amd.replay import PrioritizedReplay
+
+    ctx = mp.get_context('spawn')
+    dev = torch.device('cuda', 0)
+    cfg = make_classic_config(num_training_steps=24, batch_size=32, min_replay_size=96, use_tensorboard=False)
+    cfg.num_envs, cfg.num_simulations, cfg.checkpoint_interval, cfg.train_delay = 32, 8, 8, 0.0
+    network = build_mlp(mlp_case('cartpole')).to(dev)
+    actor_network = build_mlp(mlp_case('cartpole'))
+    actor_network.share_memory()  # classic/run_training.py:100
+    before = {k: v.clone() for k, v in actor_network.state_dict().items()}
+    hl = learner.make_hip_learner(cfg, network, dev)
+    replay = PrioritizedReplay(4096, 0.0, 0.0, np.random.RandomState(0), device='cuda')  # (the HIP learner gathers its batch from HBM)
+    data_queue, counter, stop_event, out = ctx.SimpleQueue(), ctx.Value('i', 0), ctx.Event(), ctx.SimpleQueue()
+    actor = ctx.Process(target=_actor_main, args=(cfg, actor_network, data_queue, counter, stop_event, out))
+    actor.start()
+    collector = threading.Thread(target=learner.run_data_collector, args=(data_queue, replay))
+    collector.start()
+    files = []
+    learner.run_training(cfg, network, hl.optimizer, hl.lr_scheduler, dev, actor_network, replay, data_queue, counter, str(tmp_path), files, stop_event,
+                         stop_grace_seconds=1.0)
+    actor.join(timeout=120)
+    collector.join(timeout=60)
+    assert actor.exitcode == 0 and not collector.is_alive()
+    status, played = out.get()
+    assert status == 'ok', played
+    assert played > 0 and replay.num_added >= cfg.min_replay_size
+    assert counter.value == 24 and hl.steps == 24 and len(files) == 3
+    # the actor's shared-memory copy holds the weights of the last checkpoint boundary (step 24), which differ from the initial ones
+    for k, v in actor_network.state_dict().items():
+        assert torch.equal(v, network.state_dict()[k].cpu()), k
+    assert any(not torch.equal(before[k], v) for k, v in actor_network.state_dict().items())
+    ck = load_checkpoint(str(tmp_path / 'train_steps_24_final'), torch.device('cpu'))
+    assert ck['train_steps'] == 24 and set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'}
