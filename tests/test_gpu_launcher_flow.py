@@ -67,3 +67,50 @@ def test_spawned_actor_collector_and_hip_learner_train_together(tmp_path):
     assert any(not torch.equal(before[k], v) for k, v in actor_network.state_dict().items())
     ck = load_checkpoint(str(tmp_path / 'train_steps_24_final'), torch.device('cpu'))
     assert ck['train_steps'] == 24 and set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'}
+
+
+def test_threaded_actor_with_device_replay_and_hip_learner(tmp_path):
+    """The single-process layout: an actor THREAD whose planner writes finished items straight into the HBM replay (device epilogue,
+    `run_self_play(..., data_queue=<PrioritizedReplay on the GPU>)`) while `run_training` draws batches from the same ring and updates on
+    the HIP learner kernels; TicTacToe (two players, MC-return targets, int8 board observations)."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import queue
+    import types
+
+    import torch
+
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import learner, pipeline
+    from muzero_amd.config import make_tictactoe_config
+    from muzero_amd.replay import PrioritizedReplay
+
+    dev = torch.device('cuda', 0)
+    cfg = make_tictactoe_config(num_training_steps=30, batch_size=32, min_replay_size=128, use_tensorboard=False)
+    cfg.num_envs, cfg.num_simulations, cfg.checkpoint_interval, cfg.train_delay = 64, 8, 10, 0.0
+    network = build_mlp(mlp_case('tictactoe')).to(dev)
+    actor_network = build_mlp(mlp_case('tictactoe'))
+    hl = learner.make_hip_learner(cfg, network, dev)
+    replay = PrioritizedReplay(8192, 0.0, 0.0, np.random.RandomState(0), device='cuda')
+    counter, stop_event, played, errors = types.SimpleNamespace(value=0), threading.Event(), [0], []
+
+    def actor():
+        try:
+            played[0] = pipeline.run_self_play(cfg, 0, actor_network, dev, 'TicTacToe', replay, counter, stop_event, moves_per_drain=4)
+        except Exception as e:  # noqa: BLE001 -- reported by the assertion below
+            errors.append(repr(e))
+            stop_event.set()
+
+    th = threading.Thread(target=actor)
+    th.start()
+    files = []
+    learner.run_training(cfg, network, hl.optimizer, hl.lr_scheduler, dev, actor_network, replay, queue.SimpleQueue(), counter, str(tmp_path), files,
+                         stop_event, stop_grace_seconds=0.5)
+    th.join(timeout=120)
+    assert not th.is_alive() and not errors, errors
+    assert counter.value == 30 and hl.steps == 30 and len(files) == 3
+    assert played[0] > 0 and replay.num_added >= cfg.min_replay_size
+    for k, v in actor_network.state_dict().items():
+        assert torch.equal(v.cpu(), network.state_dict()[k].cpu()), k
+    # the replay is usable from the host again after the actor closed its planner (the epilogue detached)
+    batch, idx, w = replay.sample(8)
+    assert batch.state.shape[0] == 8 and np.isfinite(batch.value).all()
