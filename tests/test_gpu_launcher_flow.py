@@ -114,3 +114,47 @@ def test_threaded_actor_with_device_replay_and_hip_learner(tmp_path):
     # the replay is usable from the host again after the actor closed its planner (the epilogue detached)
     batch, idx, w = replay.sample(8)
     assert batch.state.shape[0] == 8 and np.isfinite(batch.value).all()
+
+
+def test_run_training_uses_a_prepared_graph_for_conv_nets(tmp_path):
+    """run_training with the one-graph update captured by the launcher (learner.prepare_graphed_step) on a board-game conv net: the loop
+    finds the step on the optimizer, checkpoints carry the reference's four entries, the actor network receives the trained weights."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import queue
+    import types
+
+    import torch
+
+    from muzero_amd import learner
+    from muzero_amd.config import make_gomoku_config
+    from muzero_amd.network import MuZeroBoardGameNet
+    from muzero_amd.pipeline import load_checkpoint
+    from muzero_amd.replay import PrioritizedReplay, Transition
+
+    dev = torch.device('cuda', 0)
+    N = 5
+    A, shape = N * N + 1, (9, N, N)
+    cfg = make_gomoku_config(num_training_steps=6, batch_size=16, min_replay_size=32, use_tensorboard=False)
+    cfg.checkpoint_interval, cfg.train_delay = 3, 0.0
+    torch.manual_seed(0)
+    net = MuZeroBoardGameNet(shape, A, 1, 16).to(dev)
+    actor = MuZeroBoardGameNet(shape, A, 1, 16)
+    opt = learner.make_capturable_adam(net, cfg, dev)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[4], gamma=0.1)
+    step = learner.prepare_graphed_step(cfg, net, opt, dev, shape, A)
+    rs = np.random.RandomState(0)
+    K, n = cfg.unroll_steps, 64
+    rp = PrioritizedReplay(256, 0.0, 0.0, np.random.RandomState(1), device='cuda')
+    rp.add_batch(Transition(rs.randint(0, 2, (n,) + shape).astype(np.float32), rs.randint(0, A, (n, K)).astype(np.int8),
+                            rs.dirichlet(np.ones(A), size=(n, K)).astype(np.float32), rs.uniform(-1, 1, (n, K)).astype(np.float32),
+                            rs.uniform(-1, 1, (n, K)).astype(np.float32)), np.ones(n))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    counter, stop, files = types.SimpleNamespace(value=0), threading.Event(), []
+    learner.run_training(cfg, net, opt, sched, dev, actor, rp, queue.SimpleQueue(), counter, str(tmp_path), files, stop, stop_grace_seconds=0.0)
+    assert counter.value == 6 and len(files) == 2 and opt.graphed_step is step
+    assert abs(float(opt.param_groups[0]["lr"]) - 0.1 * cfg.lr_init) < 1e-9  # (a float32 device tensor) the schedule crossed its milestone through the device tensor
+    assert any(not torch.equal(before[k], v) for k, v in net.state_dict().items() if v.dtype.is_floating_point)
+    for k, v in actor.state_dict().items():
+        assert torch.equal(v.cpu(), net.state_dict()[k].cpu()), k
+    ck = load_checkpoint(str(tmp_path / 'train_steps_6_final'), torch.device('cpu'))
+    assert set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'} and ck['train_steps'] == 6
