@@ -178,6 +178,9 @@ class HipLearner:
                 p.data = self.views[k]
         self.commit()
 
+    def _param_versions(self):
+        return tuple(p._version for p in self.network.parameters())
+
     def load_state_dict(self, sd) -> None:
         with torch.no_grad():
             for k, v in sd.items():
@@ -188,7 +191,9 @@ class HipLearner:
         return {k: v.detach().clone() for k, v in self.views.items()}
 
     def commit(self) -> None:
+        """Rebuild the MFMA operand copies from the master weights (after anything other than `apply` wrote them)."""
         _check(load_library().mzl_commit(self._h, self._stream()))
+        self._seen_versions = self._param_versions()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -235,6 +240,10 @@ class HipLearner:
         (uniform replay: ones).  Fills `self.grad_flat`, `self.loss`, `self.priorities[:batch]`; enqueues only."""
         if batch < 1 or batch > self.max_batch:
             raise LearnerError(f'batch {batch} outside [1, max_batch = {self.max_batch}]')
+        if self._param_versions() != self._seen_versions:
+            # torch wrote the parameters (network.load_state_dict on a checkpoint -- the reference's resume path, pipeline.py:810-817 -- or an
+            # in-place edit): the master weights are those tensors, the kernels' operand copies are rebuilt from them
+            self.commit()
         st, ac = ring['state'], ring['action']
         if st.dtype not in (torch.float32, torch.int8) or not st.is_contiguous():
             raise LearnerError(f'state storage must be contiguous float32 or int8, got {st.dtype}')

@@ -296,3 +296,51 @@ def test_persistent_chain_kernels_equal_the_stage_kernels(monkeypatch):
         assert out[0][0] == out[1][0]
         np.testing.assert_array_equal(out[0][1], out[1][1])
         np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+def test_resume_from_a_checkpoint_continues_the_same_run():
+    """The reference's resume path (pipeline.py:810-817): `network.load_state_dict`, `optimizer.load_state_dict`, `lr_scheduler.load_state_dict`
+    on freshly built objects, then training goes on.  Six updates in one go == three updates, a checkpoint through torch.save's format, three more
+    on a NEW learner -- bit for bit (the loaded weights reach the kernels' operand copies although torch wrote them, Adam's moments and step
+    count and the schedule's position travel in torch's own formats)."""
+    import io
+
+    case = mlp_case('cartpole')
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(5)
+    B = 48
+    batches = []
+    for _ in range(6):
+        tr = _random_batch(rs, B, (4, 5), 2)
+        ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(tr, f))).to(dev) for f in Transition._fields}
+        ring['state'] = ring['state'].reshape(B, -1).contiguous()
+        batches.append(ring)
+    kw = dict(lr=1e-2, weight_decay=1e-4, milestones=(2, 4), gamma=0.5, clip_grad=True, max_grad_norm=1.0)
+    net_a = build_mlp(case).to(dev)
+    hl_a = _hip(net_a, dev, B, **kw)
+    for ring in batches:
+        hl_a.step(ring, None, None, B, allreduce=False)
+    net_b = build_mlp(case).to(dev)
+    hl_b = _hip(net_b, dev, B, **kw)
+    for ring in batches[:3]:
+        hl_b.step(ring, None, None, B, allreduce=False)
+    buf = io.BytesIO()
+    torch.save({'network': net_b.state_dict(), 'optimizer': hl_b.optimizer.state_dict(), 'lr_scheduler': hl_b.lr_scheduler.state_dict(), 'train_steps': 3}, buf)
+    hl_b.close()
+    buf.seek(0)
+    ck = torch.load(buf, map_location='cpu', weights_only=False)
+    torch.manual_seed(123)
+    from muzero_amd.network import MuZeroMLPNet
+    net_c = MuZeroMLPNet((4, 5), 2, case[3], case[4], case[5], case[6]).to(dev)  # fresh random weights, replaced by the checkpoint's
+    hl_c = _hip(net_c, dev, B, **kw)
+    net_c.load_state_dict(ck['network'])
+    hl_c.optimizer.load_state_dict(ck['optimizer'])
+    hl_c.lr_scheduler.load_state_dict(ck['lr_scheduler'])
+    assert hl_c.steps == 3 and hl_c.current_lr() == hl_a.current_lr(3)
+    for ring in batches[3:]:
+        hl_c.step(ring, None, None, B, allreduce=False)
+    for (k, x), (_, y) in zip(net_a.state_dict().items(), net_c.state_dict().items()):
+        assert torch.equal(x, y), k
+    oa, oc = hl_a.optimizer.state_dict(), hl_c.optimizer.state_dict()
+    for i in oa['state']:
+        assert torch.equal(oa['state'][i]['exp_avg'], oc['state'][i]['exp_avg']) and torch.equal(oa['state'][i]['exp_avg_sq'], oc['state'][i]['exp_avg_sq'])
