@@ -86,11 +86,26 @@ def make_unroll_sequence(observations, actions, rewards, pi_probs, values, prior
         )
 
 
+def _compact(obj):
+    """Tensors that are views of a larger storage are cloned: torch.save writes a tensor's WHOLE storage, and the parameters of a module that
+    hip_learner.HipLearner adopted are views of one flat vector that also holds Adam's moments and the gradient slices -- a checkpoint of such
+    a module would otherwise carry that vector (4x-33x the weights) inside its 'network' entry."""
+    import torch
+
+    if torch.is_tensor(obj):
+        return obj.detach().clone() if obj.untyped_storage().nbytes() > obj.numel() * obj.element_size() else obj
+    if isinstance(obj, Mapping):
+        return type(obj)((k, _compact(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_compact(v) for v in obj)
+    return obj
+
+
 def create_checkpoint(state_to_save: Mapping[Text, Any], ckpt_file: str) -> None:
     """pipeline.py:802-803: torch.save of {'network', 'optimizer', 'lr_scheduler', 'train_steps'}."""
     import torch
 
-    torch.save(state_to_save, ckpt_file)
+    torch.save(_compact(state_to_save), ckpt_file)
 
 
 def load_checkpoint(ckpt_file: str, device) -> Mapping[Text, Any]:

@@ -237,6 +237,11 @@ def test_run_training_drives_the_hip_learner(tmp_path):
         assert torch.equal(v.cpu(), net.state_dict()[k].cpu())
     ck = load_checkpoint(str(tmp_path / 'train_steps_6_final'), torch.device('cpu'))
     assert set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'} and ck['train_steps'] == 6
+    # the file holds the weights and Adam's two moments once each -- not the learner's flat vector (weights + moments + gradient slices)
+    # behind every parameter view
+    import os
+    nbytes = 4 * sum(v.numel() for v in net.state_dict().values())
+    assert os.path.getsize(tmp_path / 'train_steps_6_final') < 3 * nbytes + (1 << 16)
     # the optimizer entry loads into a torch Adam built over the same parameters (the reference's resume path, pipeline.py:810-817)
     ref = build_mlp(mlp_case('tictactoe'))
     opt = torch.optim.Adam(ref.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
