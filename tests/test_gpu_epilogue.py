@@ -224,3 +224,36 @@ def test_slots_are_reserved_in_env_order_run_to_run_identical():
     o = runs[0][1]
     drops = int((np.diff(o) < 0).sum())  # the env index falls only where one move's block ends and the next begins
     assert drops <= 24
+
+
+def test_atari_shaped_items_match_host_assembler():
+    """BASELINE config C4's output side: the Atari conv net on the synthetic-frame env (4 x 96 x 96 float32 observations, 147 KB per item),
+    classic-control targets with mid-episode flushes -- items built on the GPU == the host assembler on the recorded stream, exact."""
+    from helpers import build_conv, conv_case
+    from muzero_amd import planner as pl
+    from muzero_amd.pipeline import EpisodeAssembler
+    from muzero_amd.replay import PrioritizedReplay
+
+    case = conv_case('atari_s')
+    shape = tuple(case[2])
+    cfg = types.SimpleNamespace(is_board_game=False, acc_seq_length=6, unroll_steps=5, td_steps=3, discount=0.997)
+    net = build_conv(case)
+    B, moves, chunk = 5, 40, 8
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, seed=4, num_simulations=3, discount=0.997), 0)
+    p.load_state_dict(net.state_dict())
+    rp = PrioritizedReplay(512, 0.0, 0.0, np.random.RandomState(0), device='cuda')
+    origin = p.attach_replay(rp, cfg, obs_shape=shape, with_origin=True)
+    p.selfplay_reset(pl.ENV_SYNTHETIC)
+    asm = [EpisodeAssembler(cfg, 1, shape) for _ in range(B)]
+    host = [[] for _ in range(B)]
+    for lo in range(0, moves, chunk):
+        p.selfplay_step(1.0, chunk)
+        rec = p.selfplay_read(chunk)
+        for b in range(B):
+            host[b].extend(asm[b].feed({k: v[:, b:b + 1] for k, v in rec.items()}))
+    n = rp.num_added
+    assert n == sum(len(h) for h in host) and n > 0
+    assert _compare(rp, origin.cpu().numpy(), host, n) == n
+    states = rp._ring['state'].cpu().numpy()[:n]
+    assert states.shape[1:] == shape and len({s.tobytes() for s in states}) > n // 2  # (frames really differ between items)
+    p.close()
