@@ -440,15 +440,15 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     }
     // long reductions (grad_slices > 1 is the caller's statement that the batch is large): 4 x 4 tiles per wave, the slices carry the
     // parallelism; short ones: 1 x 4 tiles per workgroup, its eight waves split the reduction
+    const int n_loss = 3 * K * tiles;
     if (h->cfg.grad_slices > 1 && tiles * K >= 64)
-        hipLaunchKernelGGL(k_learn_dw_big, dim3(((unsigned)h->big.size() + DWB_WAVES - 1) / DWB_WAVES), dim3(DWB_WAVES * 64), 0, st,
-                           h->d_big, (int)h->big.size(), h->grads, (size_t)h->P.total);
+        hipLaunchKernelGGL(k_learn_dw_big, dim3(((unsigned)h->big.size() + DWB_WAVES - 1) / DWB_WAVES + 1), dim3(DWB_WAVES * 64), 0, st,
+                           h->d_big, (int)h->big.size(), h->grads, (size_t)h->P.total, h->sv.lossp, n_loss, b->batch, b->d_loss);
     else
-        hipLaunchKernelGGL(k_learn_dw, dim3((unsigned)h->jobs.size(), h->cfg.grad_slices), dim3(LT), LW * 8 * 256 * 4, st, h->d_jobs, h->grads,
-                           (size_t)h->P.total);
+        hipLaunchKernelGGL(k_learn_dw, dim3((unsigned)h->jobs.size() + 1, h->cfg.grad_slices), dim3(LT), LW * 8 * 256 * 4, st, h->d_jobs, h->grads,
+                           (size_t)h->P.total, h->sv.lossp, n_loss, b->batch, b->d_loss);
     if (h->cfg.grad_slices > 1)  // slice 0 <- the complete gradient (what a data-parallel learner all-reduces)
         hipLaunchKernelGGL(k_learn_gradsum, dim3(h->sq_blocks), dim3(256), 0, st, h->grads, (size_t)h->P.total, h->cfg.grad_slices, h->P.total, h->d_sq);
-    hipLaunchKernelGGL(k_learn_finish, dim3(1), dim3(FIN_T), 0, st, h->sv.lossp, 3 * K * tiles, b->batch, b->d_loss);
     HIPCHK(hipGetLastError());
     return MZL_OK;
 }

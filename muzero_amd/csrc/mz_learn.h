@@ -15,8 +15,8 @@
 //                                               needs only h_k / u_{k+1}, so all 3 K of them run side by side (120 workgroups at batch 128)
 //   k_learn_back<k>         grid (tiles)        dL/dh_{k+1} (halved, pipeline.py:584) -> normalisation backward (+ reward's dL/du_{k+1})
 //                                               -> dynamics_k backward -> dL/dh_k                                    (k = K-1 .. 0, then repr)
-//   k_learn_dw              grid (jobs, split)  every weight / bias gradient: dW = sum over (step, sample) dZ x^T as MFMA tiles
-//   k_learn_finish          1 block             loss, gradient norm partials
+//   k_learn_dw              grid (jobs + 1, split)  every weight / bias gradient: dW = sum over (step, sample) dZ x^T as MFMA tiles; the extra
+//                                               workgroup adds up the loss
 // By batch size (the launcher, learner.hip mzl_grad): up to ~64 tiles both chains are cut across the planes (k_learn_fwd_sliced /
 // k_learn_back_sliced: more workgroups than tiles); from 96 tiles on the K dynamics stages of a tile run inside two PERSISTENT kernels
 // (k_learn_dyn_chain / k_learn_dyn_back_chain: operands loaded once per workgroup); the heads take a three-per-CU streaming build from
@@ -1121,6 +1121,28 @@ __global__ __launch_bounds__(LT) void k_learn_back_sliced(LNet net, LSave sv, LB
     copy_f4(sv.dxd + blk(k, tiles, tile, net.h_t) * DX_PARTS + (size_t)part * net.h_t * 256, lds + o.G, hf, tid);
 }
 
+// loss = mean_i w_i sum_k (reward + value + policy loss) (pipeline.py:594-597) from the heads' per-workgroup partial sums; fixed summation
+// order: LT strided partial sums (four independent chains per thread: the loads of a chain step are in flight together), then a tree.
+// Runs as ONE EXTRA WORKGROUP of the weight-gradient launch (the last block index): as a kernel of its own it cost a launch and a
+// dependent boundary for 5 us of work.  `sc`: LT floats of LDS.
+__device__ __forceinline__ void loss_finish(const float* __restrict__ lossp, int n, int B, float* __restrict__ loss_out, float* sc) {
+    const int tid = threadIdx.x;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int i = tid;
+    for (; i + 3 * LT < n; i += 4 * LT) {
+        const float a = lossp[i], b = lossp[i + LT], c = lossp[i + 2 * LT], d = lossp[i + 3 * LT];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; i < n; i += LT) s0 += lossp[i];
+    sc[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int m = LT / 2; m > 0; m >>= 1) {
+        if (tid < m) sc[tid] += sc[tid + m];
+        __syncthreads();
+    }
+    if (tid == 0) loss_out[0] = sc[0] / (float)B;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradients
 // ------------------------------------------------------------------------------------------------------------------
@@ -1138,8 +1160,13 @@ struct DwJob {
 // dW[n][c] = sum_r sum_s dz_r[n][s] x_r[c][s]: A operand = a T block of dz (16 rows x 4 samples per k-step), B operand = a T block of x.
 // The workgroup's waves split the reduction blocks; partial tiles meet in LDS and are added in wave order (deterministic).
 // grid.y = reduction split: slice y accumulates blocks [y R / ny, (y + 1) R / ny) into gradient slice y.
-__global__ __launch_bounds__(LT) void k_learn_dw(const DwJob* __restrict__ jobs, float* __restrict__ grads, size_t grad_stride) {
+__global__ __launch_bounds__(LT) void k_learn_dw(const DwJob* __restrict__ jobs, float* __restrict__ grads, size_t grad_stride, const float* __restrict__ lossp,
+                                                 int n_loss, int B, float* __restrict__ loss_out) {
     extern __shared__ __align__(16) float red[];  // LW x 8 accumulator tiles
+    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: the loss (loss_finish)
+        if (blockIdx.y == 0) loss_finish(lossp, n_loss, B, loss_out, red);
+        return;
+    }
     const DwJob J = jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = (int)((long long)blockIdx.y * J.R / gridDim.y), r1 = (int)((long long)(blockIdx.y + 1) * J.R / gridDim.y);
@@ -1238,7 +1265,14 @@ constexpr int DWB_WAVES = 8, DWB_NB = 5;
 // with the block's MFMAs issued component by component across the accumulators instead of four dependent k-steps per accumulator --
 // 130 -> 158 us at batch 4096 whichever way the MFMAs were ordered: twenty loop bodies in one kernel and the register moves of their
 // operand rotation cost more than the clamped loads and the 40-cycle dependent issue they remove.)
-__global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __restrict__ jobs, int njobs, float* __restrict__ grads, size_t grad_stride) {
+__global__ __launch_bounds__(DWB_WAVES * 64) void k_learn_dw_big(const DwBig* __restrict__ jobs, int njobs, float* __restrict__ grads, size_t grad_stride,
+                                                                 const float* __restrict__ lossp, int n_loss, int B, float* __restrict__ loss_out) {
+    static_assert(DWB_WAVES * 64 == LT, "loss_finish runs on LT threads");
+    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: the loss (loss_finish)
+        __shared__ float sc[LT];
+        loss_finish(lossp, n_loss, B, loss_out, sc);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int ji = blockIdx.x * DWB_WAVES + wave;
     if (ji >= njobs) return;
@@ -1340,27 +1374,6 @@ struct LParams {
     int kH[NLAYER], kHpad[NLAYER];  // column map of the layer's input (dynamics layer 0: [hidden | padding | actions])
     int total;
 };
-
-// loss = mean_i w_i sum_k (reward + value + policy loss) (pipeline.py:594-597); fixed summation order: 1024 strided partial sums (four
-// independent chains per thread: the loads of a chain step are in flight together), then a tree
-constexpr int FIN_T = 1024;
-__global__ __launch_bounds__(FIN_T) void k_learn_finish(const float* __restrict__ lossp, int n, int B, float* __restrict__ loss_out) {
-    __shared__ float sc[FIN_T];
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int i = threadIdx.x;
-    for (; i + 3 * FIN_T < n; i += 4 * FIN_T) {
-        const float a = lossp[i], b = lossp[i + FIN_T], c = lossp[i + 2 * FIN_T], d = lossp[i + 3 * FIN_T];
-        s0 += a; s1 += b; s2 += c; s3 += d;
-    }
-    for (; i < n; i += FIN_T) s0 += lossp[i];
-    sc[threadIdx.x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    for (int m = FIN_T / 2; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) sc[threadIdx.x] += sc[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) loss_out[0] = sc[0] / (float)B;
-}
 
 // sum of the gradient slices -> slice 0 (when the weight-gradient kernel ran with a reduction split), and per-block partial sums of
 // squares for clip_grad_norm_ (pipeline.py:246-247)
