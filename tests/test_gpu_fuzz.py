@@ -1,0 +1,132 @@
+"""Randomised differential test of the MLP search path: configurations drawn over the whole dispatch space -- tuned kernel builds (two /
+four / ten actions / general, 256 / 512 planes, categorical / MSE heads, board / single player, with / without known bounds) and the
+shape-generic kernel (odd plane counts, hidden sizes, action counts, support sizes, simulation counts) -- every env of every batch bit-exact
+against an independent oracle search on injected draws.   MZ_FUZZ_CASES=200 python -m pytest tests/test_gpu_fuzz.py -m gpu   (default 24)"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import build_mlp
+from test_oracle_nets import _oracle_net
+
+
+def _planner(net, num_envs, **search):
+    from muzero_amd import planner as pl
+
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=num_envs, **search), 0)
+    p.load_state_dict(net.state_dict())
+    return p
+
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get('MZ_FUZZ_CASES', '24'))
+
+
+def _draw_case(i):
+    rs = np.random.RandomState(9000 + i)
+    tuned = rs.rand() < 0.6
+    if tuned:  # shapes the launcher routes to k_search_fast
+        P, H = int(rs.choice([256, 512])), 64
+        A = int(rs.choice([2, 2, 4, 10, 3, 7, 16]))
+        sup = [(31, 31), (1, 1), (21, 31), (31, 7), (1, 31)][rs.randint(5)]
+    else:
+        P, H = int(rs.choice([16, 40, 96, 128, 200, 384])), int(rs.choice([8, 20, 32, 64, 100]))
+        A = int(rs.randint(2, 19))
+        sup = (int(rs.choice([1, 5, 31, 61])), int(rs.choice([1, 9, 31])))
+    ishape = [(4, 5), (3, 3, 3), (7,), (2, 2, 2), (4, 9)][rs.randint(5)]
+    board = bool(rs.rand() < 0.4)
+    bounds = (-1.0, 1.0) if (board or rs.rand() < 0.2) else None
+    S = int(rs.choice([1, 2, 5, 17, 25, 50, 60]))
+    B = int(rs.choice([1, 3, 16, 17, 40, 70]))
+    return dict(case=(f'fuzz{i}', ishape, A, P, sup[0], sup[1], H, 500 + i), board=board, bounds=bounds, S=S, B=B,
+                discount=1.0 if board else float(rs.choice([0.997, 0.9, 1.0])), alpha=float(rs.choice([0.03, 0.25, 1.0])),
+                eps=float(rs.choice([0.25, 0.0, 0.5])), seed=int(rs.randint(1 << 30)))
+
+
+@pytest.mark.parametrize('i', range(CASES))
+def test_random_configuration_bit_exact_vs_oracle(oracle, i):
+    c = _draw_case(i)
+    case, board, S, B = c['case'], c['board'], c['S'], c['B']
+    A = case[2]
+    net = build_mlp(case)
+    onet = _oracle_net(oracle, net, 'mlp')
+    kw = dict(num_simulations=S, discount=c['discount'], is_board_game=board, known_bounds=c['bounds'], root_dirichlet_alpha=c['alpha'],
+              root_exploration_eps=c['eps'])
+    ocfg = oracle.make_config(A, S, c['discount'], board, c['bounds'], c['alpha'], c['eps'])
+    p = _planner(net, B, **kw)
+    rs = np.random.RandomState(c['seed'])
+    obs = rs.uniform(-1, 1, size=(B,) + tuple(case[1])).astype(np.float32)
+    mask = rs.rand(B, A) < 0.7
+    mask[np.arange(B), rs.randint(0, A, B)] = True
+    cur = rs.randint(1, 3, B).astype(np.int32) if board else np.ones(B, np.int32)
+    opp = (3 - cur).astype(np.int32) if board else np.ones(B, np.int32)
+    temp = rs.choice([1.0, 0.5, 0.25, 0.1, 0.0], size=B)
+    noise = rs.dirichlet(np.full(A, max(c['alpha'], 0.05)), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    for det in (False, True):
+        r = p.search(obs, mask, cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie, u_final=u_final)
+        o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie,
+                                    u_final=u_final)
+        np.testing.assert_array_equal(r['visits'], o['visits'], err_msg=str(c))
+        np.testing.assert_array_equal(r['pi'], o['pi'], err_msg=str(c))
+        np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(c))
+        np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(c))
+    p.close()
+
+
+CONV_CASES_N = int(os.environ.get('MZ_FUZZ_CONV_CASES', '10'))
+
+
+def _draw_conv_case(i):
+    rs = np.random.RandomState(7000 + i)
+    N = int(rs.choice([3, 4, 5, 6, 7, 8, 9, 11]))
+    planes = int(rs.choice([8, 16, 16, 24, 32, 48]))
+    blocks = int(rs.choice([1, 1, 2]))
+    chans = int(rs.choice([3, 5, 9]))
+    # keep the scalar oracle's work per case bounded (~1 G MAC)
+    per_sim = planes * planes * 9 * N * N * (2 + 4 * blocks)
+    budget = 1.2e9
+    S = int(rs.choice([2, 5, 9, 14]))
+    B = int(rs.choice([1, 4, 9, 18, 33]))
+    while per_sim * S * B > budget and B > 1:
+        B = max(1, B // 2)
+    while per_sim * S * B > budget and S > 2:
+        S -= 1
+    return dict(case=(f'cfuzz{i}', 'board', (chans, N, N), N * N + 1, blocks, planes, 1, 1, 800 + i), S=S, B=B,
+                alpha=float(rs.choice([0.03, 0.25])), seed=int(rs.randint(1 << 30)))
+
+
+@pytest.mark.parametrize('i', range(CONV_CASES_N))
+def test_random_board_conv_configuration_bit_exact_vs_oracle(oracle, i):
+    """The conv path's kernels are chosen by geometry (images per workgroup, pixel tiles, fused residual tower or one launch per conv, the
+    sparse action terms fused into the epilogue or added by their own kernel, LDS- or HBM-resident trees): random board sizes, channel
+    counts, tower depths and batch sizes, every env bit-exact against the oracle."""
+    from helpers import build_conv
+
+    c = _draw_conv_case(i)
+    case, S, B = c['case'], c['S'], c['B']
+    A = case[3]
+    net = build_conv(case)
+    onet = _oracle_net(oracle, net, 'conv')
+    kw = dict(num_simulations=S, discount=1.0, is_board_game=True, known_bounds=(-1.0, 1.0), root_dirichlet_alpha=c['alpha'], root_exploration_eps=0.25)
+    ocfg = oracle.make_config(A, S, 1.0, True, (-1.0, 1.0), c['alpha'], 0.25)
+    p = _planner(net, B, **kw)
+    rs = np.random.RandomState(c['seed'])
+    obs = rs.randint(0, 2, size=(B,) + tuple(case[2])).astype(np.float32)
+    mask = rs.rand(B, A) < 0.8
+    mask[np.arange(B), rs.randint(0, A, B)] = True
+    cur = rs.randint(1, 3, B).astype(np.int32)
+    opp = (3 - cur).astype(np.int32)
+    temp = rs.choice([1.0, 0.5, 0.0], size=B)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    r = p.search(obs, mask, cur, opp, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
+    np.testing.assert_array_equal(r['visits'], o['visits'], err_msg=str(c))
+    np.testing.assert_array_equal(r['pi'], o['pi'], err_msg=str(c))
+    np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(c))
+    np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(c))
+    p.close()
