@@ -130,3 +130,63 @@ def test_random_board_conv_configuration_bit_exact_vs_oracle(oracle, i):
     np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(c))
     np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(c))
     p.close()
+
+
+LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_LEARN_CASES', '10'))
+
+
+def _draw_learn_case(i):
+    rs = np.random.RandomState(5000 + i)
+    if rs.rand() < 0.55:  # shapes with register-resident builds (512 / 256 planes, hidden 64)
+        P, H = int(rs.choice([512, 256])), 64
+        A = int(rs.choice([2, 4, 10, 6]))
+        sup = [(31, 31), (1, 1), (31, 1), (21, 31)][rs.randint(4)]
+        ishape = [(4, 5), (9, 3, 3), (4, 9)][rs.randint(3)]
+    else:         # anything else: the generic builds
+        P, H = int(rs.choice([32, 40, 96, 160])), int(rs.choice([16, 20, 32, 64]))
+        A = int(rs.randint(2, 12))
+        sup = (int(rs.choice([1, 7, 31])), int(rs.choice([1, 5, 31])))
+        ishape = [(7,), (3, 4), (2, 2, 2), (5, 5)][rs.randint(4)]
+    # batch sizes across the launcher's regimes: plane-sliced stages, persistent chains (>= 96 tiles), streaming heads (>= 16 tiles), split reductions
+    B = int(rs.choice([3, 16, 33, 128, 250, 640, 1600, 2100, 4100]))
+    return dict(case=(f'lfuzz{i}', ishape, A, P, sup[0], sup[1], H, 900 + i), B=B, seed=int(rs.randint(1 << 30)), weights=bool(rs.rand() < 0.5))
+
+
+@pytest.mark.parametrize('i', range(LEARN_CASES_N))
+def test_random_learner_configuration_matches_autograd(i):
+    """The HIP learner step over its launcher's regimes and the nets' shape space against PyTorch-ROCm autograd on the same batch: loss to
+    2e-4, every gradient tensor to 3e-3 of its norm (a ReLU whose pre-activation is within rounding of zero may gate differently in the two
+    summation orders; that moves single entries, not norms), priorities to 2e-3."""
+    import torch
+
+    from muzero_amd import learner
+    from muzero_amd.hip_learner import HipLearner
+    from muzero_amd.replay import Transition
+
+    c = _draw_learn_case(i)
+    case, B = c['case'], c['B']
+    A, K = case[2], 5
+    dev = torch.device('cuda', 0)
+    net_a = build_mlp(case).to(dev)
+    import copy
+    net_b = copy.deepcopy(net_a)
+    net_a.train()
+    rs = np.random.RandomState(c['seed'])
+    tr = Transition(rs.uniform(-1, 1, (B,) + tuple(case[1])).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
+                    rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), rs.uniform(-3, 3, (B, K)).astype(np.float32),
+                    rs.uniform(-1, 1, (B, K)).astype(np.float32))
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32) if c['weights'] else np.ones(B, np.float32)
+    la, pa = learner.calc_loss(net_a, dev, tr, torch.from_numpy(w).to(dev))
+    la.backward()
+    hl = HipLearner(net_b, dev, K, B, lr=1e-3)
+    ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(tr, f))).to(dev) for f in Transition._fields}
+    ring['state'] = ring['state'].reshape(B, -1).contiguous()
+    lb, pb = hl.grad(ring, None, torch.from_numpy(w).to(dev), B)
+    la_f = float(la.detach())
+    assert abs(la_f - float(lb)) <= 2e-4 * max(1.0, abs(la_f)), c
+    np.testing.assert_allclose(pb.cpu().numpy(), pa, rtol=2e-3, atol=2e-3, err_msg=str(c))
+    for k, p_ in net_a.named_parameters():
+        a, b = p_.grad.detach().cpu().numpy().ravel().astype(np.float64), hl.grad_views[k].cpu().numpy().ravel().astype(np.float64)
+        na = float(np.linalg.norm(a))
+        assert float(np.linalg.norm(a - b)) <= 3e-3 * max(na, 1e-7), (k, c, float(np.linalg.norm(a - b)), na)
+    hl.close()
