@@ -190,3 +190,23 @@ def test_random_learner_configuration_matches_autograd(i):
         na = float(np.linalg.norm(a))
         assert float(np.linalg.norm(a - b)) <= 3e-3 * max(na, 1e-7), (k, c, float(np.linalg.norm(a - b)), na)
     hl.close()
+
+
+SELFPLAY_CASES_N = int(os.environ.get('MZ_FUZZ_SELFPLAY_CASES', '6'))
+
+
+@pytest.mark.parametrize('i', range(SELFPLAY_CASES_N))
+def test_random_net_in_device_selfplay_equals_oracle_search(oracle, i):
+    """Device self-play (production Philox draws, env step fused into the search kernel where a build exists) with nets drawn over the
+    shape space that fits the device envs: every move's policy, root value and action equal the oracle's search on the recorded inputs
+    and the captured draws (the comparison of test_gpu_selfplay.py::test_selfplay_search_outputs_equal_oracle_search)."""
+    from test_gpu_selfplay import selfplay_search_vs_oracle
+
+    rs = np.random.RandomState(3000 + i)
+    game = ['cartpole', 'tictactoe'][rs.randint(2)]
+    ishape, A = ((4, 5), 2) if game == 'cartpole' else ((9, 3, 3), 10)
+    P, H = int(rs.choice([32, 96, 256, 512])), int(rs.choice([16, 32, 64, 64]))
+    sup = [(31, 31), (1, 1), (11, 31), (31, 1)][rs.randint(4)]
+    case = (f'sfuzz{i}', ishape, A, P, sup[0], sup[1], H, 1300 + i)
+    S, B = int(rs.choice([5, 25, 50])), int(rs.choice([16, 48, 100]))
+    selfplay_search_vs_oracle(oracle, game, case, S, B, 12, seed=int(rs.randint(1 << 20)), expect_resets=False)
