@@ -650,7 +650,7 @@ struct EpiLaunch {
 
 // z[t], t in [0, T): target value of every step of the open trajectory (compute_n_step_target :632-673 /
 // compute_mc_return_target :676-707); rec(i) = record index of trajectory position i
-__device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int T, int n, long long base, double* z, int lane) {
+__device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int T, int n, long long base, long long keep_from, double* z, int lane) {
     const EnvState& V = E.env;
     const ReplayRing& R = E.ring;
     const int B = E.B, A = V.A, D = V.D, K = R.K;
@@ -670,13 +670,18 @@ __device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int 
     // `base`: this env's slots, reserved by k_epi_scan in ENV ORDER (round 3 reserved with one atomicAdd per env: which env got which
     // slot then depended on workgroup scheduling, and with it every later replay draw -- the same seed gave different runs); the
     // count is published (R.num_added) only when the whole launch has filled its slots: see k_epi_publish
-    // the n items are written with the wave's lanes spread over (item, element) pairs: a flush emits acc_seq_length items at once
+    // the n items are written with the wave's lanes spread over (item, element) pairs: a flush emits acc_seq_length items at once.
+    // `keep_from`: when ONE move emits more items than the ring holds (a small ring, many envs finishing together), the items below it
+    // would be overwritten by later items of the same launch -- by another workgroup, in no defined order -- so they are not written at
+    // all: the ring ends up with exactly the last `capacity` items in order, run to run the same
     for (int j = lane; j < n * D; j += 64) {
         const int t = j / D, i = j - t * D;
+        if (base + t < keep_from) continue;
         R.state[(size_t)((base + t) % R.capacity) * D + i] = V.r_obs[rec(t) * D + i];
     }
     for (int j = lane; j < n * K; j += 64) {
         const int t = j / K, k = j - t * K, idx = t + k;
+        if (base + t < keep_from) continue;
         const size_t o = (size_t)((base + t) % R.capacity) * K + k;
         const bool real = idx < T;  // past the end: absorbing step (action 0, reward 0, value 0, uniform policy)
         if (R.action16) reinterpret_cast<short*>(R.action)[o] = real ? (short)V.r_action[rec(idx)] : (short)0;
@@ -686,9 +691,11 @@ __device__ inline void epi_emit(const EpiLaunch& E, int e, long long start, int 
     }
     for (int j = lane; j < n * K * A; j += 64) {
         const int t = j / (K * A), r = j - t * K * A, k = r / A, a = r - k * A, idx = t + k;
+        if (base + t < keep_from) continue;
         R.pi_prob[((size_t)((base + t) % R.capacity) * K + k) * A + a] = idx < T ? (float)V.r_pi[rec(idx) * A + a] : (float)(1.0 / (double)A);
     }
     for (int t = lane; t < n; t += 64) {
+        if (base + t < keep_from) continue;
         const size_t slot = (size_t)((base + t) % R.capacity);
         const double d = V.r_root[rec(t)] - z[t];
         R.priority[slot] = (float)(d < 0.0 ? -d : d);
@@ -708,14 +715,15 @@ __global__ __launch_bounds__(64) void k_epilogue(const EpiLaunch E) {
     const bool flush = !R.board && len == R.acc + R.K + R.td;
     if (flush || done) {
         long long base = R.ctr[0] + (long long)R.off[e];
+        const long long keep_from = R.ctr[0] + R.ctr[1] - (long long)R.capacity;  // (ctr[1]: this move's item count, k_epi_scan)
         if (flush) {
-            epi_emit(E, e, start, len, R.acc, base, z, lane);
+            epi_emit(E, e, start, len, R.acc, base, keep_from, z, lane);
             start += R.acc;
             len -= R.acc;
             base += R.acc;
         }
         if (done) {
-            epi_emit(E, e, start, len, len, base, z, lane);
+            epi_emit(E, e, start, len, len, base, keep_from, z, lane);
             start = E.move_abs + 1;
         }
         if (lane == 0) V.ep_start[e] = start;

@@ -210,3 +210,29 @@ def test_random_net_in_device_selfplay_equals_oracle_search(oracle, i):
     case = (f'sfuzz{i}', ishape, A, P, sup[0], sup[1], H, 1300 + i)
     S, B = int(rs.choice([5, 25, 50])), int(rs.choice([16, 48, 100]))
     selfplay_search_vs_oracle(oracle, game, case, S, B, 12, seed=int(rs.randint(1 << 20)), expect_resets=False)
+
+
+EPI_CASES_N = int(os.environ.get('MZ_FUZZ_EPILOGUE_CASES', '6'))
+
+
+@pytest.mark.parametrize('i', range(EPI_CASES_N))
+def test_random_epilogue_configuration_matches_host_assembler(i):
+    """The device epilogue (targets, priorities, unroll windows written into the HBM replay ring) over its parameter space -- unroll length,
+    mid-episode flush length, n-step horizon, env count, chunking of the moves, ring capacities that wrap -- against the host assembler on
+    the same records, exact."""
+    import types
+
+    from test_gpu_epilogue import _compare, _run
+
+    rs = np.random.RandomState(2000 + i)
+    game = ['cartpole', 'tictactoe'][rs.randint(2)]
+    board = game == 'tictactoe'
+    K = int(rs.choice([1, 2, 3, 5, 7]))
+    cfg = types.SimpleNamespace(is_board_game=board, unroll_steps=K, discount=1.0 if board else float(rs.choice([0.997, 0.9])),
+                                acc_seq_length=200 if board else int(rs.choice([3, 6, 20, 200])), td_steps=0 if board else int(rs.choice([1, 3, 10])))
+    B, chunk = int(rs.choice([5, 16, 33, 64])), int(rs.choice([1, 4, 8, 16]))
+    moves = chunk * max(int(rs.choice([4, 8, 12])), -(-64 // chunk))  # (at least 64 moves: random CartPole episodes last ~20 steps)
+    capacity = int(rs.choice([64, 256, 8192]))
+    p, rp, origin, host, n = _run(game, B, moves, chunk, cfg, capacity=capacity, seed=int(rs.randint(1 << 20)))
+    assert _compare(rp, origin, host, n) == min(n, capacity)
+    p.close()
