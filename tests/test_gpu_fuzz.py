@@ -236,3 +236,22 @@ def test_random_epilogue_configuration_matches_host_assembler(i):
     p, rp, origin, host, n = _run(game, B, moves, chunk, cfg, capacity=capacity, seed=int(rs.randint(1 << 20)))
     assert _compare(rp, origin, host, n) == min(n, capacity)
     p.close()
+
+
+GOMOKU_CASES_N = int(os.environ.get('MZ_FUZZ_GOMOKU_CASES', '4'))
+
+
+@pytest.mark.parametrize('i', range(GOMOKU_CASES_N))
+def test_random_conv_net_in_device_gomoku_selfplay_equals_oracle_search(oracle, i):
+    """The same for the conv path: device Gomoku (N x N, five in a row, stacked history) with board nets drawn over sizes, plane counts and
+    tower depths -- HBM-resident trees, fused towers or per-conv launches, fused action terms -- every move of device self-play equal to the
+    oracle's search on the recorded board and the captured draws."""
+    from test_gpu_selfplay import selfplay_search_vs_oracle
+
+    rs = np.random.RandomState(4000 + i)
+    N = int(rs.choice([5, 6, 7, 9]))
+    stack = 4 + 0 * int(rs.choice([1, 2, 4]))  # (the device Gomoku env is the reference configuration: 4 stacked positions, 9 planes)
+    planes, blocks = int(rs.choice([8, 16, 32])), int(rs.choice([1, 2]))
+    case = (f'gfuzz{i}', 'board', (2 * stack + 1, N, N), N * N + 1, blocks, planes, 1, 1, 1500 + i)
+    S, B = int(rs.choice([3, 8])), int(rs.choice([4, 12]))
+    selfplay_search_vs_oracle(oracle, 'gomoku', case, S, B, 10, seed=int(rs.randint(1 << 20)), expect_resets=False)

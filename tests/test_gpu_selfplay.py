@@ -258,19 +258,28 @@ def selfplay_search_vs_oracle(oracle, game, case, S, B, M, seed=77, expect_reset
     from test_oracle_nets import _oracle_net
     from muzero_amd import planner as pl
 
-    board = game == 'tictactoe'
-    net = build_mlp(case)
-    A = case[2]
+    board = game in ('tictactoe', 'gomoku')
+    conv = game == 'gomoku'  # `case`: a conv case tuple (helpers.CONV_CASES layout), observations (2 * stack + 1, N, N)
+    if conv:
+        from helpers import build_conv
+
+        net = build_conv(case)
+        A, obs_shape = case[3], tuple(case[2])
+        N, stack = obs_shape[1], (obs_shape[0] - 1) // 2
+    else:
+        net = build_mlp(case)
+        A, obs_shape = case[2], tuple(case[1])
     kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None,
               root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
     p = _planner(net, B, seed=seed, **kw)
     p.lib.mz_debug_capture_rng.argtypes = [C.c_void_p, C.c_int32]
     p.lib.mz_debug_read_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     assert p.lib.mz_debug_capture_rng(p.h, 1) == 0
-    p.selfplay_reset(pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE)
-    onet = _oracle_net(oracle, net, 'mlp')
+    p.selfplay_reset(pl.ENV_GOMOKU if conv else (pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE))
+    onet = _oracle_net(oracle, net, 'conv' if conv else 'mlp')
     cfg = oracle.make_config(A, S, kw['discount'], board, kw['known_bounds'], 0.25, 0.25)
-    envs = [oracle.BoardEnv(3, 4, 3) for _ in range(B)] if board else None
+    t_switch = 30 if conv else 6  # env steps at temperature 1 (config.py:236-249)
+    envs = [oracle.BoardEnv(N, stack, 5) if conv else oracle.BoardEnv(3, 4, 3) for _ in range(B)] if board else None
     if board:
         for e in envs:
             e.reset()
@@ -283,13 +292,13 @@ def selfplay_search_vs_oracle(oracle, game, case, S, B, M, seed=77, expect_reset
         ufin = np.empty(B, np.float64)
         assert p.lib.mz_debug_read_rng(p.h, noise.ctypes.data_as(C.c_void_p), utie.ctypes.data_as(C.c_void_p), ufin.ctypes.data_as(C.c_void_p)) == 0
         rec = p.selfplay_read(1)
-        obs = rec['obs'][0].reshape((B,) + tuple(case[1]))
+        obs = rec['obs'][0].reshape((B,) + obs_shape)
         if board:
             mask = np.stack([e.actions_mask for e in envs]).astype(np.uint8)
             cur = np.array([e.current_player for e in envs], np.int32)
             np.testing.assert_array_equal(rec['player'][0], cur)
             opp = 3 - cur
-            T = np.where(steps < 6, 1.0, 0.1)
+            T = np.where(steps < t_switch, 1.0, 0.1)
         else:
             mask, cur, opp, T = np.ones((B, A), np.uint8), 1, 1, 1.0
         o = oracle.uct_search_batch(cfg, onet, obs, mask, cur, opp, T, False, noise=noise, u_tie=utie, u_final=ufin)
