@@ -255,3 +255,40 @@ def test_random_conv_net_in_device_gomoku_selfplay_equals_oracle_search(oracle, 
     case = (f'gfuzz{i}', 'board', (2 * stack + 1, N, N), N * N + 1, blocks, planes, 1, 1, 1500 + i)
     S, B = int(rs.choice([3, 8])), int(rs.choice([4, 12]))
     selfplay_search_vs_oracle(oracle, 'gomoku', case, S, B, 10, seed=int(rs.randint(1 << 20)), expect_resets=False)
+
+
+ATARI_CASES_N = int(os.environ.get('MZ_FUZZ_ATARI_CASES', '4'))
+
+
+@pytest.mark.parametrize('i', range(ATARI_CASES_N))
+def test_random_atari_conv_configuration_bit_exact_vs_oracle(oracle, i):
+    """Atari-shaped nets (96 x 96 frames through the stride-2 / pooled representation down to 6 x 6, categorical heads) over frame
+    counts, plane counts, tower depths, action counts and support sizes: batched search bit-exact against the oracle."""
+    from helpers import build_conv
+
+    rs = np.random.RandomState(6000 + i)
+    frames, planes, blocks = int(rs.choice([2, 4, 8])), int(rs.choice([8, 16, 32])), int(rs.choice([1, 2]))
+    A, sup = int(rs.randint(3, 19)), [(11, 11), (31, 61), (61, 31), (5, 21)][rs.randint(4)]
+    case = (f'afuzz{i}', 'atari', (frames, 96, 96), A, blocks, planes, sup[0], sup[1], 1700 + i)
+    S, B = int(rs.choice([2, 6, 10])), int(rs.choice([1, 3, 6]))
+    net = build_conv(case)
+    onet = _oracle_net(oracle, net, 'conv')
+    kw = dict(num_simulations=S, discount=0.997, is_board_game=False, known_bounds=None, root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
+    ocfg = oracle.make_config(A, S, 0.997, False, None, 0.25, 0.25)
+    p = _planner(net, B, **kw)
+    obs = rs.uniform(0, 1, size=(B, frames, 96, 96)).astype(np.float32)
+    mask = np.ones((B, A), bool)
+    cur = opp = np.ones(B, np.int32)
+    temp = rs.choice([1.0, 0.5, 0.0], size=B)
+    noise = rs.dirichlet(np.full(A, 0.25), size=B)
+    u_tie = rs.rand(B, 4 * S + 8)
+    u_final = rs.rand(B)
+    for det in (False, True):
+        r = p.search(obs, mask, cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie, u_final=u_final)
+        o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie,
+                                    u_final=u_final)
+        np.testing.assert_array_equal(r['visits'], o['visits'], err_msg=str(case))
+        np.testing.assert_array_equal(r['pi'], o['pi'], err_msg=str(case))
+        np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(case))
+        np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(case))
+    p.close()
