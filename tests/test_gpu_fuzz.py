@@ -37,7 +37,7 @@ def _draw_case(i):
     ishape = [(4, 5), (3, 3, 3), (7,), (2, 2, 2), (4, 9)][rs.randint(5)]
     board = bool(rs.rand() < 0.4)
     bounds = (-1.0, 1.0) if (board or rs.rand() < 0.2) else None
-    S = int(rs.choice([1, 2, 5, 17, 25, 50, 60]))
+    S = int(rs.choice([1, 2, 5, 17, 25, 50, 60, 120, 300]))  # (long searches leave the LDS-resident tree layouts: other kernels)
     B = int(rs.choice([1, 3, 16, 17, 40, 70]))
     return dict(case=(f'fuzz{i}', ishape, A, P, sup[0], sup[1], H, 500 + i), board=board, bounds=bounds, S=S, B=B,
                 discount=1.0 if board else float(rs.choice([0.997, 0.9, 1.0])), alpha=float(rs.choice([0.03, 0.25, 1.0])),
