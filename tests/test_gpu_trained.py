@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(REPO, 'tools'))
+sys.path.insert(0, os.path.join(REPO, 'tests'))  # trained_parity.py: the training + comparison helpers (a checker: it lives with the tests)
 
 
 def test_trained_network_searches_equal_oracle(oracle, monkeypatch):

@@ -2,7 +2,7 @@
 """Diagnostic: GPU search vs oracle on a network TRAINED on the box (trained value ranges are where near-ties live; checkpoints
 cannot travel).  Trains CartPole for --train-steps, then searches states of evaluation episodes with every kernel variant and the
 oracle, deterministic and sampled, and plays deterministic evaluation episodes with each variant.
-    python tools/trained_parity.py --train-steps 4000"""
+    python tests/trained_parity.py --train-steps 4000"""
 import argparse
 import json
 import os
