@@ -21,10 +21,11 @@ def _planner(net, num_envs, **search):
 
 pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get('MZ_FUZZ_CASES', '24'))
+OFFSET = int(os.environ.get('MZ_FUZZ_SEED_OFFSET', '0'))  # soak runs: another region of every case generator's seed space
 
 
 def _draw_case(i):
-    rs = np.random.RandomState(9000 + i)
+    rs = np.random.RandomState(9000 + i + 100000 * OFFSET)
     tuned = rs.rand() < 0.6
     if tuned:  # shapes the launcher routes to k_search_fast
         P, H = int(rs.choice([256, 512])), 64
@@ -80,7 +81,7 @@ CONV_CASES_N = int(os.environ.get('MZ_FUZZ_CONV_CASES', '10'))
 
 
 def _draw_conv_case(i):
-    rs = np.random.RandomState(7000 + i)
+    rs = np.random.RandomState(7000 + i + 100000 * OFFSET)
     N = int(rs.choice([3, 4, 5, 6, 7, 8, 9, 11]))
     planes = int(rs.choice([8, 16, 16, 24, 32, 48]))
     blocks = int(rs.choice([1, 1, 2]))
@@ -136,7 +137,7 @@ LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_LEARN_CASES', '10'))
 
 
 def _draw_learn_case(i):
-    rs = np.random.RandomState(5000 + i)
+    rs = np.random.RandomState(5000 + i + 100000 * OFFSET)
     if rs.rand() < 0.55:  # shapes with register-resident builds (512 / 256 planes, hidden 64)
         P, H = int(rs.choice([512, 256])), 64
         A = int(rs.choice([2, 4, 10, 6]))
@@ -155,8 +156,8 @@ def _draw_learn_case(i):
 @pytest.mark.parametrize('i', range(LEARN_CASES_N))
 def test_random_learner_configuration_matches_autograd(i):
     """The HIP learner step over its launcher's regimes and the nets' shape space against PyTorch-ROCm autograd on the same batch: loss to
-    2e-4, every gradient tensor to 3e-3 of its norm (a ReLU whose pre-activation is within rounding of zero may gate differently in the two
-    summation orders; that moves single entries, not norms), priorities to 2e-3."""
+    2e-4, every gradient tensor to 3e-3 of its norm, priorities to 2e-3.  Batches that sit within rounding of a kink of the loss (detected on
+    the autograd side, see below: once in ~7 000 cases) are only held to 5e-2."""
     import torch
 
     from muzero_amd import learner
@@ -176,8 +177,30 @@ def test_random_learner_configuration_matches_autograd(i):
                     rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), rs.uniform(-3, 3, (B, K)).astype(np.float32),
                     rs.uniform(-1, 1, (B, K)).astype(np.float32))
     w = rs.uniform(0.3, 1.0, B).astype(np.float32) if c['weights'] else np.ones(B, np.float32)
+    # non-smooth points of the loss: a ReLU pre-activation within rounding of zero, or two features of an un-normalised state within rounding
+    # of each other at its minimum / maximum (util.py:31-36: the min / max gradient goes to ONE index).  There the two implementations'
+    # summation orders may pick different branches, and everything upstream of that sample moves by its contribution.
+    margins = []
+
+    def watch_relu(_m, _i, out):
+        margins.append(float(out.detach().abs().min()))
+
+    def watch_state(_m, _i, out):
+        v = out.detach().sort(dim=1).values
+        rng = (v[:, -1] - v[:, 0]).clamp_min(1e-30)
+        margins.append(float(torch.minimum((v[:, 1] - v[:, 0]) / rng, (v[:, -1] - v[:, -2]) / rng).min()))
+
+    hooks = []
+    for name, m in net_a.named_modules():
+        if isinstance(m, torch.nn.Linear) and name.endswith('.0'):
+            hooks.append(m.register_forward_hook(watch_relu))
+        if name in ('represent_net.net.2', 'dynamics_net.transition_net.2'):
+            hooks.append(m.register_forward_hook(watch_state))
     la, pa = learner.calc_loss(net_a, dev, tr, torch.from_numpy(w).to(dev))
     la.backward()
+    for hk in hooks:
+        hk.remove()
+    smooth = min(margins) > 5e-6
     hl = HipLearner(net_b, dev, K, B, lr=1e-3)
     ring = {f: torch.from_numpy(np.ascontiguousarray(getattr(tr, f))).to(dev) for f in Transition._fields}
     ring['state'] = ring['state'].reshape(B, -1).contiguous()
@@ -187,8 +210,10 @@ def test_random_learner_configuration_matches_autograd(i):
     np.testing.assert_allclose(pb.cpu().numpy(), pa, rtol=2e-3, atol=2e-3, err_msg=str(c))
     for k, p_ in net_a.named_parameters():
         a, b = p_.grad.detach().cpu().numpy().ravel().astype(np.float64), hl.grad_views[k].cpu().numpy().ravel().astype(np.float64)
-        na = float(np.linalg.norm(a))
-        assert float(np.linalg.norm(a - b)) <= 3e-3 * max(na, 1e-7), (k, c, float(np.linalg.norm(a - b)), na)
+        na, err = float(np.linalg.norm(a)), float(np.linalg.norm(a - b))
+        if err <= 3e-3 * max(na, 1e-7):
+            continue  # (the normal case, kink nearby or not)
+        assert not smooth and err <= 5e-2 * max(na, 1e-7), (k, c, err, na, 'smooth' if smooth else 'near a kink', min(margins))
     hl.close()
 
 
@@ -202,7 +227,7 @@ def test_random_net_in_device_selfplay_equals_oracle_search(oracle, i):
     and the captured draws (the comparison of test_gpu_selfplay.py::test_selfplay_search_outputs_equal_oracle_search)."""
     from test_gpu_selfplay import selfplay_search_vs_oracle
 
-    rs = np.random.RandomState(3000 + i)
+    rs = np.random.RandomState(3000 + i + 100000 * OFFSET)
     game = ['cartpole', 'tictactoe'][rs.randint(2)]
     ishape, A = ((4, 5), 2) if game == 'cartpole' else ((9, 3, 3), 10)
     P, H = int(rs.choice([32, 96, 256, 512])), int(rs.choice([16, 32, 64, 64]))
@@ -224,7 +249,7 @@ def test_random_epilogue_configuration_matches_host_assembler(i):
 
     from test_gpu_epilogue import _compare, _run
 
-    rs = np.random.RandomState(2000 + i)
+    rs = np.random.RandomState(2000 + i + 100000 * OFFSET)
     game = ['cartpole', 'tictactoe'][rs.randint(2)]
     board = game == 'tictactoe'
     K = int(rs.choice([1, 2, 3, 5, 7]))
@@ -248,7 +273,7 @@ def test_random_conv_net_in_device_gomoku_selfplay_equals_oracle_search(oracle, 
     oracle's search on the recorded board and the captured draws."""
     from test_gpu_selfplay import selfplay_search_vs_oracle
 
-    rs = np.random.RandomState(4000 + i)
+    rs = np.random.RandomState(4000 + i + 100000 * OFFSET)
     N = int(rs.choice([5, 6, 7, 9]))
     stack = 4 + 0 * int(rs.choice([1, 2, 4]))  # (the device Gomoku env is the reference configuration: 4 stacked positions, 9 planes)
     planes, blocks = int(rs.choice([8, 16, 32])), int(rs.choice([1, 2]))
@@ -266,7 +291,7 @@ def test_random_atari_conv_configuration_bit_exact_vs_oracle(oracle, i):
     counts, plane counts, tower depths, action counts and support sizes: batched search bit-exact against the oracle."""
     from helpers import build_conv
 
-    rs = np.random.RandomState(6000 + i)
+    rs = np.random.RandomState(6000 + i + 100000 * OFFSET)
     frames, planes, blocks = int(rs.choice([2, 4, 8])), int(rs.choice([8, 16, 32])), int(rs.choice([1, 2]))
     A, sup = int(rs.randint(3, 19)), [(11, 11), (31, 61), (61, 31), (5, 21)][rs.randint(4)]
     case = (f'afuzz{i}', 'atari', (frames, 96, 96), A, blocks, planes, sup[0], sup[1], 1700 + i)
