@@ -53,6 +53,7 @@ struct mz_learner {
     float* d_sq = nullptr;     // partial sums of squares of the gradient
     int sq_blocks = 0;
     int num_cus = 256;
+    const void* checked_ptr[9] = {};  // batch pointers already verified to be device memory (mzl_grad)
     int fast_max_tiles = 16, stage_fast_max_tiles = 256;  // MZL_FAST_MAX_TILES / MZL_CHAIN_FAST_MAX_TILES at create (see mzl_grad)
     int chain_min_tiles = 96, chain_max_tiles = 1 << 30;  // batch range of the persistent chain kernels (MZL_CHAIN_MIN_TILES / MZL_CHAIN_MAX_TILES at create)
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
@@ -355,6 +356,20 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     if (!b->d_state || !b->d_action || !b->d_pi_prob || !b->d_value || !b->d_reward || !b->d_weights || !b->d_loss || !b->d_priorities)
         return fail(MZL_E_INVALID, "null batch pointer");
     if (b->action_bytes != 1 && b->action_bytes != 2) return fail(MZL_E_INVALID, "action_bytes must be 1 or 2");
+    {   // every pointer must be memory of this GPU (a host pointer would fault inside a kernel: checked here, once per distinct value)
+        const void* ptrs[9] = {b->d_state, b->d_action, b->d_pi_prob, b->d_value, b->d_reward, b->d_index, b->d_weights, b->d_loss, b->d_priorities};
+        static const char* names[9] = {"d_state", "d_action", "d_pi_prob", "d_value", "d_reward", "d_index", "d_weights", "d_loss", "d_priorities"};
+        for (int i = 0; i < 9; i++) {
+            if (ptrs[i] == h->checked_ptr[i]) continue;
+            hipPointerAttribute_t at{};
+            const hipError_t e = hipPointerGetAttributes(&at, ptrs[i]);
+            if (e != hipSuccess || at.type != hipMemoryTypeDevice || at.device != h->device) {
+                (void)hipGetLastError();
+                return fail(MZL_E_INVALID, std::string(names[i]) + " is not memory of the learner's GPU (the batch is read where the replay lives: keep it in HBM)");
+            }
+            h->checked_ptr[i] = ptrs[i];
+        }
+    }
     if (b->action_bytes == 1 && h->cfg.num_actions > 128) return fail(MZL_E_INVALID, "num_actions > 128 needs int16 actions");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -154,6 +154,17 @@ def test_errors_are_reported_not_swallowed():
     host_ring['state'] = host_ring['state'].reshape(8, -1).contiguous()
     with pytest.raises(LearnerError, match="device='cuda'"):
         hl.grad(host_ring, None, None, 8)
+    # ... and so does the C ABI itself, for callers that do not go through hip_learner.py: a host pointer in mzl_batch
+    import ctypes as C
+
+    from muzero_amd.hip_learner import MzlBatch, load_library
+
+    dring = {f: t.to(dev) for f, t in host_ring.items()}
+    idx, w = hl._iota[:8], hl._ones
+    b = MzlBatch(host_ring['state'].data_ptr(), dring['action'].data_ptr(), dring['pi_prob'].data_ptr(), dring['value'].data_ptr(), dring['reward'].data_ptr(),
+                 idx.data_ptr(), w.data_ptr(), hl.loss.data_ptr(), hl.priorities.data_ptr(), 8, 0, 1)
+    L = load_library()
+    assert L.mzl_grad(hl._h, C.byref(b), None) == -1 and b'd_state is not memory' in L.mzl_last_error()
     from helpers import build_conv, conv_case
 
     with pytest.raises(LearnerError, match='MuZeroMLPNet'):
