@@ -1032,6 +1032,19 @@ extern "C" int mz_selfplay_attach_replay(mz_planner* p, const mz_replay_ring* ri
         return fail(MZ_E_INVALID, "mz_replay_ring: capacity and every array but `origin` are required");
     if (ring->unroll_steps < 1 || ring->td_steps < 0 || ring->td_steps > 32 || ring->acc_seq_length < 1)
         return fail(MZ_E_INVALID, "mz_replay_ring: unroll_steps >= 1, 0 <= td_steps <= 32, acc_seq_length >= 1");
+    {   // the epilogue kernels write through these pointers: every one must be memory of the planner's GPU (a host-resident replay would fault)
+        const void* ptrs[8] = {ring->state, ring->action, ring->pi_prob, ring->value, ring->reward, ring->priority, ring->num_added, ring->origin};
+        static const char* names[8] = {"state", "action", "pi_prob", "value", "reward", "priority", "num_added", "origin"};
+        for (int i = 0; i < 8; i++) {
+            if (!ptrs[i]) continue;  // (origin is optional)
+            hipPointerAttribute_t at{};
+            const hipError_t e = hipPointerGetAttributes(&at, ptrs[i]);
+            if (e != hipSuccess || at.type != hipMemoryTypeDevice || at.device != p->device) {
+                (void)hipGetLastError();
+                return fail(MZ_E_INVALID, std::string("mz_replay_ring.") + names[i] + " is not memory of the planner's GPU");
+            }
+        }
+    }
     ReplayRing& R = p->replay;
     R.capacity = ring->capacity; R.state = ring->state; R.action = reinterpret_cast<signed char*>(ring->action); R.action16 = c.num_actions > 128 ? 1 : 0; R.pi_prob = ring->pi_prob;
     R.value = ring->value; R.reward = ring->reward; R.priority = ring->priority; R.num_added = reinterpret_cast<long long*>(ring->num_added);

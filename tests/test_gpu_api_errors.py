@@ -139,3 +139,28 @@ def test_mlp_nets_beyond_the_lds_kernel_use_hbm_trees(oracle, shape, monkeypatch
     o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, np.ones(B), False, noise=noise, u_tie=u_tie, u_final=u_final)
     for k in ('visits', 'pi', 'action', 'root_value'):
         np.testing.assert_array_equal(r[k], o[k])
+
+
+def test_attach_replay_refuses_host_memory_through_the_abi():
+    """`mz_replay_ring` carries device pointers; a C caller that hands over host arrays gets MZ_E_INVALID naming the field, not a fault inside
+    the epilogue kernel (the Python wrapper checks the tensors' device before it ever gets there)."""
+    import ctypes as C
+
+    import torch
+
+    from muzero_amd import planner as pl
+
+    net = build_mlp(mlp_case('cartpole'))
+    p = pl.Planner(_cfg(net, num_envs=4, num_simulations=5), 0)
+    p.load_state_dict(net.state_dict())
+    cap, K, A, D = 64, 5, 2, 20
+    dev = torch.device('cuda', 0)
+    st, ac, pi = torch.zeros(cap, D, device=dev), torch.zeros(cap, K, dtype=torch.int8, device=dev), torch.zeros(cap, K, A, device=dev)
+    va, re, pr, cnt = torch.zeros(cap, K, device=dev), torch.zeros(cap, K, device=dev), torch.zeros(cap, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    host_state = torch.zeros(cap, D)  # NOT on the GPU
+    r = pl.MzReplayRing(cap, host_state.data_ptr(), ac.data_ptr(), pi.data_ptr(), va.data_ptr(), re.data_ptr(), pr.data_ptr(), cnt.data_ptr(), None, 200, K, 10)
+    assert p.lib.mz_selfplay_attach_replay(p.h, C.byref(r)) == -1
+    assert b'mz_replay_ring.state is not memory' in p.lib.mz_last_error()
+    r = pl.MzReplayRing(cap, st.data_ptr(), ac.data_ptr(), pi.data_ptr(), va.data_ptr(), re.data_ptr(), pr.data_ptr(), cnt.data_ptr(), None, 200, K, 10)
+    assert p.lib.mz_selfplay_attach_replay(p.h, C.byref(r)) == 0  # the same ring in HBM is accepted
+    p.close()
