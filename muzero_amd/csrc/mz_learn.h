@@ -610,7 +610,9 @@ __global__ __launch_bounds__(LT, OCC * LW / 4) void k_learn_unroll(LNet net, LSa
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = blockIdx.x, tiles = bt.tiles;
     // grid (tiles, roles, steps): role = role0 + blockIdx.y; the launch's step index blockIdx.z addresses h_k for the dynamics / policy / value
     // roles and u_k (reward of step k - 1) for the reward role, whose steps are therefore shifted by one
-    const int role = role0 + (int)blockIdx.y, k = k0 + (int)blockIdx.z + ((role == 3 && gridDim.z > 1) ? 1 : 0);
+    // (the all-heads launch is grid.y == 3: its reward role is shifted by one step.  Round 4's first form tested gridDim.z > 1 -- "more than
+    // one step in the launch" -- which dropped the reward head altogether for unroll_steps == 1: found by the randomised learner test)
+    const int role = role0 + (int)blockIdx.y, k = k0 + (int)blockIdx.z + ((role == 3 && gridDim.y > 1) ? 1 : 0);
     const int K = net.K, hf = net.h_t * 64;
     const int e = tid >> 5, j = tid & 31, s = tile * TILE + e;
     WideW w1;

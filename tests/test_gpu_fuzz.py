@@ -150,7 +150,8 @@ def _draw_learn_case(i):
         ishape = [(7,), (3, 4), (2, 2, 2), (5, 5)][rs.randint(4)]
     # batch sizes across the launcher's regimes: plane-sliced stages, persistent chains (>= 96 tiles), streaming heads (>= 16 tiles), split reductions
     B = int(rs.choice([3, 16, 33, 128, 250, 640, 1600, 2100, 4100]))
-    return dict(case=(f'lfuzz{i}', ishape, A, P, sup[0], sup[1], H, 900 + i), B=B, seed=int(rs.randint(1 << 30)), weights=bool(rs.rand() < 0.5))
+    return dict(case=(f'lfuzz{i}', ishape, A, P, sup[0], sup[1], H, 900 + i), B=B, seed=int(rs.randint(1 << 30)), weights=bool(rs.rand() < 0.5),
+                K=int(rs.choice([5, 5, 1, 2, 3, 8])))  # (unroll length: 5 in every reference configuration)
 
 
 @pytest.mark.parametrize('i', range(LEARN_CASES_N))
@@ -166,7 +167,7 @@ def test_random_learner_configuration_matches_autograd(i):
 
     c = _draw_learn_case(i)
     case, B = c['case'], c['B']
-    A, K = case[2], 5
+    A, K = case[2], c['K']
     dev = torch.device('cuda', 0)
     net_a = build_mlp(case).to(dev)
     import copy
