@@ -37,7 +37,7 @@ def _draw_case(i):
         sup = (int(rs.choice([1, 5, 31, 61])), int(rs.choice([1, 9, 31])))
     ishape = [(4, 5), (3, 3, 3), (7,), (2, 2, 2), (4, 9)][rs.randint(5)]
     board = bool(rs.rand() < 0.4)
-    bounds = (-1.0, 1.0) if (board or rs.rand() < 0.2) else None
+    bounds = [(-1.0, 1.0), (0.0, 1.0), (-3.5, 7.25)][rs.randint(3)] if (board or rs.rand() < 0.3) else None  # (MinMaxStats' known bounds, mcts.py:36-38)
     S = int(rs.choice([1, 2, 5, 17, 25, 50, 60, 120, 300]))  # (long searches leave the LDS-resident tree layouts: other kernels)
     B = int(rs.choice([1, 3, 16, 17, 40, 70]))
     return dict(case=(f'fuzz{i}', ishape, A, P, sup[0], sup[1], H, 500 + i), board=board, bounds=bounds, S=S, B=B,
@@ -151,7 +151,9 @@ def _draw_learn_case(i):
     # batch sizes across the launcher's regimes: plane-sliced stages, persistent chains (>= 96 tiles), streaming heads (>= 16 tiles), split reductions
     B = int(rs.choice([3, 16, 33, 128, 250, 640, 1600, 2100, 4100]))
     return dict(case=(f'lfuzz{i}', ishape, A, P, sup[0], sup[1], H, 900 + i), B=B, seed=int(rs.randint(1 << 30)), weights=bool(rs.rand() < 0.5),
-                K=int(rs.choice([5, 5, 1, 2, 3, 8])))  # (unroll length: 5 in every reference configuration)
+                K=int(rs.choice([5, 5, 1, 2, 3, 8])),  # (unroll length: 5 in every reference configuration)
+                opt=dict(lr=float(rs.choice([1e-3, 2e-2, 3e-4])), betas=(float(rs.choice([0.9, 0.8])), float(rs.choice([0.999, 0.95]))),
+                         eps=float(rs.choice([1e-8, 1e-6])), wd=float(rs.choice([0.0, 1e-4, 1e-2])), clip=float(rs.choice([0.0, 0.5, 40.0]))))
 
 
 @pytest.mark.parametrize('i', range(LEARN_CASES_N))
@@ -215,6 +217,23 @@ def test_random_learner_configuration_matches_autograd(i):
         if err <= 3e-3 * max(na, 1e-7):
             continue  # (the normal case, kink nearby or not)
         assert not smooth and err <= 5e-2 * max(na, 1e-7), (k, c, err, na, 'smooth' if smooth else 'near a kink', min(margins))
+    # one optimizer step with the drawn hyper-parameters against torch.optim.Adam + clip_grad_norm_ on the autograd gradients.  Adam's first
+    # update is -lr g / (|g| + eps): compared where the gradient is clear of the eps scale (elsewhere a last-bit difference of g changes it)
+    hp = c['opt']
+    before_b = {k: v.detach().clone() for k, v in net_b.named_parameters()}
+    before_a = {k: v.detach().clone() for k, v in net_a.named_parameters()}
+    opt = torch.optim.Adam(net_a.parameters(), lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['wd'])
+    if hp['clip'] > 0:
+        torch.nn.utils.clip_grad_norm_(net_a.parameters(), hp['clip'])
+    ga = {k: (p_.grad.detach() + hp['wd'] * before_a[k]).abs() for k, p_ in net_a.named_parameters()}
+    opt.step()
+    hl.lr_init, hl.betas, hl.eps, hl.weight_decay, hl.max_grad_norm = hp['lr'], hp['betas'], hp['eps'], hp['wd'], hp['clip']
+    hl.apply(clip=hp['clip'] > 0)
+    for k, p_ in net_a.named_parameters():
+        da, db = (p_.detach() - before_a[k]).cpu().numpy(), (dict(net_b.named_parameters())[k].detach() - before_b[k]).cpu().numpy()
+        clear = (ga[k] > 1e3 * hp['eps'] + 1e-7 * float(ga[k].max())).cpu().numpy()
+        if clear.any():
+            assert float(np.abs(da - db)[clear].max()) <= 2e-3 * hp['lr'] + 1e-9, (k, c)
     hl.close()
 
 
