@@ -33,7 +33,7 @@ def _draw_case(i):
         sup = [(31, 31), (1, 1), (21, 31), (31, 7), (1, 31)][rs.randint(5)]
     else:
         P, H = int(rs.choice([16, 40, 96, 128, 200, 384])), int(rs.choice([8, 20, 32, 64, 100]))
-        A = int(rs.randint(2, 19))
+        A = int(rs.randint(2, 19)) if rs.rand() < 0.8 else int(rs.choice([30, 64, 130, 226]))  # (wide action sets: other tree layouts)
         sup = (int(rs.choice([1, 5, 31, 61])), int(rs.choice([1, 9, 31])))
     ishape = [(4, 5), (3, 3, 3), (7,), (2, 2, 2), (4, 9)][rs.randint(5)]
     board = bool(rs.rand() < 0.4)
