@@ -337,3 +337,57 @@ def test_random_atari_conv_configuration_bit_exact_vs_oracle(oracle, i):
         np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(case))
         np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(case))
     p.close()
+
+
+PLUMB_CASES_N = int(os.environ.get('MZ_FUZZ_PLUMBING_CASES', '6'))
+
+
+@pytest.mark.parametrize('i', range(PLUMB_CASES_N))
+def test_random_learner_batch_plumbing_is_exact(i):
+    """One learner serving a SEQUENCE of batches of different sizes (below its capacity), gathered from a larger replay ring by index vectors
+    with repeats, float32 or int8 states, int8 or int16 action fields, with and without importance weights -- against a fresh learner of
+    exactly that batch size on the same rows stacked contiguously: loss, priorities and every gradient bit for bit (the job tables follow
+    the batch size, stale gradient slices are cleared, samples past the batch contribute nothing)."""
+    import copy
+
+    import torch
+
+    from muzero_amd.hip_learner import HipLearner
+    from muzero_amd.replay import Transition
+
+    rs = np.random.RandomState(1000 + i + 100000 * OFFSET)
+    P, H = (int(rs.choice([512, 256])), 64) if rs.rand() < 0.6 else (int(rs.choice([32, 96])), int(rs.choice([16, 32])))
+    A = int(rs.choice([2, 4, 10, 200])) if P >= 256 else int(rs.randint(2, 9))
+    A = A if A <= 32 else (A if P < 256 else 10)  # (the tuned builds cover <= 32 actions; 200 actions exercise int16 fields on the generic builds)
+    if P < 256 and rs.rand() < 0.3:
+        A = 200
+    sup = [(31, 31), (1, 1), (11, 31)][rs.randint(3)]
+    ishape = [(4, 5), (9, 3, 3), (7,)][rs.randint(3)]
+    case = (f'pfuzz{i}', ishape, A, P, sup[0], sup[1], H, 2100 + i)
+    K = int(rs.choice([5, 5, 2, 7]))
+    int8_state, act16 = bool(rs.rand() < 0.3), A > 128
+    dev = torch.device('cuda', 0)
+    net = build_mlp(case).to(dev)
+    cap, Bmax = int(rs.choice([300, 1000])), int(rs.choice([64, 200, 700]))
+    slices = int(rs.choice([1, 1, 3]))
+    st = rs.randint(0, 2, (cap,) + tuple(ishape)).astype(np.int8) if int8_state else rs.uniform(-1, 1, (cap,) + tuple(ishape)).astype(np.float32)
+    ring = dict(state=torch.from_numpy(st).to(dev).reshape(cap, -1).contiguous(),
+                action=torch.from_numpy(rs.randint(0, A, (cap, K)).astype(np.int16 if act16 else np.int8)).to(dev),
+                pi_prob=torch.from_numpy(rs.dirichlet(np.ones(A), size=(cap, K)).astype(np.float32)).to(dev),
+                value=torch.from_numpy(rs.uniform(-3, 3, (cap, K)).astype(np.float32)).to(dev),
+                reward=torch.from_numpy(rs.uniform(-1, 1, (cap, K)).astype(np.float32)).to(dev))
+    big = HipLearner(copy.deepcopy(net), dev, K, Bmax, lr=1e-3, grad_slices=slices)
+    for step in range(3):
+        b = int(rs.randint(1, Bmax + 1))
+        idx = torch.from_numpy(rs.randint(0, cap, b).astype(np.int64)).to(dev)
+        w = torch.from_numpy(rs.uniform(0.3, 1.0, b).astype(np.float32)).to(dev) if rs.rand() < 0.5 else None
+        loss, prio = big.grad(ring, idx, w, b)
+        got = (float(loss), prio.cpu().numpy().copy(), big.grad_flat.cpu().numpy().copy())
+        ref = HipLearner(copy.deepcopy(net), dev, K, b, lr=1e-3, grad_slices=slices)
+        stacked = {f: t.index_select(0, idx).contiguous() for f, t in ring.items()}
+        l2, p2 = ref.grad(stacked, None, w, b)
+        assert got[0] == float(l2), (case, step, b)
+        np.testing.assert_array_equal(got[1], p2.cpu().numpy(), err_msg=str((case, step, b)))
+        np.testing.assert_array_equal(got[2], ref.grad_flat.cpu().numpy(), err_msg=str((case, step, b)))
+        ref.close()
+    big.close()
