@@ -74,6 +74,11 @@ def test_random_configuration_bit_exact_vs_oracle(oracle, i):
         np.testing.assert_array_equal(r['pi'], o['pi'], err_msg=str(c))
         np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(c))
         np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(c))
+    if B > 1:  # a smaller batch on the same planner (fewer envs than it was created for): the same rows again
+        b = int(rs.randint(1, B))
+        r2 = p.search(obs[:b], mask[:b], cur[:b], opp[:b], temp[:b], True, noise=None, u_tie=u_tie[:b], u_final=u_final[:b])
+        for key in ('visits', 'pi', 'action', 'root_value'):
+            np.testing.assert_array_equal(r2[key], r[key][:b], err_msg=str((c, 'sub-batch', b)))
     p.close()
 
 
