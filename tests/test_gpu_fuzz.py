@@ -259,7 +259,8 @@ def test_random_net_in_device_selfplay_equals_oracle_search(oracle, i):
     sup = [(31, 31), (1, 1), (11, 31), (31, 1)][rs.randint(4)]
     case = (f'sfuzz{i}', ishape, A, P, sup[0], sup[1], H, 1300 + i)
     S, B = int(rs.choice([5, 25, 50])), int(rs.choice([16, 48, 100]))
-    selfplay_search_vs_oracle(oracle, game, case, S, B, 12, seed=int(rs.randint(1 << 20)), expect_resets=False)
+    reload_case = (case[0] + 'r',) + tuple(case[1:7]) + (case[7] + 5000,) if rs.rand() < 0.5 else None  # the same net with other weights
+    selfplay_search_vs_oracle(oracle, game, case, S, B, 12, seed=int(rs.randint(1 << 20)), expect_resets=False, reload_case=reload_case)
 
 
 EPI_CASES_N = int(os.environ.get('MZ_FUZZ_EPILOGUE_CASES', '6'))
@@ -304,7 +305,8 @@ def test_random_conv_net_in_device_gomoku_selfplay_equals_oracle_search(oracle, 
     planes, blocks = int(rs.choice([8, 16, 32])), int(rs.choice([1, 2]))
     case = (f'gfuzz{i}', 'board', (2 * stack + 1, N, N), N * N + 1, blocks, planes, 1, 1, 1500 + i)
     S, B = int(rs.choice([3, 8])), int(rs.choice([4, 12]))
-    selfplay_search_vs_oracle(oracle, 'gomoku', case, S, B, 10, seed=int(rs.randint(1 << 20)), expect_resets=False)
+    reload_case = (case[0] + 'r',) + tuple(case[1:8]) + (case[8] + 5000,) if rs.rand() < 0.5 else None
+    selfplay_search_vs_oracle(oracle, 'gomoku', case, S, B, 10, seed=int(rs.randint(1 << 20)), expect_resets=False, reload_case=reload_case)
 
 
 ATARI_CASES_N = int(os.environ.get('MZ_FUZZ_ATARI_CASES', '4'))

@@ -251,7 +251,7 @@ def test_selfplay_search_outputs_equal_oracle_search(oracle, game):
     selfplay_search_vs_oracle(oracle, game, mlp_case(game), 25 if game == 'tictactoe' else 50, B, M)
 
 
-def selfplay_search_vs_oracle(oracle, game, case, S, B, M, seed=77, expect_resets=True):
+def selfplay_search_vs_oracle(oracle, game, case, S, B, M, seed=77, expect_resets=True, reload_case=None):
     """The comparison of test_selfplay_search_outputs_equal_oracle_search for any MLP net that fits `game`'s observations and actions."""
     import ctypes as C
 
@@ -286,6 +286,11 @@ def selfplay_search_vs_oracle(oracle, game, case, S, B, M, seed=77, expect_reset
     steps = np.zeros(B, np.int64)  # env steps of the running episode (the board games' temperature schedule, config.py:236-241)
     finished = 0
     for m in range(M):
+        if reload_case is not None and m == M // 2:
+            # new weights in the middle of self-play (what run_self_play does when the learner publishes a checkpoint, pipeline.py:261-267)
+            net = build_conv(reload_case) if conv else build_mlp(reload_case)
+            p.load_state_dict(net.state_dict())
+            onet = _oracle_net(oracle, net, 'conv' if conv else 'mlp')
         p.selfplay_step(-1.0 if board else 1.0, 1)
         noise = np.empty((B, A), np.float64)
         utie = np.empty((B, p.max_ties), np.float64)
