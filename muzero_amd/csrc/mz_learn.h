@@ -275,8 +275,12 @@ __device__ __forceinline__ void ks_load(KsW& W, const float* __restrict__ wp, co
     const int t = wave % nt, part = wave / nt;
     const int g0 = part * kg / parts, g1 = (part + 1) * kg / parts;
     const float4* wb = reinterpret_cast<const float4*>(wp) + (size_t)t * kg * 64 + lane;
+    // (all KSB, clamped to a block that exists: see wide_load.  With fewer reduction blocks than parts -- 32 planes over 8 parts -- a part's
+    // range is EMPTY, g1 - 1 may be -1: round 4's first form read 1 KiB in front of the layer's operands there, never used, but a fault
+    // when the operands start their allocation -- found by the randomised plumbing test)
+    const int gl = g1 > g0 ? g1 - 1 : (g0 < kg ? g0 : kg - 1);
 #pragma unroll
-    for (int d = 0; d < KSB; d++) W.w[d] = ldg4(wb + (g0 + d < g1 ? g0 + d : g1 - 1) * 64);  // (all KSB, clamped: see wide_load)
+    for (int d = 0; d < KSB; d++) W.w[d] = ldg4(wb + (g0 + d < g1 ? g0 + d : gl) * 64);
 }
 template <bool F, typename Epi, typename Pf>
 __device__ __forceinline__ void ks_mma(const KsW& W, const float* __restrict__ wp, const float* __restrict__ bias, int nt, int kg, const float* Xs,
