@@ -222,23 +222,31 @@ def test_random_learner_configuration_matches_autograd(i):
         if err <= 3e-3 * max(na, 1e-7):
             continue  # (the normal case, kink nearby or not)
         assert not smooth and err <= 5e-2 * max(na, 1e-7), (k, c, err, na, 'smooth' if smooth else 'near a kink', min(margins))
-    # one optimizer step with the drawn hyper-parameters against torch.optim.Adam + clip_grad_norm_ on the autograd gradients.  Adam's first
-    # update is -lr g / (|g| + eps): compared where the gradient is clear of the eps scale (elsewhere a last-bit difference of g changes it)
+    # one optimizer step with the drawn hyper-parameters against torch.optim.Adam + clip_grad_norm_ -- on IDENTICAL gradients (the kernels'
+    # gradient copied into the torch parameters: gradient parity is the comparison above; with each side on its own gradient an entry next
+    # to zero takes -lr sign(g) with opposite signs, seen twice in 6 000 cases), so this checks the clip / Adam / weight-decay arithmetic alone
     hp = c['opt']
-    before_b = {k: v.detach().clone() for k, v in net_b.named_parameters()}
+    pb = dict(net_b.named_parameters())
+    before_b = {k: v.detach().clone() for k, v in pb.items()}
     before_a = {k: v.detach().clone() for k, v in net_a.named_parameters()}
+    for k, p_ in net_a.named_parameters():
+        p_.grad.copy_(hl.grad_views[k])
     opt = torch.optim.Adam(net_a.parameters(), lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['wd'])
     if hp['clip'] > 0:
         torch.nn.utils.clip_grad_norm_(net_a.parameters(), hp['clip'])
-    ga = {k: (p_.grad.detach() + hp['wd'] * before_a[k]).abs() for k, p_ in net_a.named_parameters()}
+    gclip = {k: p_.grad.detach().clone() for k, p_ in net_a.named_parameters()}
     opt.step()
     hl.lr_init, hl.betas, hl.eps, hl.weight_decay, hl.max_grad_norm = hp['lr'], hp['betas'], hp['eps'], hp['wd'], hp['clip']
     hl.apply(clip=hp['clip'] > 0)
     for k, p_ in net_a.named_parameters():
-        da, db = (p_.detach() - before_a[k]).cpu().numpy(), (dict(net_b.named_parameters())[k].detach() - before_b[k]).cpu().numpy()
-        clear = (ga[k] > 1e3 * hp['eps'] + 1e-7 * float(ga[k].max())).cpu().numpy()
-        if clear.any():
-            assert float(np.abs(da - db)[clear].max()) <= 2e-3 * hp['lr'] + 1e-9, (k, c)
+        da, db = (p_.detach() - before_a[k]).cpu().numpy(), (pb[k].detach() - before_b[k]).cpu().numpy()
+        ulp = 2.4e-7 * max(1.0, float(before_a[k].abs().max()))  # (the updated weight is rounded to float32: one ulp of the weight either way)
+        # Adam's first update is -lr g' / (|g'| + eps) with g' = clipped gradient + wd w: where the two terms cancel (seen: 2.53265e-4 -
+        # 2.53247e-4 against eps 1e-8) the rounding of g' itself is amplified by lr eps / (|g'| + eps)^2
+        gc, ww = gclip[k].cpu().numpy().astype(np.float64), hp['wd'] * before_a[k].cpu().numpy().astype(np.float64)
+        amp = hp['lr'] * hp['eps'] / (np.abs(gc + ww) + hp['eps']) ** 2 * 4e-7 * (np.abs(gc) + np.abs(ww))
+        excess = np.abs(da - db) - (2e-4 * hp['lr'] + ulp + amp)
+        assert float(excess.max()) <= 0.0, (k, c, float(np.abs(da - db).max()))
     hl.close()
 
 
