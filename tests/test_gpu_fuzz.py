@@ -219,7 +219,7 @@ def test_random_learner_configuration_matches_autograd(i):
     for k, p_ in net_a.named_parameters():
         a, b = p_.grad.detach().cpu().numpy().ravel().astype(np.float64), hl.grad_views[k].cpu().numpy().ravel().astype(np.float64)
         na, err = float(np.linalg.norm(a)), float(np.linalg.norm(a - b))
-        if err <= 3e-3 * max(na, 1e-7):
+        if err <= 3e-3 * max(na, 1e-7) + 2e-7:  # (+ float32 rounding of the sums themselves: a two-action policy bias gradient cancels to ~5e-6)
             continue  # (the normal case, kink nearby or not)
         assert not smooth and err <= 5e-2 * max(na, 1e-7), (k, c, err, na, 'smooth' if smooth else 'near a kink', min(margins))
     # one optimizer step with the drawn hyper-parameters against torch.optim.Adam + clip_grad_norm_ -- on IDENTICAL gradients (the kernels'
