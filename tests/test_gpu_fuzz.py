@@ -406,3 +406,47 @@ def test_random_learner_batch_plumbing_is_exact(i):
         np.testing.assert_array_equal(got[2], ref.grad_flat.cpu().numpy(), err_msg=str((case, step, b)))
         ref.close()
     big.close()
+
+
+INFER_CASES_N = int(os.environ.get('MZ_FUZZ_INFER_CASES', '8'))
+
+
+@pytest.mark.parametrize('i', range(INFER_CASES_N))
+def test_random_net_inference_api_bit_exact_vs_oracle(oracle, i):
+    """`initial_inference` / `recurrent_inference` (network.py:62-111) as the planner's batched API serves them -- their own kernels and dense
+    output paths, not the search's -- for nets drawn over the MLP and board-conv shape spaces and ragged batch sizes: hidden states, policies,
+    rewards and values bit-exact against the oracle's networks."""
+    rs = np.random.RandomState(8000 + i + 100000 * OFFSET)
+    if rs.rand() < 0.5:
+        P, H = int(rs.choice([16, 40, 96, 256, 512])), int(rs.choice([8, 20, 64]))
+        A, sup = int(rs.randint(2, 19)), (int(rs.choice([1, 5, 31, 61])), int(rs.choice([1, 9, 31])))
+        ishape = [(4, 5), (3, 3, 3), (7,), (4, 9)][rs.randint(4)]
+        case, kind = (f'ifuzz{i}', ishape, A, P, sup[0], sup[1], H, 2500 + i), 'mlp'
+        net = build_mlp(case)
+        obs_shape = ishape
+    else:
+        from helpers import build_conv
+
+        N, planes, blocks = int(rs.choice([3, 5, 6, 7, 9, 11])), int(rs.choice([8, 16, 32, 48])), int(rs.choice([1, 2]))
+        chans = int(rs.choice([3, 5, 9]))
+        A = N * N + 1
+        case, kind = (f'ifuzz{i}', 'board', (chans, N, N), A, blocks, planes, 1, 1, 2500 + i), 'conv'
+        net = build_conv(case)
+        obs_shape = (chans, N, N)
+    B = int(rs.choice([1, 5, 17, 37]))
+    onet = _oracle_net(oracle, net, kind)
+    p = _planner(net, 64)
+    obs = (rs.randint(0, 2, size=(B,) + tuple(obs_shape)) if kind == 'conv' else rs.uniform(-1, 1, size=(B,) + tuple(obs_shape))).astype(np.float32)
+    hidden, pi, value = p.initial_inference(obs)
+    actions = rs.randint(0, A, size=B).astype(np.int32)
+    h2, reward, pi2, value2 = p.recurrent_inference(hidden, actions)
+    for b in range(B):
+        oh, _, opi, ov = onet.initial_inference(obs[b])
+        np.testing.assert_array_equal(np.asarray(hidden[b]).reshape(-1), np.asarray(oh).reshape(-1), err_msg=str(case))
+        np.testing.assert_array_equal(pi[b], opi, err_msg=str(case))
+        assert value[b] == np.float32(ov), case
+        oh2, orw, opi2, ov2 = onet.recurrent_inference(oh, int(actions[b]))
+        np.testing.assert_array_equal(np.asarray(h2[b]).reshape(-1), np.asarray(oh2).reshape(-1), err_msg=str(case))
+        np.testing.assert_array_equal(pi2[b], opi2, err_msg=str(case))
+        assert reward[b] == np.float32(orw) and value2[b] == np.float32(ov2), case
+    p.close()
