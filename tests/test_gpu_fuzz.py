@@ -129,12 +129,14 @@ def test_random_board_conv_configuration_bit_exact_vs_oracle(oracle, i):
     noise = rs.dirichlet(np.full(A, 0.25), size=B)
     u_tie = rs.rand(B, 4 * S + 8)
     u_final = rs.rand(B)
-    r = p.search(obs, mask, cur, opp, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
-    o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, False, noise=noise, u_tie=u_tie, u_final=u_final)
-    np.testing.assert_array_equal(r['visits'], o['visits'], err_msg=str(c))
-    np.testing.assert_array_equal(r['pi'], o['pi'], err_msg=str(c))
-    np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(c))
-    np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(c))
+    for det in ((False, True) if i % 2 else (False,)):  # (every other case also in deterministic mode: float32 prior path, argmax play)
+        r = p.search(obs, mask, cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie, u_final=u_final)
+        o = oracle.uct_search_batch(ocfg, onet, obs, mask.astype(np.uint8), cur, opp, temp, det, noise=None if det else noise, u_tie=u_tie,
+                                    u_final=u_final)
+        np.testing.assert_array_equal(r['visits'], o['visits'], err_msg=str(c))
+        np.testing.assert_array_equal(r['pi'], o['pi'], err_msg=str(c))
+        np.testing.assert_array_equal(r['action'], o['action'], err_msg=str(c))
+        np.testing.assert_array_equal(r['root_value'], o['root_value'], err_msg=str(c))
     p.close()
 
 
