@@ -1,5 +1,6 @@
 /*
- * mzlearner.h -- C ABI of the MI355X-native MuZero learner step for the MLP nets (libmzlearner_hip.so).
+ * mzlearner.h -- C ABI of the MI355X-native MuZero learner step (libmzlearner_hip.so): the MLP nets (MuZeroMLPNet, network.py:236-267)
+ * and -- round 5 -- the board-game conv nets (MuZeroBoardGameNet, network.py:540-574: residual towers with train-mode BatchNorm).
  *
  * Row f2 of SURVEY.md section 8: what the reference does per training step in `run_training` (pipeline.py:238-255) --
  * `calc_loss` (:541-612) + `loss.backward()` + optional `clip_grad_norm_` (:246-247) + `optimizer.step()` (torch.optim.Adam with
@@ -26,9 +27,13 @@ extern "C" {
 #define MZL_E_HIP (-2)
 #define MZL_E_STATE (-3)
 
-/* MuZeroMLPNet's constructor arguments (network.py:239-247) + the batch geometry of calc_loss (pipeline.py:541-575). */
+#define MZL_NET_MLP 0    /* MuZeroMLPNet (network.py:236-267); kernels: muzero_amd/csrc/mz_learn.h */
+#define MZL_NET_BOARD 1  /* MuZeroBoardGameNet (network.py:540-574); kernels: muzero_amd/csrc/mz_learn_conv.h */
+
+/* The network's constructor arguments (MuZeroMLPNet network.py:239-247 | MuZeroBoardGameNet :543-549) + the batch geometry of calc_loss
+ * (pipeline.py:541-575). */
 typedef struct {
-    int32_t in_dim;               /* flattened observation (network.py:153-154) */
+    int32_t in_dim;               /* flattened observation (network.py:153-154); conv nets: in_channels * board_h * board_w */
     int32_t num_actions;
     int32_t num_planes;
     int32_t hidden_dim;
@@ -36,7 +41,12 @@ typedef struct {
     int32_t reward_support_size;
     int32_t unroll_steps;         /* K, config.py:87 */
     int32_t max_batch;            /* capacity: mzl_grad accepts any batch <= max_batch */
-    int32_t grad_slices;          /* >= 1: the weight-gradient kernel splits its reduction over this many workgroup rows (large batches) */
+    int32_t grad_slices;          /* >= 1: the weight-gradient kernel splits its reduction over this many workgroup rows (large batches); conv nets: 1 */
+    int32_t net_kind;             /* MZL_NET_MLP | MZL_NET_BOARD */
+    /* MZL_NET_BOARD only (hidden_dim is unused there; both support sizes are 1: squared-error heads, network.py:551): */
+    int32_t in_channels;          /* planes of the observation (network.py:549 input_shape[0]) */
+    int32_t board_h, board_w;     /* board_h * board_w <= 240 */
+    int32_t num_res_blocks;       /* residual blocks of each of the three towers (network.py:546) */
 } mzl_config;
 
 /* One batch of `Transition`s (replay.py:27-32) addressed inside the replay ring's storages. */
@@ -66,8 +76,19 @@ int mzl_destroy(mz_learner* h);
  * torch layout) and the size in floats of the gradient buffer the caller must provide (grad_slices * parameters). */
 int64_t mzl_num_params(const mz_learner* h);
 int64_t mzl_grad_floats(const mz_learner* h);
-/* i-th tensor of the flat vector: name (state_dict key), float offset, rows, columns (columns == 0: a bias vector) */
+/* Number of parameter tensors (MLP nets: 20), and the i-th tensor of the flat vector: name (state_dict key), float offset, rows, columns
+ * (columns == 0: a vector; conv weights [cout][cin][3][3] report rows = cout, columns = cin * 9) */
+int32_t mzl_num_tensors(const mz_learner* h);
 int mzl_tensor_info(const mz_learner* h, int32_t i, const char** name, int64_t* offset, int32_t* rows, int32_t* cols);
+/* Conv nets: the BatchNorm2d buffers (network.py:283-291; train mode updates them on every forward, pipeline.py:575-582).  Buffer i is the
+ * layer `name` (state_dict prefix): name.running_mean = d_running[offset .. offset + count), name.running_var = the `count` floats behind it,
+ * name.num_batches_tracked = d_num_batches[i].  mzl_num_running = floats of d_running.  MLP nets: 0 buffers. */
+int32_t mzl_num_buffers(const mz_learner* h);
+int64_t mzl_num_running(const mz_learner* h);
+int mzl_buffer_info(const mz_learner* h, int32_t i, const char** name, int64_t* offset, int32_t* count);
+/* Caller-owned device buffers of the BatchNorm statistics (float32 [mzl_num_running], int64 [mzl_num_buffers]); required before mzl_grad
+ * for conv nets.  Replaces: the module buffers that network.state_dict() carries (pipeline.py:224-230). */
+int mzl_bind_buffers(mz_learner* h, float* d_running, int64_t* d_num_batches);
 
 /* Caller-owned flat device buffers: master weights, gradients, Adam's exp_avg / exp_avg_sq (torch.optim.Adam state), all float32.
  * Replaces: network.parameters() / optimizer.state (pipeline.py:224-230).  The caller keeps them alive while bound. */

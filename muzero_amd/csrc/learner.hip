@@ -11,6 +11,7 @@
 
 #include "../../include/mzlearner.h"
 #include "mz_learn.h"
+#include "mz_learn_conv_host.h"
 
 using namespace mzl;
 
@@ -35,6 +36,7 @@ static const char* kNames[NLAYER] = {
 struct mz_learner {
     mzl_config cfg{};
     int device = 0;
+    mzlc_learner* conv = nullptr;  // net_kind == MZL_NET_BOARD: the conv-net learner (learner_conv.hip); every entry point forwards to it
     LNet net{};
     LSave sv{};
     LLds o{};
@@ -158,6 +160,27 @@ static void build_big_jobs(mz_learner* h) {
 
 extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out) {
     if (!cfg || !out) return fail(MZL_E_INVALID, "null argument");
+    if (cfg->net_kind != MZL_NET_MLP && cfg->net_kind != MZL_NET_BOARD) return fail(MZL_E_INVALID, "net_kind must be MZL_NET_MLP or MZL_NET_BOARD");
+    if (cfg->net_kind == MZL_NET_BOARD) {
+        if (cfg->in_dim < 1 || cfg->num_actions < 1 || cfg->num_actions > 32767 || cfg->num_planes < 1 || cfg->unroll_steps < 1 || cfg->unroll_steps > 32 ||
+            cfg->max_batch < 1)
+            return fail(MZL_E_INVALID, "bad learner dimensions");
+        int ndev = 0;
+        HIPCHK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) return fail(MZL_E_HIP, "no HIP device visible: the learner kernels have no CPU fallback");
+        if (device_id < 0 || device_id >= ndev) return fail(MZL_E_INVALID, "device_id out of range");
+        HIPCHK(hipSetDevice(device_id));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 256;
+        mzlc_learner* c = nullptr;
+        std::string err;
+        const int rc = mzlc_create(cfg, device_id, cus, &c, err);
+        if (rc != MZL_OK) return fail(rc, err);
+        mz_learner* h = new mz_learner();
+        h->cfg = *cfg; h->device = device_id; h->conv = c;
+        *out = h;
+        return MZL_OK;
+    }
     if (cfg->in_dim < 1 || cfg->num_actions < 1 || cfg->num_planes < 1 || cfg->hidden_dim < 1 || cfg->value_support_size < 1 ||
         cfg->reward_support_size < 1 || cfg->unroll_steps < 1 || cfg->unroll_steps > 32 || cfg->max_batch < 1 || cfg->grad_slices < 1 || cfg->grad_slices > 64)
         return fail(MZL_E_INVALID, "bad learner dimensions");
@@ -282,11 +305,14 @@ extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out
                                    (const void*)&k_learn_unroll<false>, (const void*)&k_learn_back<true>,  (const void*)&k_learn_back<false>,
                                    (const void*)&k_learn_back_sliced<true>, (const void*)&k_learn_fwd_sliced<true>,
                                    (const void*)&k_learn_unroll<false, 3>, (const void*)&k_learn_dyn_chain, (const void*)&k_learn_dyn_back_chain};
+    // the attribute belongs to the kernel symbol, not to this handle: a later, smaller learner in the same process must not lower the limit of a
+    // live larger one -- every handle sets the hardware maximum
     for (const void* f : stage_kernels)
-        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_learn_dw), hipFuncAttributeMaxDynamicSharedMemorySize, LW * 8 * 256 * 4);
     if (e != hipSuccess) return cleanup(fail(MZL_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)));
-    HIPCHK(hipDeviceSynchronize());  // (dalloc's fills run on the NULL stream; the caller's stream need not wait for it)
+    e = hipDeviceSynchronize();  // (dalloc's fills run on the NULL stream; the caller's stream need not wait for it)
+    if (e != hipSuccess) return cleanup(fail(MZL_E_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)));
     *out = h;
     return MZL_OK;
 }
@@ -295,6 +321,7 @@ extern "C" int mzl_destroy(mz_learner* h) {
     if (!h) return MZL_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->conv) mzlc_destroy(h->conv);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return MZL_OK;
@@ -303,10 +330,34 @@ extern "C" int mzl_destroy(mz_learner* h) {
 // diagnostic: device pointer of the cycle stamps (MZL_STAMPS=1 at create), or NULL
 extern "C" void* mzl_debug_stamps(const mz_learner* h) { return h ? h->sv.stamps : nullptr; }
 
-extern "C" int64_t mzl_num_params(const mz_learner* h) { return h ? h->P.total : 0; }
-extern "C" int64_t mzl_grad_floats(const mz_learner* h) { return h ? (int64_t)h->P.total * h->cfg.grad_slices : 0; }
+extern "C" int64_t mzl_num_params(const mz_learner* h) { return !h ? 0 : (h->conv ? mzlc_num_params(h->conv) : h->P.total); }
+extern "C" int64_t mzl_grad_floats(const mz_learner* h) {
+    return !h ? 0 : (h->conv ? mzlc_num_params(h->conv) : (int64_t)h->P.total * h->cfg.grad_slices);
+}
+extern "C" int32_t mzl_num_tensors(const mz_learner* h) { return !h ? 0 : (h->conv ? mzlc_num_tensors(h->conv) : 2 * NLAYER); }
+extern "C" int32_t mzl_num_buffers(const mz_learner* h) { return (h && h->conv) ? mzlc_num_buffers(h->conv) : 0; }
+extern "C" int64_t mzl_num_running(const mz_learner* h) { return (h && h->conv) ? mzlc_num_running(h->conv) : 0; }
+extern "C" int mzl_buffer_info(const mz_learner* h, int32_t i, const char** name, int64_t* offset, int32_t* count) {
+    if (!h || !h->conv || mzlc_buffer_info(h->conv, i, name, offset, count) != MZL_OK) return fail(MZL_E_INVALID, "buffer index out of range");
+    return MZL_OK;
+}
+extern "C" int mzl_bind_buffers(mz_learner* h, float* d_running, int64_t* d_num_batches) {
+    if (!h) return fail(MZL_E_INVALID, "null learner");
+    if (!h->conv) return MZL_OK;  // (MLP nets have no buffers)
+    if (!d_running || !d_num_batches) return fail(MZL_E_INVALID, "null argument to mzl_bind_buffers");
+    return mzlc_bind_buffers(h->conv, d_running, d_num_batches);
+}
+// diagnostic (tests): device pointers of the conv learner's saved tensors (learner_conv.hip mzlc_debug_tensor)
+extern "C" int mzl_debug_tensor(const mz_learner* h, const char* what, int a, int b, void** ptr, int64_t* count) {
+    if (!h || !h->conv || !what || !ptr || !count || mzlc_debug_tensor(h->conv, what, a, b, ptr, count) != MZL_OK) return fail(MZL_E_INVALID, "no such tensor");
+    return MZL_OK;
+}
 
 extern "C" int mzl_tensor_info(const mz_learner* h, int32_t i, const char** name, int64_t* offset, int32_t* rows, int32_t* cols) {
+    if (h && h->conv) {
+        if (mzlc_tensor_info(h->conv, i, name, offset, rows, cols) != MZL_OK) return fail(MZL_E_INVALID, "tensor index out of range");
+        return MZL_OK;
+    }
     if (!h || i < 0 || i >= 2 * NLAYER) return fail(MZL_E_INVALID, "tensor index out of range");
     const LTensor& t = h->P.t[i];
     if (name) *name = h->names[i].c_str();
@@ -318,6 +369,7 @@ extern "C" int mzl_tensor_info(const mz_learner* h, int32_t i, const char** name
 
 extern "C" int mzl_bind(mz_learner* h, float* d_params, float* d_grads, float* d_exp_avg, float* d_exp_avg_sq) {
     if (!h || !d_params || !d_grads || !d_exp_avg || !d_exp_avg_sq) return fail(MZL_E_INVALID, "null argument to mzl_bind");
+    if (h->conv) return mzlc_bind(h->conv, d_params, d_grads, d_exp_avg, d_exp_avg_sq);
     h->params = d_params; h->grads = d_grads; h->m = d_exp_avg; h->v = d_exp_avg_sq;
     h->committed = false;
     h->jobs_tiles = -1;  // (the job tables are re-uploaded and the new gradient slices zeroed by the next mzl_grad)
@@ -338,6 +390,11 @@ static int launch_adam(mz_learner* h, const AdamArgs& a, hipStream_t st) {
 
 extern "C" int mzl_commit(mz_learner* h, void* stream) {
     if (!h) return fail(MZL_E_INVALID, "null learner");
+    if (h->conv) {
+        std::string err;
+        const int rc = mzlc_commit(h->conv, stream, err);
+        return rc == MZL_OK ? MZL_OK : fail(rc, err);
+    }
     if (!h->params) return fail(MZL_E_STATE, "mzl_bind first");
     HIPCHK(hipSetDevice(h->device));
     AdamArgs a{};
@@ -350,6 +407,11 @@ extern "C" int mzl_commit(mz_learner* h, void* stream) {
 
 extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
     if (!h || !b) return fail(MZL_E_INVALID, "null argument to mzl_grad");
+    if (h->conv) {
+        std::string err;
+        const int rc = mzlc_grad(h->conv, b, stream, err);
+        return rc == MZL_OK ? MZL_OK : fail(rc, err);
+    }
     if (!h->committed) return fail(MZL_E_STATE, "weights not committed: mzl_bind, then mzl_commit");
     if (b->batch < 1 || b->batch > h->cfg.max_batch) return fail(MZL_E_INVALID, "batch must be in [1, max_batch]");
     if (!b->d_index) return fail(MZL_E_INVALID, "d_index is required (rows 0 .. batch-1 for a stacked batch)");
@@ -471,6 +533,12 @@ extern "C" int mzl_grad(mz_learner* h, const mzl_batch* b, void* stream) {
 extern "C" int mzl_apply(mz_learner* h, double lr, double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, int64_t step,
                          void* stream) {
     if (!h) return fail(MZL_E_INVALID, "null learner");
+    if (step < 1) return fail(MZL_E_INVALID, "Adam step numbers start at 1");
+    if (h->conv) {
+        std::string err;
+        const int rc = mzlc_apply(h->conv, lr, beta1, beta2, eps, weight_decay, max_grad_norm, step, stream, err);
+        return rc == MZL_OK ? MZL_OK : fail(rc, err);
+    }
     if (!h->committed) return fail(MZL_E_STATE, "weights not committed");
     if (step < 1) return fail(MZL_E_INVALID, "Adam step numbers start at 1");
     HIPCHK(hipSetDevice(h->device));

@@ -1,0 +1,1212 @@
+// mz_learn_conv.h -- learner-step kernels of the CONV nets (MuZeroBoardGameNet, network.py:540-574) for gfx950: row f2 of SURVEY 8, second half.
+//
+// What one update computes (pipeline.py:541-612 `calc_loss` on network.py:273-299 ResNetBlock, :396-446 DynamicsConvNet, :449-498 PredictionConvNet,
+// :356-393 RepresentationConvNet, all BatchNorm2d layers in TRAIN mode: batch statistics, running-stat update), then backward:
+//
+//   k_lc_gather        replay rows -> dense float32 observations [B][C0][hw], actions [K][B]
+//   k_lc_conv<NPT>     3x3 convolution as implicit GEMM on v_mfma_f32_16x16x4_f32, used for BOTH directions:
+//                        forward   y = conv(f(x))         f applied while staging: identity | relu(a x + b) (the previous layer's BatchNorm + ReLU,
+//                                                          never materialised) | action planes generated on the fly (network.py:440-444)
+//                                  epilogue: per-channel partial sums (sum y, sum y^2) of the batch statistics
+//                        dgrad     g = convT(dy)          dy = c1 dz + c2 y + c3 (BatchNorm backward, applied while staging from TWO tensors),
+//                                                          weights = the transposed / tap-flipped packed copy
+//                                  epilogue: + skip gradient, ReLU mask of the layer below, partial sums (sum dz, sum dz y) of ITS BatchNorm backward
+//   k_lc_wgrad         dW[co][ci][tap] = sum_{b,p} dy[b][co][p] x[b][ci][p + tap]: MFMA with the reduction over PIXELS; both operands staged through
+//                      LDS in a zero-padded row-pitch layout so that a tap is a register choice, never a re-read; partials per image chunk
+//   k_lc_wreduce       chunk partials -> gradient (torch layout), fixed order
+//   k_lc_bn_fwd / k_lc_bn_bwd   finalize the partial sums -> per-channel coefficients (a, b | c1, c2, c3), running statistics, dgamma / dbeta
+//   k_lc_apply         block output x' = relu(a y + b + x) (the residual needs it materialised)
+//   k_lc_entry         gradient entering a tower: [normalize_hidden_state backward (util.py:31-36) of the next step's gradient, x 0.5 (pipeline.py:584)]
+//                      + head gradient, ReLU mask, BatchNorm-backward partial sums
+//   k_lc_normalize     min / max normalisation over the channels of each pixel (forward)
+//   k_lch_*            the three heads (1x1 conv + BatchNorm + ReLU + Linear, network.py:424-430,472-486): forward, losses (pipeline.py:586-597:
+//                      squared error | soft-target cross entropy, importance weights, 1/K gradient scale :600), priorities (:603-609), backward
+//   k_lc_sqsum / k_lc_adam / k_lc_pack   clip_grad_norm_ + torch.optim.Adam (L2 decay in the gradient) on the flat vector, operand re-pack
+//
+// No atomics: every reduction has a fixed order, an update is bit-reproducible.  fp32 throughout (the reference's arithmetic); parity with the
+// reference / autograd is by tolerance (tests/test_gpu_conv_learner.py), summation orders are this file's own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mzlc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { IN_IDENT = 0, IN_BNRELU = 1, IN_BNBWD = 2 };
+enum { ST_NONE = 0, ST_FWD = 1, ST_BWD = 2 };
+
+__device__ __forceinline__ int lc_idiv(int p, float rcp_d) { return (int)(((float)p + 0.5f) * rcp_d); }  // exact for 0 <= p < 4096 (index arithmetic)
+__device__ __forceinline__ float4 ld4(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
+__device__ __forceinline__ float ld1(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrs(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000); }
+
+// two independent jobs of the same kind side by side in one launch (blockIdx.y < na: job a): the prediction and dynamics towers of one unroll
+// step have no dependency on each other, and a batch-128 conv launch alone is one workgroup per CU
+template <typename J>
+struct Pair {
+    J a, b;
+    int na;  // workgroup rows (blockIdx.y) of job a; rows of job b follow
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution, whole images per workgroup.  workgroup = 256 threads = G images (blockIdx.y) x 64 output channels (blockIdx.z; wave w owns
+// channel tile 4 z + w) x all pixels (NPT tiles of 16 pixel slots).  Per 16-channel input block: the slab (images + zero halo,
+// [slot = channel & 3][position][channel >> 2]) is double-buffered in LDS, the next block fetched global -> registers between the MFMAs of
+// this one, transformed and written behind the tap loop; weights stream out of L2 through a register ring (1 KiB per (block, tap) and wave).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LcConv {
+    const float* in0;      // [B][cin_real][hw]: x | y (IN_BNRELU) | dz (IN_BNBWD)
+    const float* in1;      // IN_BNBWD: y
+    const float* coef;     // [3][cpad_in]: (a, b, -) | (c1, c2, c3)
+    const int* action;     // [B] or null: channels cin_real .. cin - 1 are the action planes
+    const float* w;        // packed [co_tiles][n_cb][9][64][4]: element [lane = (q, j)][i] = W[co = 16 ct + j][ci = 16 cb + 4 i + q][tap]
+    float* out;            // [B][cout][hw]
+    const float* skip;     // epilogue: added to the result (residual-path gradient), or null
+    const float* mask;     // epilogue: result zeroed where (ma * mask + mb) <= 0 (mcoef == null: mask <= 0), or null
+    const float* mcoef;    // [2][cpad_out] or null
+    const float* partner;  // ST_BWD: y of the layer whose BatchNorm backward the partial sums feed
+    float* stat_part;      // [groups][cpad_out][2]
+    int in_mode, stat_mode;
+    int num_actions, cin_real, cin, n_cb, cpad_in;
+    int cout, co_tiles, cpad_out;
+    int B, G, h, w_img;
+    int qstride;           // LDS floats per slot plane (>= 4 * G * (h + 2) * (w + 2), multiple of 64)
+};
+
+template <int NPT>
+__global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
+    const bool second = (int)blockIdx.y >= PJ.na;
+    const LcConv L = second ? PJ.b : PJ.a;
+    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* slab = reinterpret_cast<float*>(smem);
+    const int bufsz = 4 * L.qstride;
+    float* s_coef = slab + 2 * bufsz;  // [3][cpad_in]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+    const int hw = L.h * L.w_img, siw = L.w_img + 2, plane = (L.h + 2) * siw;
+    const int img0 = by * L.G;
+    const int QP = (hw + 3) >> 2;
+    const float r_qp = 1.0f / (float)QP, r_iw = 1.0f / (float)L.w_img, r_hw = 1.0f / (float)hw;
+    const __amdgpu_buffer_rsrc_t rs_in0 = mkrs(L.in0), rs_in1 = mkrs(L.in1 ? L.in1 : L.in0);
+    // ---- staging plan: lane t of every wave owns pixel quad t of the group; wave w the channels {w, 4 + w, 8 + w, 12 + w} of each block ----
+    const int sg = lc_idiv(lane, r_qp), qd = lane - sg * QP, p0 = qd * 4, bimg = img0 + sg;
+    const bool w_ok = lane < L.G * QP && bimg < L.B;
+    const int cimg = bimg < L.B ? bimg : L.B - 1;
+    const unsigned w_voff = (unsigned)(((size_t)cimg * L.cin_real * hw + (size_t)(w_ok ? p0 : 0)) * sizeof(float));
+    const int w_act = (w_ok && L.action) ? L.action[cimg] : -1;
+    int w_spos[4], w_pm[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
+        w_spos[e] = (w_ok && pp < hw) ? ((sg < L.G ? sg : 0) * plane + (py + 1) * siw + px + 1) * 4 + wave * L.qstride : -1;
+        w_pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
+    }
+    for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers, halo included
+    if (L.in_mode != IN_IDENT)
+        for (int i = tid; i < 3 * L.cpad_in; i += 256) s_coef[i] = L.coef[i];
+    __syncthreads();
+    float4 sv0[4], sv1[4];  // [i]: channel 4 i + wave of the block in flight, pixels p0 .. p0 + 3
+    auto fetch = [&](int cb, int i) {
+        const int ch = cb * 16 + 4 * i + wave, chc = ch < L.cin_real ? ch : 0;
+        sv0[i] = ld4(rs_in0, w_voff, chc * hw * (int)sizeof(float));
+        if (L.in_mode == IN_BNBWD) sv1[i] = ld4(rs_in1, w_voff, chc * hw * (int)sizeof(float));
+    };
+    auto transform_store = [&](int cb, int buf) {
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ch = cb * 16 + 4 * i + wave;  // wave-uniform
+            const float x[4] = {sv0[i].x, sv0[i].y, sv0[i].z, sv0[i].w};
+            if (ch < L.cin_real) {
+                if (L.in_mode == IN_BNRELU) {
+                    const float a = s_coef[ch], b = s_coef[L.cpad_in + ch];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float t = fmaf(a, x[e], b);
+                        v[i][e] = t > 0.0f ? t : 0.0f;
+                    }
+                } else if (L.in_mode == IN_BNBWD) {
+                    const float c1 = s_coef[ch], c2 = s_coef[L.cpad_in + ch], c3 = s_coef[2 * L.cpad_in + ch];
+                    const float y[4] = {sv1[i].x, sv1[i].y, sv1[i].z, sv1[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[i][e] = fmaf(c1, x[e], fmaf(c2, y[e], c3));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[i][e] = x[e];
+                }
+            } else {  // action planes (network.py:440-444: flat element f = c * hw + pixel of the [A, h, w] block is 1 iff f % A == action), or padding
+                const int t = ch < L.cin ? (int)(((long long)(ch - L.cin_real) * hw) % L.num_actions) : 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    int m = w_pm[e] + t;
+                    m = m >= L.num_actions ? m - L.num_actions : m;
+                    v[i][e] = (ch < L.cin && m == w_act) ? 1.0f : 0.0f;
+                }
+            }
+        }
+        float* d = slab + buf * bufsz;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (w_spos[e] >= 0) *reinterpret_cast<float4*>(d + w_spos[e]) = make_float4(v[0][e], v[1][e], v[2][e], v[3][e]);
+    };
+    // ---- A-operand rows of this lane: pixel slot p = pt * 16 + j -> image g of the group, pixel (py, px) ----
+    int off[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; pt++) {
+        const int p = pt * 16 + j, g = lc_idiv(p, r_hw), pp = p - g * hw, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
+        off[pt] = (g < L.G ? g * plane + py * siw + px : 0) * 4 + q * L.qstride;
+    }
+    f32x4 acc[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; pt++) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int cot = blockIdx.z * 4 + wave, ctc = cot < L.co_tiles ? cot : L.co_tiles - 1;
+    const __amdgpu_buffer_rsrc_t rs_w = mkrs(L.w);
+    const int wbase = ctc * L.n_cb * 9 * 1024, n_steps = L.n_cb * 9;
+    auto wload = [&](int step) {
+        const int sc = step < n_steps ? step : n_steps - 1;
+        return ld4(rs_w, lane * 16, wbase + sc * 1024);
+    };
+    constexpr int WD = (NPT <= 9) ? 9 : 3;
+    float4 wr[WD];
+#pragma unroll
+    for (int s0 = 0; s0 < WD - 1; s0++) wr[s0] = wload(s0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) fetch(0, i);
+    transform_store(0, 0);
+    __syncthreads();
+    float4 xr[3];
+    const int FL = L.in_mode == IN_BNBWD ? 2 : 1;  // staging loads per tap (taps 0..3)
+    for (int cb = 0; cb < L.n_cb; cb++) {
+        const float* sb = slab + (cb & 1) * bufsz;
+        xr[0] = *reinterpret_cast<const float4*>(sb + off[0]);
+        xr[1] = *reinterpret_cast<const float4*>(sb + off[NPT > 1 ? 1 : 0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            wr[(tap + WD - 1) % WD] = wload(cb * 9 + tap + WD - 1);
+            if (tap < 4) fetch(cb + 1 < L.n_cb ? cb + 1 : cb, tap);
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++) {
+                const int n = tap * NPT + pt, n2 = n + 2;
+                if (n2 < 9 * NPT) {
+                    const int tap2 = n2 / NPT, pt2 = n2 - tap2 * NPT;
+                    xr[n2 % 3] = *reinterpret_cast<const float4*>(sb + off[pt2] + ((tap2 / 3) * siw + (tap2 % 3)) * 4);
+                }
+                const float4 x4 = xr[n % 3], w4 = wr[tap % WD];
+                acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x, w4.x, acc[pt], 0, 0, 0);
+                acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y, w4.y, acc[pt], 0, 0, 0);
+                acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.z, w4.z, acc[pt], 0, 0, 0);
+                acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.w, w4.w, acc[pt], 0, 0, 0);
+            }
+            // schedule: weight load first, then per pixel tile one LDS read, (one staging load), its four MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++) {
+                if (tap * NPT + pt + 2 < 9 * NPT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (tap < 4 && pt < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // (IN_BNBWD: two loads per tap; otherwise the second group comes up short)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        (void)FL;
+        if (cb + 1 < L.n_cb) transform_store(cb + 1, (cb + 1) & 1);
+        __syncthreads();
+    }
+    // ---- epilogue: lane (q, j) holds pixel slots pt * 16 + 4 q + r (r = 0..3) of output channel 16 cot + j ----
+    if (cot >= L.co_tiles) return;  // wave-uniform (no barrier below)
+    const int co = cot * 16 + j;
+    const bool co_ok = co < L.cout;
+    const __amdgpu_buffer_rsrc_t rs_out = mkrs(L.out), rs_skip = mkrs(L.skip ? L.skip : L.out), rs_mask = mkrs(L.mask ? L.mask : L.out),
+                                 rs_part = mkrs(L.partner ? L.partner : L.out);
+    const unsigned soff = (unsigned)((size_t)img0 * L.cout * hw * sizeof(float));
+    float ma = 1.0f, mb = 0.0f;
+    if (L.mask && L.mcoef && co_ok) { ma = L.mcoef[co]; mb = L.mcoef[L.cpad_out + co]; }
+    const bool part_is_mask = L.partner == L.mask;
+    float s1 = 0.0f, s2 = 0.0f;
+    constexpr int EC = NPT < 3 ? NPT : 3;
+#pragma unroll
+    for (int pb = 0; pb < NPT; pb += EC) {
+        unsigned vo[EC][4];
+        bool ok[EC][4], vec[EC];
+        f32x4 kv[EC], mv[EC], yv[EC];
+#pragma unroll
+        for (int e = 0; e < EC; e++) {
+            const int pt = pb + e < NPT ? pb + e : NPT - 1;
+            const int p = pt * 16 + 4 * q;
+            int g = lc_idiv(p, r_hw), pp = p - g * hw;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                ok[e][r] = co_ok && (pb + e < NPT) && (g < L.G) && (img0 + g < L.B);
+                vo[e][r] = (unsigned)((g * L.cout + co) * hw + pp) * (unsigned)sizeof(float);
+                pp++;
+                if (pp == hw) { pp = 0; g++; }
+            }
+            vec[e] = ok[e][0] && ok[e][1] && ok[e][2] && ok[e][3] && vo[e][3] == vo[e][0] + 12;
+            kv[e] = mv[e] = yv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto ldv = [&](const __amdgpu_buffer_rsrc_t rs, f32x4& d) {
+                if (vec[e]) {
+                    const float4 t = ld4(rs, vo[e][0], soff);
+                    d = f32x4{t.x, t.y, t.z, t.w};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (ok[e][r]) d[r] = ld1(rs, vo[e][r], soff);
+                }
+            };
+            if (L.skip) ldv(rs_skip, kv[e]);
+            if (L.mask) ldv(rs_mask, mv[e]);
+            if (L.partner && !part_is_mask) ldv(rs_part, yv[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EC; e++) {
+            if (pb + e >= NPT) continue;
+            f32x4 v = acc[pb + e];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float t = v[r] + kv[e][r];
+                if (L.mask && !(fmaf(ma, mv[e][r], mb) > 0.0f)) t = 0.0f;
+                if (!ok[e][r]) t = 0.0f;
+                const float pv = part_is_mask ? mv[e][r] : yv[e][r];
+                s1 += t;
+                s2 = L.stat_mode == ST_BWD ? fmaf(t, pv, s2) : fmaf(t, t, s2);
+                v[r] = t;
+            }
+            if (vec[e]) {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs_out,
+                                                       vo[e][0], soff, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (ok[e][r]) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_out, vo[e][r], soff, 0);
+            }
+        }
+    }
+    if (L.stat_mode != ST_NONE) {  // the four lane groups q hold disjoint pixels of channel j: (q0 + q1) + (q2 + q3)
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (q == 0 && co < L.cpad_out) {
+            float* d = L.stat_part + ((size_t)by * L.cpad_out + co) * 2;
+            d[0] = s1; d[1] = s2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  workgroup = 4 waves = a 32 x 32 block (co x ci) of one conv layer x all 9 taps x one chunk of images; wave (wm, wn) owns
+// the 16 x 16 tile (co tile 2 cob + wm, ci tile 2 cib + wn) for the 9 taps: 9 accumulators.  The reduction index of the MFMAs is the PIXEL:
+// both operands are staged per image into LDS planes [channel][flat position] with row pitch P4 = 4 ceil((w + 1) / 4) and zero padding (at
+// least one zero column behind every row, zero rows above and below), so that the flat position f + dy P4 + dx IS the tap's neighbour and
+// a pad position contributes 0.  Lane (i, kq) multiplies positions 16 g + 4 kq + s in k-step s: dy is one aligned 16-byte read, and the tap
+// shifts dx = -1 / +1 of x are the same quad with one element taken from the neighbouring dword -- a register choice.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LcWgrad {
+    const float* dz;       // [B][cout][hw]
+    const float* y;        // [B][cout][hw]
+    const float* dcoef;    // [3][cpad_out]: dy = c1 dz + c2 y + c3
+    const float* x0;       // [B][cin_real][hw]
+    const float* xcoef;    // [3][cpad_in] (x_mode == IN_BNRELU: a, b)
+    const int* action;     // [B] or null
+    float* part;           // [chunks][9][co_pad][ci_pad]
+    int x_mode, num_actions;
+    int cin_real, cin, cout, ci_tiles, co_tiles, cpad_in, cpad_out;
+    int B, ipw;            // images per chunk
+    int h, w_img, P4, nsteps, SPY, SPX;
+    int co_blocks;         // blockIdx.y = chunk * co_blocks + cob
+};
+
+__global__ __launch_bounds__(256, 1) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
+    const bool second = (int)blockIdx.y >= PJ.na;
+    const LcWgrad L = second ? PJ.b : PJ.a;
+    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sm = reinterpret_cast<float*>(smem);
+    const int ybuf = 32 * L.SPY, xbuf = 32 * L.SPX;
+    float* s_y = sm;                    // [2][32][SPY]: position f of the padded image at f - P4 (rows 0 .. h - 1 only)
+    float* s_x = sm + 2 * ybuf;         // [2][32][SPX]: position f at f + 4 (4 floats of margin in front)
+    float* s_dc = s_x + 2 * xbuf;       // [3][32] dy coefficients of this block's channels
+    float* s_xc = s_dc + 96;            // [2][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, i16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cib = blockIdx.x, cob = by % L.co_blocks, chunk = by / L.co_blocks;
+    const int hw = L.h * L.w_img, QP = (hw + 3) >> 2;
+    const float r_iw = 1.0f / (float)L.w_img;
+    const int co0 = cob * 32, ci0 = cib * 32;
+    for (int i = tid; i < (2 * ybuf + 2 * xbuf) / 4; i += 256) reinterpret_cast<float4*>(sm)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 96) {
+        const int c = co0 + (tid & 31);
+        s_dc[tid] = c < L.cout ? L.dcoef[(tid >> 5) * L.cpad_out + c] : 0.0f;
+    }
+    if (tid >= 128 && tid < 192) {
+        const int t = tid - 128, c = ci0 + (t & 31);
+        s_xc[t] = (L.x_mode == IN_BNRELU && c < L.cin_real) ? L.xcoef[(t >> 5) * L.cpad_in + c] : 0.0f;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_dz = mkrs(L.dz), rs_y = mkrs(L.y), rs_x = mkrs(L.x0);
+    // staging plan: lane = pixel quad (lanes >= QP idle), wave w the channels w, 4 + w, .., 28 + w of each operand
+    const bool s_ok = lane < QP;
+    const int p0 = (s_ok ? lane : 0) * 4;
+    int spos[4], pm[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
+        spos[e] = (s_ok && pp < hw) ? py * L.P4 + px : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
+        pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
+    }
+    float4 rdz[8], ry[8], rx[8];
+    int r_act = -1;
+    const int b_lo = chunk * L.ipw, b_hi = (b_lo + L.ipw < L.B) ? b_lo + L.ipw : L.B;
+    auto fetch = [&](int b) {
+        const int bc = b < L.B ? b : L.B - 1;
+        const unsigned vo = (unsigned)(p0 * sizeof(float));
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = co0 + 4 * k + wave, cc = c < L.cout ? c : 0;
+            const int so = (int)(((size_t)bc * L.cout + cc) * hw * sizeof(float));
+            rdz[k] = ld4(rs_dz, vo, so);
+            ry[k] = ld4(rs_y, vo, so);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = ci0 + 4 * k + wave, cc = c < L.cin_real ? c : 0;
+            rx[k] = ld4(rs_x, vo, (int)(((size_t)bc * L.cin_real + cc) * hw * sizeof(float)));
+        }
+        r_act = L.action ? L.action[bc] : -1;
+    };
+    auto stage = [&](int buf) {
+        float* dy_ = s_y + buf * ybuf;
+        float* dx_ = s_x + buf * xbuf + L.P4 + 4;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int cl = 4 * k + wave;
+            const float c1 = s_dc[cl], c2 = s_dc[32 + cl], c3 = s_dc[64 + cl];
+            const bool live = co0 + cl < L.cout;
+            const float a[4] = {rdz[k].x, rdz[k].y, rdz[k].z, rdz[k].w}, yy[4] = {ry[k].x, ry[k].y, ry[k].z, ry[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (spos[e] >= 0) dy_[cl * L.SPY + spos[e]] = live ? fmaf(c1, a[e], fmaf(c2, yy[e], c3)) : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int cl = 4 * k + wave, c = ci0 + cl;
+            const float xa = s_xc[cl], xb = s_xc[32 + cl];
+            const float x[4] = {rx[k].x, rx[k].y, rx[k].z, rx[k].w};
+            const int t = (c >= L.cin_real && c < L.cin) ? (int)(((long long)(c - L.cin_real) * hw) % L.num_actions) : 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v;
+                if (c < L.cin_real) {
+                    v = x[e];
+                    if (L.x_mode == IN_BNRELU) {
+                        v = fmaf(xa, v, xb);
+                        v = v > 0.0f ? v : 0.0f;
+                    }
+                } else {
+                    int m = pm[e] + t;
+                    m = m >= L.num_actions ? m - L.num_actions : m;
+                    v = (c < L.cin && m == r_act) ? 1.0f : 0.0f;
+                }
+                if (spos[e] >= 0) dx_[cl * L.SPX + spos[e]] = v;
+            }
+        }
+    };
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (b_lo < b_hi) {
+        fetch(b_lo);
+        stage(0);
+    }
+    __syncthreads();
+    const int ya = (wm * 16 + i16) * L.SPY + 4 * kq;             // + 16 g: the lane's dy quad
+    const int xa0 = (wn * 16 + i16) * L.SPX + L.P4 + 4 + 4 * kq;  // + 16 g + dy P4: the centre quad of row dy
+    for (int b = b_lo; b < b_hi; b++) {
+        const int buf = (b - b_lo) & 1;
+        if (b + 1 < b_hi) fetch(b + 1);
+        const float* py_ = s_y + buf * ybuf + ya;
+        const float* px_ = s_x + buf * xbuf + xa0;
+        for (int g = 0; g < L.nsteps; g++) {
+            const float4 a4 = *reinterpret_cast<const float4*>(py_ + 16 * g);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const float* r = px_ + 16 * g + (dy - 1) * L.P4;
+                const float4 c4 = *reinterpret_cast<const float4*>(r);
+                const float lft = r[-1], rgt = r[4];
+                const float xs[6] = {lft, c4.x, c4.y, c4.z, c4.w, rgt};
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs[s + dx], acc[dy * 3 + dx], 0, 0, 0);
+                }
+            }
+        }
+        if (b + 1 < b_hi) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // D[m = co][n = ci]: lane (kq, i16) holds rows 4 kq + r of column i16
+    const int cot = cob * 2 + wm, cit = cib * 2 + wn;
+    if (cot >= L.co_tiles || cit >= L.ci_tiles) return;
+    const int co_pad = L.co_tiles * 16, ci_pad = L.ci_tiles * 16;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        float* d = L.part + (((size_t)chunk * 9 + t) * co_pad + cot * 16 + 4 * kq) * ci_pad + cit * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; r++) d[(size_t)r * ci_pad] = acc[t][r];
+    }
+}
+
+// chunk partials -> gradient of the conv weight in torch layout [cout][cin][3][3]; accumulate: += (later unroll steps of a shared layer)
+struct LcWreduce {
+    const float* part;
+    float* grad;
+    int chunks, cout, cin, co_pad, ci_pad, accumulate;
+};
+__global__ __launch_bounds__(256) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
+    const bool second = (int)blockIdx.y >= PJ.na;
+    const LcWreduce L = second ? PJ.b : PJ.a;
+    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    const int n = 9 * L.cout * L.cin;
+    const int i = by * 256 + threadIdx.x;  // (tap, co, ci), ci fastest: coalesced reads
+    if (i >= n) return;
+    const int ci = i % L.cin, co = (i / L.cin) % L.cout, tap = i / (L.cin * L.cout);
+    const float* p = L.part + ((size_t)tap * L.co_pad + co) * L.ci_pad + ci;
+    const size_t cs = (size_t)9 * L.co_pad * L.ci_pad;
+    float s = 0.0f;
+    for (int c = 0; c < L.chunks; c++) s += p[c * cs];
+    float* g = L.grad + ((size_t)co * L.cin + ci) * 9 + tap;
+    *g = L.accumulate ? *g + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// BatchNorm2d in train mode (network.py:283-291): finalize the per-workgroup partial sums.  One thread per channel; the groups are added
+// in order in float64 (the partials are float32 sums of <= a few hundred values).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LcBnFwd {
+    const float* part;     // [groups][cpad][2]
+    const float* gamma;    // [C]
+    const float* beta;
+    float* coef;           // [3][cpad]: a, b, (unused)    -- what the next conv's staging applies
+    float* save;           // [2][cpad]: mean, invstd       -- for the backward pass
+    float* running_mean;   // [C] or null
+    float* running_var;
+    int64_t* num_batches;  // or null
+    int groups, C, cpad;
+    float count;           // B * hw
+};
+// workgroup = 16 channels x 16 group slices: slice j adds groups j, j + 16, .. in float64, the 16 slices meet in LDS in slice order
+__device__ __forceinline__ void lc_group_sums(const float* part, int groups, int cpad, int c, int slice, double (*s_acc)[16][2], double& s1, double& s2) {
+    double a = 0.0, b = 0.0;
+    for (int g = slice; g < groups; g += 16) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)g * cpad + c) * 2);
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+    s_acc[threadIdx.x & 15][slice][0] = a;
+    s_acc[threadIdx.x & 15][slice][1] = b;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    for (int k = 0; k < 16; k++) { s1 += s_acc[threadIdx.x & 15][k][0]; s2 += s_acc[threadIdx.x & 15][k][1]; }
+}
+
+__global__ __launch_bounds__(256) void k_lc_bn_fwd(const Pair<LcBnFwd> PJ) {
+    __shared__ double s_acc[16][16][2];
+    const bool second = (int)blockIdx.y >= PJ.na;
+    const LcBnFwd L = second ? PJ.b : PJ.a;
+    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    const int c = by * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
+    const int cc = c < L.cpad ? c : L.cpad - 1;
+    double s1, s2;
+    lc_group_sums(L.part, L.groups, L.cpad, cc, slice, s_acc, s1, s2);
+    if (slice != 0 || c >= L.cpad) return;
+    if (c >= L.C) {
+        L.coef[c] = 0.0f; L.coef[L.cpad + c] = 0.0f; L.coef[2 * L.cpad + c] = 0.0f;
+        L.save[c] = 0.0f; L.save[L.cpad + c] = 0.0f;
+        return;
+    }
+    const double mean = s1 / (double)L.count;
+    double var = s2 / (double)L.count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float a = L.gamma[c] * invstd;
+    L.coef[c] = a;
+    L.coef[L.cpad + c] = L.beta[c] - (float)mean * a;
+    L.coef[2 * L.cpad + c] = 0.0f;
+    L.save[c] = (float)mean;
+    L.save[L.cpad + c] = invstd;
+    if (L.running_mean) {  // momentum 0.1, unbiased variance (torch.nn.BatchNorm2d defaults)
+        const double unb = L.count > 1.0f ? var * (double)L.count / ((double)L.count - 1.0) : var;
+        L.running_mean[c] = (float)(0.9 * (double)L.running_mean[c] + 0.1 * mean);
+        L.running_var[c] = (float)(0.9 * (double)L.running_var[c] + 0.1 * unb);
+    }
+    if (L.num_batches && c == 0) *L.num_batches += 1;
+}
+
+struct LcBnBwd {
+    const float* part;     // [groups][cpad][2]: sum dz, sum dz * y
+    const float* gamma;
+    const float* save;     // mean, invstd
+    float* coef;           // [3][cpad]: dy = c1 dz + c2 y + c3
+    float* dgamma;         // gradient slots
+    float* dbeta;
+    int groups, C, cpad, accumulate;
+    float count;
+};
+__global__ __launch_bounds__(256) void k_lc_bn_bwd(const Pair<LcBnBwd> PJ) {
+    __shared__ double s_acc[16][16][2];
+    const bool second = (int)blockIdx.y >= PJ.na;
+    const LcBnBwd L = second ? PJ.b : PJ.a;
+    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    const int c = by * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
+    const int cc = c < L.cpad ? c : L.cpad - 1;
+    double s1, s2;
+    lc_group_sums(L.part, L.groups, L.cpad, cc, slice, s_acc, s1, s2);
+    if (slice != 0 || c >= L.cpad) return;
+    if (c >= L.C) {
+        L.coef[c] = 0.0f; L.coef[L.cpad + c] = 0.0f; L.coef[2 * L.cpad + c] = 0.0f;
+        return;
+    }
+    const double mean = L.save[c], invstd = L.save[L.cpad + c], gam = L.gamma[c], M = L.count;
+    const double dgam = (s2 - mean * s1) * invstd;
+    const double c1 = gam * invstd;
+    L.coef[c] = (float)c1;
+    L.coef[L.cpad + c] = (float)(-c1 * invstd * dgam / M);
+    L.coef[2 * L.cpad + c] = (float)(-c1 * s1 / M + c1 * mean * invstd * dgam / M);
+    L.dgamma[c] = L.accumulate ? L.dgamma[c] + (float)dgam : (float)dgam;
+    L.dbeta[c] = L.accumulate ? L.dbeta[c] + (float)s1 : (float)s1;
+}
+
+// x' = relu(a y + b [+ res]) materialised (block outputs, ResNetBlock network.py:293-299; the first conv block's output)
+struct LcApply {
+    const float* y;
+    const float* res;   // or null
+    const float* coef;  // [3][cpad]
+    float* out;
+    int C, hw, cpad;
+    long long n;        // B * C * hw
+};
+__global__ __launch_bounds__(256) void k_lc_apply(const Pair<LcApply> PJ) {
+    const bool second = (int)blockIdx.y >= PJ.na;
+    const LcApply L = second ? PJ.b : PJ.a;
+    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    const long long i0 = ((long long)by * 256 + threadIdx.x) * 4;
+    if (i0 >= L.n) return;
+    const float r_hw = 1.0f / (float)L.hw;
+    if (i0 + 3 < L.n) {
+        const float* py = L.y + i0;
+        float yv[4] = {py[0], py[1], py[2], py[3]}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (L.res) { rv[0] = L.res[i0]; rv[1] = L.res[i0 + 1]; rv[2] = L.res[i0 + 2]; rv[3] = L.res[i0 + 3]; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const long long i = i0 + e;
+            const int c = (int)((i / L.hw) % L.C);
+            const float t = fmaf(L.coef[c], yv[e], L.coef[L.cpad + c]) + rv[e];
+            L.out[i] = t > 0.0f ? t : 0.0f;
+        }
+        (void)r_hw;
+        return;
+    }
+    for (long long i = i0; i < L.n; i++) {
+        const int c = (int)((i / L.hw) % L.C);
+        const float t = fmaf(L.coef[c], L.y[i], L.coef[L.cpad + c]) + (L.res ? L.res[i] : 0.0f);
+        L.out[i] = t > 0.0f ? t : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// normalize_hidden_state (util.py:31-36) over the channels of each pixel.  workgroup = one image x 32 pixels; thread (pixel, channel group of 8).
+// forward: s = (x - min) / (max - min + 1e-8).
+// k_lc_entry: the gradient entering a tower's output x (post-ReLU): g = [normalize backward of `gs` scaled by `scale`] + `extra`, masked
+// by x > 0, plus the partial sums (sum dz, sum dz y) of the last BatchNorm of the tower.  normalize backward (min / max gradients go to
+// the FIRST attaining channel, as torch's min(dim) / max(dim) backward does):
+//     dx_c = G_c / d - [c == imin] sum_k G_k / d - ([c == imax] - [c == imin]) sum_k G_k s_k / d,     d = max - min + 1e-8
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int CPT>
+__global__ __launch_bounds__(256) void k_lc_normalize(const float* in, float* out, int B, int C, int hw) {
+    __shared__ float s_mn[8][32], s_mx[8][32];
+    const int b = blockIdx.y, px = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + px;
+    const bool ok = p < hw;
+    const int cpt = (C + 7) >> 3;
+    const float* s = in + (size_t)b * C * hw + (ok ? p : 0);
+    float v[CPT];
+    float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        if (i < cpt && c < C) {
+            v[i] = s[(size_t)c * hw];
+            mn = v[i] < mn ? v[i] : mn;
+            mx = v[i] > mx ? v[i] : mx;
+        }
+    }
+    s_mn[cg][px] = mn; s_mx[cg][px] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        mn = s_mn[g][px] < mn ? s_mn[g][px] : mn;
+        mx = s_mx[g][px] > mx ? s_mx[g][px] : mx;
+    }
+    if (!ok) return;
+    const float d = (mx - mn) + 1e-8f;
+    float* o = out + (size_t)b * C * hw + p;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        if (i < cpt && c < C) o[(size_t)c * hw] = (v[i] - mn) / d;
+    }
+}
+
+struct LcEntry {
+    const float* x;        // tower output (post-ReLU) [B][C][hw]
+    const float* gs;       // gradient wrt normalize(x), or null
+    const float* extra;    // gradient added directly (head backward), or null
+    const float* partner;  // y of the tower's last BatchNorm
+    float* dz;             // out
+    float* stat_part;      // [B * chunks][cpad][2]
+    float scale;           // on gs (0.5: pipeline.py:584)
+    int B, C, hw, cpad;
+};
+template <int CPT>
+__global__ __launch_bounds__(256) void k_lc_entry(const LcEntry L) {
+    __shared__ float s_a[8][32], s_b[8][32];
+    __shared__ int s_ia[8][32], s_ib[8][32];
+    const int b = blockIdx.y, px = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + px;
+    const bool ok = p < L.hw;
+    const int cpt = (L.C + 7) >> 3;
+    const size_t base = (size_t)b * L.C * L.hw + (ok ? p : 0);
+    float x[CPT], g[CPT];
+    float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
+    int imn = 0x7fffffff, imx = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        x[i] = 0.0f; g[i] = 0.0f;
+        if (i < cpt && c < L.C) {
+            x[i] = L.x[base + (size_t)c * L.hw];
+            if (L.gs) g[i] = L.gs[base + (size_t)c * L.hw] * L.scale;
+            if (x[i] < mn) { mn = x[i]; imn = c; }   // strict: the first attaining channel of this thread's ascending run
+            if (x[i] > mx) { mx = x[i]; imx = c; }
+        }
+    }
+    float dx[CPT];
+    if (L.gs) {  // (workgroup-uniform)
+        s_a[cg][px] = mn; s_b[cg][px] = mx; s_ia[cg][px] = imn; s_ib[cg][px] = imx;
+        __syncthreads();
+        mn = s_a[0][px]; imn = s_ia[0][px]; mx = s_b[0][px]; imx = s_ib[0][px];
+#pragma unroll
+        for (int k = 1; k < 8; k++) {  // channel groups ascend: strict comparison keeps the first attaining channel
+            if (s_a[k][px] < mn) { mn = s_a[k][px]; imn = s_ia[k][px]; }
+            if (s_b[k][px] > mx) { mx = s_b[k][px]; imx = s_ib[k][px]; }
+        }
+        const float d = (mx - mn) + 1e-8f;
+        float sg = 0.0f, sgs = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg * cpt + i;
+            if (i < cpt && c < L.C) {
+                sg += g[i];
+                sgs = fmaf(g[i], (x[i] - mn) / d, sgs);
+            }
+        }
+        __syncthreads();
+        s_a[cg][px] = sg; s_b[cg][px] = sgs;
+        __syncthreads();
+        sg = 0.0f; sgs = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { sg += s_a[k][px]; sgs += s_b[k][px]; }
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg * cpt + i;
+            float t = g[i] / d;
+            if (c == imn) t = t - sg / d + sgs / d;
+            if (c == imx) t = t - sgs / d;
+            dx[i] = t;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) dx[i] = 0.0f;
+    }
+    // + head gradient, ReLU mask, store, per-channel partial sums over this workgroup's 32 pixels (the 32 lanes of a channel group are one
+    // half of a wave: xor-butterfly 16-8-4-2-1, a fixed order)
+    const int chunks = gridDim.x;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        float t = 0.0f, yv = 0.0f;
+        if (ok && i < cpt && c < L.C) {
+            t = dx[i] + (L.extra ? L.extra[base + (size_t)c * L.hw] : 0.0f);
+            t = x[i] > 0.0f ? t : 0.0f;
+            L.dz[base + (size_t)c * L.hw] = t;
+            yv = L.partner[base + (size_t)c * L.hw];
+        }
+        float a = t, bb = t * yv;
+        for (int m = 16; m >= 1; m >>= 1) { a += __shfl_xor(a, m); bb += __shfl_xor(bb, m); }
+        if (px == 0 && i < cpt && c < L.C) {
+            float* d = L.stat_part + (((size_t)b * chunks + blockIdx.x) * L.cpad + c) * 2;
+            d[0] = a; d[1] = bb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Batch plumbing: replay rows -> dense observations and actions (replay.py:27-32 `Transition` storages addressed by row index)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LcBatch {
+    const void* state;     // [cap][C0 * hw] float32 or int8
+    const void* action;    // [cap][K] int8 or int16
+    const float* pi;       // [cap][K][A]
+    const float* value;    // [cap][K]
+    const float* reward;   // [cap][K]
+    const int64_t* idx;    // [B]
+    const float* w;        // [B]
+    float* prio;           // [B]
+    int B, state_i8, action_bytes, K, A, in_dim;
+};
+__global__ __launch_bounds__(256) void k_lc_gather(const LcBatch bt, float* obs, int* act) {
+    const int b = blockIdx.y;
+    const int64_t row = bt.idx[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < bt.in_dim; i += gridDim.x * 256)
+        obs[(size_t)b * bt.in_dim + i] = bt.state_i8 ? (float)reinterpret_cast<const int8_t*>(bt.state)[row * bt.in_dim + i]
+                                                    : reinterpret_cast<const float*>(bt.state)[row * bt.in_dim + i];
+    if (blockIdx.x == 0 && threadIdx.x < bt.K) {
+        const int k = threadIdx.x;
+        const int a = bt.action_bytes == 2 ? (int)reinterpret_cast<const int16_t*>(bt.action)[row * bt.K + k]
+                                           : (int)reinterpret_cast<const int8_t*>(bt.action)[row * bt.K + k];
+        act[(size_t)k * bt.B + b] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Heads (network.py:424-430 reward, :472-486 policy / value): 1x1 conv (P -> oc) + BatchNorm2d(oc) + ReLU + Flatten + Linear(oc * hw -> n_out).
+// A "group" is one application: (unroll step t, head).  All groups run side by side (grid.y): the towers' outputs are saved, and a head's
+// loss gradient is known as soon as its logits are.
+//   k_lch_conv   u[o][p] = sum_c w1[o][c] F[b][c][p]; partial sums (sum u, sum u^2) per (group, image)
+//   k_lch_bn     batch statistics per head (the K steps of a head update its running statistics in step order)
+//   k_lch_loss   feat = relu(a u + b); logits; loss; dlogits; dfeat; dz = dfeat [feat > 0]; partial sums (sum dz, sum dz u); priorities
+//   k_lch_bnb    BatchNorm backward coefficients, dgamma / dbeta (summed over the steps), the reported loss
+//   k_lch_dx     dF[b][c][p] = sum over the heads on F, o: w1[o][c] du[o][p],  du = c1 dz + c2 u + c3
+//   k_lch_dw1 / k_lch_dlin   weight gradients (sums over steps and batch in fixed order)
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int LCH_MAXOC = 2;
+struct LchHead {           // one of reward / policy / value
+    int oc, n_out, kind;   // kind 0: squared error (n_out == 1), 1: soft-target cross entropy (policy)
+    int w1_off, gamma_off, beta_off, lw_off, lb_off;  // offsets into params / grads
+    int rm_off, rv_off, nbt_idx;                      // running statistics
+};
+struct LchGroup {
+    const float* F;        // [B][P][hw] tower output this application reads
+    int head, t;
+};
+struct LchArgs {
+    LchHead head[3];
+    const LchGroup* groups;  // [ngroups] device
+    int ngroups, K, B, P, hw, A;
+    const float* params;
+    float* grads;
+    float* running;        // flat running statistics
+    int64_t* nbt;
+    const float* lwT;      // per head: transposed Linear weights [oc * hw][n_out] at lwT_off[head]
+    int lwT_off[3];
+    float* u;              // [ngroups][B][2][hw]
+    float* dzb;            // [ngroups][B][2][hw]
+    float* feat;           // [ngroups][B][2 * hw]
+    float* dlogit;         // [ngroups][B][n_max]
+    float* spart;          // [ngroups][B][2 oc][2] forward partials, then backward partials
+    float* coef;           // [ngroups][2 oc][5]: a, b (forward); c1, c2, c3 (backward)
+    float* save;           // [ngroups][2 oc][2]: mean, invstd
+    float* lpart;          // [ngroups][B] weighted loss terms
+    int n_max;
+    LcBatch bt;
+    float* loss;           // [1]
+};
+
+__global__ __launch_bounds__(256) void k_lch_conv(const LchArgs A) {
+    __shared__ float s_w[LCH_MAXOC][1024];
+    __shared__ float s_red[2 * LCH_MAXOC][4];
+    const int g = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const LchGroup G = A.groups[g];
+    const LchHead H = A.head[G.head];
+    for (int i = tid; i < H.oc * A.P; i += 256) s_w[i / A.P][i % A.P] = A.params[H.w1_off + i];
+    __syncthreads();
+    const float* F = G.F + (size_t)b * A.P * A.hw;
+    float s1[LCH_MAXOC] = {0.f, 0.f}, s2[LCH_MAXOC] = {0.f, 0.f};
+    for (int p = tid; p < A.hw; p += 256) {
+        float acc[LCH_MAXOC] = {0.f, 0.f};
+        for (int c = 0; c < A.P; c++) {
+            const float f = F[(size_t)c * A.hw + p];
+#pragma unroll
+            for (int o = 0; o < LCH_MAXOC; o++)
+                if (o < H.oc) acc[o] = fmaf(s_w[o][c], f, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < LCH_MAXOC; o++)
+            if (o < H.oc) {
+                A.u[(((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p] = acc[o];
+                s1[o] += acc[o];
+                s2[o] = fmaf(acc[o], acc[o], s2[o]);
+            }
+    }
+    // block sums in a fixed order: wave butterflies, then the four waves in order
+#pragma unroll
+    for (int o = 0; o < LCH_MAXOC; o++) {
+        for (int m = 32; m >= 1; m >>= 1) { s1[o] += __shfl_xor(s1[o], m); s2[o] += __shfl_xor(s2[o], m); }
+        if ((tid & 63) == 0) { s_red[2 * o][tid >> 6] = s1[o]; s_red[2 * o + 1][tid >> 6] = s2[o]; }
+    }
+    __syncthreads();
+    if (tid < 2 * H.oc) {
+        const float s = ((s_red[tid][0] + s_red[tid][1]) + s_red[tid][2]) + s_red[tid][3];
+        A.spart[(((size_t)g * A.B + b) * LCH_MAXOC + (tid >> 1)) * 2 + (tid & 1)] = s;
+    }
+}
+
+// one thread per (head, plane): the K applications of a head in step order (their running-statistics updates are sequential)
+__global__ void k_lch_bn(const LchArgs A) {
+    const int hd = threadIdx.x / LCH_MAXOC, o = threadIdx.x % LCH_MAXOC;
+    if (hd >= 3 || o >= A.head[hd].oc) return;
+    const LchHead H = A.head[hd];
+    const double M = (double)A.B * A.hw;
+    for (int t = 0; t < A.K; t++) {
+        int g = -1;
+        for (int k = 0; k < A.ngroups; k++)
+            if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
+        if (g < 0) continue;
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = 0; b < A.B; b++) {
+            const float* p = A.spart + (((size_t)g * A.B + b) * LCH_MAXOC + o) * 2;
+            s1 += (double)p[0]; s2 += (double)p[1];
+        }
+        const double mean = s1 / M;
+        double var = s2 / M - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float a = A.params[H.gamma_off + o] * invstd;
+        float* cf = A.coef + ((size_t)g * LCH_MAXOC + o) * 5;
+        cf[0] = a;
+        cf[1] = A.params[H.beta_off + o] - (float)mean * a;
+        A.save[((size_t)g * LCH_MAXOC + o) * 2] = (float)mean;
+        A.save[((size_t)g * LCH_MAXOC + o) * 2 + 1] = invstd;
+        const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+        A.running[H.rm_off + o] = (float)(0.9 * (double)A.running[H.rm_off + o] + 0.1 * mean);
+        A.running[H.rv_off + o] = (float)(0.9 * (double)A.running[H.rv_off + o] + 0.1 * unb);
+        if (o == 0) A.nbt[H.nbt_idx] += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lch_loss(const LchArgs A) {
+    extern __shared__ float lsm[];
+    const int g = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const LchGroup G = A.groups[g];
+    const LchHead H = A.head[G.head];
+    const int nf = H.oc * A.hw;
+    float* s_feat = lsm;               // [nf]
+    float* s_lg = s_feat + nf;         // [n_out]
+    float* s_dl = s_lg + H.n_out;      // [n_out]
+    float* s_red = s_dl + H.n_out;     // [16]
+    const float* u = A.u + ((size_t)g * A.B + b) * LCH_MAXOC * A.hw;
+    const float* cf = A.coef + (size_t)g * LCH_MAXOC * 5;
+    for (int k = tid; k < nf; k += 256) {
+        const int o = k / A.hw, p = k - o * A.hw;
+        const float z = fmaf(cf[o * 5], u[o * A.hw + p], cf[o * 5 + 1]);
+        const float f = z > 0.0f ? z : 0.0f;
+        s_feat[k] = f;
+        A.feat[((size_t)g * A.B + b) * LCH_MAXOC * A.hw + k] = f;
+    }
+    __syncthreads();
+    const float* lwT = A.lwT + A.lwT_off[G.head];
+    for (int n = tid; n < H.n_out; n += 256) {
+        float a = A.params[H.lb_off + n];
+        for (int k = 0; k < nf; k++) a = fmaf(s_feat[k], lwT[(size_t)k * H.n_out + n], a);
+        s_lg[n] = a;
+    }
+    __syncthreads();
+    const int64_t row = A.bt.idx[b];
+    const float wgt = A.bt.w[b];
+    const float gscale = wgt / ((float)A.B * (float)A.K);  // mean over the batch, 1 / K on the gradient (pipeline.py:597-600)
+    if (H.kind == 0) {  // squared error (pipeline.py:625: F.mse_loss, reduction none)
+        if (tid == 0) {
+            const float target = (G.head == 0 ? A.bt.reward : A.bt.value)[row * A.K + G.t];
+            const float d = s_lg[0] - target;
+            A.lpart[(size_t)g * A.B + b] = d * d * wgt;
+            s_dl[0] = 2.0f * d * gscale;
+            if (G.head == 2 && G.t == 0) A.bt.prio[b] = fabsf(d);  // pipeline.py:603-609
+        }
+    } else {            // cross entropy against soft targets (pipeline.py:629)
+        const float* pi = A.bt.pi + ((size_t)row * A.K + G.t) * A.A;
+        float mx = __uint_as_float(0xff800000u);
+        for (int n = tid; n < H.n_out; n += 256) mx = s_lg[n] > mx ? s_lg[n] : mx;
+        for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(mx, m); mx = o > mx ? o : mx; }
+        if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        float se = 0.0f, sp = 0.0f, spl = 0.0f;
+        for (int n = tid; n < H.n_out; n += 256) {
+            const float e = expf(s_lg[n] - mx);
+            se += e;
+            sp += pi[n];
+            spl = fmaf(pi[n], s_lg[n] - mx, spl);
+        }
+        for (int m = 32; m >= 1; m >>= 1) { se += __shfl_xor(se, m); sp += __shfl_xor(sp, m); spl += __shfl_xor(spl, m); }
+        __syncthreads();
+        if ((tid & 63) == 0) { s_red[tid >> 6] = se; s_red[4 + (tid >> 6)] = sp; s_red[8 + (tid >> 6)] = spl; }
+        __syncthreads();
+        se = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        sp = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
+        spl = ((s_red[8] + s_red[9]) + s_red[10]) + s_red[11];
+        const float lse = logf(se);
+        if (tid == 0) A.lpart[(size_t)g * A.B + b] = (sp * lse - spl) * wgt;   // -sum pi (l - mx - lse)
+        for (int n = tid; n < H.n_out; n += 256) s_dl[n] = (expf(s_lg[n] - mx) / se * sp - pi[n]) * gscale;
+    }
+    __syncthreads();
+    for (int n = tid; n < H.n_out; n += 256) A.dlogit[((size_t)g * A.B + b) * A.n_max + n] = s_dl[n];
+    // dfeat[k] = sum_n lw[n][k] dlogit[n]; dz = dfeat [feat > 0]; partial sums of the BatchNorm backward
+    const float* lw = A.params + H.lw_off;
+    float s1[LCH_MAXOC] = {0.f, 0.f}, s2[LCH_MAXOC] = {0.f, 0.f};
+    for (int k = tid; k < nf; k += 256) {
+        float a = 0.0f;
+        for (int n = 0; n < H.n_out; n++) a = fmaf(lw[(size_t)n * nf + k], s_dl[n], a);
+        const float dz = s_feat[k] > 0.0f ? a : 0.0f;
+        const int o = k / A.hw, p = k - o * A.hw;
+        A.dzb[(((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p] = dz;
+#pragma unroll
+        for (int oo = 0; oo < LCH_MAXOC; oo++)
+            if (oo == o) { s1[oo] += dz; s2[oo] = fmaf(dz, u[o * A.hw + p], s2[oo]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < LCH_MAXOC; o++) {
+        for (int m = 32; m >= 1; m >>= 1) { s1[o] += __shfl_xor(s1[o], m); s2[o] += __shfl_xor(s2[o], m); }
+        if ((tid & 63) == 0) { s_red[(2 * o) * 4 + (tid >> 6)] = s1[o]; s_red[(2 * o + 1) * 4 + (tid >> 6)] = s2[o]; }
+    }
+    __syncthreads();
+    if (tid < 2 * H.oc) {
+        const float s = ((s_red[tid * 4] + s_red[tid * 4 + 1]) + s_red[tid * 4 + 2]) + s_red[tid * 4 + 3];
+        A.spart[(((size_t)g * A.B + b) * LCH_MAXOC + (tid >> 1)) * 2 + (tid & 1)] = s;
+    }
+}
+
+// BatchNorm backward of the heads + the reported loss (one workgroup)
+__global__ __launch_bounds__(256) void k_lch_bnb(const LchArgs A) {
+    const int tid = threadIdx.x;
+    const int hd = tid / LCH_MAXOC, o = tid % LCH_MAXOC;
+    if (hd < 3 && o < A.head[hd].oc) {
+        const LchHead H = A.head[hd];
+        const double M = (double)A.B * A.hw;
+        double dg_sum = 0.0, db_sum = 0.0;
+        for (int t = 0; t < A.K; t++) {
+            int g = -1;
+            for (int k = 0; k < A.ngroups; k++)
+                if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
+            if (g < 0) continue;
+            double s1 = 0.0, s2 = 0.0;
+            for (int b = 0; b < A.B; b++) {
+                const float* p = A.spart + (((size_t)g * A.B + b) * LCH_MAXOC + o) * 2;
+                s1 += (double)p[0]; s2 += (double)p[1];
+            }
+            const double mean = A.save[((size_t)g * LCH_MAXOC + o) * 2], invstd = A.save[((size_t)g * LCH_MAXOC + o) * 2 + 1];
+            const double gam = A.params[H.gamma_off + o];
+            const double dgam = (s2 - mean * s1) * invstd, c1 = gam * invstd;
+            float* cf = A.coef + ((size_t)g * LCH_MAXOC + o) * 5;
+            cf[2] = (float)c1;
+            cf[3] = (float)(-c1 * invstd * dgam / M);
+            cf[4] = (float)(-c1 * s1 / M + c1 * mean * invstd * dgam / M);
+            dg_sum += dgam; db_sum += s1;
+        }
+        A.grads[H.gamma_off + o] = (float)dg_sum;
+        A.grads[H.beta_off + o] = (float)db_sum;
+    }
+    if (tid == 255) {  // loss = mean_b w_b sum_t (reward + value + policy) (pipeline.py:594-597)
+        double s = 0.0;
+        for (int i = 0; i < A.ngroups * A.B; i++) s += (double)A.lpart[i];
+        *A.loss = (float)(s / (double)A.B);
+    }
+}
+
+// gradient wrt a tower output from the heads reading it: grid (B, K, 2): z = 0 the prediction tower's f_t (policy + value), z = 1 the dynamics
+// tower's raw g_t (reward)
+struct LchDx {
+    float* out[2];  // [K][B][P][hw] each
+};
+__global__ __launch_bounds__(256) void k_lch_dx(const LchArgs A, const LchDx D) {
+    __shared__ float s_w[3][LCH_MAXOC][1024];
+    const int b = blockIdx.x, t = blockIdx.y, which = blockIdx.z, tid = threadIdx.x;
+    int gs[3], ng = 0;
+    for (int k = 0; k < A.ngroups; k++)
+        if (A.groups[k].t == t && ((A.groups[k].head == 0) == (which == 1))) gs[ng++] = k;
+    int noc[3] = {0, 0, 0};
+    for (int e = 0; e < ng; e++) {
+        const LchHead H = A.head[A.groups[gs[e]].head];
+        noc[e] = H.oc;
+        for (int i = tid; i < H.oc * A.P; i += 256) s_w[e][i / A.P][i % A.P] = A.params[H.w1_off + i];
+    }
+    __syncthreads();
+    float* out = D.out[which] + ((size_t)t * A.B + b) * A.P * A.hw;
+    for (int p = tid; p < A.hw; p += 256) {
+        float du[3][LCH_MAXOC];
+        for (int e = 0; e < ng; e++) {
+            const int g = gs[e];
+            const LchHead H = A.head[A.groups[g].head];
+            for (int o = 0; o < LCH_MAXOC; o++) {
+                du[e][o] = 0.0f;
+                if (o < H.oc) {
+                    const float* cf = A.coef + ((size_t)g * LCH_MAXOC + o) * 5;
+                    const size_t ix = (((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p;
+                    du[e][o] = fmaf(cf[2], A.dzb[ix], fmaf(cf[3], A.u[ix], cf[4]));
+                }
+            }
+        }
+        for (int c = 0; c < A.P; c++) {
+            float a = 0.0f;
+            for (int e = 0; e < ng; e++)
+                for (int o = 0; o < LCH_MAXOC; o++)
+                    if (o < noc[e]) a = fmaf(s_w[e][o][c], du[e][o], a);  // (planes a head does not have were never staged: LDS garbage, possibly NaN)
+            out[(size_t)c * A.hw + p] = a;
+        }
+    }
+}
+
+// dw1[o][c] = sum_t sum_b sum_p du[t][b][o][p] F_t[b][c][p]: grid (P, 3 * LCH_MAXOC)
+__global__ __launch_bounds__(256) void k_lch_dw1(const LchArgs A) {
+    __shared__ float s_red[4];
+    const int c = blockIdx.x, hd = blockIdx.y / LCH_MAXOC, o = blockIdx.y % LCH_MAXOC, tid = threadIdx.x;
+    const LchHead H = A.head[hd];
+    if (o >= H.oc) return;
+    float total = 0.0f;
+    for (int t = 0; t < A.K; t++) {
+        int g = -1;
+        for (int k = 0; k < A.ngroups; k++)
+            if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
+        if (g < 0) continue;
+        const float* cf = A.coef + ((size_t)g * LCH_MAXOC + o) * 5;
+        const float c1 = cf[2], c2 = cf[3], c3 = cf[4];
+        const float* F = A.groups[g].F;
+        float s = 0.0f;
+        const int n = A.B * A.hw;
+        for (int i = tid; i < n; i += 256) {
+            const int b = i / A.hw, p = i - b * A.hw;
+            const size_t ix = (((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p;
+            const float du = fmaf(c1, A.dzb[ix], fmaf(c2, A.u[ix], c3));
+            s = fmaf(du, F[((size_t)b * A.P + c) * A.hw + p], s);
+        }
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = s;
+        __syncthreads();
+        total += ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    }
+    if (tid == 0) A.grads[H.w1_off + o * A.P + c] = total;
+}
+
+// dlw[n][k] = sum_{t, b} dlogit[n] feat[k]; dlb[n] = sum dlogit[n].  grid (ceil(nf / 256), n_out, 3): thread = feature k
+__global__ __launch_bounds__(256) void k_lch_dlin(const LchArgs A) {
+    const int hd = blockIdx.z, n = blockIdx.y;
+    const LchHead H = A.head[hd];
+    if (n >= H.n_out) return;
+    const int nf = H.oc * A.hw, k = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f, sb = 0.0f;
+    for (int t = 0; t < A.K; t++) {
+        int g = -1;
+        for (int q = 0; q < A.ngroups; q++)
+            if (A.groups[q].head == hd && A.groups[q].t == t) g = q;
+        if (g < 0) continue;
+        for (int b = 0; b < A.B; b++) {
+            const float dl = A.dlogit[((size_t)g * A.B + b) * A.n_max + n];
+            sb += dl;
+            if (k < nf) s = fmaf(dl, A.feat[((size_t)g * A.B + b) * LCH_MAXOC * A.hw + k], s);
+        }
+    }
+    if (k < nf) A.grads[H.lw_off + (size_t)n * nf + k] = s;
+    if (k == 0) A.grads[H.lb_off + n] = sb;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Operand copies and the optimizer
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LcPackJob {
+    int w_off;             // master weight [cout][cin][3][3] in params
+    int cout, cin, cin_d;  // cin_d: input channels that receive a gradient (the hidden part), 0: no dgrad copy
+    int f_off, d_off;      // float offsets of the forward / dgrad copies in the packed buffer
+    int n_cb, co_tiles;    // forward: 16-blocks of cin, tiles of cout
+    int n_cb_d, co_tiles_d;  // dgrad: 16-blocks of cout, tiles of cin_d
+};
+__global__ __launch_bounds__(256) void k_lc_pack(const LcPackJob* jobs, const float* params, float* packed) {
+    const LcPackJob J = jobs[blockIdx.y];
+    const int nf = J.co_tiles * J.n_cb * 9 * 256, nd = J.co_tiles_d * J.n_cb_d * 9 * 256;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += gridDim.x * 256) {
+        const bool fwd = e < nf;
+        const int x = fwd ? e : e - nf;
+        const int i = x & 3, lane = (x >> 2) & 63, rest = x >> 8;
+        const int tap = rest % 9, cb = (rest / 9) % (fwd ? J.n_cb : J.n_cb_d), ct = rest / (9 * (fwd ? J.n_cb : J.n_cb_d));
+        const int q = lane >> 4, jj = lane & 15;
+        float v = 0.0f;
+        if (fwd) {
+            const int co = 16 * ct + jj, ci = 16 * cb + 4 * i + q;
+            if (co < J.cout && ci < J.cin) v = params[J.w_off + ((size_t)co * J.cin + ci) * 9 + tap];
+            packed[J.f_off + x] = v;
+        } else {  // "output" channel = ci of the forward layer, "input" = co, taps flipped
+            const int ci = 16 * ct + jj, co = 16 * cb + 4 * i + q;
+            if (co < J.cout && ci < J.cin_d) v = params[J.w_off + ((size_t)co * J.cin + ci) * 9 + (8 - tap)];
+            packed[J.d_off + x] = v;
+        }
+    }
+}
+// transposed Linear weights of the heads: lwT[k][n] = lw[n][k]
+__global__ __launch_bounds__(256) void k_lc_pack_lin(const float* params, float* lwT, int lw_off, int n_out, int nf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out * nf) return;
+    const int n = i / nf, k = i - n * nf;
+    lwT[(size_t)k * n_out + n] = params[lw_off + i];
+}
+
+__global__ __launch_bounds__(256) void k_lc_sqsum(const float* g, int n, float* part) {
+    __shared__ float s_red[4];
+    float s = 0.0f;
+    const int i0 = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = i0 + k * 256;
+        if (i < n) s = fmaf(g[i], g[i], s);
+    }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+struct LcAdam {
+    float lr, beta1, beta2, eps, weight_decay, max_norm, bc1, bc2;
+    int sq_blocks, n;
+};
+// torch.optim.Adam with L2 weight decay in the gradient (gomoku/run_training.py builds it so), clip_grad_norm_ coefficient from the partials
+__global__ __launch_bounds__(256) void k_lc_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  const float* __restrict__ sq_part, const LcAdam a) {
+    __shared__ float s_coef;
+    if (threadIdx.x == 0) {
+        float coef = 1.0f;
+        if (a.max_norm > 0.0f) {
+            double s = 0.0;
+            for (int b = 0; b < a.sq_blocks; b++) s += (double)sq_part[b];
+            const float c = a.max_norm / ((float)sqrt(s) + 1e-6f);
+            coef = c < 1.0f ? c : 1.0f;
+        }
+        s_coef = coef;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    float gi = g[i] * s_coef;
+    const float pi = p[i];
+    gi = gi + a.weight_decay * pi;
+    const float mi = a.beta1 * m[i] + (1.0f - a.beta1) * gi;
+    const float vi = a.beta2 * v[i] + (1.0f - a.beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(a.bc2) + a.eps;
+    p[i] = pi - (a.lr / a.bc1) * (mi / denom);
+}
+
+}  // namespace mzlc

@@ -1,5 +1,6 @@
-"""ctypes binding of libmzlearner_hip.so (C ABI: include/mzlearner.h) and `HipLearner`, the learner step of the MLP nets on
-hand-written gfx950 kernels (`calc_loss` pipeline.py:541-612 + backward + clip + Adam / MultiStepLR :238-255).
+"""ctypes binding of libmzlearner_hip.so (C ABI: include/mzlearner.h) and `HipLearner`, the learner step of the MLP nets and -- round 5 --
+of the board-game conv nets (`MuZeroBoardGameNet`: residual towers with train-mode BatchNorm) on hand-written gfx950 kernels (SURVEY 8 f2:
+`calc_loss` pipeline.py:541-612 + backward + clip + Adam / MultiStepLR :238-255).
 
 `HipLearner` owns ONE flat float32 device tensor holding master weights, gradient, exp_avg and exp_avg_sq; the network's
 parameters are views into it (so `network.state_dict()` / checkpoints keep the reference's layout, pipeline.py:224-230), and
@@ -17,8 +18,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmzlearner_hip.so')
 
 # every symbol include/mzlearner.h declares (tests/test_abi.py checks the library exports all of them)
-ABI_SYMBOLS = ['mzl_last_error', 'mzl_create', 'mzl_destroy', 'mzl_num_params', 'mzl_grad_floats', 'mzl_tensor_info', 'mzl_bind', 'mzl_commit',
-               'mzl_grad', 'mzl_apply']
+ABI_SYMBOLS = ['mzl_last_error', 'mzl_create', 'mzl_destroy', 'mzl_num_params', 'mzl_grad_floats', 'mzl_num_tensors', 'mzl_tensor_info',
+               'mzl_num_buffers', 'mzl_num_running', 'mzl_buffer_info', 'mzl_bind_buffers', 'mzl_bind', 'mzl_commit', 'mzl_grad', 'mzl_apply']
+NET_MLP, NET_BOARD = 0, 1
 
 
 class LearnerError(RuntimeError):
@@ -28,7 +30,8 @@ class LearnerError(RuntimeError):
 class MzlConfig(C.Structure):
     _fields_ = [('in_dim', C.c_int32), ('num_actions', C.c_int32), ('num_planes', C.c_int32), ('hidden_dim', C.c_int32),
                 ('value_support_size', C.c_int32), ('reward_support_size', C.c_int32), ('unroll_steps', C.c_int32), ('max_batch', C.c_int32),
-                ('grad_slices', C.c_int32)]
+                ('grad_slices', C.c_int32), ('net_kind', C.c_int32), ('in_channels', C.c_int32), ('board_h', C.c_int32), ('board_w', C.c_int32),
+                ('num_res_blocks', C.c_int32)]
 
 
 class MzlBatch(C.Structure):
@@ -56,6 +59,14 @@ def load_library():
     L.mzl_grad_floats.argtypes = [vp]
     L.mzl_grad_floats.restype = i64
     L.mzl_tensor_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    L.mzl_num_tensors.argtypes = [vp]
+    L.mzl_num_tensors.restype = i32
+    L.mzl_num_buffers.argtypes = [vp]
+    L.mzl_num_buffers.restype = i32
+    L.mzl_num_running.argtypes = [vp]
+    L.mzl_num_running.restype = i64
+    L.mzl_buffer_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32)]
+    L.mzl_bind_buffers.argtypes = [vp, vp, vp]
     L.mzl_bind.argtypes = [vp, vp, vp, vp, vp]
     L.mzl_commit.argtypes = [vp, vp]
     L.mzl_grad.argtypes = [vp, C.POINTER(MzlBatch), vp]
@@ -105,8 +116,23 @@ class _SchedulerView:
         pass
 
 
+def conv_learner_flops(input_shape, num_actions: int, num_res_blocks: int, num_planes: int, unroll_steps: int) -> float:
+    """Algorithmic FLOPs (2 x multiply-accumulate) of ONE sample's update of a MuZeroBoardGameNet: forward + weight gradient of every 3 x 3
+    conv of the K-step unroll (pipeline.py:575-592; the dynamics net's first conv over its num_planes + num_actions inputs, network.py:440-446)
+    + data gradient wherever an input needs one (not the observation, not the constant action planes).  Heads and elementwise work are not
+    counted (< 0.1 %)."""
+    c0, h, w = input_shape
+    P, A, R, K, hw = num_planes, num_actions, num_res_blocks, unroll_steps, h * w
+    tower = 2 * R * P * P * 9 * hw
+    fwd = (c0 * P * 9 * hw + tower) + K * ((P + A) * P * 9 * hw + tower) + K * tower
+    dgrad = tower + K * (P * P * 9 * hw + tower) + K * tower
+    return 2.0 * (2 * fwd + dgrad)
+
+
 class HipLearner:
-    """The learner step of `run_training` (pipeline.py:238-255) for a `MuZeroMLPNet` on the GPU, as HIP kernels.
+    """The learner step of `run_training` (pipeline.py:238-255) for a `MuZeroMLPNet` or a `MuZeroBoardGameNet` on the GPU, as HIP kernels.
+    (Conv nets: the BatchNorm layers run in TRAIN mode whatever `network.training` says -- a learner step is a training step -- and their
+    running statistics, `num_batches_tracked` included, are module buffers re-pointed at the learner's flat buffer vectors.)
 
     `network`'s parameters are re-pointed at views of the learner's flat weight vector: after every `apply()` the module holds the
     new weights (its `state_dict()` is the checkpoint's 'network' entry as before).  Adam / MultiStepLR follow torch's definitions
@@ -123,17 +149,24 @@ class HipLearner:
         if self.device.type == 'cuda' and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
         spec = network.planner_spec()
-        if spec['kind'] != 'mlp':
-            raise LearnerError('HipLearner covers MuZeroMLPNet; the conv nets train through muzero_amd.learner.train_step')
+        if spec['kind'] not in ('mlp', 'board'):
+            raise LearnerError('HipLearner covers MuZeroMLPNet and MuZeroBoardGameNet; the Atari net trains through muzero_amd.learner.train_step')
+        self.kind = spec['kind']
         tiles = (max_batch + 15) // 16
+        if self.kind == 'board':
+            grad_slices = 1
         if grad_slices is None:
             # long reductions (large batches): the weight-gradient kernel runs one 8-wave workgroup per (layer, slice) -- 8 unrolled layers
             # with grad_slices slices each, 2 representation layers with grad_slices / K -- and all of them should be resident at once
             cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
             grad_slices = 1 if tiles * unroll_steps < 256 else max(2, min(64, int(cus / (8.0 + 2.0 / unroll_steps)), tiles * unroll_steps // 8))
         in_dim = int(np.prod(spec['input_shape']))
-        cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], spec['hidden_dim'], spec['value_support_size'], spec['reward_support_size'],
-                        unroll_steps, max_batch, grad_slices)
+        if self.kind == 'board':
+            c0, bh, bw = spec['input_shape']
+            cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], 1, 1, 1, unroll_steps, max_batch, 1, NET_BOARD, c0, bh, bw, spec['num_res_blocks'])
+        else:
+            cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], spec['hidden_dim'], spec['value_support_size'], spec['reward_support_size'],
+                            unroll_steps, max_batch, grad_slices, NET_MLP, 0, 0, 0, 0)
         _check(L.mzl_create(C.byref(cfg), self.device.index or 0, C.byref(self._h)))
         self.K, self.A, self.in_dim, self.max_batch = unroll_steps, spec['num_actions'], in_dim, max_batch
         self.total = int(L.mzl_num_params(self._h))
@@ -143,14 +176,32 @@ class HipLearner:
         self.grads = self.flat[3 * self.total:]
         self.grad_flat = self.grads[:self.total]  # the complete gradient after grad() (slice 0)
         self.views, self.grad_views = {}, {}
-        for i in range(20):
+        module_shapes = {k: tuple(p.shape) for k, p in network.named_parameters()}
+        for i in range(int(L.mzl_num_tensors(self._h))):
             name, off, rows, cols = C.c_char_p(), C.c_int64(), C.c_int32(), C.c_int32()
             _check(L.mzl_tensor_info(self._h, i, C.byref(name), C.byref(off), C.byref(rows), C.byref(cols)))
-            shape = (rows.value, cols.value) if cols.value else (rows.value,)
-            n = int(np.prod(shape))
-            self.views[name.value.decode()] = self.params[off.value:off.value + n].view(shape)
-            self.grad_views[name.value.decode()] = self.grad_flat[off.value:off.value + n].view(shape)
+            key = name.value.decode()
+            n = rows.value * (cols.value if cols.value else 1)
+            shape = module_shapes.get(key, (rows.value, cols.value) if cols.value else (rows.value,))  # (conv weights: [cout, cin, 3, 3] / [oc, P, 1, 1])
+            if int(np.prod(shape)) != n:
+                raise LearnerError(f'{key}: the module holds {shape}, the learner {n} elements')
+            self.views[key] = self.params[off.value:off.value + n].view(shape)
+            self.grad_views[key] = self.grad_flat[off.value:off.value + n].view(shape)
         _check(L.mzl_bind(self._h, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()))
+        # BatchNorm buffers (conv nets): flat running statistics + one num_batches_tracked per layer, written by the kernels
+        self.buffer_views = {}
+        nbuf = int(L.mzl_num_buffers(self._h))
+        self.running = torch.zeros(max(1, int(L.mzl_num_running(self._h))), dtype=torch.float32, device=self.device)
+        self.num_batches = torch.zeros(max(1, nbuf), dtype=torch.int64, device=self.device)
+        for i in range(nbuf):
+            name, off, cnt = C.c_char_p(), C.c_int64(), C.c_int32()
+            _check(L.mzl_buffer_info(self._h, i, C.byref(name), C.byref(off), C.byref(cnt)))
+            key, o, c = name.value.decode(), off.value, cnt.value
+            self.buffer_views[key + '.running_mean'] = self.running[o:o + c]
+            self.buffer_views[key + '.running_var'] = self.running[o + c:o + 2 * c]
+            self.buffer_views[key + '.num_batches_tracked'] = self.num_batches[i]
+        if nbuf:
+            _check(L.mzl_bind_buffers(self._h, self.running.data_ptr(), self.num_batches.data_ptr()))
         self.lr_init, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
         self.milestones, self.gamma = sorted(int(m) for m in milestones), float(gamma)
         self.clip_grad, self.max_grad_norm = bool(clip_grad), float(max_grad_norm)
@@ -167,15 +218,21 @@ class HipLearner:
     def adopt(self, network) -> None:
         """Copy `network`'s weights into the flat vector and make its parameters views of it."""
         sd = network.state_dict()
-        if set(sd) != set(self.views):
-            raise LearnerError(f'state_dict keys do not match MuZeroMLPNet: {sorted(set(sd) ^ set(self.views))}')
+        mine = set(self.views) | set(self.buffer_views)
+        if set(sd) != mine:
+            raise LearnerError(f'state_dict keys do not match the learner\'s network: {sorted(set(sd) ^ mine)}')
         with torch.no_grad():
             for k, v in sd.items():
-                if tuple(v.shape) != tuple(self.views[k].shape):
-                    raise LearnerError(f'{k}: shape {tuple(v.shape)} != {tuple(self.views[k].shape)}')
-                self.views[k].copy_(v.to(self.device, torch.float32))
+                dst = self.views[k] if k in self.views else self.buffer_views[k]
+                if tuple(v.shape) != tuple(dst.shape):
+                    raise LearnerError(f'{k}: shape {tuple(v.shape)} != {tuple(dst.shape)}')
+                dst.copy_(v.to(self.device, dst.dtype))
             for k, p in network.named_parameters():
                 p.data = self.views[k]
+            for k, b in network.named_buffers():
+                if k in self.buffer_views:
+                    b.data = self.buffer_views[k]
+        self.network = network
         self.commit()
 
     def _param_versions(self):
@@ -184,16 +241,25 @@ class HipLearner:
     def load_state_dict(self, sd) -> None:
         with torch.no_grad():
             for k, v in sd.items():
-                self.views[k].copy_(torch.as_tensor(v).to(self.device, torch.float32))
+                dst = self.views[k] if k in self.views else self.buffer_views[k]
+                dst.copy_(torch.as_tensor(v).to(self.device, dst.dtype))
         self.commit()
 
     def state_dict(self):
-        return {k: v.detach().clone() for k, v in self.views.items()}
+        out = {k: v.detach().clone() for k, v in self.views.items()}
+        out.update({k: v.detach().clone() for k, v in self.buffer_views.items()})
+        return out
+
+    def _bump_epoch(self) -> None:
+        # torch's version counters do not see writes through the flat vector's views or by the kernels: the module's inference engine
+        # (network.MuZeroNet._weights_version) rebinds on this epoch (load_state_dict / adopt left it on the old weights)
+        self.network._mz_weights_epoch = getattr(self.network, '_mz_weights_epoch', 0) + 1
 
     def commit(self) -> None:
         """Rebuild the MFMA operand copies from the master weights (after anything other than `apply` wrote them)."""
         _check(load_library().mzl_commit(self._h, self._stream()))
         self._seen_versions = self._param_versions()
+        self._bump_epoch()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -204,8 +270,11 @@ class HipLearner:
         s = self.steps if step is None else step
         return self.lr_init * self.gamma ** sum(1 for m in self.milestones if m <= s)
 
+    def _param_names(self):
+        return [k for k, _ in self.network.named_parameters()]  # torch.optim's parameter indices follow this order
+
     def optimizer_state_dict(self):
-        names = list(self.views)
+        names = self._param_names()
         state = {}
         for i, k in enumerate(names):
             v = self.views[k]
@@ -218,7 +287,7 @@ class HipLearner:
         return dict(state=state, param_groups=[group])
 
     def load_optimizer_state_dict(self, osd) -> None:
-        names = list(self.views)
+        names = self._param_names()
         for i, k in enumerate(names):
             st = osd['state'].get(i)
             if st is None:
@@ -273,6 +342,8 @@ class HipLearner:
                      1 if st.dtype == torch.int8 else 0, ac.element_size())
         _check(load_library().mzl_grad(self._h, C.byref(b), self._stream()))
         self._keep = (ring, index, w)  # alive until the next call (the kernels read them asynchronously)
+        if self.buffer_views:
+            self._bump_epoch()  # (train-mode BatchNorm: the forward pass has updated the running statistics the planner folds into its weights)
         return self.loss, self.priorities[:batch]
 
     def apply(self, clip: Optional[bool] = None) -> None:
@@ -282,7 +353,7 @@ class HipLearner:
         self.steps += 1
         _check(load_library().mzl_apply(self._h, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm if clip else 0.0,
                                         self.steps, self._stream()))
-        self.network._mz_weights_epoch = getattr(self.network, '_mz_weights_epoch', 0) + 1  # (torch's version counters do not see the kernels' writes)
+        self._bump_epoch()
 
     def step(self, ring, index, weights, batch: int, allreduce: bool = True):
         """One update.  With an initialised multi-rank process group the flat gradient is averaged over the ranks in ONE all-reduce

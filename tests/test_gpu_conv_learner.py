@@ -1,0 +1,282 @@
+"""SURVEY 8 f2, the conv half: the learner step of MuZeroBoardGameNet (residual towers, train-mode BatchNorm) as hand-written HIP kernels
+(muzero_amd/csrc/mz_learn_conv.h behind include/mzlearner.h, net_kind MZL_NET_BOARD) against
+(1) the vectors recorded from the REFERENCE's calc_loss / backward / clip / Adam / MultiStepLR on its own MuZeroBoardGameNet
+    (tests/golden/learn_cases.npz `learn_conv_board3`, generator oracle/gen_golden.py learn): loss 1e-4, gradients 2e-3, three updates,
+    BatchNorm running statistics included;
+(2) PyTorch-ROCm autograd (muzero_amd.learner, pinned to the same vectors by tests/test_learner.py) in float64 on the same batch over the
+    geometries that pick different kernel builds (pixel tilings NPT 6 / 9 / 15, images per workgroup, plane counts off the 16-tile, wide
+    action-plane convs, int8 states, int16 actions).
+Tolerance: every gradient tensor within 2e-3 of its largest element (fp32, different summation orders) -- unless the float64 run itself sits
+on a KINK of the loss: a ReLU pre-activation or a min / max gap of normalize_hidden_state within 2e-6 of a tie (`_KinkProbe`).  There a float32
+evaluation may take the other branch, and everything upstream of that element differs by its contribution: PyTorch-ROCm's own float32 autograd
+differs from its float64 run by 1e-2 .. 7e-2 on such batches (tools/dev/conv_learner_check.py prints both next to the HIP step's error; on
+kink-free batches all three agree to 1e-5).  Kinked cases are held to 8e-2 and counted: most of the small geometries below must be kink-free."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_conv, conv_case, load_golden, seeded_state_dict
+from muzero_amd import learner
+from muzero_amd.replay import Transition
+
+pytestmark = pytest.mark.gpu
+G = load_golden('learn_cases.npz')
+
+
+def _hip(net, dev, max_batch, K=5, **kw):
+    from muzero_amd.hip_learner import HipLearner
+
+    kw.setdefault('lr', 1e-3)
+    return HipLearner(net, dev, K, max_batch, **kw)
+
+
+def _ring(tr, dev):
+    B = tr.state.shape[0]
+    return dict(state=torch.from_numpy(tr.state).to(dev).reshape(B, -1).contiguous(), action=torch.from_numpy(tr.action).to(dev),
+                pi_prob=torch.from_numpy(tr.pi_prob).to(dev), value=torch.from_numpy(tr.value).to(dev), reward=torch.from_numpy(tr.reward).to(dev))
+
+
+def test_loss_gradients_and_three_updates_match_the_reference():
+    """The recipe of gen_golden.gen_learn on the reference's MuZeroBoardGameNet (3 x 3 board, 16 planes, 2 blocks): Adam(lr 1e-3),
+    MultiStepLR([2], 0.1), clip_grad_norm_(10) on the second step only, the network in train mode."""
+    pre = 'learn_conv_board3'
+    dev = torch.device('cuda', 0)
+    net = build_conv(conv_case('board3')).to(dev)
+    net.train()
+    hl = _hip(net, dev, 16, lr=1e-3, milestones=[2], gamma=0.1, max_grad_norm=10.0)
+    tr = Transition(*[G[f'{pre}_{f}'] for f in Transition._fields])
+    B = tr.state.shape[0]
+    ring = _ring(tr, dev)
+    w = torch.from_numpy(G[f'{pre}_weights']).to(dev)
+    losses = []
+    for step in range(3):
+        loss, prio = hl.grad(ring, None, w, B)
+        if step == 0:
+            np.testing.assert_allclose(prio.cpu().numpy(), G[f'{pre}_prio'], rtol=1e-3, atol=1e-3)
+            for pn in hl.views:
+                ref = G[f'{pre}_grad_{pn}']
+                np.testing.assert_allclose(hl.grad_views[pn].cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-7, err_msg=pn)
+        hl.apply(clip=(step == 1))
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, G[f'{pre}_losses'], rtol=1e-4)
+    sd = net.state_dict()  # the module's parameters AND BatchNorm buffers are the learner's vectors
+    for pn in sd:
+        ref = G[f'{pre}_final_{pn}']
+        np.testing.assert_allclose(sd[pn].cpu().numpy(), ref, rtol=2e-3, atol=2e-5 + 1e-4 * float(np.abs(ref).max()), err_msg=pn)
+    assert abs(hl.current_lr() - 1e-4) < 1e-12 and hl.steps == 3
+
+
+def _net(board, planes, blocks, chan, seed, dev):
+    from muzero_amd.network import MuZeroBoardGameNet
+
+    A = board * board + 1
+    net = MuZeroBoardGameNet((chan, board, board), A, blocks, planes)
+    net.load_state_dict(seeded_state_dict(net, seed))
+    return net.to(dev), A
+
+
+def _batch(rs, B, shape, A, K=5, int8_state=False):
+    st = rs.randint(0, 2, (B,) + shape).astype(np.int8) if int8_state else rs.uniform(0, 1, (B,) + shape).astype(np.float32)
+    return Transition(st, rs.randint(0, A, (B, K)).astype(np.int16 if A > 128 else np.int8), rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32),
+                      rs.uniform(-1, 1, (B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
+
+
+class _KinkProbe:
+    """While active, records how close the float64 forward pass comes to a kink: the smallest |pre-activation| over every ReLU (nn.ReLU calls
+    F.relu), and the smallest gap between the two largest / two smallest DISTINCT-POSITION channel values of every normalize_hidden_state
+    (a tie at exactly 0 between ReLU zeros is harmless: their gradient is masked either way)."""
+
+    def __init__(self):
+        self.closest = float('inf')
+
+    def __enter__(self):
+        import torch.nn.functional as F
+
+        from muzero_amd import network as nw
+
+        self._F, self._nw, self._relu, self._norm = F, nw, F.relu, nw.normalize_hidden_state
+        probe = self
+
+        def relu(x, inplace=False):
+            nz = x.detach().abs()
+            probe.closest = min(probe.closest, float(nz[nz > 0].min()) if bool((nz > 0).any()) else float('inf'))
+            return probe._relu(x, inplace=False)
+
+        def normalize(h):
+            v = h.detach().flatten(2) if h.dim() > 2 else h.detach()
+            top = v.topk(2, dim=1).values
+            low = (-v).topk(2, dim=1).values
+            probe.closest = min(probe.closest, float((top[:, 0] - top[:, 1]).min()))
+            gap = (low[:, 0] - low[:, 1]).abs()
+            live = (-low[:, 0]) > 0  # the minimum is not a ReLU zero
+            if bool(live.any()):
+                probe.closest = min(probe.closest, float(gap[live].min()))
+            return probe._norm(h)
+
+        F.relu, nw.normalize_hidden_state = relu, normalize
+        return self
+
+    def __exit__(self, *exc):
+        self._F.relu, self._nw.normalize_hidden_state = self._relu, self._norm
+
+
+def _f64_reference(net, tr, w, dev):
+    net_d = copy.deepcopy(net).double()
+    net_d.train()
+    t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x)).to(dev, dt)  # noqa: E731
+    with _KinkProbe() as probe:
+        loss, prio = learner.loss_tensors(net_d, t(tr.state, torch.float64), t(tr.action, torch.int64), t(tr.value, torch.float64), t(tr.reward, torch.float64),
+                                          t(tr.pi_prob, torch.float64), t(w, torch.float64))
+    loss.backward()
+    return float(loss.detach()), prio.detach(), {k: p.grad for k, p in net_d.named_parameters()}, net_d.state_dict(), probe.closest
+
+
+# board, planes, blocks, observation planes, batch, int8 states
+GEOMETRIES = [(3, 16, 2, 9, 4, False), (5, 8, 1, 5, 7, False), (9, 8, 1, 9, 6, False), (9, 32, 3, 9, 64, True), (6, 128, 1, 2, 17, True), (7, 40, 1, 4, 33, False),
+              (11, 8, 2, 9, 9, False), (13, 24, 1, 3, 5, False), (15, 16, 1, 9, 3, False), (15, 32, 2, 9, 10, True), (4, 16, 1, 3, 5, False), (8, 16, 1, 2, 6, False),
+              (10, 8, 1, 2, 4, False), (12, 16, 1, 2, 3, False), (14, 8, 1, 3, 2, False), (15, 8, 1, 2, 2, False)]
+
+
+KINKS = {}
+
+
+@pytest.mark.parametrize('board,planes,blocks,chan,B,int8_state', GEOMETRIES, ids=[f'b{g[0]}-p{g[1]}-r{g[2]}-n{g[4]}' for g in GEOMETRIES])
+def test_gradient_matches_float64_autograd(board, planes, blocks, chan, B, int8_state):
+    dev = torch.device('cuda', 0)
+    net, A = _net(board, planes, blocks, chan, 100 + board, dev)
+    net.train()
+    rs = np.random.RandomState(board * 7 + B)
+    tr = _batch(rs, B, (chan, board, board), A, int8_state=int8_state)
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    hl = _hip(net, dev, B)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    kinked = closest < 2e-6
+    KINKS[(board, planes, blocks, B)] = kinked
+    tol = 8e-2 if kinked else 2e-3
+    for k, g in gd.items():
+        scale = max(1e-8, float(g.abs().max()))
+        err = float((g - hl.grad_views[k].double()).abs().max())
+        assert err <= tol * scale, (k, err, scale, 'closest pre-activation / gap to a tie', closest)
+    sd = net.state_dict()  # the train-mode forward pass has updated the running statistics (network.py:283-291), one step per application
+    for k, v in sd_d.items():
+        if 'running' in k:
+            assert float((v - sd[k].double()).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+        if 'num_batches_tracked' in k:
+            assert int(v) == int(sd[k]), k
+
+
+def test_most_small_geometries_were_kink_free():
+    """The loose tolerance must stay the exception: of the cases above at least eight ran under the 2e-3 bar."""
+    if len(KINKS) < len(GEOMETRIES):
+        pytest.skip('runs after the parametrised cases')
+    assert sum(1 for v in KINKS.values() if not v) >= 8, KINKS
+
+
+def test_six_updates_follow_the_autograd_learner():
+    """Same start, same batches: six updates (clipping, weight decay, an LR milestone inside) of the HIP learner and of learner.train_step
+    (PyTorch-ROCm autograd + torch.optim.Adam, float64) on a small net -- few enough ReLU elements that the batches stay off the kinks;
+    weights and BatchNorm buffers stay together.  (Adam's first steps move every weight by ~lr whatever its gradient's size, so a gradient
+    component at rounding distance from 0 goes the other way in a float32 run: a handful of weights may differ by 2 lr per step -- hence a mean and
+    a max bar.)"""
+    dev = torch.device('cuda', 0)
+    net_b, A = _net(5, 8, 1, 5, 77, dev)
+    net_a = copy.deepcopy(net_b).double()
+    net_a.train()
+    net_b.train()
+    cfg = type('Cfg', (), dict(clip_grad=True, max_grad_norm=5.0))()
+    opt = torch.optim.Adam(net_a.parameters(), lr=2e-3, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[3], gamma=0.1)
+    B = 12
+    hl = _hip(net_b, dev, B, lr=2e-3, weight_decay=1e-4, milestones=[3], gamma=0.1, clip_grad=True, max_grad_norm=5.0)
+    rs = np.random.RandomState(5)
+    t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x)).to(dev, dt)  # noqa: E731
+    for step in range(6):
+        tr = _batch(rs, B, (5, 5, 5), A)
+        w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+        opt.zero_grad()
+        la, pa = learner.loss_tensors(net_a, t(tr.state, torch.float64), t(tr.action, torch.int64), t(tr.value, torch.float64), t(tr.reward, torch.float64),
+                                      t(tr.pi_prob, torch.float64), t(w, torch.float64))
+        la.backward()
+        torch.nn.utils.clip_grad_norm_(net_a.parameters(), cfg.max_grad_norm)
+        opt.step()
+        sch.step()
+        lb, pb = hl.step_transitions(tr, w)
+        assert abs(float(la) - float(lb)) <= 1e-3 * max(1.0, abs(float(la))), (step, float(la), float(lb))
+        np.testing.assert_allclose(pb.cpu().numpy(), pa.detach().cpu().numpy(), rtol=5e-3, atol=5e-3)
+        assert abs(sch.get_last_lr()[0] - hl.current_lr()) < 1e-12
+    for (n, x), (_, y) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        d = (x.double() - y.double()).abs()
+        sc = max(1.0, float(x.double().abs().max()))
+        assert float(d.mean()) < 2e-4 * sc and float(d.max()) < 1.4e-2 * sc, (n, float(d.mean()), float(d.max()))
+
+
+def test_batch_read_from_the_ring_by_index_and_unpaired_launches_agree_bit_for_bit():
+    """(a) rows gathered from the replay ring by an index vector with repeats == the same items stacked; (b) the paired launches (dynamics and
+    prediction tower of a step side by side) == one job per launch (MZLC_NO_PAIR=1): no atomics, fixed reduction orders."""
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(11)
+    cap, B = 50, 21
+    net, A = _net(15, 16, 1, 5, 31, dev)  # A = 226: int16 actions
+    items = _batch(rs, cap, (5, 15, 15), A, int8_state=True)
+    ring = _ring(items, dev)
+    idx = torch.from_numpy(rs.randint(0, cap, B).astype(np.int64)).to(dev)
+    idx[5] = idx[4]
+    w = torch.from_numpy(rs.uniform(0.3, 1.0, B).astype(np.float32)).to(dev)
+    hl = _hip(copy.deepcopy(net), dev, 32)
+    la, pa = hl.grad(ring, idx, w, B)
+    ga, la, pa = hl.grad_flat.clone(), la.clone(), pa.clone()
+    stacked = {k: v[idx].contiguous() for k, v in ring.items()}
+    os.environ['MZLC_NO_PAIR'] = '1'
+    try:
+        hl2 = _hip(copy.deepcopy(net), dev, B)
+    finally:
+        del os.environ['MZLC_NO_PAIR']
+    lb, pb = hl2.grad(stacked, None, w, B)
+    assert torch.equal(la, lb) and torch.equal(pa, pb) and torch.equal(ga, hl2.grad_flat)
+    assert torch.equal(hl.running, hl2.running) and torch.equal(hl.num_batches, hl2.num_batches)
+
+
+def test_checkpoint_round_trip_and_inference_after_load_state_dict():
+    """weights written through the learner (load_state_dict, apply) must reach the module's inference engine; the
+    optimizer / scheduler views keep torch's checkpoint format (pipeline.py:224-230)."""
+    dev = torch.device('cuda', 0)
+    net, A = _net(5, 8, 1, 5, 41, dev)
+    other, _ = _net(5, 8, 1, 5, 42, dev)
+    net.eval()
+    other.eval()
+    hl = _hip(net, dev, 8)
+    x = torch.rand(1, 5, 5, 5, device=dev)
+    before = net.initial_inference(x)
+    hl.load_state_dict(other.state_dict())
+    after, want = net.initial_inference(x), other.initial_inference(x)
+    assert not np.allclose(before.pi_probs, after.pi_probs)
+    np.testing.assert_array_equal(after.pi_probs, want.pi_probs)
+    assert after.value == want.value
+    osd = hl.optimizer.state_dict()
+    assert len(osd['state']) == len(list(net.parameters())) and osd['param_groups'][0]['lr'] == 1e-3
+    for i, p in enumerate(net.parameters()):
+        assert tuple(osd['state'][i]['exp_avg'].shape) == tuple(p.shape)
+    sd = net.state_dict()
+    assert set(sd) == set(other.state_dict()) and all(torch.equal(sd[k], other.state_dict()[k]) for k in sd)
+
+
+def test_errors_are_loud():
+    from muzero_amd.hip_learner import HipLearner, LearnerError
+    from muzero_amd.network import MuZeroBoardGameNet
+
+    dev = torch.device('cuda', 0)
+    with pytest.raises(LearnerError):  # 19 x 19 = 361 points: beyond the kernels' whole-image tiling
+        HipLearner(MuZeroBoardGameNet((3, 19, 19), 362, 1, 8).to(dev), dev, 5, 4, lr=1e-3)
+    net, A = _net(3, 16, 1, 9, 1, dev)
+    hl = HipLearner(net, dev, 5, 4, lr=1e-3)
+    tr = _batch(np.random.RandomState(0), 4, (9, 3, 3), A)
+    with pytest.raises(LearnerError):  # host-resident batch
+        hl.grad({k: v.cpu() for k, v in _ring(tr, dev).items()}, None, None, 4)
+    with pytest.raises(LearnerError):
+        hl.grad(_ring(tr, dev), None, None, 5)  # > max_batch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Learner step of the CONV nets (row f2's PyTorch-ROCm half: the hand-written kernels cover the MLP nets): ms per update of learner.train_step
-(eager autograd + Adam) and of learner.GraphedTrainStep (the same update replayed as one HIP graph) for the board-game net.
-    python tools/conv_learner_bench.py [--board 15 --planes 128 --blocks 8 --batch 128]"""
+"""Learner step of the board-game CONV net: ms per update of the HIP learner (muzero_amd/csrc/mz_learn_conv.h, row f2) with its fraction of the
+fp32 MFMA peak, beside learner.train_step (eager PyTorch-ROCm autograd + Adam: MIOpen) and learner.GraphedTrainStep (the same update as one HIP graph).
+    python tools/conv_learner_bench.py [--board 15 --planes 128 --blocks 8 --batch 128] [--hip-only]"""
 import argparse
 import copy
 import json
@@ -22,6 +22,8 @@ def main():
     ap.add_argument('--blocks', type=int, default=8)
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--hip-only', action='store_true')
+    ap.add_argument('--chan', type=int, default=9)
     args = ap.parse_args()
     from muzero_amd import learner
     from muzero_amd.config import make_gomoku_config
@@ -31,7 +33,7 @@ def main():
     dev = torch.device('cuda', 0)
     cfg = make_gomoku_config(use_tensorboard=False)
     N, B, K = args.board, args.batch, cfg.unroll_steps
-    A, shape = N * N + 1, (9, N, N)
+    A, shape = N * N + 1, (args.chan, N, N)
     torch.manual_seed(0)
     net_a = MuZeroBoardGameNet(shape, A, args.blocks, args.planes).to(dev)
     net_b = copy.deepcopy(net_a)
@@ -51,6 +53,22 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / n
 
+    from muzero_amd.hip_learner import HipLearner, conv_learner_flops
+
+    net_h = copy.deepcopy(net_a)
+    hl = HipLearner(net_h, dev, K, B, lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+    ring = dict(state=tr.state.to(torch.int8).reshape(B, -1).contiguous(), action=tr.action, pi_prob=tr.pi_prob, value=tr.value, reward=tr.reward)
+
+    def hip_step():
+        hl.grad(ring, None, w, B)
+        hl.apply()
+
+    flops = conv_learner_flops(shape, A, args.blocks, args.planes, K) * B
+    ms = timeit(hip_step, args.iters)
+    hip = dict(ms_hip=ms, samples_per_s_hip=B / (ms * 1e-3), flop_per_update=flops, tflops=flops / (ms * 1e-3) / 1e12, mfma_frac=flops / (ms * 1e-3) / 157.3e12)
+    if args.hip_only:
+        print(json.dumps(dict(net=f'MuZeroBoardGameNet {N}x{N}, {args.planes} planes, {args.blocks} blocks, A={A}', batch=B, unroll=K, **hip)))
+        return
     opt_a = torch.optim.Adam(net_a.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
     sch_a = torch.optim.lr_scheduler.MultiStepLR(opt_a, milestones=[10 ** 9], gamma=0.1)
     row = dict(net=f'MuZeroBoardGameNet {N}x{N}, {args.planes} planes, {args.blocks} blocks, A={A}', batch=B, unroll=K,
@@ -60,6 +78,7 @@ def main():
     graphed = learner.GraphedTrainStep(cfg, net_b, opt_b, dev, B, shape, K, A)
     row['ms_graphed'] = timeit(lambda: graphed(tr, w), args.iters)
     row['samples_per_s_graphed'] = B / (row['ms_graphed'] * 1e-3)
+    row.update(hip)
     print(json.dumps(row))
 
 
