@@ -192,14 +192,14 @@ bool alloc_app(mzlc_learner* h, const TowerInfo& t, AppBufs& a) {
 }
 
 size_t conv_lds(const mzlc_learner* h, int cpad_in) { return ((size_t)8 * h->qstride + (size_t)3 * cpad_in) * sizeof(float); }
-size_t wgrad_lds(const mzlc_learner* h) { return ((size_t)64 * (h->SPY + h->SPX) + 160) * sizeof(float); }
+size_t wgrad_lds(const mzlc_learner* h) { return ((size_t)32 * (h->SPY + h->SPX) + 160) * sizeof(float); }
 
 // ---- op builders -------------------------------------------------------------------------------------------------------------
 struct Sched {
     mzlc_learner* h;
     int B, lane;
+    bool lane_pairs;  // this tower's launches are paired with another tower's
     int groups() const { return cdiv(B, h->G); }
-    int pending_groups = 0;  // groups of the partial sums the next BatchNorm-backward finalize reads
 
     LcConv conv_base(const LayerInfo& L, bool dgrad) const {
         LcConv c{};
@@ -253,7 +253,7 @@ struct Sched {
         g.B = B; g.h = h->h; g.w_img = h->w; g.P4 = h->P4; g.nsteps = h->nsteps; g.SPY = h->SPY; g.SPX = h->SPX;
         g.co_blocks = cdiv(g.co_tiles, 2);
         const int ci_blocks = cdiv(g.ci_tiles, 2);
-        int chunks = h->num_cus / (g.co_blocks * ci_blocks);
+        int chunks = (lane_pairs ? 1 : 2) * h->num_cus / (g.co_blocks * ci_blocks);  // two workgroups per CU in all (a paired launch brings the other half)
         chunks = chunks < 1 ? 1 : (chunks > B ? B : chunks);
         g.ipw = cdiv(B, chunks);
         chunks = cdiv(B, g.ipw);
@@ -376,7 +376,8 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (b) pj.b = b->wg;
             int x = cdiv(a->wg.ci_tiles, 2);
             if (b && cdiv(b->wg.ci_tiles, 2) > x) x = cdiv(b->wg.ci_tiles, 2);
-            hipLaunchKernelGGL(k_lc_wgrad, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
+            if (a->wg.action || (b && b->wg.action)) hipLaunchKernelGGL(k_lc_wgrad<true>, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
+            else hipLaunchKernelGGL(k_lc_wgrad<false>, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
             break;
         }
         case OP_WREDUCE: {
@@ -482,7 +483,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
             if (64 / QP < G) G = 64 / QP;
             if (G < 1) continue;
             const double eff = (double)G * h->hw / (16.0 * cand[i]);
-            if (eff >= best) { best = eff; h->npt = cand[i]; h->G = G; }
+            if (eff > best + 1e-9) { best = eff; h->npt = cand[i]; h->G = G; }  // (ties: the smaller tiling -- fewer accumulators per wave)
         }
         if (best < 0.0) return bad("board does not fit the conv kernels' tiling");
         h->qstride = (4 * h->G * (h->h + 2) * (h->w + 2) + 63) & ~63;
@@ -490,7 +491,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         h->nsteps = cdiv(h->h * h->P4, 16);
         h->SPY = 16 * h->nsteps + 4;
         h->SPX = 2 * h->P4 + 16 * h->nsteps + 12;
-        if (wgrad_lds(h) > 160 * 1024 || conv_lds(h, pad16(h->P + h->A)) > 64 * 1024) return bad("board too large for the conv learner's LDS layout");
+        if (wgrad_lds(h) > 160 * 1024 || conv_lds(h, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
     }
     // ---- parameter / buffer tables in state_dict order (network.py:356-498) ----
     add_tower(h, 0, "represent_net", true, h->C0, 0, false);
@@ -538,7 +539,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         size_t mx = 0;
         for (const LayerInfo& L : h->layers) {
             const int cot = L.co_tiles, cit = cdiv(L.cin, 16), blocks = cdiv(cot, 2) * cdiv(cit, 2);
-            int chunks = h->num_cus / blocks;
+            int chunks = 2 * h->num_cus / blocks;
             chunks = chunks < 1 ? 1 : (chunks > h->maxB ? h->maxB : chunks);
             const size_t n = (size_t)chunks * 9 * cot * 16 * cit * 16;
             mx = n > mx ? n : mx;
@@ -564,10 +565,11 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         mzlc_destroy(h);
         return MZL_E_HIP;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (dalloc's fills run on the NULL stream)
     if (e != hipSuccess) {
         err = std::string("conv learner init: ") + hipGetErrorString(e);
@@ -670,10 +672,10 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     bt.w = b->d_weights; bt.prio = b->d_priorities; bt.B = B; bt.state_i8 = b->state_is_int8; bt.action_bytes = b->action_bytes; bt.K = K; bt.A = h->A;
     bt.in_dim = h->C0 * h->hw;
     hipLaunchKernelGGL(k_lc_gather, dim3(cdiv(bt.in_dim, 256) > 8 ? 8 : cdiv(bt.in_dim, 256), B), dim3(256), 0, st, bt, h->obs, h->act);
-    Sched s0{h, B, 0}, s1{h, B, 1};
+    Sched sr{h, B, 0, false}, s0{h, B, 0, paired}, s1{h, B, 1, paired};
     // ---- forward ----
     std::vector<Op> ops, ops2;
-    float* hraw = s0.tower_fwd(ops, h->tower[0], h->app_rep, h->obs, nullptr);
+    float* hraw = sr.tower_fwd(ops, h->tower[0], h->app_rep, h->obs, nullptr);
     for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
     launch_normalize(h, hraw, h->s[0], B, st);
     std::vector<float*> g_raw(K), f_out(K);
@@ -738,7 +740,7 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
         er.scale = 1.0f; er.B = B; er.C = h->P; er.hw = h->hw; er.cpad = pad16(h->P);
         launch_entry(h, er, st);
         ops.clear();
-        s0.tower_bwd(ops, h->tower[0], h->app_rep, h->obs, nullptr, eg, 0, nullptr, nullptr);
+        sr.tower_bwd(ops, h->tower[0], h->app_rep, h->obs, nullptr, eg, 0, nullptr, nullptr);
         for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
     }
     if (hipGetLastError() != hipSuccess) { err = "a conv-learner kernel failed to launch"; return MZL_E_HIP; }

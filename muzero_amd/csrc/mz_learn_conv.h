@@ -321,35 +321,40 @@ struct LcWgrad {
     int co_blocks;         // blockIdx.y = chunk * co_blocks + cob
 };
 
-__global__ __launch_bounds__(256, 1) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
+// ACT: the layer has action-plane input channels (the dynamics net's first conv); the other builds carry none of that code.
+// LDS is single-buffered (67.6 KB at 15 x 15): TWO workgroups share a CU, one's staging (global -> registers is in flight during the MFMAs, but the
+// transform and the LDS writes are VALU / LDS issue) runs under the other's MFMAs.
+template <bool ACT>
+__global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const bool second = (int)blockIdx.y >= PJ.na;
     const LcWgrad L = second ? PJ.b : PJ.a;
     const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm = reinterpret_cast<float*>(smem);
     const int ybuf = 32 * L.SPY, xbuf = 32 * L.SPX;
-    float* s_y = sm;                    // [2][32][SPY]: position f of the padded image at f - P4 (rows 0 .. h - 1 only)
-    float* s_x = sm + 2 * ybuf;         // [2][32][SPX]: position f at f + 4 (4 floats of margin in front)
-    float* s_dc = s_x + 2 * xbuf;       // [3][32] dy coefficients of this block's channels
-    float* s_xc = s_dc + 96;            // [2][32]
+    float* s_y = sm;                // [32][SPY]: position f of the padded image at f - P4 (rows 0 .. h - 1 only)
+    float* s_x = sm + ybuf;         // [32][SPX]: position f at f + 4 (4 floats of margin in front)
+    float* s_dc = s_x + xbuf;       // [3][32] dy coefficients of this block's channels
+    float* s_xc = s_dc + 96;        // [2][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, i16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     const int cib = blockIdx.x, cob = by % L.co_blocks, chunk = by / L.co_blocks;
+    if (cib * 2 >= L.ci_tiles) return;  // (a paired job with fewer input-channel blocks; workgroup-uniform, before any barrier)
     const int hw = L.h * L.w_img, QP = (hw + 3) >> 2;
     const float r_iw = 1.0f / (float)L.w_img;
     const int co0 = cob * 32, ci0 = cib * 32;
-    for (int i = tid; i < (2 * ybuf + 2 * xbuf) / 4; i += 256) reinterpret_cast<float4*>(sm)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (ybuf + xbuf) / 4; i += 256) reinterpret_cast<float4*>(sm)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 96) {
         const int c = co0 + (tid & 31);
-        s_dc[tid] = c < L.cout ? L.dcoef[(tid >> 5) * L.cpad_out + c] : 0.0f;
+        s_dc[tid] = c < L.cout ? L.dcoef[(tid >> 5) * L.cpad_out + c] : 0.0f;  // (channels past cout: dy = 0 * dz + 0 * y + 0)
     }
     if (tid >= 128 && tid < 192) {
         const int t = tid - 128, c = ci0 + (t & 31);
         s_xc[t] = (L.x_mode == IN_BNRELU && c < L.cin_real) ? L.xcoef[(t >> 5) * L.cpad_in + c] : 0.0f;
     }
-    __syncthreads();
     const __amdgpu_buffer_rsrc_t rs_dz = mkrs(L.dz), rs_y = mkrs(L.y), rs_x = mkrs(L.x0);
-    // staging plan: lane = pixel quad (lanes >= QP idle), wave w the channels w, 4 + w, .., 28 + w of each operand
+    // staging plan: lane = pixel quad (lanes >= QP idle), wave w the channels w, 4 + w, .., 28 + w of each operand.  Elements past the image
+    // (the last quad) get their own exec-mask region per element index: 8 lane branches per image instead of one per store
     const bool s_ok = lane < QP;
     const int p0 = (s_ok ? lane : 0) * 4;
     int spos[4], pm[4];
@@ -357,14 +362,14 @@ __global__ __launch_bounds__(256, 1) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
         spos[e] = (s_ok && pp < hw) ? py * L.P4 + px : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
-        pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
+        pm[e] = ACT ? pp % L.num_actions : 0;
     }
     float4 rdz[8], ry[8], rx[8];
     int r_act = -1;
     const int b_lo = chunk * L.ipw, b_hi = (b_lo + L.ipw < L.B) ? b_lo + L.ipw : L.B;
+    const unsigned vo = (unsigned)(p0 * sizeof(float));
     auto fetch = [&](int b) {
         const int bc = b < L.B ? b : L.B - 1;
-        const unsigned vo = (unsigned)(p0 * sizeof(float));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int c = co0 + 4 * k + wave, cc = c < L.cout ? c : 0;
@@ -377,78 +382,112 @@ __global__ __launch_bounds__(256, 1) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
             const int c = ci0 + 4 * k + wave, cc = c < L.cin_real ? c : 0;
             rx[k] = ld4(rs_x, vo, (int)(((size_t)bc * L.cin_real + cc) * hw * sizeof(float)));
         }
-        r_act = L.action ? L.action[bc] : -1;
+        if (ACT) r_act = L.action[bc];
     };
-    auto stage = [&](int buf) {
-        float* dy_ = s_y + buf * ybuf;
-        float* dx_ = s_x + buf * xbuf + L.P4 + 4;
+    auto stage = [&]() {
+        float vy[8][4], vx[8][4];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int cl = 4 * k + wave;
             const float c1 = s_dc[cl], c2 = s_dc[32 + cl], c3 = s_dc[64 + cl];
-            const bool live = co0 + cl < L.cout;
             const float a[4] = {rdz[k].x, rdz[k].y, rdz[k].z, rdz[k].w}, yy[4] = {ry[k].x, ry[k].y, ry[k].z, ry[k].w};
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (spos[e] >= 0) dy_[cl * L.SPY + spos[e]] = live ? fmaf(c1, a[e], fmaf(c2, yy[e], c3)) : 0.0f;
+            for (int e = 0; e < 4; e++) vy[k][e] = fmaf(c1, a[e], fmaf(c2, yy[e], c3));
         }
+        const bool bnrelu = L.x_mode == IN_BNRELU;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int cl = 4 * k + wave, c = ci0 + cl;
-            const float xa = s_xc[cl], xb = s_xc[32 + cl];
             const float x[4] = {rx[k].x, rx[k].y, rx[k].z, rx[k].w};
-            const int t = (c >= L.cin_real && c < L.cin) ? (int)(((long long)(c - L.cin_real) * hw) % L.num_actions) : 0;
+            if (!ACT || c < L.cin_real) {
+                if (c >= L.cin_real) {  // (padding channels of a layer without action planes; wave-uniform)
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float v;
-                if (c < L.cin_real) {
-                    v = x[e];
-                    if (L.x_mode == IN_BNRELU) {
-                        v = fmaf(xa, v, xb);
-                        v = v > 0.0f ? v : 0.0f;
+                    for (int e = 0; e < 4; e++) vx[k][e] = 0.0f;
+                } else if (bnrelu) {
+                    const float xa = s_xc[cl], xb = s_xc[32 + cl];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float t = fmaf(xa, x[e], xb);
+                        vx[k][e] = t > 0.0f ? t : 0.0f;
                     }
                 } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) vx[k][e] = x[e];
+                }
+            } else {  // action planes (network.py:440-444)
+                const int t = c < L.cin ? (int)(((long long)(c - L.cin_real) * hw) % L.num_actions) : 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
                     int m = pm[e] + t;
                     m = m >= L.num_actions ? m - L.num_actions : m;
-                    v = (c < L.cin && m == r_act) ? 1.0f : 0.0f;
+                    vx[k][e] = (c < L.cin && m == r_act) ? 1.0f : 0.0f;
                 }
-                if (spos[e] >= 0) dx_[cl * L.SPX + spos[e]] = v;
+            }
+        }
+        float* dx_ = s_x + L.P4 + 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (spos[e] >= 0) {
+                float* py = s_y + spos[e] + wave * L.SPY;
+                float* px = dx_ + spos[e] + wave * L.SPX;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    py[4 * k * L.SPY] = vy[k][e];
+                    px[4 * k * L.SPX] = vx[k][e];
+                }
             }
         }
     };
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (b_lo < b_hi) {
-        fetch(b_lo);
-        stage(0);
-    }
-    __syncthreads();
-    const int ya = (wm * 16 + i16) * L.SPY + 4 * kq;             // + 16 g: the lane's dy quad
-    const int xa0 = (wn * 16 + i16) * L.SPX + L.P4 + 4 + 4 * kq;  // + 16 g + dy P4: the centre quad of row dy
+    if (b_lo < b_hi) fetch(b_lo);
+    const float* py_ = s_y + (wm * 16 + i16) * L.SPY + 4 * kq;             // + 16 g: the lane's dy quad
+    const float* px_ = s_x + (wn * 16 + i16) * L.SPX + L.P4 + 4 + 4 * kq;   // + 16 g + dy P4: the centre quad of row dy
+    const int P4 = L.P4;
     for (int b = b_lo; b < b_hi; b++) {
-        const int buf = (b - b_lo) & 1;
-        if (b + 1 < b_hi) fetch(b + 1);
-        const float* py_ = s_y + buf * ybuf + ya;
-        const float* px_ = s_x + buf * xbuf + xa0;
-        for (int g = 0; g < L.nsteps; g++) {
-            const float4 a4 = *reinterpret_cast<const float4*>(py_ + 16 * g);
-            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+        __syncthreads();  // the previous image's MFMAs have read the planes (first pass: the zero fill is complete)
+        stage();
+        __syncthreads();
+        if (b + 1 < b_hi) fetch(b + 1);  // in flight during this image's MFMAs
+        // operands of step g + 1 are requested before the MFMAs of step g: two register sets, the loop unrolled by two, scheduling barriers between
+        // "request" and "multiply" (left alone the scheduler sinks the reads to their first use and every step waits for its own LDS round trip)
+        struct OpSet { float4 a4; float4 c4[3]; float lf[3], rg[3]; };
+        auto request = [&](int g, OpSet& o) {
+            const int gc = g < L.nsteps ? g : L.nsteps - 1;
+            o.a4 = *reinterpret_cast<const float4*>(py_ + 16 * gc);
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
-                const float* r = px_ + 16 * g + (dy - 1) * L.P4;
-                const float4 c4 = *reinterpret_cast<const float4*>(r);
-                const float lft = r[-1], rgt = r[4];
-                const float xs[6] = {lft, c4.x, c4.y, c4.z, c4.w, rgt};
+                const float* r = px_ + 16 * gc + (dy - 1) * P4;
+                o.c4[dy] = *reinterpret_cast<const float4*>(r);
+                o.lf[dy] = r[-1];
+                o.rg[dy] = r[4];
+            }
+        };
+        auto multiply = [&](const OpSet& o) {
+            const float a[4] = {o.a4.x, o.a4.y, o.a4.z, o.a4.w};
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const float xs[6] = {o.lf[dy], o.c4[dy].x, o.c4[dy].y, o.c4[dy].z, o.c4[dy].w, o.rg[dy]};
 #pragma unroll
                 for (int dx = 0; dx < 3; dx++) {
 #pragma unroll
                     for (int s = 0; s < 4; s++) acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs[s + dx], acc[dy * 3 + dx], 0, 0, 0);
                 }
             }
+        };
+        OpSet o0, o1;
+        request(0, o0);
+        for (int g = 0; g < L.nsteps; g += 2) {
+            request(g + 1, o1);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            request(g + 2, o0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < L.nsteps) multiply(o1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (b + 1 < b_hi) stage(buf ^ 1);
-        __syncthreads();
     }
     // D[m = co][n = ci]: lane (kq, i16) holds rows 4 kq + r of column i16
     const int cot = cob * 2 + wm, cit = cib * 2 + wn;
