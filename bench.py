@@ -214,7 +214,7 @@ def measure_workload(args, name, rank, local_rank, world, torch, dist, red_dev, 
             'env_steps_per_sec': sims_per_s / S,
             'roofline': {'bound': 'mfma', 'kernel': 'mz::' + DOMINANT[name] + ('...> (the one kernel of a move: search + env step fused)' if name == 'c3'
                                                                                else '...> (dominant kernel; the whole per-move kernel sequence is timed)'),
-                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                         'dispatch': p.describe(), 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'frac_step': flop_per_move / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_unit': 'bytes of HBM per launch of the dominant kernel', 'traffic_source': traffic_src,
                          'avg_move_ms': ms, 'flop_per_move': flop_per_move, 'flop_per_sim': f_sim,
@@ -308,6 +308,7 @@ def lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=100, warm=20,
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    lunar_dispatch = p.describe()
     p.close()
     # transition (64 + 4) x 512 + 512 x 64, reward and value 64 x 512 + 512 x 31 each; root: representation 36 x 512 + 512 x 64 + policy 64 x 512 + 512 x 4
     f_sim = 2 * ((68 * 512 + 512 * 64) + 2 * (64 * 512 + 512 * 31))
@@ -319,7 +320,7 @@ def lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=100, warm=20,
     return {'workload': 'LunarLander-shaped: MLP 512/64/31, obs (4, 9), A=4, 50 sims/move, 4096 envs per MI355X, synthetic observations (Box2D absent)',
             'value': world * B * S * steps / elapsed, 'unit': 'sims/s', 'env_steps_per_sec': world * B * steps / elapsed, 'steps': steps, 'warmup': warm,
             'ms_per_step': ms_step, 'n_gpus': world,
-            'roofline': {'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, false, 4, true, false> (four-action build; env step in its own kernels)',
+            'roofline': {'bound': 'mfma', 'kernel': lunar_dispatch,
                          'achieved': flop / (k_ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flop / (k_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          'frac_step': flop / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'avg_move_ms': k_ms, 'flop_per_move': flop}}
@@ -361,9 +362,67 @@ def learner_leg(rank, local_rank, world, torch, dist, backend, batches=(128, 409
         tf = 6.0 * mac * B / (ms * 1e-3) / 1e12
         rows.append({'batch_per_gpu': B, 'ms_per_update': ms, 'samples_per_sec': world * B / (ms * 1e-3), 'achieved_tflops_per_gpu': tf,
                      'mfma_frac': tf / PEAK_FP32_MFMA_TFLOPS, 'gradient_allreduce': 'RCCL, one flat %.2f MB bucket per update' % (hl.total * 4 / 1e6) if ar else None})
+        if world > 1 and ar:  # after the all-reduced updates every rank must hold bit-identical weights
+            mine = hl.params.clone()
+            ref = mine.clone()
+            dist.broadcast(ref, src=0)
+            same = torch.tensor([1 if torch.equal(mine, ref) else 0], device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            rows[-1]['ranks_hold_identical_weights'] = bool(int(same))
+            assert bool(int(same)), 'data-parallel learner: ranks diverged after all-reduced updates'
         hl.close()
     return {'what': 'hip_learner.HipLearner: loss + backward + Adam + operand re-pack as gfx950 kernels, MuZeroMLPNet 512/64/31, unroll 5', 'rows': rows,
-            'flop_per_sample': 6.0 * mac}
+            'flop_per_sample': 6.0 * mac, 'conv': conv_learner_leg(rank, local_rank, world, torch, dist, backend)}
+
+
+def conv_learner_leg(rank, local_rank, world, torch, dist, backend, batch=128, iters=10):
+    """Row f2, the conv half (round 5): one update of the C5 network -- MuZeroBoardGameNet 15 x 15, 128 planes, 8 residual blocks, 226 actions,
+    unroll 5, the reference's Gomoku batch size 128 (config.py:113-119) -- on the kernels of csrc/mz_learn_conv.h: train-mode BatchNorm towers,
+    heads, losses, backward, Adam, operand re-pack.  Algorithmic FLOPs: hip_learner.conv_learner_flops (forward + weight gradient of every 3 x 3
+    conv + data gradient wherever an input needs one).  With N > 1 ranks the 30.4 MB flat gradient is averaged by one RCCL all-reduce per update."""
+    from muzero_amd.config import make_gomoku_config
+    from muzero_amd.hip_learner import HipLearner, conv_learner_flops
+    from muzero_amd.network import MuZeroBoardGameNet
+
+    dev = torch.device('cuda', local_rank)
+    cfg = make_gomoku_config(use_tensorboard=False)
+    N, K, cap = 15, cfg.unroll_steps, 1024
+    A, shape = N * N + 1, (9, N, N)
+    g = torch.Generator(device='cpu').manual_seed(17 + rank)
+    ring = dict(state=torch.randint(0, 2, (cap, 9 * N * N), generator=g).to(torch.int8).to(dev), action=torch.randint(0, A, (cap, K), generator=g).to(torch.int16).to(dev),
+                pi_prob=torch.full((cap, K, A), 1.0 / A, device=dev), value=(torch.rand(cap, K, generator=g) * 2 - 1).to(dev),
+                reward=(torch.rand(cap, K, generator=g) * 2 - 1).to(dev))
+    torch.manual_seed(0)
+    net = MuZeroBoardGameNet(shape, A, cfg.num_res_blocks, cfg.num_planes).to(dev)
+    hl = HipLearner(net, dev, K, batch, lr=cfg.lr_init, weight_decay=cfg.weight_decay, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    idx = torch.randint(0, cap, (batch,), generator=g).to(dev)
+    ar = world > 1 and backend == 'nccl'
+    for _ in range(3):
+        hl.step(ring, idx, None, batch, allreduce=ar)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        hl.step(ring, idx, None, batch, allreduce=ar)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    flop = conv_learner_flops(shape, A, cfg.num_res_blocks, cfg.num_planes, K)
+    tf = flop * batch / (ms * 1e-3) / 1e12
+    rec = {'what': 'hip_learner.HipLearner on MuZeroBoardGameNet 15x15 / 128 planes / 8 blocks / A=226, unroll 5 (the C5 net): loss + backward + Adam as gfx950 kernels',
+           'batch_per_gpu': batch, 'ms_per_update': ms, 'samples_per_sec': world * batch / (ms * 1e-3), 'flop_per_sample': flop, 'achieved_tflops_per_gpu': tf,
+           'mfma_frac': tf / PEAK_FP32_MFMA_TFLOPS, 'parameters': int(hl.total),
+           'gradient_allreduce': 'RCCL, one flat %.1f MB bucket per update' % (hl.total * 4 / 1e6) if ar else None,
+           'pytorch_rocm_same_update_ms': {'eager_miopen': 73.6, 'hip_graph_miopen': 71.9, 'source': 'tools/conv_learner_bench.py, round 4 (DESIGN 4b)'}}
+    if world > 1 and ar:
+        mine = hl.params.clone()
+        ref = mine.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1 if torch.equal(mine, ref) else 0], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        rec['ranks_hold_identical_weights'] = bool(int(same))
+    hl.close()
+    return rec
 
 
 def train_leg(rank, local_rank, world, torch, dist, seconds=2.0, batch=4096, moves=8):
@@ -390,17 +449,21 @@ def train_leg(rank, local_rank, world, torch, dist, seconds=2.0, batch=4096, mov
     net.eval()
     p.load_state_dict(net.state_dict())
     rp = PrioritizedReplay(1 << 20, 0.0, 0.0, np.random.RandomState(11 + rank), device='cuda')
-    p.attach_replay(rp, types.SimpleNamespace(is_board_game=False, acc_seq_length=200, unroll_steps=5, td_steps=10, discount=0.997), obs_shape=(4, 5))
+    # make_classic_config's own flush rule (acc_seq_length 9999: items at episode ends only, config.py:198)
+    p.attach_replay(rp, types.SimpleNamespace(is_board_game=False, acc_seq_length=cfg.acc_seq_length, unroll_steps=cfg.unroll_steps, td_steps=cfg.td_steps,
+                                              discount=cfg.discount), obs_shape=(4, 5))
     p.selfplay_reset(pl.ENV_CARTPOLE)
-    p.selfplay_step(1.0, 240)  # past the first mid-episode flush: the replay is filling
+    p.selfplay_step(1.0, 240)  # past the first episode ends: the replay is filling
     p.synchronize()
+
+    sampler = rp.device_sampler(seed=23 + rank)  # draws on the device from the committed counter the epilogue publishes: no host read per update
 
     def iteration():
         p.selfplay_step(1.0, moves)
         p.synchronize()
         for _ in range(moves):
-            idx, _, ring = rp.sample_indices(batch)
-            hl.step(ring, torch.from_numpy(idx).to(dev), None, batch, allreduce=False)
+            idx, _, ring = sampler.sample(batch)
+            hl.step(ring, idx, None, batch, allreduce=False)
 
     for _ in range(3):
         iteration()
@@ -418,7 +481,9 @@ def train_leg(rank, local_rank, world, torch, dist, seconds=2.0, batch=4096, mov
     hl.close()
     return {'what': 'C2 planner (4096 envs, 50 sims, device epilogue -> HBM replay) and the HIP learner (batch %d gathered from the replay) taking turns on one GPU, event order' % batch,
             'seconds': dt, 'iterations': it, 'env_steps_per_sec': it * moves * B / dt, 'sims_per_sec': it * moves * B * 50 / dt, 'updates_per_sec': it * moves / dt,
-            'samples_per_sec': it * moves * batch / dt, 'samples_per_env_step': batch / B, 'last_loss': loss, 'replay_items': int(rp.size)}
+            'samples_per_sec': it * moves * batch / dt, 'samples_per_env_step': batch / B, 'last_loss': loss, 'replay_items': int(rp.size),
+            'sampling': 'replay.DeviceSampler (Philox indices drawn on the GPU from the device-owned counter; no host synchronisation per update)',
+            'replay_flush': 'make_classic_config: acc_seq_length 9999 (items at episode ends)'}
 
 
 def allreduce_leg(rank, local_rank, world, torch, dist, backend, nbytes=30_400_000, iters=10):
@@ -525,7 +590,7 @@ def sustained_leg(p, T, ms_per_move_hint, flop_per_launch, seconds=2.0):
             'frac': ach / PEAK_FP32_MFMA_TFLOPS}
 
 
-def e2e_leg(p, pl, env_kind, T, obs_shape, classic_cfg, moves=300):
+def e2e_leg(p, pl, env_kind, T, obs_shape, classic_cfg, moves=300, warm_moves=None):
     """Env steps that END UP IN THE REPLAY as (Transition, priority) items: the planner with the device epilogue attached
     (n-step / MC targets, priorities, K-step unroll windows written into an HBM replay ring on the GPU, pipeline.py:118-165 +
     replay.py:67-75), this GPU only.  Warm-up runs past the first mid-episode flush (acc_seq_length + unroll + td moves)."""
@@ -536,6 +601,8 @@ def e2e_leg(p, pl, env_kind, T, obs_shape, classic_cfg, moves=300):
     p.attach_replay(rp, classic_cfg, obs_shape=obs_shape)
     p.selfplay_reset(env_kind)
     warm = 0 if classic_cfg.is_board_game else classic_cfg.acc_seq_length + classic_cfg.unroll_steps + classic_cfg.td_steps + 5
+    if warm_moves is not None:
+        warm = warm_moves
     p.selfplay_step(T, max(warm, 20))
     p.synchronize()
     n0 = rp.num_added
@@ -651,16 +718,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     counters = p.selfplay_counters()
+    dispatch = p.describe()  # the instantiation the timed launches ran, as the library reports it (mz_planner_describe)
     flop_per_launch = B * (S * FLOP_PER_SIM + FLOP_PER_ROOT)
     sustained = None if args.no_sustained else sustained_leg(p, 1.0, 1e3 * elapsed / args.steps, flop_per_launch)
     e2e = None
     if not args.no_e2e:
         import types
 
-        # the reference's classic-control settings (config.py:170-201): acc_seq_length 200, unroll 5, td_steps 10
+        # the reference's classic-control settings (make_classic_config, config.py:170-201): acc_seq_length 9999 -- items leave an env only at
+        # its episode ends (pipeline.py:118-165) --, unroll 5, td_steps 10; warm-up past the first episode ends
         e2e = e2e_leg(p, pl, pl.ENV_CARTPOLE, 1.0, (4, 5),
-                      types.SimpleNamespace(is_board_game=False, acc_seq_length=200, unroll_steps=5, td_steps=10, discount=0.997))
+                      types.SimpleNamespace(is_board_game=False, acc_seq_length=9999, unroll_steps=5, td_steps=10, discount=0.997), warm_moves=120)
+        e2e['settings'] = 'make_classic_config: acc_seq_length 9999 (flush at episode ends only), unroll 5, td_steps 10'
         e2e['fraction_of_planner_rate'] = e2e['env_steps_per_sec'] / (B * args.steps / elapsed)
+        # the Atari-style mid-episode flush (make_atari_config's acc_seq_length 200, config.py:203-232) on the same planner: round 4's `e2e` figure
+        fl = e2e_leg(p, pl, pl.ENV_CARTPOLE, 1.0, (4, 5),
+                     types.SimpleNamespace(is_board_game=False, acc_seq_length=200, unroll_steps=5, td_steps=10, discount=0.997))
+        fl['settings'] = 'Atari-style flush: acc_seq_length 200 (make_atari_config), unroll 5, td_steps 10'
+        fl['fraction_of_planner_rate'] = fl['env_steps_per_sec'] / (B * args.steps / elapsed)
+        e2e['atari_style_flush'] = fl
     p.close()
     del p
     torch.cuda.empty_cache()
@@ -710,7 +786,7 @@ def main():
             'env_steps_per_sec': sims_per_s / S,
             'episodes_finished_rank0': counters['episodes'],
             'roofline': {
-                'bound': 'mfma', 'kernel': 'mz::k_search_fast<512, 2, 2, true, 2, true, false> (P, TR, TV, FUSE, AC, HW, SPB: the one kernel of a move -- search + env step, 8 waves)', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'bound': 'mfma', 'kernel': dispatch, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 # the same FLOPs over the driver-timed step (env kernels and launch gaps included), not only the search kernel
                 'frac_step': flop_per_launch / (1e-3 * 1e3 * elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -728,8 +804,8 @@ def main():
             'per_rank': {'sims_per_sec_by_kernel_time': per_rank, 'min': min(per_rank), 'max': max(per_rank), 'sum': sum(per_rank)},
             'distributed': dist_record(dist, world, backend),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(S, sample_envs=B)
+        if not args.no_cpu_baseline:  # rank 0's host cores; under N > 1 a short sample (the other ranks wait at the final barrier)
+            out['cpu_baseline'] = cpu_baseline(S, sample_envs=B, budget_s=20.0 if world == 1 else 3.0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -69,6 +69,15 @@ typedef struct mz_learner mz_learner;
 
 const char* mzl_last_error(void);
 
+/* DIAGNOSTIC ENVIRONMENT SWITCHES (none needed in production; every alternative computes the same update -- the tests prove it -- and all are
+ * read once, at mzl_create, except MZL_NO_HEADS3 which is read once per process):
+ *   MLP nets:  MZL_GENERIC=1 (shape-generic <F = false> kernels), MZL_NO_SLICE=1 (no plane-sliced stages at small batches),
+ *              MZL_NO_HEADS3=1 (heads' launch two instead of three workgroups per CU), MZL_FAST_MAX_TILES / MZL_CHAIN_FAST_MAX_TILES /
+ *              MZL_CHAIN_MIN_TILES / MZL_CHAIN_MAX_TILES=n (batch thresholds between the register-resident, streaming and persistent-chain
+ *              builds), MZL_STAMPS=1 (allocate the cycle-stamp buffer read by tools/dev/learn_stamps.py)
+ *   conv nets: MZLC_NO_PAIR=1 (one tower job per launch instead of the dynamics / prediction towers of a step paired), MZLC_NO_SIDE=1 (the
+ *              generic conv build instead of the 15 x 15 one) */
+
 int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out);
 int mzl_destroy(mz_learner* h);
 
@@ -102,6 +111,30 @@ int mzl_grad(mz_learner* h, const mzl_batch* batch, void* stream);
  * learning rate `lr` as MultiStepLR gives it for this step (:250), and the refresh of the operand copies. */
 int mzl_apply(mz_learner* h, double lr, double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, int64_t step,
               void* stream);
+
+/* ---- Replay sampling and priority updates on the device (replay.py:81-113) ----------------------------------------------------
+ * For a replay ring whose bookkeeping lives in HBM (muzero_amd.replay.PrioritizedReplay with a device writer attached: the planner's epilogue
+ * publishes the committed item count and the priorities on the GPU): the learner draws its batch and writes the new priorities back without a
+ * host read of either.  Uniform (priority_exponent == 0: every launcher's default, replay.py:87-89): index = floor(u * size), weights 1.
+ * Proportional (replay.py:90-98): inverse-CDF picks on float64 prefix sums of priority ^ alpha, importance weights ((1 / size) / p) ^ beta divided by
+ * their batch maximum.  Uniforms: Philox4x32-10 keyed by (seed; draw, sample) -- pass a new `draw` number per batch. */
+typedef struct {
+    const float* d_priority;      /* [capacity]; may be NULL for uniform draws */
+    const int64_t* d_num_added;   /* [1] committed item count (replay.py:115-118); size = min(count, capacity) */
+    int64_t capacity;
+    double priority_exponent;             /* alpha */
+    double importance_sampling_exponent;  /* beta */
+    uint64_t seed, draw;
+    int32_t batch;
+    int64_t* d_index;             /* out [batch] */
+    float* d_weights;             /* out [batch]; may be NULL for uniform draws */
+    double* d_scratch;            /* [mzl_replay_scratch_doubles(capacity)], proportional draws only */
+} mzl_replay_draw;
+int64_t mzl_replay_scratch_doubles(int64_t capacity);
+int mzl_replay_sample(const mzl_replay_draw* draw, void* stream);
+/* priority[d_index[b]] = d_new[b] (replay.py:106-113; of a repeated index the last b wins).  d_owner: int32 [capacity] scratch. */
+int mzl_replay_update_priorities(float* d_priority, int64_t capacity, const int64_t* d_index, const float* d_new, int32_t batch, int32_t* d_owner,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

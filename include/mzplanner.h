@@ -77,6 +77,31 @@ typedef struct mz_planner mz_planner;
 const char* mz_last_error(void);
 const char* mz_version(void);
 
+/* Which kernel build this handle's LAST search launch dispatched to (e.g. "k_search_fast<planes=512, TR=2, TV=2, FUSE=true, AC=2, ...>",
+ * or the conv-tower / HBM-tree sequence), followed by every diagnostic switch below as this handle read it.  The string lives until
+ * the calling thread's next mz_planner_describe.  A bench line prints the instantiation it ran, not a hard-coded name.
+ *
+ * DIAGNOSTIC ENVIRONMENT SWITCHES.  None is needed in production; each selects an alternative, bit-identical path for A/B measurements and
+ * for the tests that prove the paths agree.  They are read ONCE -- the first group when a handle is created (mz_planner_create), the second
+ * once per process at the first planner that needs it -- never between two calls on a handle, so a C-ABI caller cannot be handed a
+ * different kernel from one call to the next.
+ *   per handle, at mz_planner_create:
+ *     MZ_FORCE_GENERIC=1    the shape-generic k_search instead of the tuned k_search_fast builds
+ *     MZ_FUSE_ENV=0|1       device self-play as three launches per move (0) or one (1, default for LDS-resident MLP searches)
+ *     MZ_GTREE_WAVE=0|1     HBM trees: select with 16 lanes per env (0) or one wave per env (1, default up to 256 actions)
+ *     MZ_HWX=0..3           work split of k_search_fast's helper waves (default by head kinds)
+ *     MZ_TREE_OLD=1         evaluate every level of every descent (no selection cache; the anchor of the tree parity tests)
+ *     MZ_HBM_TREE=1         MLP nets: trees in HBM around batched k_infer launches even where they fit LDS
+ *     MZ_NO_FAST_LAYOUT=1   never give k_search_fast its own LDS carve-out (the LunarLander-shaped search then runs the generic kernel)
+ *     MZ_FAST_AC4=0         the general-action-count build instead of the four-action one
+ *   per process, at first use (conv nets):
+ *     MZ_ACTION_SPARSE=0    evaluate the dynamics net's action planes densely
+ *     MZ_ACTION_FUSE=0      add the sparse action terms in their own kernel instead of the first conv's epilogue
+ *     MZ_CONV_SPEC=0        no shape-specialised conv / tower builds
+ *     MZ_TOWER=0            one launch per conv instead of the persistent residual tower
+ *     MZ_CONV_TILE=th*100+tw, MZ_CONV_G=n, MZ_CONV_NCT=n   force the tiled conv kernel's output tile / images per workgroup / channel tiles per wave */
+const char* mz_planner_describe(mz_planner* p);
+
 /* Lifetime.  Replaces: network construction + .to(device) in the launchers (classic/run_training.py:83-99) and the
  * per-search allocations of Node objects (mcts.py:75-102). */
 int mz_planner_create(const mz_config* cfg, int device_id, mz_planner** out);

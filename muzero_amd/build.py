@@ -18,8 +18,8 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmzplanner_hip.so')
 SOURCES = ['planner.hip']
 LEARNER_LIB_PATH = os.path.join(LIB_DIR, 'libmzlearner_hip.so')
-LEARNER_SOURCES = ['learner.hip', 'learner_conv.hip']
-LEARNER_FILES = ('learner.hip', 'learner_conv.hip', 'mz_learn.h', 'mz_learn_conv.h', 'mz_learn_conv_host.h', 'mzlearner.h')  # what only the learner library is compiled from (besides mz_device.h)
+LEARNER_SOURCES = ['learner.hip', 'learner_conv.hip', 'learner_replay.hip']
+LEARNER_FILES = ('learner.hip', 'learner_conv.hip', 'learner_replay.hip', 'mz_learn.h', 'mz_learn_conv.h', 'mz_learn_conv_host.h', 'mzlearner.h')  # what only the learner library is compiled from (besides mz_device.h)
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs where they fit.  The search kernels read every accumulator
 # with VALU code right after the layer (ReLU, normalisation, partial sums); in the default AGPR form each of those reads is a
 # v_accvgpr_read first (96 per simulation in k_search_fast: +2 % on C2, measured), and no kernel of this library needs the
@@ -38,7 +38,7 @@ def _deps():
 
 
 def _learner_deps():
-    return [os.path.join(CSRC, 'learner.hip'), os.path.join(CSRC, 'learner_conv.hip'), os.path.join(CSRC, 'mz_learn.h'), os.path.join(CSRC, 'mz_learn_conv.h'),
+    return [os.path.join(CSRC, 'learner.hip'), os.path.join(CSRC, 'learner_conv.hip'), os.path.join(CSRC, 'learner_replay.hip'), os.path.join(CSRC, 'mz_learn.h'), os.path.join(CSRC, 'mz_learn_conv.h'),
             os.path.join(CSRC, 'mz_learn_conv_host.h'), os.path.join(CSRC, 'mz_device.h'),
             os.path.join(HERE, '..', 'include', 'mzlearner.h'), os.path.abspath(__file__)]
 

@@ -20,6 +20,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+void mzl_internal_set_error(const std::string& msg) { g_err = msg; }  // (learner_replay.hip)
 #define HIPCHK(expr)                                                                                                                     \
     do {                                                                                                                                 \
         hipError_t _e = (expr);                                                                                                          \

@@ -68,6 +68,7 @@ struct mzlc_learner {
     int device = 0, num_cus = 256;
     int P = 0, C0 = 0, A = 0, R = 0, K = 0, h = 0, w = 0, hw = 0, maxB = 0;
     int npt = 15, G = 1, qstride = 0;
+    bool side15 = false;  // the 15 x 15 build of the conv kernel (geometry as compile-time constants); MZLC_NO_SIDE=1 at create: the generic build
     int P4 = 0, nsteps = 0, SPY = 0, SPX = 0;
     std::vector<LayerInfo> layers;
     TowerInfo tower[3];  // 0 representation, 1 dynamics, 2 prediction
@@ -346,14 +347,27 @@ struct Sched {
     }
 };
 
-template <int NPT>
-void launch_conv(const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL(k_lc_conv<NPT>, grid, dim3(256), lds, st, pj);
+template <int NPT, int SIDE>
+void launch_conv(int mode, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
+    if (mode == IN_IDENT) hipLaunchKernelGGL((k_lc_conv<NPT, IN_IDENT, SIDE>), grid, dim3(256), lds, st, pj);
+    else if (mode == IN_BNRELU) hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNRELU, SIDE>), grid, dim3(256), lds, st, pj);
+    else hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNBWD, SIDE>), grid, dim3(256), lds, st, pj);
+}
+template <int NPT, int SIDE>
+hipError_t conv_attr() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_IDENT, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_BNRELU, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_BNBWD, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
 }
 
 int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
     switch (a->kind) {
         case OP_CONV: {
+            if (b && b->conv.in_mode != a->conv.in_mode) {  // (never the case for the zipped towers; kept correct anyway)
+                launch_ops(h, a, nullptr, st);
+                return launch_ops(h, b, nullptr, st);
+            }
             Pair<LcConv> pj{};
             pj.a = a->conv;
             const int ga = cdiv(a->conv.B, a->conv.G), gb = b ? cdiv(b->conv.B, b->conv.G) : 0;
@@ -363,9 +377,11 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (b) { z = cdiv(b->conv.co_tiles, 4) > z ? cdiv(b->conv.co_tiles, 4) : z; cp = b->conv.cpad_in > cp ? b->conv.cpad_in : cp; }
             const dim3 grid(1, ga + gb, z);
             const size_t lds = conv_lds(h, cp);
-            if (h->npt == 15) launch_conv<15>(pj, grid, lds, st);
-            else if (h->npt == 9) launch_conv<9>(pj, grid, lds, st);
-            else launch_conv<6>(pj, grid, lds, st);
+            const int mode = a->conv.in_mode;
+            if (h->npt == 15 && h->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
+            else if (h->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
+            else if (h->npt == 9) launch_conv<9, 0>(mode, pj, grid, lds, st);
+            else launch_conv<6, 0>(mode, pj, grid, lds, st);
             break;
         }
         case OP_WGRAD: {
@@ -487,6 +503,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         }
         if (best < 0.0) return bad("board does not fit the conv kernels' tiling");
         h->qstride = (4 * h->G * (h->h + 2) * (h->w + 2) + 63) & ~63;
+        h->side15 = h->h == 15 && h->w == 15 && h->G == 1 && h->npt == 15 && !getenv("MZLC_NO_SIDE");
         h->P4 = 4 * cdiv(h->w + 1, 4);
         h->nsteps = cdiv(h->h * h->P4, 16);
         h->SPY = 16 * h->nsteps + 4;
@@ -567,9 +584,10 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = conv_attr<15, 15>();
+    if (e == hipSuccess) e = conv_attr<15, 0>();
+    if (e == hipSuccess) e = conv_attr<9, 0>();
+    if (e == hipSuccess) e = conv_attr<6, 0>();
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (dalloc's fills run on the NULL stream)
     if (e != hipSuccess) {
         err = std::string("conv learner init: ") + hipGetErrorString(e);

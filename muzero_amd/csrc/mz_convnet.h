@@ -66,6 +66,22 @@ inline int env_int_early(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && v[0] ? atoi(v) : dflt;
 }
+// Diagnostic switches of the conv path (A/B measurements, tests; documented in include/mzplanner.h).  Read ONCE per process, at the first
+// planner that needs them: a C-ABI caller gets one dispatch per process, never a different kernel from one call to the next.
+struct ConvSwitches {
+    int action_sparse;  // MZ_ACTION_SPARSE (1): the dynamics net's action planes as <= 9 folded weights per output (k_action_sparse / SP epilogue)
+    int action_fuse;    // MZ_ACTION_FUSE (1): those terms in the first conv's epilogue instead of their own kernel
+    int conv_spec;      // MZ_CONV_SPEC (1): the shape-specialised builds of k_conv3x3 / k_res_tower
+    int tower;          // MZ_TOWER (1): a residual tower as one persistent kernel where the hidden state is small
+    int conv_tile;      // MZ_CONV_TILE (0 = automatic): th * 100 + tw output tile of the tiled conv kernel
+    int conv_g;         // MZ_CONV_G (-1 = automatic): images per workgroup
+    int conv_nct;       // MZ_CONV_NCT (-1 = automatic): channel tiles per wave
+};
+inline const ConvSwitches& conv_switches() {
+    static const ConvSwitches s = {env_int_early("MZ_ACTION_SPARSE", 1), env_int_early("MZ_ACTION_FUSE", 1), env_int_early("MZ_CONV_SPEC", 1),
+                                   env_int_early("MZ_TOWER", 1), env_int_early("MZ_CONV_TILE", 0), env_int_early("MZ_CONV_G", -1), env_int_early("MZ_CONV_NCT", -1)};
+    return s;
+}
 
 inline hipError_t dev_upload(ConvNetDev& n, const std::vector<float>& h, float** d) {
     hipError_t e = hipMalloc(d, h.size() * sizeof(float));
@@ -222,7 +238,7 @@ inline int convnet_build(ConvNetDev& n, const ParamMap& pm, std::string* err) {
     {
         auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
         n.dyn_inv_hw = 0;
-        if ((P & 15) == 0 && gcd(hw, n.A) == 1 && env_int_early("MZ_ACTION_SPARSE", 1)) {
+        if ((P & 15) == 0 && gcd(hw, n.A) == 1 && conv_switches().action_sparse) {
             if ((rc = build_conv(n, pm, "dynamics_net.conv_block.0.weight", "dynamics_net.conv_block.1", P + n.A, P, P, 3, 1, &n.dyn_real, err, P,
                                  &n.dyn_act_w, &n.dyn_sp_w)))
                 return rc;
@@ -312,10 +328,6 @@ struct ConvGeom {
     bool whole;  // tile == whole image, stride 1: quad-based staging (k_conv3x3<.., true>)
 };
 
-inline int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && v[0] ? atoi(v) : dflt;
-}
 
 inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool allow_group = true) {
     static const int kNpt[9] = {1, 2, 3, 4, 5, 6, 9, 12, 15};
@@ -332,7 +344,7 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
     // barrier; C4 +0.6 %).  MZ_CONV_TILE = th * 100 + tw overrides (diagnostics).
     int tth = 8, ttw = 8;
     if (!whole && stride == 1) {
-        const int forced = env_int("MZ_CONV_TILE", 0);
+        const int forced = conv_switches().conv_tile;
         const int cand[3][2] = {{forced / 100, forced % 100}, {12, 16}, {12, 12}};
         for (int i = forced ? 0 : 1; i < 3; i++) {
             const int wh = cand[i][0], ww = cand[i][1];
@@ -357,13 +369,13 @@ inline ConvGeom conv_geometry(int B, int oh, int ow, int stride, int cout, bool 
             if (fill > best + 1e-9) { best = fill; g.G = G; }
         }
     }
-    g.G = env_int("MZ_CONV_G", g.G);
+    if (conv_switches().conv_g >= 0) g.G = conv_switches().conv_g;
     g.whole = whole;
     g.npt = round_npt((g.G * TP + 15) / 16);
     const long tiles = (long)((oh + g.th - 1) / g.th) * ((ow + g.tw - 1) / g.tw);
     const long wgs1 = tiles * ((B + g.G - 1) / g.G) * zs1;
     g.nct = (cout > 64 && wgs1 >= 1024) ? 2 : 1;  // two channel tiles per wave halve the staging work when there are workgroups to spare
-    g.nct = env_int("MZ_CONV_NCT", g.nct);
+    if (conv_switches().conv_nct >= 0) g.nct = conv_switches().conv_nct;
     g.qstride = (g.G * plane * 4 + 63) & ~63;
     g.cstride = 4 * g.qstride;
     return g;
@@ -421,7 +433,7 @@ inline bool conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
     size_t lds = (size_t)2 * g.cstride * sizeof(float);
     const dim3 grid(L.tiles_x * L.tiles_y, (B + g.G - 1) / g.G, (Lr.cout + 64 * g.nct - 1) / (64 * g.nct));
     // SP: whole-image builds with one 64-channel slice per workgroup, stride 1; the term rows of the workgroup's images live behind the slabs
-    static const bool sp_on = env_int("MZ_ACTION_FUSE", 1) != 0;
+    const bool sp_on = conv_switches().action_fuse != 0;
     const bool fuse = sp && sp_on && g.whole && g.nct == 1 && L.stride == 1 && L.oh == L.ih && L.ow == L.iw &&
                       lds + (size_t)g.G * ih * iw * 48 <= 64 * 1024;
     if (fuse) {
@@ -431,7 +443,7 @@ inline bool conv_run(hipStream_t st, const ConvLayerDev& Lr, int B, const float*
         L.relu = 0;  // k_action_sparse reads the pre-activation and applies the ReLU after its additions
     }
     // shape-specialised builds (mz_conv.h, SIDE): a whole 15x15 image per workgroup, 128 output channels (Gomoku's towers)
-    static const bool spec_ok = env_int("MZ_CONV_SPEC", 1) != 0;
+    const bool spec_ok = conv_switches().conv_spec != 0;
     if (spec_ok && g.whole && g.nct == 1 && g.npt == 15 && g.G == 1 && L.stride == 1 && L.ih == 15 && L.iw == 15 && L.oh == 15 && L.ow == 15 &&
         Lr.cout == 128 && L.tiles_x == 1 && L.tiles_y == 1 && g.qstride == (((15 + 2) * (15 + 2) * 4 + 63) & ~63) && g.cstride == 4 * g.qstride) {
         if (fuse) hipLaunchKernelGGL((k_conv3x3<15, 1, true, 15, true>), grid, dim3(256), lds, st, L);
@@ -463,7 +475,7 @@ struct TowerGeom {
 
 inline TowerGeom tower_geometry(int B, int P, int h, int w) {
     TowerGeom best{0, 0, 0, 0};
-    if (P > 128 || (P & 15) || env_int("MZ_TOWER", 1) == 0) return best;
+    if (P > 128 || (P & 15) || conv_switches().tower == 0) return best;
     const int hw = h * w, n_cb = P / 16;
     double best_score = -1.0;
     for (int G = 1; G <= 16 && G <= B; G++) {
@@ -508,7 +520,7 @@ inline float* tower_run(hipStream_t st, const std::vector<ResBlockDev>& blocks, 
                 case 3: tower_launch_npt<3>(st, L, wgs, g.lds); break;
                 case 4: tower_launch_npt<4>(st, L, wgs, g.lds); break;
                 case 5:
-                    if (env_int("MZ_CONV_SPEC", 1) != 0 && Pc == 128 && h == 6 && w == 6 && g.G == 2) {  // (mz_tower.h, SPEC == 1)
+                    if (conv_switches().conv_spec != 0 && Pc == 128 && h == 6 && w == 6 && g.G == 2) {  // (mz_tower.h, SPEC == 1)
                         static bool attr1 = false;
                         if (!attr1) {
                             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res_tower<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -80,10 +80,16 @@ struct LcConv {
     int qstride;           // LDS floats per slot plane (>= 4 * G * (h + 2) * (w + 2), multiple of 64)
 };
 
-template <int NPT>
+// MODE: the staging transform (IN_*) as a compile-time fact; SIDE > 0: a SIDE x SIDE board, one image per workgroup, as compile-time constants
+// (the launcher checks them) -- index arithmetic, tap offsets and predicates become immediates.
+template <int NPT, int MODE, int SIDE>
 __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const bool second = (int)blockIdx.y >= PJ.na;
-    const LcConv L = second ? PJ.b : PJ.a;
+    LcConv L = second ? PJ.b : PJ.a;
+    if constexpr (SIDE > 0) {
+        L.h = SIDE; L.w_img = SIDE; L.G = 1; L.qstride = (4 * (SIDE + 2) * (SIDE + 2) + 63) & ~63;
+    }
+    L.in_mode = MODE;
     const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* slab = reinterpret_cast<float*>(smem);

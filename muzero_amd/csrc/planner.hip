@@ -76,6 +76,9 @@ struct mz_planner {
     bool fuse_env = false;       // device self-play as one kernel per move instead of three (MZ_FUSE_ENV=0/1 overrides the default)
     int hwx = -1;  // k_search_fast helper-wave work split (MZ_HWX=0..3 overrides the default: A/B measurements)
     bool gtree_wave = true;   // HBM trees: select with one wave per env
+    bool no_fast_layout = false;  // MZ_NO_FAST_LAYOUT=1: never give k_search_fast its own LDS carve-out (diagnostic)
+    bool fast_ac4 = true;         // MZ_FAST_AC4=0: the general build instead of the four-action one (diagnostic)
+    std::string last_dispatch = "none yet";  // what the last search launch ran (mz_planner_describe)
     float* d_stream[1] = {};
     float* d_bias_all = nullptr;
     double *d_dbg_noise = nullptr, *d_dbg_utie = nullptr, *d_dbg_ufinal = nullptr;  // mz_debug_capture_rng
@@ -139,6 +142,21 @@ static int pad16(int x) { return (x + 15) & ~15; }
 
 extern "C" const char* mz_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mz_version(void) { return "mzplanner 0.1 (gfx950)"; }
+
+// Which kernel build this handle's last search launch dispatched to, and every diagnostic switch as this handle read it (mzplanner.h)
+static thread_local std::string g_describe;
+extern "C" const char* mz_planner_describe(mz_planner* p) {
+    if (!p) return "null planner";
+    char b[512];
+    const ConvSwitches& cs = conv_switches();
+    snprintf(b, sizeof b,
+             "; switches: MZ_FORCE_GENERIC=%d MZ_FUSE_ENV=%d MZ_GTREE_WAVE=%d MZ_HWX=%d MZ_TREE_OLD=%d MZ_HBM_TREE=%d MZ_NO_FAST_LAYOUT=%d MZ_FAST_AC4=%d"
+             " | per process: MZ_ACTION_SPARSE=%d MZ_ACTION_FUSE=%d MZ_CONV_SPEC=%d MZ_TOWER=%d MZ_CONV_TILE=%d MZ_CONV_G=%d MZ_CONV_NCT=%d",
+             (int)p->force_generic, (int)p->fuse_env, (int)p->gtree_wave, p->hwx, (int)p->tree_old, (int)p->hbm_tree, (int)p->no_fast_layout, (int)p->fast_ac4,
+             cs.action_sparse, cs.action_fuse, cs.conv_spec, cs.tower, cs.conv_tile, cs.conv_g, cs.conv_nct);
+    g_describe = "search: " + p->last_dispatch + b;
+    return g_describe.c_str();
+}
 
 static void compute_layout(mz_planner* p) {
     const mz_config& c = p->cfg;
@@ -329,6 +347,10 @@ static int planner_init(mz_planner* p, bool conv) {
         if (hx) p->hwx = atoi(hx);
         const char* to = getenv("MZ_TREE_OLD");
         p->tree_old = to && to[0] == '1';
+        const char* nf = getenv("MZ_NO_FAST_LAYOUT");
+        p->no_fast_layout = nf && nf[0] == '1';
+        const char* a4 = getenv("MZ_FAST_AC4");
+        p->fast_ac4 = !(a4 && a4[0] == '0');
     }
     p->conv = conv;
     if (conv) {
@@ -702,13 +724,28 @@ static int next_kernel_events(mz_planner* p, hipEvent_t* a, hipEvent_t* b) {
     return MZ_OK;
 }
 
+// Whether the dispatch of launch_search has a k_search_fast build for this net's categorical-head shape.  Always true in the product build;
+// -DMZ_DEV_SHAPES compiles only two of the four (planes, head tiles) builds and falls back to the shape-generic kernel for the others, which
+// must then keep the generic LDS carve-out (the fast carve-out under the generic kernel overruns LDS).
+static bool fast_build_exists(const mz_planner* p) {
+#ifdef MZ_DEV_SHAPES
+    const int two = p->net.L[L_VAL1].n_tiles == 2;
+    const mz_config& c = p->cfg;
+    const bool four_act = p->fast_ac4 && c.num_actions == 4 && c.reward_support_size > 1 && c.value_support_size > 1 && p->fast_planes == 512 && two;
+    return four_act || (p->fast_planes == 512 && two) || (p->fast_planes == 256 && !two);
+#else
+    (void)p;
+    return true;
+#endif
+}
+
 // launches the fused search kernel over inputs that are already resident in the planner's device buffers
 static int launch_search(mz_planner* p, int batch, int deterministic, bool has_mask, bool injected_rng, bool scripted, const EnvLaunch* fenv = nullptr) {
     const mz_config& c = p->cfg;
     // the tuned kernel with its own LDS carve-out (sp2f): only where the generic carve-out does not fit AND k_search_fast is the kernel
     // the dispatch below picks (categorical heads; the ten-action MSE build is 256 planes wide and always fits the generic one)
     const bool fastlayout = !p->tree2_ok && p->tree2f_ok && p->fast_planes && !p->force_generic && !p->tree_old && !scripted &&
-                            c.value_support_size > 1 && c.reward_support_size > 1 && !getenv("MZ_NO_FAST_LAYOUT");
+                            c.value_support_size > 1 && c.reward_support_size > 1 && !p->no_fast_layout && fast_build_exists(p);
     const bool mode2 = (p->tree2_ok && !p->tree_old) || fastlayout;
     SearchParams s = fastlayout ? p->sp2f : (mode2 ? p->sp2 : p->sp);
     s.tree_mode = mode2 ? 2 : 0;
@@ -744,9 +781,17 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         if (rc) return rc;
         HIPCHK(hipEventRecord(ea, p->stream));
     }
+    auto fast_name = [&](int planes, int tiles, bool fuse, int ac, bool spb) {
+        char b[160];
+        snprintf(b, sizeof b, "k_search_fast<planes=%d, TR=%d, TV=%d, FUSE=%s, AC=%d, HW=%s%s> (LDS trees%s, one launch per move)", planes, tiles, tiles,
+                 fuse ? "true" : "false", ac, kFastHW ? "true" : "false", spb ? ", SPB=true" : "", fastlayout ? ", own carve-out" : "");
+        p->last_dispatch = b;
+    };
     if (p->conv || p->hbm_tree) {
         // HBM-resident trees: root inference -> init -> S x {select, network evaluation, expand + backup} -> play
         const bool mlp = !p->conv;
+        p->last_dispatch = std::string(mlp ? "k_infer" : "conv towers (mz_convnet.h: k_conv3x3 / k_res_tower / k_head)") + " around HBM trees: " +
+                           (p->gtree_wave ? "k_gtree_select_wave" : "k_gtree_select") + " + k_gtree_backup per simulation";
         InferParams ip = p->ip;
         ip.net = p->net; ip.B = batch; ip.in = nullptr; ip.in_ptrs = nullptr; ip.action = p->d_sim_action; ip.hidden_out = nullptr;
         ip.out_ptrs = nullptr; ip.reward = p->d_sim_reward; ip.value = p->d_sim_value; ip.pi = p->d_pi_scratch;
@@ -800,30 +845,33 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         }
         hipLaunchKernelGGL(k_gtree_finish, grid, block, 0, p->stream, G);
     } else
-    if (scripted) hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
-    else if (p->fast_planes && !p->force_generic && s.tree_mode == 2) {  // (k_search_fast is written for the tree_mode 2 layout)
+    if (scripted) {
+        p->last_dispatch = "k_search<SCRIPTED=true> (scripted-network test hook)";
+        hipLaunchKernelGGL(k_search<true>, grid, block, s.lds_bytes, p->stream, s);
+    } else if (p->fast_planes && !p->force_generic && s.tree_mode == 2) {  // (k_search_fast is written for the tree_mode 2 layout)
         const int two = p->net.L[L_VAL1].n_tiles == 2;
-#define MZ_FAST4(PL, T, F, W) hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W, kFastHW>), grid, dim3(kFastHW ? 2 * WG_THREADS : WG_THREADS), s.lds_bytes, p->stream, s, p->fw)
-#define MZ_FAST(PL, T) do { if (fenv) { if (two_act) MZ_FAST4(PL, T, true, 2); else MZ_FAST4(PL, T, true, 0); } \
-                            else { if (two_act) MZ_FAST4(PL, T, false, 2); else MZ_FAST4(PL, T, false, 0); } } while (0)
+#define MZ_FAST4(PL, T, F, W) fast_name(PL, T, F, W, false); hipLaunchKernelGGL((k_search_fast<PL, T, T, F, W, kFastHW>), grid, dim3(kFastHW ? 2 * WG_THREADS : WG_THREADS), s.lds_bytes, p->stream, s, p->fw)
+#define MZ_FAST(PL, T) do { if (fenv) { if (two_act) { MZ_FAST4(PL, T, true, 2); } else { MZ_FAST4(PL, T, true, 0); } } \
+                            else { if (two_act) { MZ_FAST4(PL, T, false, 2); } else { MZ_FAST4(PL, T, false, 0); } } } while (0)
         // compile-time specialisation (mz_tree2.h, AM): two actions, single player, categorical reward and value heads
         const bool two_act = fast_two_act(c);  // (also fixes the depth of the weight ring the stream is packed for: load_weights)
         // four actions, categorical heads, the 512-plane net (mz_tree2.h, ACT: the backup's refresh unrolled, the action count a constant)
-        static const bool ac4_on = env_int("MZ_FAST_AC4", 1) != 0;
-        const bool four_act = ac4_on && c.num_actions == 4 && c.reward_support_size > 1 && c.value_support_size > 1 && p->fast_planes == 512 && two;
+        const bool four_act = p->fast_ac4 && c.num_actions == 4 && c.reward_support_size > 1 && c.value_support_size > 1 && p->fast_planes == 512 && two;
         if (fast_ac10(p)) {  // (TicTacToe: ten actions)
             // SPB: the build with the board games' self-play settings as compile-time constants (mz_search_fast.h)
             const bool spb = s.board && s.has_bounds && s.discount == 1.0 && s.noise_mode == 2 && s.rng_mode == 1 && !s.deterministic && s.has_mask;
             const dim3 fblock(kFastHW ? 2 * WG_THREADS : WG_THREADS);
             if (spb) {
+                fast_name(256, 1, fenv != nullptr, 10, true);
                 if (fenv) hipLaunchKernelGGL((k_search_fast<256, 1, 1, true, 10, kFastHW, true>), grid, fblock, s.lds_bytes, p->stream, s, p->fw);
                 else hipLaunchKernelGGL((k_search_fast<256, 1, 1, false, 10, kFastHW, true>), grid, fblock, s.lds_bytes, p->stream, s, p->fw);
-            } else if (fenv) MZ_FAST4(256, 1, true, 10); else MZ_FAST4(256, 1, false, 10);
+            } else if (fenv) { MZ_FAST4(256, 1, true, 10); } else { MZ_FAST4(256, 1, false, 10); }
         } else
-        if (four_act) { if (fenv) MZ_FAST4(512, 2, true, 4); else MZ_FAST4(512, 2, false, 4); }
+        if (four_act) { if (fenv) { MZ_FAST4(512, 2, true, 4); } else { MZ_FAST4(512, 2, false, 4); } }
         else if (c.value_support_size == 1 || c.reward_support_size == 1) {
             // an MSE head's one-neuron layer runs on the vector ALUs in its own summation order (mz_mlp.h, scalar_head_tile): of the
             // tuned kernel's builds only the ten-action one has that form
+            p->last_dispatch = "k_search<false> (shape-generic; MSE head outside the ten-action build)";
             hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
         } else
 #ifdef MZ_DEV_SHAPES
@@ -837,7 +885,10 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
 #undef MZ_FAST4
 #undef MZ_FAST
     }
-    else hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
+    else {
+        p->last_dispatch = p->force_generic ? "k_search<false> (shape-generic, forced by MZ_FORCE_GENERIC=1)" : "k_search<false> (shape-generic: no tuned build for this shape)";
+        hipLaunchKernelGGL(k_search<false>, grid, block, s.lds_bytes, p->stream, s);
+    }
     HIPCHK(hipGetLastError());
     if (p->profiling) HIPCHK(hipEventRecord(eb, p->stream));
     return MZ_OK;
@@ -952,7 +1003,11 @@ extern "C" int mz_selfplay_reset(mz_planner* p, int32_t env_kind, const double* 
     p->ring_len = (size_t)c.num_envs * obs_dim(c) * sizeof(float) * 64 > ((size_t)4 << 30) ? 16 : 64;  // record ring: at most a few GB
     if (p->has_replay) {
         // the record ring is every env's open trajectory: a whole board game, or the acc + unroll + td window (pipeline.py:118-121)
-        const int need = c.is_board_game ? c.num_actions + 1 : p->replay.acc + p->replay.K + p->replay.td;
+        // -- but never longer than an episode can get: the classic configs set acc_seq_length = 9999 ("never flush mid-episode", config.py:198), and
+        // gym's TimeLimit ends CartPole after 500 steps (the synthetic frames env after 1000): 10 014 slots x 4096 envs of records would be ~5 GB
+        const int limit = env_kind == MZ_ENV_CARTPOLE ? 500 : (env_kind == MZ_ENV_SYNTHETIC ? 1000 : (1 << 30) - 64);
+        const int window = p->replay.acc + p->replay.K + p->replay.td, capped = limit + p->replay.K + p->replay.td;
+        const int need = c.is_board_game ? c.num_actions + 1 : (window < capped ? window : capped);
         if (need > p->ring_len) p->ring_len = (need + 7) & ~7;
     }
     p->selfplay_moves = 0;

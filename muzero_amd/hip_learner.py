@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmzlearner_hip.so')
 
 # every symbol include/mzlearner.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = ['mzl_last_error', 'mzl_create', 'mzl_destroy', 'mzl_num_params', 'mzl_grad_floats', 'mzl_num_tensors', 'mzl_tensor_info',
-               'mzl_num_buffers', 'mzl_num_running', 'mzl_buffer_info', 'mzl_bind_buffers', 'mzl_bind', 'mzl_commit', 'mzl_grad', 'mzl_apply']
+               'mzl_num_buffers', 'mzl_num_running', 'mzl_buffer_info', 'mzl_bind_buffers', 'mzl_bind', 'mzl_commit', 'mzl_grad', 'mzl_apply',
+               'mzl_replay_scratch_doubles', 'mzl_replay_sample', 'mzl_replay_update_priorities']
 NET_MLP, NET_BOARD = 0, 1
 
 
@@ -32,6 +33,12 @@ class MzlConfig(C.Structure):
                 ('value_support_size', C.c_int32), ('reward_support_size', C.c_int32), ('unroll_steps', C.c_int32), ('max_batch', C.c_int32),
                 ('grad_slices', C.c_int32), ('net_kind', C.c_int32), ('in_channels', C.c_int32), ('board_h', C.c_int32), ('board_w', C.c_int32),
                 ('num_res_blocks', C.c_int32)]
+
+
+class MzlReplayDraw(C.Structure):
+    _fields_ = [('d_priority', C.c_void_p), ('d_num_added', C.c_void_p), ('capacity', C.c_int64), ('priority_exponent', C.c_double),
+                ('importance_sampling_exponent', C.c_double), ('seed', C.c_uint64), ('draw', C.c_uint64), ('batch', C.c_int32), ('d_index', C.c_void_p),
+                ('d_weights', C.c_void_p), ('d_scratch', C.c_void_p)]
 
 
 class MzlBatch(C.Structure):
@@ -71,6 +78,10 @@ def load_library():
     L.mzl_commit.argtypes = [vp, vp]
     L.mzl_grad.argtypes = [vp, C.POINTER(MzlBatch), vp]
     L.mzl_apply.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]
+    L.mzl_replay_scratch_doubles.argtypes = [i64]
+    L.mzl_replay_scratch_doubles.restype = i64
+    L.mzl_replay_sample.argtypes = [C.POINTER(MzlReplayDraw), vp]
+    L.mzl_replay_update_priorities.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     _lib = L
     return L
 

@@ -355,44 +355,62 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
             dist.barrier()  # nobody loads a checkpoint that rank 0 is still writing
         return path
 
+    sampler = None  # HIP learner + a replay whose bookkeeping lives on the device: draws and priority updates stay there (replay.DeviceSampler)
+    if hip is not None and getattr(replay, '_attached', None) is not None and torch.device(device).type == 'cuda':
+        sampler = replay.device_sampler(seed=int(getattr(config, 'seed', 0)) + 7919 * rank)
+    if graphed is not None and multi:
+        # a captured update has no gradient all-reduce inside: with several learner ranks the weights would drift apart silently
+        import warnings
+
+        warnings.warn('run_training: optimizer.graphed_step ignored with %d learner ranks (the one-graph update has no all-reduce); '
+                      'using the eager step' % dist.get_world_size())
+        graphed = None
+    warm = False
     while True:
-        cold = replay.size < config.min_replay_size or replay.size < config.batch_size
-        if _all_ranks(stop_event.is_set() and cold, device):
-            return  # stopped before training could start (pipeline.py:232-236), on every rank at once
-        if _all_ranks(cold, device):
-            time.sleep(0.001)
-            continue
+        if not warm:  # (replay.size reads the device counter: once the ring is warm it stays warm, and the loop stops asking)
+            cold = replay.size < config.min_replay_size or replay.size < config.batch_size
+            if _all_ranks(stop_event.is_set() and cold, device):
+                return  # stopped before training could start (pipeline.py:232-236), on every rank at once
+            if _all_ranks(cold, device):
+                time.sleep(0.001)
+                continue
+            warm = True
         if _all_ranks(train_steps_counter.value >= config.num_training_steps, device):
             break
+        transitions = indices = weights = None
         if hip is not None:
-            # the kernels gather the batch from the HBM ring by index; gradients of several learner ranks meet in one all-reduce inside step()
-            indices, is_w, ring = replay.sample_indices(config.batch_size)
-            idx_t = torch.from_numpy(indices).to(device)
-            w_t = None if replay._alpha == 0 else torch.from_numpy(np.asarray(is_w, np.float32)).to(device)
+            # the kernels gather the batch from the HBM ring by index; gradients of several learner ranks meet in one all-reduce inside step().
+            # Nothing below synchronises with the device except the metrics line every 100 updates (and at checkpoints): the reference
+            # logs every step (pipeline.py:252-255) because its loss is already on the host; here that read-back would serialise the loop
+            if sampler is not None:
+                idx_t, w_t, ring = sampler.sample(config.batch_size)
+            else:
+                indices, is_w, ring = replay.sample_indices(config.batch_size)
+                idx_t = torch.from_numpy(indices).to(device)
+                w_t = None if replay._alpha == 0 else torch.from_numpy(np.asarray(is_w, np.float32)).to(device)
             loss_t, prio_t = hip.step(ring, idx_t, w_t, config.batch_size)
+            if tuple(prio_t.shape) != (config.batch_size,):
+                raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {tuple(prio_t.shape)}')
             if replay._alpha != 0:
-                replay.update_priorities(indices, prio_t.cpu().numpy())
+                if sampler is not None:
+                    sampler.update_priorities(idx_t, prio_t)
+                else:
+                    replay.update_priorities(indices, prio_t.cpu().numpy())
             train_steps_counter.value += 1
             if train_steps_counter.value % 100 == 0 or train_steps_counter.value % config.checkpoint_interval == 0:
-                metrics.step(float(loss_t), lr_scheduler.get_last_lr()[0], train_steps_counter.value)  # (the only host read-backs of the loop)
-            transitions = weights = None
+                metrics.step(float(loss_t), lr_scheduler.get_last_lr()[0], train_steps_counter.value)
         else:
             transitions, indices, weights = replay.sample_tensors(config.batch_size)
-        if hip is not None:
-            pass
-        elif graphed is None and not multi and torch.device(device).type == 'cuda' and all(g.get('capturable', False) for g in optimizer.param_groups):
-            # an optimizer built by make_capturable_adam on one learner rank: the update runs as one HIP graph (GraphedTrainStep)
-            graphed = GraphedTrainStep(config, network, optimizer, device, config.batch_size, tuple(transitions.state.shape[1:]),
-                                       int(transitions.action.shape[1]), int(transitions.pi_prob.shape[2]))
-        if hip is not None:
-            pass
-        elif graphed is not None:
-            loss_t, prio_t = graphed(transitions, weights)
-            lr_scheduler.step()
-            loss, priorities = float(loss_t), prio_t.cpu().numpy()
-        else:
-            loss, priorities = train_step(config, network, optimizer, lr_scheduler, device, transitions, weights)
-        if hip is None:
+            if graphed is None and not multi and torch.device(device).type == 'cuda' and all(g.get('capturable', False) for g in optimizer.param_groups):
+                # an optimizer built by make_capturable_adam on one learner rank: the update runs as one HIP graph (GraphedTrainStep)
+                graphed = GraphedTrainStep(config, network, optimizer, device, config.batch_size, tuple(transitions.state.shape[1:]),
+                                           int(transitions.action.shape[1]), int(transitions.pi_prob.shape[2]))
+            if graphed is not None:
+                loss_t, prio_t = graphed(transitions, weights)
+                lr_scheduler.step()
+                loss, priorities = float(loss_t), prio_t.cpu().numpy()
+            else:
+                loss, priorities = train_step(config, network, optimizer, lr_scheduler, device, transitions, weights)
             if priorities is not None:
                 if priorities.shape != (config.batch_size,):
                     raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {priorities.shape}')

@@ -10,6 +10,8 @@ Functions with a reference counterpart keep its name, arguments and error behavi
 compute_n_step_target (pipeline.py:632-673), compute_mc_return_target (:676-707), make_unroll_sequence (:710-767),
 create_checkpoint / load_checkpoint (:802-807), run_self_play (:41-167).
 """
+import collections
+import copy
 import os
 import time
 from typing import Any, Iterable, List, Mapping, NamedTuple, Optional, Text
@@ -94,9 +96,17 @@ def _compact(obj):
 
     if torch.is_tensor(obj):
         return obj.detach().clone() if obj.untyped_storage().nbytes() > obj.numel() * obj.element_size() else obj
-    if isinstance(obj, Mapping):
-        return type(obj)((k, _compact(v)) for k, v in obj.items())
-    if isinstance(obj, (list, tuple)):
+    # only plain containers are rebuilt; everything else (namedtuples, defaultdicts, user classes) passes through unchanged.  An OrderedDict --
+    # network.state_dict() -- is shallow-copied and its values replaced in place, so its `_metadata` attribute (the per-module version
+    # info torch.save writes and load_state_dict reads) stays with it
+    if isinstance(obj, dict) and type(obj) in (dict, collections.OrderedDict):
+        out = copy.copy(obj)
+        for k, v in obj.items():
+            out[k] = _compact(v)
+        if hasattr(obj, '_metadata'):
+            out._metadata = obj._metadata
+        return out
+    if type(obj) in (list, tuple):
         return type(obj)(_compact(v) for v in obj)
     return obj
 

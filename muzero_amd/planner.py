@@ -17,7 +17,7 @@ _NET_KINDS = {'mlp': NET_MLP, 'board': NET_BOARD, 'atari': NET_ATARI}
 
 # every symbol include/mzplanner.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
-    'mz_last_error', 'mz_version', 'mz_planner_create', 'mz_planner_destroy', 'mz_planner_set_param', 'mz_planner_commit_params',
+    'mz_last_error', 'mz_version', 'mz_planner_describe', 'mz_planner_create', 'mz_planner_destroy', 'mz_planner_set_param', 'mz_planner_commit_params',
     'mz_planner_initial_inference', 'mz_planner_recurrent_inference', 'mz_planner_hidden_size', 'mz_planner_search',
     'mz_planner_search_scripted', 'mz_selfplay_reset', 'mz_selfplay_step', 'mz_selfplay_read', 'mz_selfplay_counters',
     'mz_selfplay_attach_replay',
@@ -67,6 +67,8 @@ def load_library():
     vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
     L.mz_last_error.restype = C.c_char_p
     L.mz_version.restype = C.c_char_p
+    L.mz_planner_describe.restype = C.c_char_p
+    L.mz_planner_describe.argtypes = [C.c_void_p]
     L.mz_planner_create.argtypes = [C.POINTER(MzConfig), C.c_int, C.POINTER(vp)]
     L.mz_planner_destroy.argtypes = [vp]
     L.mz_planner_set_param.argtypes = [vp, C.c_char_p, vp, i64p, i32]
@@ -310,6 +312,10 @@ class Planner:
 
     def profile_begin(self):
         _chk(self.lib.mz_profile_begin(self.h))
+
+    def describe(self) -> str:
+        """The kernel build the last search launch dispatched to + the diagnostic switches as this handle read them (mz_planner_describe)."""
+        return self.lib.mz_planner_describe(self.h).decode()
 
     def profile_end(self):
         ms, kms, n = C.c_double(), C.c_double(), C.c_int64()

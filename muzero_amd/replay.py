@@ -221,6 +221,11 @@ class PrioritizedReplay:
             picks, is_w = self._draw(batch_size)
         return picks, is_w, self._ring
 
+    def device_sampler(self, seed: int = 0) -> 'DeviceSampler':
+        """Sampling and priority updates ON THE DEVICE for a ring whose bookkeeping lives there (a device writer attached: the planner's
+        epilogue): see `DeviceSampler`.  The host path above stays the draw-for-draw parity mode."""
+        return DeviceSampler(self, seed)
+
     def sample(self, batch_size: int) -> Tuple[Transition, np.ndarray, np.ndarray]:
         """A batch with replacement (replay.py:81-104): numpy arrays stacked on axis 0, the indices, the IS weights."""
         batch, picks, is_w = self.sample_tensors(batch_size)
@@ -271,3 +276,66 @@ class PrioritizedReplay:
         self._count = state['num_added']
         self._ring = None if state['storage'] is None else {k: v.to(self._dev) for k, v in state['storage'].items()}
         self._prio = state['priorities']
+
+
+class DeviceSampler:
+    """`PrioritizedReplay.sample` / `update_priorities` (replay.py:81-113) without the host: the kernels of libmzlearner_hip.so
+    (include/mzlearner.h, mzl_replay_sample / mzl_replay_update_priorities) read the committed item count and the priorities where the
+    planner's device epilogue publishes them and leave indices and importance weights in HBM for `hip_learner.HipLearner.grad`.  No `.item()`,
+    no copy of the priority array, nothing synchronises: a learner loop built on it enqueues and returns.
+
+    Uniform replay (priority_exponent == 0, all launchers' default): index = floor(u * size), weights None (= ones).  Proportional replay:
+    inverse-CDF picks on float64 prefix sums of priority ^ alpha -- np.random.choice's own method, with Philox uniforms keyed by
+    (seed, draw number, sample) instead of the process-global MT19937 -- and importance weights ((1 / size) / p) ^ beta / max.  Same
+    distribution as the reference, not the same draws: the host path of `PrioritizedReplay` remains the draw-for-draw mode."""
+
+    def __init__(self, replay: PrioritizedReplay, seed: int = 0):
+        from muzero_amd import hip_learner as _hl  # (loads libmzlearner_hip.so; raises without it: no CPU fallback)
+
+        if replay._attached is None or replay._dev.type != 'cuda':
+            raise RuntimeError('DeviceSampler needs a replay in HBM whose bookkeeping the device owns: PrioritizedReplay(device=\'cuda\') with a '
+                               'planner epilogue attached (Planner.attach_replay) or attach_device_writer() called')
+        self._hl, self._lib = _hl, _hl.load_library()
+        self.replay, self.seed, self.draws = replay, int(seed) & (2 ** 64 - 1), 0
+        self._prio, self._count = replay._attached
+        dev, cap = replay._dev, replay._cap
+        self._scratch = None if replay._alpha == 0 else torch.zeros(int(self._lib.mzl_replay_scratch_doubles(cap)), dtype=torch.float64, device=dev)
+        self._owner = None
+        self._bufs = {}
+
+    def _stream(self):
+        import ctypes as C
+
+        return C.c_void_p(torch.cuda.current_stream(self.replay._dev).cuda_stream)
+
+    def sample(self, batch_size: int):
+        """(indices int64 [B] on the device, importance weights float32 [B] on the device -- None for uniform replay --, the ring's storages).
+        The caller must know the replay holds at least one item (the kernels cannot raise): check `replay.size` once, before the loop."""
+        import ctypes as C
+
+        rp = self.replay
+        if self._attached_changed():
+            raise RuntimeError('the replay\'s device writer was detached: build a new DeviceSampler')
+        if batch_size not in self._bufs:
+            self._bufs[batch_size] = (torch.zeros(batch_size, dtype=torch.int64, device=rp._dev), torch.ones(batch_size, dtype=torch.float32, device=rp._dev))
+        idx, w = self._bufs[batch_size]
+        d = self._hl.MzlReplayDraw(self._prio.data_ptr(), self._count.data_ptr(), rp._cap, float(rp._alpha), float(rp._beta), self.seed, self.draws, batch_size,
+                                   idx.data_ptr(), w.data_ptr(), 0 if self._scratch is None else self._scratch.data_ptr())
+        self.draws += 1
+        self._hl._check(self._lib.mzl_replay_sample(C.byref(d), self._stream()))
+        return idx, (None if rp._alpha == 0 else w), rp._ring
+
+    def update_priorities(self, indices: torch.Tensor, priorities: torch.Tensor) -> None:
+        """replay.py:106-113 on device tensors (of a repeated index the last value wins).  Values are not validated on the host (that would
+        be the read-back this class exists to avoid): the learner's |v - z| is finite and non-negative by construction."""
+        rp = self.replay
+        if self._owner is None:
+            self._owner = torch.zeros(rp._cap, dtype=torch.int32, device=rp._dev)
+        n = int(indices.numel())
+        if indices.dtype != torch.int64 or priorities.dtype != torch.float32 or priorities.numel() < n or indices.device != rp._dev or priorities.device != rp._dev:
+            raise ValueError('update_priorities: int64 indices and float32 priorities on the replay\'s device')
+        self._hl._check(self._lib.mzl_replay_update_priorities(self._prio.data_ptr(), rp._cap, indices.data_ptr(), priorities.data_ptr(), n,
+                                                               self._owner.data_ptr(), self._stream()))
+
+    def _attached_changed(self) -> bool:
+        return self.replay._attached is None or self.replay._attached[0] is not self._prio
