@@ -6,11 +6,13 @@ loop as examples/train_tictactoe.py.  The reference's gomoku hyper-parameters (c
 random opponent as black and as white (win = five in a row before the opponent; the random player never resigns).
 
 By default the trajectories never leave the GPU: the device epilogue writes (Transition, priority) items into an HBM replay ring
-(`Planner.attach_replay`; int16 action fields where num_actions > 128, e.g. --board 15), batches are gathered on the device, and the
-update -- PyTorch-ROCm autograd for the conv nets -- can run as ONE HIP graph (--graphed, learner.GraphedTrainStep, captured before the
-loop).  --host-assembly keeps the reference's host-side assembler (pipeline.py:118-165).
+(`Planner.attach_replay`; int16 action fields where num_actions > 128, e.g. --board 15), the batch indices are drawn on the device
+(`replay.DeviceSampler`) and the update runs on the hand-written conv-learner kernels (round 5: `hip_learner.HipLearner`, csrc/mz_learn_conv.h:
+train-mode BatchNorm towers, heads, losses, backward, Adam -- no ATen kernel on the step).  --autograd keeps the PyTorch-ROCm update
+(learner.train_step), --graphed replays it as ONE HIP graph (learner.GraphedTrainStep, captured before the loop).  --host-assembly keeps the
+reference's host-side assembler (pipeline.py:118-165).
 
-    python examples/train_gomoku.py --train-steps 2000 --envs 128 [--graphed] [--board 9]"""
+    python examples/train_gomoku.py --train-steps 2000 --envs 128 [--autograd | --graphed] [--board 9]"""
 import argparse
 import json
 import os
@@ -54,7 +56,8 @@ def main():
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--board', type=int, default=9)
     ap.add_argument('--host-assembly', action='store_true', help='trajectories through selfplay_read + the host EpisodeAssembler instead of the device epilogue')
-    ap.add_argument('--graphed', action='store_true', help='the update as one HIP graph (learner.GraphedTrainStep)')
+    ap.add_argument('--graphed', action='store_true', help='the PyTorch-ROCm update as one HIP graph (learner.GraphedTrainStep)')
+    ap.add_argument('--autograd', action='store_true', help='the PyTorch-ROCm update, eager (learner.train_step)')
     ap.add_argument('--out', default='')
     args = ap.parse_args()
 
@@ -72,16 +75,20 @@ def main():
     N = args.board
     A, obs_shape = N * N + 1, (9, N, N)
     net = MuZeroBoardGameNet(obs_shape, A, cfg.num_res_blocks, cfg.num_planes).to(dev)
-    graphed = None
+    graphed = hip = None
+    use_hip = not (args.graphed or args.autograd or args.host_assembly)
     if args.graphed:  # captured here, before anything else drives the GPU (learner.prepare_graphed_step)
         import warnings
 
         warnings.filterwarnings('ignore', message='Detected call of `lr_scheduler.step\\(\\)` before')  # (optimizer.step() runs inside the graph)
         opt = learner.make_capturable_adam(net, cfg, dev)
         graphed = learner.prepare_graphed_step(cfg, net, opt, dev, obs_shape, A)
+    elif use_hip:  # the conv learner's kernels; the module's parameters and BatchNorm buffers become views of the learner's flat vectors
+        hip = learner.make_hip_learner(cfg, net, dev)
+        opt = None
     else:
         opt = torch.optim.Adam(net.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    sched = None if hip is not None else torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
     replay = PrioritizedReplay(20000, 0.0, 0.0, np.random.RandomState(args.seed), device='cuda')
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=args.envs, seed=args.seed), 0)
     net.eval()
@@ -89,6 +96,7 @@ def main():
     if not args.host_assembly:
         p.attach_replay(replay, cfg, obs_shape=obs_shape)
     p.selfplay_reset(pl.ENV_GOMOKU)
+    sampler = replay.device_sampler(seed=args.seed) if hip is not None else None
     asm = EpisodeAssembler(cfg, args.envs, obs_shape)
     rs = np.random.RandomState(args.seed + 7)
 
@@ -109,6 +117,17 @@ def main():
             continue
         net.train()
         for _ in range(args.updates_per_iter):
+            if hip is not None:  # draw, gather, update: all on the device, nothing read back
+                idx_t, w_t, ring = sampler.sample(cfg.batch_size)
+                loss, prio = hip.step(ring, idx_t, w_t, cfg.batch_size)
+                steps += 1
+                if steps % args.report_every == 0:
+                    net.eval()
+                    rec = dict(train_steps=steps, loss=float(loss), seconds=round(time.time() - t0, 1), env_steps=p.selfplay_counters()['env_steps'],
+                               black=evaluate(1), white=evaluate(2), learner='hip')
+                    log.append(rec)
+                    print(json.dumps(rec), flush=True)
+                continue
             batch, idx, w = replay.sample_tensors(cfg.batch_size)
             if graphed is not None:  # uniform replay (the launchers' default) ignores priorities: no host read-back per update
                 loss, prio = graphed(batch, w)

@@ -61,6 +61,11 @@ typedef struct {
     int32_t num_envs;  /* capacity B: environments searched in lock-step on this GPU */
     int32_t max_ties;  /* length of the injected tie-break stream per env (parity mode) */
     uint64_t seed;     /* Philox key for on-device randomness (production mode) */
+    /* child_U's product in searches WITHOUT root noise (evaluators: deterministic = True, pipeline.py:374,468).  There `child.prior` is an
+     * np.float32 scalar multiplied by a Python float (mcts.py:189-197): numpy >= 2 (NEP 50) keeps the product in float32, numpy 1.x -- the
+     * reference pins 1.21.6 (requirements.txt:21) -- promotes it to float64 and rounds once.  0 (default): the numpy-2 form, the one every
+     * recorded fixture of this repo was produced under; 1: the numpy-1.21 form.  Self-play (float64 prior after the noise) is the same in both. */
+    int32_t legacy_scalar_promotion;
 } mz_config;
 
 /* Injected randomness for a batch of searches: replaces the reference's global numpy RNG

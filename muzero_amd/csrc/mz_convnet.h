@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_gtree_select_wave(const GTreeLaunch G) 
     const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
     const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
     const double mn = mm[0], mx = mm[1];
-    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0);
+    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0 && !P.legacy_promo);
     const int nch = (P.A + 63) >> 6;
     int n = 0, cp = P.cur[env_g], op = P.opp[env_g], ties = sel[3];
     int lp = 0, la = 0, lpl = 0, depth = 0;

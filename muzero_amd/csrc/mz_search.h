@@ -42,6 +42,7 @@ struct SearchParams {
     double kb_min, kb_max, alpha, eps;
     int deterministic, has_mask;
     int noise_mode;  // 0: none, 1: injected, 2: Philox Dirichlet on device
+    int legacy_promo;  // mz_config.legacy_scalar_promotion: child_U's product in float64 even where the prior stayed float32 (numpy 1.21)
     int rng_mode;    // 0: injected tie/final uniforms, 1: Philox
     int max_ties;
     // batch
@@ -173,7 +174,7 @@ __device__ __forceinline__ int select_level(unsigned char* smem, const SearchPar
     const double* ftab = reinterpret_cast<const double*>(smem + P.t_ftab);
     const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
     const bool norm = mx > mn;
-    const bool prior_f32 = (P.noise_mode == 0);
+    const bool prior_f32 = (P.noise_mode == 0 && !P.legacy_promo);
     const int nch = (P.A + 15) >> 4;
     const int Nn = node_at(smem, P, e, n)->N;
     const double* frow = ftab + Nn * (P.S + 1);

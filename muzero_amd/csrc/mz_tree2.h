@@ -384,7 +384,7 @@ __device__ __forceinline__ Backup2Pre tree2_backup_prefetch(unsigned char* smem,
         const double* frow = reinterpret_cast<const double*>(smem + P.t2_ftab) + tri(n_after);
         const double* prior = reinterpret_cast<const double*>(smem + P.t_prior) + e * P.A;
         const double f0 = frow[pre.cn0], f1 = frow[pre.cn1], p0 = prior[0], p1 = prior[1];
-        const bool prior_f32 = (P.noise_mode == 0);
+        const bool prior_f32 = (P.noise_mode == 0 && !P.legacy_promo);
         if (prior_f32) {  // (one wave-uniform branch for the pair, not two forms per product)
             pre.ua0 = (float)p0 * (float)f0;
             pre.ua1 = (float)p1 * (float)f1;
@@ -536,7 +536,7 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
     MZ_TS(4);  // [4] backup: drift / rinv bookkeeping + stores
     // pass 2: child_U and best child of every path node with the final statistics (same lane ownership; LDS ops are in
     // order, so the entry writes of pass 1 -- all from this wave -- are visible)
-    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0);
+    const bool norm = mx > mn, prior_f32 = (P.noise_mode == 0 && !P.legacy_promo);
     const float thr = 2.0f * __double2float_ru(st.drift) + kCacheSlack;  // what the next select will compare the margins with
     int resume = 0;
     for (int base = 0; __any(base < L); base += 16) {

@@ -759,7 +759,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
     s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
     s.deterministic = deterministic; s.has_mask = has_mask ? 1 : 0;
     const bool want_noise = !deterministic && c.root_dirichlet_alpha > 0.0 && c.root_exploration_eps > 0.0;  // mcts.py:361
-    s.noise_mode = want_noise ? (injected_rng ? 1 : 2) : 0;
+    s.noise_mode = want_noise ? (injected_rng ? 1 : 2) : 0; s.legacy_promo = c.legacy_scalar_promotion ? 1 : 0;
     s.rng_mode = injected_rng ? 0 : 1;
     s.max_ties = c.max_ties;
     s.B = batch;
@@ -800,7 +800,7 @@ static int launch_search(mz_planner* p, int batch, int deterministic, bool has_m
         s.discount = c.discount; s.board = c.is_board_game; s.has_bounds = c.has_known_bounds;
         s.kb_min = c.known_bounds_min; s.kb_max = c.known_bounds_max; s.alpha = c.root_dirichlet_alpha; s.eps = c.root_exploration_eps;
         s.deterministic = deterministic; s.has_mask = has_mask ? 1 : 0;
-        s.noise_mode = want_noise ? (injected_rng ? 1 : 2) : 0;
+        s.noise_mode = want_noise ? (injected_rng ? 1 : 2) : 0; s.legacy_promo = c.legacy_scalar_promotion ? 1 : 0;
         s.rng_mode = injected_rng ? 0 : 1;
         s.max_ties = c.max_ties; s.B = batch;
         s.obs = p->d_obs; s.mask = p->d_mask; s.cur = p->d_cur; s.opp = p->d_opp; s.temperature = p->d_temp;

@@ -199,15 +199,17 @@ class Node:
 
     def child_U(self, config: MuZeroConfig) -> np.ndarray:
         """mcts.py:180-200: prior * ((ln((N + c_base + 1) / c_base) + c_init) * sqrt(N) / (N_child + 1)); float32.  The prior
-        keeps its scalar type: a float32 prior multiplies in float32 (the scalar promotion numpy applies in the reference's
-        per-child expression), a float64 (noised) prior in float64."""
+        keeps its scalar type: a float32 prior multiplies in float32 (the scalar promotion numpy >= 2 applies in the reference's
+        per-child expression), a float64 (noised) prior in float64.  `config.legacy_scalar_promotion` (optional attribute, default False)
+        selects what numpy 1.21 -- the reference's pinned version -- computes for the float32 case: a float64 product, rounded once."""
+        legacy = bool(getattr(config, 'legacy_scalar_promotion', False))
         t, s = self._t, self._child_slice()
         n_self = int(t.N[self._i])
         f = (math.log((n_self + config.pb_c_base + 1) / config.pb_c_base) + config.pb_c_init) * math.sqrt(n_self) / (t.N[s] + 1)
         pri = t.prior[s]
         out = np.empty(len(pri), np.float32)
         for k, p in enumerate(pri):
-            out[k] = np.float32(p) * np.float32(f[k]) if isinstance(p, np.float32) else np.float32(p * f[k])
+            out[k] = np.float32(p) * np.float32(f[k]) if (isinstance(p, np.float32) and not legacy) else np.float32(float(p) * f[k])
         return out
 
     @property
@@ -269,7 +271,8 @@ def _planner_for(network, config, num_envs, device):
 
     kb = config.known_bounds
     key = (config.num_simulations, config.discount, config.pb_c_base, config.pb_c_init, bool(config.is_board_game),
-           None if kb is None else (kb.min, kb.max), config.root_dirichlet_alpha, config.root_exploration_eps, int(num_envs))
+           None if kb is None else (kb.min, kb.max), config.root_dirichlet_alpha, config.root_exploration_eps, int(num_envs),
+           bool(getattr(config, 'legacy_scalar_promotion', False)))
     cache = network.__dict__.setdefault('_search_planners', {})
     entry = cache.get(key)
     version = network._weights_version()

@@ -36,7 +36,7 @@ class MzConfig(C.Structure):
         ('reward_support_size', C.c_int32), ('num_simulations', C.c_int32), ('discount', C.c_double), ('pb_c_base', C.c_double),
         ('pb_c_init', C.c_double), ('is_board_game', C.c_int32), ('has_known_bounds', C.c_int32), ('known_bounds_min', C.c_double),
         ('known_bounds_max', C.c_double), ('root_dirichlet_alpha', C.c_double), ('root_exploration_eps', C.c_double),
-        ('num_envs', C.c_int32), ('max_ties', C.c_int32), ('seed', C.c_uint64),
+        ('num_envs', C.c_int32), ('max_ties', C.c_int32), ('seed', C.c_uint64), ('legacy_scalar_promotion', C.c_int32),
     ]
 
 
@@ -121,6 +121,7 @@ def make_mz_config(spec, config=None, num_envs=1, max_ties=0, seed=1, **search_o
         has_known_bounds=int(kb is not None), known_bounds_min=float(kb[0]) if kb is not None else 0.0,
         known_bounds_max=float(kb[1]) if kb is not None else 0.0, root_dirichlet_alpha=float(g('root_dirichlet_alpha', 0.25)),
         root_exploration_eps=float(g('root_exploration_eps', 0.25)), num_envs=int(num_envs), max_ties=int(max_ties), seed=int(seed),
+        legacy_scalar_promotion=int(bool(g('legacy_scalar_promotion', False))),
     )
 
 

@@ -332,7 +332,7 @@ class DeviceSampler:
         if self._owner is None:
             self._owner = torch.zeros(rp._cap, dtype=torch.int32, device=rp._dev)
         n = int(indices.numel())
-        if indices.dtype != torch.int64 or priorities.dtype != torch.float32 or priorities.numel() < n or indices.device != rp._dev or priorities.device != rp._dev:
+        if indices.dtype != torch.int64 or priorities.dtype != torch.float32 or priorities.numel() < n or indices.device != self._prio.device or priorities.device != self._prio.device:
             raise ValueError('update_priorities: int64 indices and float32 priorities on the replay\'s device')
         self._hl._check(self._lib.mzl_replay_update_priorities(self._prio.data_ptr(), rp._cap, indices.data_ptr(), priorities.data_ptr(), n,
                                                                self._owner.data_ptr(), self._stream()))

@@ -17,6 +17,9 @@ Groups:
   ckpt   G3  the same on the SHIPPED trained checkpoints (saved_checkpoints/*): inputs, recorded draws and the reference's
              outputs only -- the weights never leave /root/reference, so the test that replays these through the oracle
              (tests/test_oracle_ckpt.py) runs in the build container only
+  legacy G3' deterministic (evaluator) searches with the scalar promotion of numpy 1.21 -- the version the reference pins
+             (requirements.txt:21) -- emulated exactly under this container's numpy 2: child priors stored as float64 scalars, so that
+             mcts.py:189-197 multiplies in float64 and rounds once (tests/golden/legacy_cases.npz; oracle / kernels: legacy_scalar_promotion)
   pipe   G4  pipeline/util/mcts helper functions (incl. the reference's own KATs)
   env    G5  TicTacToe / Gomoku scripted games (incl. the reference tests' win lines)
   learn  L   PrioritizedReplay sampling, calc_loss (loss, priorities, gradients), 3 optimizer steps, 2-hot projection
@@ -1078,7 +1081,155 @@ def gen_classic():
     print('classic: done,', len(out), 'arrays')
 
 
-GROUPS = dict(classic=gen_classic, tree=gen_tree, nets=gen_nets, search=gen_search, ckpt=gen_ckpt, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
+
+# --------------------------------------------------------------------------------------------
+# G3': the numpy-1.21 form of child_U for searches without root noise.  In mcts.py:189-197 `child.prior` is an
+# np.float32 scalar there and the other factor a Python float: numpy >= 2 (NEP 50) multiplies in float32, numpy 1.21.6 -- the
+# reference's pinned version -- promotes scalar x scalar to float64 and np.array(..., dtype=np.float32) rounds once.  numpy 1.21 cannot
+# be installed here, but its result can be produced exactly: with the child priors stored as FLOAT64 scalars (the float32 values
+# widened, which is exact) numpy 2 evaluates the very same float64 product.  Nothing else in uct_search depends on the scalar type.
+# --------------------------------------------------------------------------------------------
+class _Numpy121Promotion:
+    def __enter__(self):
+        self._orig = ref_mcts.Node.expand
+        orig = self._orig
+
+        def expand(node, prior, player_id, hidden_state, reward):
+            return orig(node, np.asarray(prior).astype(np.float64), player_id, hidden_state, reward)
+
+        ref_mcts.Node.expand = expand
+        return self
+
+    def __exit__(self, *exc):
+        ref_mcts.Node.expand = self._orig
+
+
+def _legacy_case(net, cfg, obs, mask, players, prefix, out, A, stats):
+    """One deterministic search in both promotion forms on the same root; the legacy one is stored, the numpy-2 one only compared."""
+    tmp = {}
+    _search_case(net, cfg, obs, mask, players, 1.0, True, 7000, 'n2', tmp, A)
+    with _Numpy121Promotion():
+        _search_case(net, cfg, obs, mask, players, 1.0, True, 7000, prefix, out, A)
+    same = np.array_equal(tmp['n2_visits'], out[f'{prefix}_visits']) and tmp['n2_out_action'] == out[f'{prefix}_out_action']
+    out[f'{prefix}_same_as_numpy2'] = np.int32(same)
+    stats.append(same)
+
+
+def gen_legacy():
+    out, stats = {}, []
+    rng = np.random.RandomState(777)
+    # seeded random-weight nets (rebuilt from their seeds wherever the tests run)
+    for gname, case, kind, cfgargs, n_roots in [('cartpole', MLP_CASES[0], 'mlp', (0.997, 0.25, 50, False, None, 31, 31), 12),
+                                                ('tictactoe', MLP_CASES[2], 'mlp', (1.0, 0.25, 25, True, (-1, 1), 1, 1), 12),
+                                                ('board3', CONV_CASES[0], 'conv', (1.0, 0.25, 20, True, (-1, 1), 1, 1), 6)]:
+        net = build_mlp(case) if kind == 'mlp' else build_conv(case)
+        cfg = make_config(*cfgargs)
+        for k, v in cfg_arrays(cfg).items():
+            out[f'{gname}_{k}'] = v
+        A = case[2] if kind == 'mlp' else case[3]
+        for j in range(n_roots):
+            if gname == 'cartpole':
+                obs = rng.uniform(-0.5, 0.5, size=(4, 5)).astype(np.float32)
+                obs[:, 4] = (rng.randint(0, 2, size=4) + 1) / 2.0
+                mask, players = np.ones(2, bool), (1, 1)
+            else:
+                env = TicTacToeEnv()
+                obs = env.reset()
+                for _ in range(rng.randint(0, 5)):
+                    obs, _, done, _ = env.step(int(rng.choice(np.where(env.actions_mask[:9])[0])))
+                    if done:
+                        break
+                if env.is_game_over:
+                    env = TicTacToeEnv()
+                    obs = env.reset()
+                obs = obs.astype(np.int8) if gname == 'tictactoe' else obs.astype(np.float32)
+                mask, players = env.actions_mask.copy(), (env.current_player, env.opponent_player)
+            _legacy_case(net, cfg, obs, mask, players, f'{gname}_{j}', out, A, stats)
+        out[f'{gname}_n'] = np.int32(n_roots)
+    # the shipped trained checkpoints (where near-ties live); replayed by the container-only test
+    for name, fname, ishape, A, P, sup, (disc, sims, board, bounds) in CKPT_CASES:
+        net = ref_network.MuZeroMLPNet(ishape, A, P, sup, sup, 64)
+        net.load_state_dict(torch.load(os.path.join(CKPT_DIR, fname), map_location='cpu', weights_only=False)['network'])
+        net.eval()
+        cfg = make_config(disc, 0.25, sims, board, bounds, sup, sup)
+        for k, v in cfg_arrays(cfg).items():
+            out[f'ckpt_{name}_{k}'] = v
+        for j in range(16):
+            if board:
+                env = TicTacToeEnv()
+                obs = env.reset()
+                for _ in range(rng.randint(0, 6)):
+                    obs, _, done, _ = env.step(int(rng.choice(np.where(env.actions_mask[:9])[0])))
+                    if done:
+                        break
+                if env.is_game_over:
+                    env = TicTacToeEnv()
+                    obs = env.reset()
+                obs, mask, players = obs.astype(np.int8), env.actions_mask.copy(), (env.current_player, env.opponent_player)
+            else:
+                D = ishape[1] - 1
+                obs = rng.uniform(-0.2 if name == 'cartpole' else -1.0, 0.2 if name == 'cartpole' else 1.0, size=ishape).astype(np.float32)
+                obs[:, D] = (rng.randint(0, A, size=ishape[0]) + 1) / float(A)
+                mask, players = np.ones(A, bool), (1, 1)
+            _legacy_case(net, cfg, obs, mask, players, f'ckpt_{name}_{j}', out, A, stats)
+        out[f'ckpt_{name}_n'] = np.int32(16)
+    # scripted trees (G1 format, prefix lt<i>_) where the two forms provably DIFFER: priors in pairs one to three float32 ulps apart, so that
+    # child_U products fall on either side of a float32 rounding boundary depending on where the product is rounded.  The first 8 searches
+    # whose per-simulation (parent, action) trace differs between the forms are kept, plus 2 that agree.
+    hunt = np.random.RandomState(5)
+    kept_diff = kept_same = 0
+    ci = 0
+    for trial in range(2000):
+        if kept_diff >= 8 and kept_same >= 2:
+            break
+        A = int(hunt.choice([4, 10, 30]))
+        S = 40
+        base = hunt.randn(A // 2 + 1).astype(np.float32)
+        logits = np.repeat(base, 2)[:A].copy()
+        logits[1::2] += (hunt.randint(-3, 4, size=logits[1::2].shape) * 1e-7).astype(np.float32)
+        pi0 = torch.softmax(torch.from_numpy(logits), dim=0).numpy()
+        vk = trial % 3
+        values = (np.zeros(S) if vk == 0 else hunt.uniform(-1, 1, S) * (1e-3 if vk == 1 else 1.0)).astype(np.float32)
+        rewards = np.zeros(S, np.float32)
+        board = bool(trial % 2)
+        cfg = make_config(1.0 if board else 0.997, 0.0, S, board, (-1, 1) if board else None)
+        players = (1, 2) if board else (1, 1)
+        runs = []
+        for legacy in (False, True):
+            net = ScriptedNet(pi0, values, rewards)
+            np.random.seed(9000 + trial)
+            with DrawRecorder() as rec:
+                if legacy:
+                    with _Numpy121Promotion():
+                        res = ref_mcts.uct_search(state=np.zeros((1,), np.float32), network=net, device=torch.device('cpu'), config=cfg, temperature=1.0,
+                                                  actions_mask=np.ones(A, bool), current_player=players[0], opponent_player=players[1], deterministic=True)
+                else:
+                    res = ref_mcts.uct_search(state=np.zeros((1,), np.float32), network=net, device=torch.device('cpu'), config=cfg, temperature=1.0,
+                                              actions_mask=np.ones(A, bool), current_player=players[0], opponent_player=players[1], deterministic=True)
+            runs.append((net, res, rec))
+        differs = runs[0][0].trace_parent != runs[1][0].trace_parent or runs[0][0].trace_action != runs[1][0].trace_action
+        if (differs and kept_diff >= 8) or (not differs and kept_same >= 2):
+            continue
+        kept_diff += int(differs)
+        kept_same += int(not differs)
+        net, (action, pi, root_value), rec = runs[1]
+        d = dict(A=np.int32(A), pi0=pi0, values=values, rewards=rewards, mask=np.ones(A, np.uint8), temperature=np.float64(1.0), deterministic=np.int32(1),
+                 cur_player=np.int32(players[0]), opp_player=np.int32(players[1]), trace_parent=np.array(net.trace_parent, np.int32),
+                 trace_action=np.array(net.trace_action, np.int32), out_action=np.int32(action), out_pi=np.asarray(pi, np.float64),
+                 out_root_value=np.float64(root_value), differs_from_numpy2=np.int32(differs), seed=np.int64(9000 + trial),
+                 numpy2_trace_parent=np.array(runs[0][0].trace_parent, np.int32), numpy2_trace_action=np.array(runs[0][0].trace_action, np.int32))
+        d.update(cfg_arrays(cfg))
+        d.update(rec.as_dict(A, max_ties=4 * S + 8))
+        for k, v in d.items():
+            out[f'lt{ci}_{k}'] = v
+        ci += 1
+    out['lt_n'] = np.int32(ci)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'legacy_cases.npz'), **out)
+    print('legacy: done,', len(out), 'arrays;', len(stats) - int(np.sum(stats)), 'of', len(stats), 'network searches and', kept_diff, 'of', ci,
+          'scripted trees differ from the numpy-2 form')
+
+
+GROUPS = dict(legacy=gen_legacy, classic=gen_classic, tree=gen_tree, nets=gen_nets, search=gen_search, ckpt=gen_ckpt, pipe=gen_pipe, env=gen_env, play=gen_play, learn=gen_learn)
 
 if __name__ == '__main__':
     os.makedirs(GOLDEN_DIR, exist_ok=True)

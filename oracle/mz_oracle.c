@@ -722,7 +722,10 @@ mzo_search_result mzo_uct_search(const mzo_search_config* cfg, mzo_net* net, con
     mzo_initial_inference(net, obs, hidden, pi0, &v0);
     int use_noise = (!deterministic) && cfg->dirichlet_alpha > 0.0 && cfg->exploration_eps > 0.0 && rng && rng->noise;
     mzo_prepare_root_prior(pi0, A, use_noise ? rng->noise : NULL, cfg->exploration_eps, mask, deterministic, prior64, prior32);
-    const int prior_is_f64 = use_noise;
+    /* child_U (mcts.py:189-197): `child.prior * (python float)`.  With noise the prior is float64.  Without, it is an np.float32 SCALAR:
+     * numpy >= 2 (NEP 50) multiplies in float32 (the form the fixtures were recorded under: this container runs numpy 2.2.6); numpy 1.x -- the
+     * reference pins 1.21.6, requirements.txt:21 -- promotes scalar x scalar to float64 and np.array(dtype=float32) rounds once. */
+    const int prior_is_f64 = use_noise || cfg->legacy_scalar_promotion;
     parent[0] = -1; move[0] = -1; player[0] = current_player; reward[0] = 0.0;
 
     int tie_used = 0;

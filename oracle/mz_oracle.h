@@ -35,6 +35,7 @@ typedef struct {
     double kb_min, kb_max;
     double dirichlet_alpha;  /* root_dirichlet_alpha */
     double exploration_eps;  /* root_exploration_eps = 0.25 config.py:68 */
+    int32_t legacy_scalar_promotion; /* 1: child_U's np.float32-scalar x Python-float product as numpy 1.21 computes it (float64, one rounding) */
 } mzo_search_config;
 
 /* injected randomness for one search (replaces the global numpy RNG, mcts.py:124,245,404) */

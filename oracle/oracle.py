@@ -34,6 +34,7 @@ class SearchConfig(C.Structure):
         ('kb_max', C.c_double),
         ('dirichlet_alpha', C.c_double),
         ('exploration_eps', C.c_double),
+        ('legacy_scalar_promotion', C.c_int32),
     ]
 
 
@@ -135,11 +136,11 @@ def _f32(a):
 
 
 def make_config(num_actions, num_simulations, discount, is_board_game=False, known_bounds=None, dirichlet_alpha=0.25,
-                exploration_eps=0.25, pb_c_base=19652, pb_c_init=1.25):
+                exploration_eps=0.25, pb_c_base=19652, pb_c_init=1.25, legacy_scalar_promotion=False):
     return SearchConfig(
         int(num_actions), int(num_simulations), float(discount), float(pb_c_base), float(pb_c_init), int(bool(is_board_game)),
         int(known_bounds is not None), float(known_bounds[0]) if known_bounds is not None else 0.0,
-        float(known_bounds[1]) if known_bounds is not None else 0.0, float(dirichlet_alpha), float(exploration_eps),
+        float(known_bounds[1]) if known_bounds is not None else 0.0, float(dirichlet_alpha), float(exploration_eps), int(bool(legacy_scalar_promotion)),
     )
 
 
