@@ -104,7 +104,8 @@ struct mzlc_learner {
     // heads
     LchGroup* d_groups = nullptr;
     std::vector<LchGroup> groups_host;
-    float *hu = nullptr, *hdz = nullptr, *hfeat = nullptr, *hdl = nullptr, *hspart = nullptr, *hcoef = nullptr, *hsave = nullptr, *hlpart = nullptr;
+    float *hu = nullptr, *hdz = nullptr, *hfeat = nullptr, *hdl = nullptr, *hspart = nullptr, *hcoef = nullptr, *hsave = nullptr, *hlpart = nullptr, *hwpart = nullptr;
+    int hp_off[3] = {0, 0, 0}, hp_total = 0;
     int n_max = 1;
     float* d_sq = nullptr;
     int sq_blocks = 0;
@@ -458,8 +459,15 @@ int run_zip(mzlc_learner* h, const std::vector<Op>& A, const std::vector<Op>& Bv
     return 0;
 }
 
+constexpr int ENTRY_SPLIT = 8;  // workgroups per image of the entry kernel (each walks every ENTRY_SPLIT-th 32-pixel chunk: 15 x 15 -> one chunk each;
+                                // measured: 2 per image -- 256 workgroups looping -- is latency-bound, 90 us against 62)
+int entry_groups(const mzlc_learner* h, int B) {
+    const int nchunks = cdiv(h->hw, 32);
+    return B * (nchunks < ENTRY_SPLIT ? nchunks : ENTRY_SPLIT);
+}
 void launch_entry(mzlc_learner* h, const LcEntry& e, hipStream_t st) {
-    const dim3 grid(cdiv(h->hw, 32), e.B);
+    const int nchunks = cdiv(h->hw, 32);
+    const dim3 grid(nchunks < ENTRY_SPLIT ? nchunks : ENTRY_SPLIT, e.B);
     const int cpt = cdiv(e.C, 8);
     if (cpt <= 2) hipLaunchKernelGGL(k_lc_entry<2>, grid, dim3(256), 0, st, e);
     else if (cpt <= 8) hipLaunchKernelGGL(k_lc_entry<8>, grid, dim3(256), 0, st, e);
@@ -574,6 +582,11 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         AL(&h->hu, gb * LCH_MAXOC * h->hw); AL(&h->hdz, gb * LCH_MAXOC * h->hw); AL(&h->hfeat, gb * LCH_MAXOC * h->hw);
         AL(&h->hdl, gb * h->n_max); AL(&h->hspart, gb * LCH_MAXOC * 2); AL(&h->hcoef, (size_t)ng * LCH_MAXOC * 5); AL(&h->hsave, (size_t)ng * LCH_MAXOC * 2);
         AL(&h->hlpart, gb);
+        for (int i = 0; i < 3; i++) {
+            h->hp_off[i] = h->hp_total;
+            h->hp_total += h->head[i].oc * h->P + h->head[i].n_out * h->head[i].oc * h->hw + h->head[i].n_out;
+        }
+        AL(&h->hwpart, (size_t)h->K * h->hp_total);
     }
     h->sq_blocks = (int)((h->total + 1023) / 1024);
     AL(&h->d_sq, (size_t)h->sq_blocks);
@@ -718,21 +731,23 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     HA.groups = h->d_groups; HA.ngroups = ng; HA.K = K; HA.B = B; HA.P = h->P; HA.hw = h->hw; HA.A = h->A;
     HA.params = h->params; HA.grads = h->grads; HA.running = h->running; HA.nbt = h->nbt; HA.lwT = h->lwT;
     HA.u = h->hu; HA.dzb = h->hdz; HA.feat = h->hfeat; HA.dlogit = h->hdl; HA.spart = h->hspart; HA.coef = h->hcoef; HA.save = h->hsave; HA.lpart = h->hlpart;
-    HA.n_max = h->n_max; HA.bt = bt; HA.loss = b->d_loss;
+    HA.n_max = h->n_max; HA.bt = bt; HA.loss = b->d_loss; HA.wpart = h->hwpart; HA.hp_total = h->hp_total;
+    for (int i = 0; i < 3; i++) HA.hp_off[i] = h->hp_off[i];
     hipLaunchKernelGGL(k_lch_conv, dim3(B, ng), dim3(256), 0, st, HA);
-    hipLaunchKernelGGL(k_lch_bn, dim3(1), dim3(64), 0, st, HA);
+    hipLaunchKernelGGL(k_lch_bn, dim3(1), dim3(64 * 3 * LCH_MAXOC), 0, st, HA);
     {
         const size_t lds = ((size_t)LCH_MAXOC * h->hw + 2 * (size_t)h->n_max + 16) * sizeof(float);
         hipLaunchKernelGGL(k_lch_loss, dim3(B, ng), dim3(256), lds, st, HA);
     }
-    hipLaunchKernelGGL(k_lch_bnb, dim3(1), dim3(256), 0, st, HA);
+    hipLaunchKernelGGL(k_lch_bnb, dim3(1), dim3(64 * (3 * LCH_MAXOC + 1)), 0, st, HA);
     LchDx dx{};
     dx.out[0] = h->dF_pred; dx.out[1] = h->dF_rew;
     hipLaunchKernelGGL(k_lch_dx, dim3(B, K, 2), dim3(256), 0, st, HA, dx);
-    hipLaunchKernelGGL(k_lch_dw1, dim3(h->P, 3 * LCH_MAXOC), dim3(256), 0, st, HA);
-    hipLaunchKernelGGL(k_lch_dlin, dim3(cdiv(LCH_MAXOC * h->hw, 256), h->n_max, 3), dim3(256), 0, st, HA);
+    hipLaunchKernelGGL(k_lch_dw1, dim3(h->P, 2, K), dim3(256), 0, st, HA);
+    hipLaunchKernelGGL(k_lch_dlin, dim3(cdiv(LCH_MAXOC * h->hw, 256), cdiv(h->n_max, LCH_DLN), 3 * K), dim3(256), 0, st, HA);
+    hipLaunchKernelGGL(k_lch_wsum, dim3(cdiv(h->hp_total, 256)), dim3(256), 0, st, HA);
     // ---- backward ----
-    const int eg = B * cdiv(h->hw, 32);
+    const int eg = entry_groups(h, B);
     const float* gs_next = nullptr;  // gradient wrt s_{t+1}
     float* gs_bufs[2] = {h->GsA, h->GsB};
     for (int t = K - 1; t >= 0; t--) {

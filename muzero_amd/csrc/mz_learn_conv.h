@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mz_device.h"
+
 namespace mzlc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -717,83 +719,91 @@ struct LcEntry {
     float scale;           // on gs (0.5: pipeline.py:584)
     int B, C, hw, cpad;
 };
+// grid (nsplit, B): workgroup (s, b) walks the 32-pixel chunks s, s + nsplit, .. of image b; its per-channel partial sums stay in registers
+// across the chunks and are reduced over the 32 pixel lanes ONCE, at the end (DPP butterflies inside the 16-lane rows + one cross-row exchange:
+// a fixed order) -- with one reduction per chunk the ds_bpermute traffic of 2 * CPT * 5 shuffles per thread was most of the kernel
 template <int CPT>
 __global__ __launch_bounds__(256) void k_lc_entry(const LcEntry L) {
     __shared__ float s_a[8][32], s_b[8][32];
     __shared__ int s_ia[8][32], s_ib[8][32];
-    const int b = blockIdx.y, px = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + px;
-    const bool ok = p < L.hw;
-    const int cpt = (L.C + 7) >> 3;
-    const size_t base = (size_t)b * L.C * L.hw + (ok ? p : 0);
-    float x[CPT], g[CPT];
-    float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
-    int imn = 0x7fffffff, imx = 0x7fffffff;
+    const int b = blockIdx.y, px = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int cpt = (L.C + 7) >> 3, nchunks = (L.hw + 31) >> 5;
+    float s1[CPT], s2[CPT];
 #pragma unroll
-    for (int i = 0; i < CPT; i++) {
-        const int c = cg * cpt + i;
-        x[i] = 0.0f; g[i] = 0.0f;
-        if (i < cpt && c < L.C) {
-            x[i] = L.x[base + (size_t)c * L.hw];
-            if (L.gs) g[i] = L.gs[base + (size_t)c * L.hw] * L.scale;
-            if (x[i] < mn) { mn = x[i]; imn = c; }   // strict: the first attaining channel of this thread's ascending run
-            if (x[i] > mx) { mx = x[i]; imx = c; }
-        }
-    }
-    float dx[CPT];
-    if (L.gs) {  // (workgroup-uniform)
-        s_a[cg][px] = mn; s_b[cg][px] = mx; s_ia[cg][px] = imn; s_ib[cg][px] = imx;
-        __syncthreads();
-        mn = s_a[0][px]; imn = s_ia[0][px]; mx = s_b[0][px]; imx = s_ib[0][px];
-#pragma unroll
-        for (int k = 1; k < 8; k++) {  // channel groups ascend: strict comparison keeps the first attaining channel
-            if (s_a[k][px] < mn) { mn = s_a[k][px]; imn = s_ia[k][px]; }
-            if (s_b[k][px] > mx) { mx = s_b[k][px]; imx = s_ib[k][px]; }
-        }
-        const float d = (mx - mn) + 1e-8f;
-        float sg = 0.0f, sgs = 0.0f;
+    for (int i = 0; i < CPT; i++) { s1[i] = 0.0f; s2[i] = 0.0f; }
+    for (int ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
+        const int p = ck * 32 + px;
+        const bool ok = p < L.hw;
+        const size_t base = (size_t)b * L.C * L.hw + (ok ? p : 0);
+        float x[CPT], g[CPT];
+        float mn = __uint_as_float(0x7f800000u), mx = __uint_as_float(0xff800000u);
+        int imn = 0x7fffffff, imx = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = cg * cpt + i;
+            x[i] = 0.0f; g[i] = 0.0f;
             if (i < cpt && c < L.C) {
-                sg += g[i];
-                sgs = fmaf(g[i], (x[i] - mn) / d, sgs);
+                x[i] = L.x[base + (size_t)c * L.hw];
+                if (L.gs) g[i] = L.gs[base + (size_t)c * L.hw] * L.scale;
+                if (x[i] < mn) { mn = x[i]; imn = c; }   // strict: the first attaining channel of this thread's ascending run
+                if (x[i] > mx) { mx = x[i]; imx = c; }
             }
         }
-        __syncthreads();
-        s_a[cg][px] = sg; s_b[cg][px] = sgs;
-        __syncthreads();
-        sg = 0.0f; sgs = 0.0f;
+        float dinv = 0.0f, sg = 0.0f, sgs = 0.0f;
+        if (L.gs) {  // (workgroup-uniform)
+            __syncthreads();  // (the previous chunk's reads of the exchange arrays are done)
+            s_a[cg][px] = mn; s_b[cg][px] = mx; s_ia[cg][px] = imn; s_ib[cg][px] = imx;
+            __syncthreads();
+            mn = s_a[0][px]; imn = s_ia[0][px]; mx = s_b[0][px]; imx = s_ib[0][px];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { sg += s_a[k][px]; sgs += s_b[k][px]; }
+            for (int k = 1; k < 8; k++) {  // channel groups ascend: strict comparison keeps the first attaining channel
+                if (s_a[k][px] < mn) { mn = s_a[k][px]; imn = s_ia[k][px]; }
+                if (s_b[k][px] > mx) { mx = s_b[k][px]; imx = s_ib[k][px]; }
+            }
+            const float d = (mx - mn) + 1e-8f;
+#pragma unroll
+            for (int i = 0; i < CPT; i++) {
+                const int c = cg * cpt + i;
+                if (i < cpt && c < L.C) {
+                    sg += g[i];
+                    sgs = fmaf(g[i], (x[i] - mn) / d, sgs);
+                }
+            }
+            __syncthreads();
+            s_a[cg][px] = sg; s_b[cg][px] = sgs;
+            __syncthreads();
+            sg = 0.0f; sgs = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { sg += s_a[k][px]; sgs += s_b[k][px]; }
+            dinv = d;
+        }
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = cg * cpt + i;
-            float t = g[i] / d;
-            if (c == imn) t = t - sg / d + sgs / d;
-            if (c == imx) t = t - sgs / d;
-            dx[i] = t;
+            if (ok && i < cpt && c < L.C) {
+                float t = 0.0f;
+                if (L.gs) {
+                    t = g[i] / dinv;
+                    if (c == imn) t = t - sg / dinv + sgs / dinv;
+                    if (c == imx) t = t - sgs / dinv;
+                }
+                if (L.extra) t += L.extra[base + (size_t)c * L.hw];
+                t = x[i] > 0.0f ? t : 0.0f;
+                L.dz[base + (size_t)c * L.hw] = t;
+                s1[i] += t;
+                s2[i] = fmaf(t, L.partner[base + (size_t)c * L.hw], s2[i]);
+            }
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < CPT; i++) dx[i] = 0.0f;
     }
-    // + head gradient, ReLU mask, store, per-channel partial sums over this workgroup's 32 pixels (the 32 lanes of a channel group are one
-    // half of a wave: xor-butterfly 16-8-4-2-1, a fixed order)
-    const int chunks = gridDim.x;
+    // per-channel sums over the 32 pixel lanes of this channel group (one half of a wave): two 16-lane DPP butterflies + the other row
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
+        float a = mz::butterfly16(s1[i]), bb = mz::butterfly16(s2[i]);
+        a += __shfl_xor(a, 16);
+        bb += __shfl_xor(bb, 16);
         const int c = cg * cpt + i;
-        float t = 0.0f, yv = 0.0f;
-        if (ok && i < cpt && c < L.C) {
-            t = dx[i] + (L.extra ? L.extra[base + (size_t)c * L.hw] : 0.0f);
-            t = x[i] > 0.0f ? t : 0.0f;
-            L.dz[base + (size_t)c * L.hw] = t;
-            yv = L.partner[base + (size_t)c * L.hw];
-        }
-        float a = t, bb = t * yv;
-        for (int m = 16; m >= 1; m >>= 1) { a += __shfl_xor(a, m); bb += __shfl_xor(bb, m); }
         if (px == 0 && i < cpt && c < L.C) {
-            float* d = L.stat_part + (((size_t)b * chunks + blockIdx.x) * L.cpad + c) * 2;
+            float* d = L.stat_part + (((size_t)b * gridDim.x + blockIdx.x) * L.cpad + c) * 2;
             d[0] = a; d[1] = bb;
         }
     }
@@ -869,6 +879,8 @@ struct LchArgs {
     int n_max;
     LcBatch bt;
     float* loss;           // [1]
+    float* wpart;          // [K][hp_total]: per-step partial weight gradients of the heads (k_lch_dw1 / k_lch_dlin), summed in step order by k_lch_wsum
+    int hp_off[3], hp_total;  // per head: [w1 (oc * P)] [lw (n_out * oc * hw)] [lb (n_out)]
 };
 
 __global__ __launch_bounds__(256) void k_lch_conv(const LchArgs A) {
@@ -910,22 +922,36 @@ __global__ __launch_bounds__(256) void k_lch_conv(const LchArgs A) {
     }
 }
 
-// one thread per (head, plane): the K applications of a head in step order (their running-statistics updates are sequential)
-__global__ void k_lch_bn(const LchArgs A) {
-    const int hd = threadIdx.x / LCH_MAXOC, o = threadIdx.x % LCH_MAXOC;
+// one WAVE per (head, plane): the K applications of a head in step order (their running-statistics updates are sequential); the batch sum is
+// 64 strided float64 partials + a fixed-order butterfly
+__device__ __forceinline__ void lch_wave_sums(const float* spart, int g, int B, int o, double& s1, double& s2) {
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    for (int i = lane; i < B; i += 64) {
+        const float* p = spart + (((size_t)g * B + i) * LCH_MAXOC + o) * 2;
+        a += (double)p[0]; b += (double)p[1];
+    }
+    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+    s1 = a; s2 = b;
+}
+__device__ __forceinline__ int lch_group_of(const LchArgs& A, int hd, int t) {
+    int g = -1;
+    for (int k = 0; k < A.ngroups; k++)
+        if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
+    return g;
+}
+__global__ __launch_bounds__(64 * 3 * LCH_MAXOC) void k_lch_bn(const LchArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hd = wave / LCH_MAXOC, o = wave % LCH_MAXOC;
     if (hd >= 3 || o >= A.head[hd].oc) return;
     const LchHead H = A.head[hd];
     const double M = (double)A.B * A.hw;
     for (int t = 0; t < A.K; t++) {
-        int g = -1;
-        for (int k = 0; k < A.ngroups; k++)
-            if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
+        const int g = lch_group_of(A, hd, t);
         if (g < 0) continue;
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < A.B; b++) {
-            const float* p = A.spart + (((size_t)g * A.B + b) * LCH_MAXOC + o) * 2;
-            s1 += (double)p[0]; s2 += (double)p[1];
-        }
+        double s1, s2;
+        lch_wave_sums(A.spart, g, A.B, o, s1, s2);
+        if (lane != 0) continue;
         const double mean = s1 / M;
         double var = s2 / M - mean * mean;
         var = var < 0.0 ? 0.0 : var;
@@ -1035,40 +1061,41 @@ __global__ __launch_bounds__(256) void k_lch_loss(const LchArgs A) {
     }
 }
 
-// BatchNorm backward of the heads + the reported loss (one workgroup)
-__global__ __launch_bounds__(256) void k_lch_bnb(const LchArgs A) {
-    const int tid = threadIdx.x;
-    const int hd = tid / LCH_MAXOC, o = tid % LCH_MAXOC;
-    if (hd < 3 && o < A.head[hd].oc) {
-        const LchHead H = A.head[hd];
-        const double M = (double)A.B * A.hw;
-        double dg_sum = 0.0, db_sum = 0.0;
-        for (int t = 0; t < A.K; t++) {
-            int g = -1;
-            for (int k = 0; k < A.ngroups; k++)
-                if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
-            if (g < 0) continue;
-            double s1 = 0.0, s2 = 0.0;
-            for (int b = 0; b < A.B; b++) {
-                const float* p = A.spart + (((size_t)g * A.B + b) * LCH_MAXOC + o) * 2;
-                s1 += (double)p[0]; s2 += (double)p[1];
-            }
-            const double mean = A.save[((size_t)g * LCH_MAXOC + o) * 2], invstd = A.save[((size_t)g * LCH_MAXOC + o) * 2 + 1];
-            const double gam = A.params[H.gamma_off + o];
-            const double dgam = (s2 - mean * s1) * invstd, c1 = gam * invstd;
+// BatchNorm backward of the heads + the reported loss (one workgroup: waves 0 .. 3 * LCH_MAXOC - 1 own one (head, plane) each, the last
+// wave adds up the loss terms)
+__global__ __launch_bounds__(64 * (3 * LCH_MAXOC + 1)) void k_lch_bnb(const LchArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hd = wave / LCH_MAXOC, o = wave % LCH_MAXOC;
+    if (wave == 3 * LCH_MAXOC) {  // loss = mean_b w_b sum_t (reward + value + policy) (pipeline.py:594-597)
+        double s = 0.0;
+        for (int i = lane; i < A.ngroups * A.B; i += 64) s += (double)A.lpart[i];
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) *A.loss = (float)(s / (double)A.B);
+        return;
+    }
+    if (hd >= 3 || o >= A.head[hd].oc) return;
+    const LchHead H = A.head[hd];
+    const double M = (double)A.B * A.hw;
+    double dg_sum = 0.0, db_sum = 0.0;
+    for (int t = 0; t < A.K; t++) {
+        const int g = lch_group_of(A, hd, t);
+        if (g < 0) continue;
+        double s1, s2;
+        lch_wave_sums(A.spart, g, A.B, o, s1, s2);
+        const double mean = A.save[((size_t)g * LCH_MAXOC + o) * 2], invstd = A.save[((size_t)g * LCH_MAXOC + o) * 2 + 1];
+        const double gam = A.params[H.gamma_off + o];
+        const double dgam = (s2 - mean * s1) * invstd, c1 = gam * invstd;
+        if (lane == 0) {
             float* cf = A.coef + ((size_t)g * LCH_MAXOC + o) * 5;
             cf[2] = (float)c1;
             cf[3] = (float)(-c1 * invstd * dgam / M);
             cf[4] = (float)(-c1 * s1 / M + c1 * mean * invstd * dgam / M);
-            dg_sum += dgam; db_sum += s1;
         }
+        dg_sum += dgam; db_sum += s1;
+    }
+    if (lane == 0) {
         A.grads[H.gamma_off + o] = (float)dg_sum;
         A.grads[H.beta_off + o] = (float)db_sum;
-    }
-    if (tid == 255) {  // loss = mean_b w_b sum_t (reward + value + policy) (pipeline.py:594-597)
-        double s = 0.0;
-        for (int i = 0; i < A.ngroups * A.B; i++) s += (double)A.lpart[i];
-        *A.loss = (float)(s / (double)A.B);
     }
 }
 
@@ -1115,58 +1142,89 @@ __global__ __launch_bounds__(256) void k_lch_dx(const LchArgs A, const LchDx D) 
     }
 }
 
-// dw1[o][c] = sum_t sum_b sum_p du[t][b][o][p] F_t[b][c][p]: grid (P, 3 * LCH_MAXOC)
+// dw1_t[o][c] = sum_b sum_p du[t][b][o][p] F_t[b][c][p]: grid (P, 2, K): y = 0 the heads on the prediction tower's output (policy's two planes +
+// value's one: F is read ONCE for the three), y = 1 the reward head on the dynamics tower's raw output; z = unroll step (partials, k_lch_wsum)
 __global__ __launch_bounds__(256) void k_lch_dw1(const LchArgs A) {
-    __shared__ float s_red[4];
-    const int c = blockIdx.x, hd = blockIdx.y / LCH_MAXOC, o = blockIdx.y % LCH_MAXOC, tid = threadIdx.x;
-    const LchHead H = A.head[hd];
-    if (o >= H.oc) return;
-    float total = 0.0f;
-    for (int t = 0; t < A.K; t++) {
-        int g = -1;
-        for (int k = 0; k < A.ngroups; k++)
-            if (A.groups[k].head == hd && A.groups[k].t == t) g = k;
-        if (g < 0) continue;
-        const float* cf = A.coef + ((size_t)g * LCH_MAXOC + o) * 5;
-        const float c1 = cf[2], c2 = cf[3], c3 = cf[4];
-        const float* F = A.groups[g].F;
-        float s = 0.0f;
-        const int n = A.B * A.hw;
-        for (int i = tid; i < n; i += 256) {
-            const int b = i / A.hw, p = i - b * A.hw;
-            const size_t ix = (((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p;
-            const float du = fmaf(c1, A.dzb[ix], fmaf(c2, A.u[ix], c3));
-            s = fmaf(du, F[((size_t)b * A.P + c) * A.hw + p], s);
-        }
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        __syncthreads();
-        if ((tid & 63) == 0) s_red[tid >> 6] = s;
-        __syncthreads();
-        total += ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    __shared__ float s_red[3][4];
+    const int c = blockIdx.x, which = blockIdx.y, t = blockIdx.z, tid = threadIdx.x;
+    int hs[3], os_[3], gs[3], ns = 0;
+    float c1[3], c2[3], c3[3];
+    for (int hd = 0; hd < 3; hd++)
+        if ((hd == 0) == (which == 1))
+            for (int o = 0; o < A.head[hd].oc; o++) { hs[ns] = hd; os_[ns] = o; ns++; }
+    for (int e = 0; e < ns; e++) {
+        gs[e] = lch_group_of(A, hs[e], t);
+        const float* cf = A.coef + ((size_t)gs[e] * LCH_MAXOC + os_[e]) * 5;
+        c1[e] = cf[2]; c2[e] = cf[3]; c3[e] = cf[4];
     }
-    if (tid == 0) A.grads[H.w1_off + o * A.P + c] = total;
+    const float* F = A.groups[gs[0]].F;
+    float s[3] = {0.f, 0.f, 0.f};
+    const int n = A.B * A.hw;
+    for (int i = tid; i < n; i += 256) {
+        const int b = i / A.hw, p = i - b * A.hw;
+        const float f = F[((size_t)b * A.P + c) * A.hw + p];
+        for (int e = 0; e < ns; e++) {
+            const size_t ix = (((size_t)gs[e] * A.B + b) * LCH_MAXOC + os_[e]) * A.hw + p;
+            s[e] = fmaf(fmaf(c1[e], A.dzb[ix], fmaf(c2[e], A.u[ix], c3[e])), f, s[e]);
+        }
+    }
+    for (int e = 0; e < ns; e++) {
+        float v = s[e];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if ((tid & 63) == 0) s_red[e][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (int e = 0; e < ns; e++)
+            A.wpart[(size_t)t * A.hp_total + A.hp_off[hs[e]] + os_[e] * A.P + c] = ((s_red[e][0] + s_red[e][1]) + s_red[e][2]) + s_red[e][3];
 }
 
-// dlw[n][k] = sum_{t, b} dlogit[n] feat[k]; dlb[n] = sum dlogit[n].  grid (ceil(nf / 256), n_out, 3): thread = feature k
+// dlw_t[n][k] = sum_b dlogit[n] feat[k]; dlb_t[n] = sum_b dlogit[n].  grid (ceil(nf / 256), ceil(n_max / LCH_DLN), 3 K): thread = feature k x
+// LCH_DLN outputs n of one (head, step): a feature value is loaded once for LCH_DLN products, the dlogit values are wave-uniform loads
+constexpr int LCH_DLN = 4;
 __global__ __launch_bounds__(256) void k_lch_dlin(const LchArgs A) {
-    const int hd = blockIdx.z, n = blockIdx.y;
+    const int hd = blockIdx.z % 3, t = blockIdx.z / 3, n0 = blockIdx.y * LCH_DLN;
     const LchHead H = A.head[hd];
-    if (n >= H.n_out) return;
+    if (n0 >= H.n_out) return;
     const int nf = H.oc * A.hw, k = blockIdx.x * 256 + threadIdx.x;
-    float s = 0.0f, sb = 0.0f;
-    for (int t = 0; t < A.K; t++) {
-        int g = -1;
-        for (int q = 0; q < A.ngroups; q++)
-            if (A.groups[q].head == hd && A.groups[q].t == t) g = q;
-        if (g < 0) continue;
-        for (int b = 0; b < A.B; b++) {
-            const float dl = A.dlogit[((size_t)g * A.B + b) * A.n_max + n];
-            sb += dl;
-            if (k < nf) s = fmaf(dl, A.feat[((size_t)g * A.B + b) * LCH_MAXOC * A.hw + k], s);
+    const int kc = k < nf ? k : nf - 1;
+    const int g = lch_group_of(A, hd, t);
+    float s[LCH_DLN], sb[LCH_DLN];
+#pragma unroll
+    for (int u = 0; u < LCH_DLN; u++) { s[u] = 0.0f; sb[u] = 0.0f; }
+    for (int b = 0; b < A.B; b++) {
+        const float f = A.feat[((size_t)g * A.B + b) * LCH_MAXOC * A.hw + kc];
+        const float* dl = A.dlogit + ((size_t)g * A.B + b) * A.n_max + n0;
+#pragma unroll
+        for (int u = 0; u < LCH_DLN; u++) {
+            const float d = n0 + u < H.n_out ? dl[u] : 0.0f;
+            s[u] = fmaf(d, f, s[u]);
+            sb[u] += d;
         }
     }
-    if (k < nf) A.grads[H.lw_off + (size_t)n * nf + k] = s;
-    if (k == 0) A.grads[H.lb_off + n] = sb;
+    float* part = A.wpart + (size_t)t * A.hp_total + A.hp_off[hd] + H.oc * A.P;
+#pragma unroll
+    for (int u = 0; u < LCH_DLN; u++) {
+        if (n0 + u >= H.n_out) continue;
+        if (k < nf) part[(size_t)(n0 + u) * nf + k] = s[u];
+        if (k == 0) part[(size_t)H.n_out * nf + n0 + u] = sb[u];
+    }
+}
+
+// the heads' weight gradients: per-step partials summed in step order
+__global__ __launch_bounds__(256) void k_lch_wsum(const LchArgs A) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.hp_total) return;
+    int hd = 2;
+    if (i < A.hp_off[1]) hd = 0;
+    else if (i < A.hp_off[2]) hd = 1;
+    const LchHead H = A.head[hd];
+    const int l = i - A.hp_off[hd], nf = H.oc * A.hw, nw1 = H.oc * A.P, nlw = H.n_out * nf;
+    float s = 0.0f;
+    for (int t = 0; t < A.K; t++) s += A.wpart[(size_t)t * A.hp_total + i];
+    if (l < nw1) A.grads[H.w1_off + l] = s;
+    else if (l < nw1 + nlw) A.grads[H.lw_off + (l - nw1)] = s;
+    else A.grads[H.lb_off + (l - nw1 - nlw)] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
