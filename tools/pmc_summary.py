@@ -40,7 +40,7 @@ def main():
             per[name][r['Counter_Name']].append(float(r['Counter_Value']))
     pm = {}
     for k, cs in per.items():
-        if not k.startswith(('void mz::', 'mz::', 'void mzl::', 'mzl::')):
+        if not k.startswith(('void mz::', 'mz::', 'void mzl::', 'mzl::', 'void mzlc::', 'mzlc::')):
             continue
         e = {c: dict(launches=len(v), mean_per_launch=sum(v) / len(v)) for c, v in cs.items()}
         if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:

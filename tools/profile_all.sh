@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, trace args, pmc args [, program (default bench.py)]
   local W=$1 TARGS=$2 PARGS=$3 PROG=${4:-bench.py}
   mkdir -p $OUT/$W
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 $R/$PROG $TARGS > $OUT/$W/trace.log 2>&1
+  timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 $R/$PROG $TARGS > $OUT/$W/trace.log 2>&1
   local i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES"; do
     i=$((i+1))
@@ -27,6 +27,7 @@ for W in "$@"; do
     c3) run c3 "--workload c3 --steps 10 --warmup 2 --no-cpu-baseline --no-sustained" "--workload c3 --steps 4 --warmup 1 --preheat 0 --no-cpu-baseline --no-sustained" ;;
     c4) run c4 "--workload c4 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c4 --steps 1 --warmup 0 --sims 3 --no-cpu-baseline --no-sustained" ;;
     learner) run learner "--batches 128,4096 --no-torch --iters 100" "--batches 128,4096 --no-torch --iters 10" tools/learner_bench.py ;;
+    convlearner) run convlearner "--hip-only --iters 5" "--hip-only --iters 1" tools/conv_learner_bench.py ;;
     lunar) run lunar "--workload lunar --steps 10 --warmup 2 --no-cpu-baseline" "--workload lunar --steps 4 --warmup 1 --preheat 0 --no-cpu-baseline" ;;
     c5) run c5 "--workload c5 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c5 --steps 1 --warmup 0 --sims 2 --no-cpu-baseline --no-sustained" ;;
   esac
