@@ -76,7 +76,8 @@ const char* mzl_last_error(void);
  *              MZL_CHAIN_MIN_TILES / MZL_CHAIN_MAX_TILES=n (batch thresholds between the register-resident, streaming and persistent-chain
  *              builds), MZL_STAMPS=1 (allocate the cycle-stamp buffer read by tools/dev/learn_stamps.py)
  *   conv nets: MZLC_NO_PAIR=1 (one tower job per launch instead of the dynamics / prediction towers of a step paired), MZLC_NO_SIDE=1 (the
- *              generic conv build instead of the 15 x 15 one) */
+ *              generic conv build instead of the 15 x 15 one), MZLC_NO_FUSE_APPLY=1 (every block output by its own elementwise kernel instead
+ *              of the next conv's staging) */
 
 int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out);
 int mzl_destroy(mz_learner* h);

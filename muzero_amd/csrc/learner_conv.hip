@@ -68,6 +68,7 @@ struct mzlc_learner {
     int device = 0, num_cus = 256;
     int P = 0, C0 = 0, A = 0, R = 0, K = 0, h = 0, w = 0, hw = 0, maxB = 0;
     int npt = 15, G = 1, qstride = 0;
+    bool fuse_apply = true;  // block outputs formed in the next conv's staging (MZLC_NO_FUSE_APPLY=1 at create: one k_lc_apply per block)
     bool side15 = false;  // the 15 x 15 build of the conv kernel (geometry as compile-time constants); MZLC_NO_SIDE=1 at create: the generic build
     int P4 = 0, nsteps = 0, SPY = 0, SPX = 0;
     std::vector<LayerInfo> layers;
@@ -255,7 +256,9 @@ struct Sched {
         g.B = B; g.h = h->h; g.w_img = h->w; g.P4 = h->P4; g.nsteps = h->nsteps; g.SPY = h->SPY; g.SPX = h->SPX;
         g.co_blocks = cdiv(g.co_tiles, 2);
         const int ci_blocks = cdiv(g.ci_tiles, 2);
-        int chunks = (lane_pairs ? 1 : 2) * h->num_cus / (g.co_blocks * ci_blocks);  // two workgroups per CU in all (a paired launch brings the other half)
+        // two workgroups per CU in all: a paired launch brings the other half; the first conv blocks (action planes: the dynamics tower's extra
+        // ops) are never paired
+        int chunks = ((lane_pairs && !action) ? 1 : 2) * h->num_cus / (g.co_blocks * ci_blocks);
         chunks = chunks < 1 ? 1 : (chunks > B ? B : chunks);
         g.ipw = cdiv(B, chunks);
         chunks = cdiv(B, g.ipw);
@@ -282,19 +285,37 @@ struct Sched {
             cur = a.x[0];
             li = 1; xi = 1;
         }
+        // A block's output x' = relu(a2 y2 + b2 + x) is formed by the NEXT block's first conv while it stages its input (IN_BNRES) and written
+        // through once (mat_out): the residual, the weight gradient and the ReLU masks read it later.  Only the tower's last block output has no
+        // consumer conv: k_lc_apply materialises it.  (h->fuse_apply == false: one k_lc_apply per block, the round's first form; same bits.)
+        const float* pend_y = nullptr;      // y2 of the previous block, if its output has not been materialised yet
+        const float* pend_coef = nullptr;
+        const float* pend_res = nullptr;
+        float* pend_out = nullptr;
         for (int r = 0; r < h->R; r++) {
             const int l1 = li + 2 * r, l2 = l1 + 1;
             const LayerInfo &L1 = h->layers[t.layers[l1]], &L2 = h->layers[t.layers[l2]];
             LcConv c = conv_base(L1, false);
-            c.in0 = cur; c.in_mode = IN_IDENT; c.out = a.y[l1]; c.stat_mode = ST_FWD; c.stat_part = h->stat[lane];
+            if (pend_y) {
+                c.in0 = pend_y; c.in1 = pend_res; c.coef = pend_coef; c.in_mode = IN_BNRES; c.mat_out = pend_out;
+                cur = pend_out;
+                pend_y = nullptr;
+            } else {
+                c.in0 = cur; c.in_mode = IN_IDENT;
+            }
+            c.out = a.y[l1]; c.stat_mode = ST_FWD; c.stat_part = h->stat[lane];
             ops.push_back(op_conv(c));
             ops.push_back(op_bnfwd(L1, a.fcoef[l1], a.save[l1]));
             LcConv d = conv_base(L2, false);
             d.in0 = a.y[l1]; d.in_mode = IN_BNRELU; d.coef = a.fcoef[l1]; d.out = a.y[l2]; d.stat_mode = ST_FWD; d.stat_part = h->stat[lane];
             ops.push_back(op_conv(d));
             ops.push_back(op_bnfwd(L2, a.fcoef[l2], a.save[l2]));
-            ops.push_back(op_apply(a.y[l2], cur, a.fcoef[l2], a.x[xi + r]));
-            cur = a.x[xi + r];
+            if (h->fuse_apply && r + 1 < h->R) {
+                pend_y = a.y[l2]; pend_coef = a.fcoef[l2]; pend_res = cur; pend_out = a.x[xi + r];
+            } else {
+                ops.push_back(op_apply(a.y[l2], cur, a.fcoef[l2], a.x[xi + r]));
+                cur = a.x[xi + r];
+            }
         }
         return const_cast<float*>(cur);
     }
@@ -352,6 +373,7 @@ template <int NPT, int SIDE>
 void launch_conv(int mode, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
     if (mode == IN_IDENT) hipLaunchKernelGGL((k_lc_conv<NPT, IN_IDENT, SIDE>), grid, dim3(256), lds, st, pj);
     else if (mode == IN_BNRELU) hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNRELU, SIDE>), grid, dim3(256), lds, st, pj);
+    else if (mode == IN_BNRES) hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNRES, SIDE>), grid, dim3(256), lds, st, pj);
     else hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNBWD, SIDE>), grid, dim3(256), lds, st, pj);
 }
 template <int NPT, int SIDE>
@@ -359,6 +381,7 @@ hipError_t conv_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_IDENT, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_BNRELU, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_BNBWD, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_BNRES, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 
@@ -492,6 +515,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->P = cfg->num_planes; h->C0 = cfg->in_channels; h->A = cfg->num_actions; h->R = cfg->num_res_blocks; h->K = cfg->unroll_steps;
     h->h = cfg->board_h; h->w = cfg->board_w; h->hw = h->h * h->w; h->maxB = cfg->max_batch;
     h->paired = !getenv("MZLC_NO_PAIR");
+    h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
     if (h->C0 < 1 || h->h < 1 || h->w < 1 || h->R < 1 || h->P < 1) return bad("bad conv-net geometry (in_channels, board_h, board_w, num_res_blocks, num_planes)");
     if (cfg->in_dim != h->C0 * h->hw) return bad("in_dim must equal in_channels * board_h * board_w");

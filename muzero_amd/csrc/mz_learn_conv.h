@@ -6,7 +6,8 @@
 //   k_lc_gather        replay rows -> dense float32 observations [B][C0][hw], actions [K][B]
 //   k_lc_conv<NPT>     3x3 convolution as implicit GEMM on v_mfma_f32_16x16x4_f32, used for BOTH directions:
 //                        forward   y = conv(f(x))         f applied while staging: identity | relu(a x + b) (the previous layer's BatchNorm + ReLU,
-//                                                          never materialised) | action planes generated on the fly (network.py:440-444)
+//                                                          never materialised) | relu(a y2 + b + x) (the previous BLOCK's output, written through once) |
+//                                                          action planes generated on the fly (network.py:440-444)
 //                                  epilogue: per-channel partial sums (sum y, sum y^2) of the batch statistics
 //                        dgrad     g = convT(dy)          dy = c1 dz + c2 y + c3 (BatchNorm backward, applied while staging from TWO tensors),
 //                                                          weights = the transposed / tap-flipped packed copy
@@ -36,7 +37,7 @@ namespace mzlc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum { IN_IDENT = 0, IN_BNRELU = 1, IN_BNBWD = 2 };
+enum { IN_IDENT = 0, IN_BNRELU = 1, IN_BNBWD = 2, IN_BNRES = 3 };  // IN_BNRES: relu(c1 x0 + c2 x1 + c3) -- a block output relu(a y2 + b + x) formed while staging
 enum { ST_NONE = 0, ST_FWD = 1, ST_BWD = 2 };
 
 __device__ __forceinline__ int lc_idiv(int p, float rcp_d) { return (int)(((float)p + 0.5f) * rcp_d); }  // exact for 0 <= p < 4096 (index arithmetic)
@@ -65,7 +66,9 @@ struct Pair {
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct LcConv {
     const float* in0;      // [B][cin_real][hw]: x | y (IN_BNRELU) | dz (IN_BNBWD)
-    const float* in1;      // IN_BNBWD: y
+    const float* in1;      // IN_BNBWD: y; IN_BNRES: the residual x
+    float* mat_out;        // IN_BNRES / IN_BNRELU: the staged (transformed) input is also WRITTEN here by the channel-slice-0 workgroups (the block output the
+                           // residual, the weight gradient and the masks need materialised), or null
     const float* coef;     // [3][cpad_in]: (a, b, -) | (c1, c2, c3)
     const int* action;     // [B] or null: channels cin_real .. cin - 1 are the action planes
     const float* w;        // packed [co_tiles][n_cb][9][64][4]: element [lane = (q, j)][i] = W[co = 16 ct + j][ci = 16 cb + 4 i + q][tap]
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const int img0 = by * L.G;
     const int QP = (hw + 3) >> 2;
     const float r_qp = 1.0f / (float)QP, r_iw = 1.0f / (float)L.w_img, r_hw = 1.0f / (float)hw;
-    const __amdgpu_buffer_rsrc_t rs_in0 = mkrs(L.in0), rs_in1 = mkrs(L.in1 ? L.in1 : L.in0);
+    const __amdgpu_buffer_rsrc_t rs_in0 = mkrs(L.in0), rs_in1 = mkrs(L.in1 ? L.in1 : L.in0), rs_mat = mkrs(L.mat_out ? L.mat_out : L.in0);
     // ---- staging plan: lane t of every wave owns pixel quad t of the group; wave w the channels {w, 4 + w, 8 + w, 12 + w} of each block ----
     const int sg = lc_idiv(lane, r_qp), qd = lane - sg * QP, p0 = qd * 4, bimg = img0 + sg;
     const bool w_ok = lane < L.G * QP && bimg < L.B;
@@ -116,15 +119,11 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
         w_spos[e] = (w_ok && pp < hw) ? ((sg < L.G ? sg : 0) * plane + (py + 1) * siw + px + 1) * 4 + wave * L.qstride : -1;
         w_pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
     }
-    for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers, halo included
-    if (L.in_mode != IN_IDENT)
-        for (int i = tid; i < 3 * L.cpad_in; i += 256) s_coef[i] = L.coef[i];
-    __syncthreads();
     float4 sv0[4], sv1[4];  // [i]: channel 4 i + wave of the block in flight, pixels p0 .. p0 + 3
     auto fetch = [&](int cb, int i) {
         const int ch = cb * 16 + 4 * i + wave, chc = ch < L.cin_real ? ch : 0;
         sv0[i] = ld4(rs_in0, w_voff, chc * hw * (int)sizeof(float));
-        if (L.in_mode == IN_BNBWD) sv1[i] = ld4(rs_in1, w_voff, chc * hw * (int)sizeof(float));
+        if (L.in_mode == IN_BNBWD || L.in_mode == IN_BNRES) sv1[i] = ld4(rs_in1, w_voff, chc * hw * (int)sizeof(float));
     };
     auto transform_store = [&](int cb, int buf) {
         float v[4][4];
@@ -145,6 +144,14 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
                     const float y[4] = {sv1[i].x, sv1[i].y, sv1[i].z, sv1[i].w};
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[i][e] = fmaf(c1, x[e], fmaf(c2, y[e], c3));
+                } else if (L.in_mode == IN_BNRES) {  // relu(a y2 + b + x): the op order of k_lc_apply (same bits)
+                    const float a = s_coef[ch], b = s_coef[L.cpad_in + ch];
+                    const float r[4] = {sv1[i].x, sv1[i].y, sv1[i].z, sv1[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float t = fmaf(a, x[e], b) + r[e];
+                        v[i][e] = t > 0.0f ? t : 0.0f;
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[i][e] = x[e];
@@ -163,6 +170,23 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
 #pragma unroll
         for (int e = 0; e < 4; e++)
             if (w_spos[e] >= 0) *reinterpret_cast<float4*>(d + w_spos[e]) = make_float4(v[0][e], v[1][e], v[2][e], v[3][e]);
+        if ((MODE == IN_BNRES || MODE == IN_BNRELU) && L.mat_out && blockIdx.z == 0 && w_ok) {  // write-through: every (image, channel, pixel) is staged once per slice
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int ch = cb * 16 + 4 * i + wave;
+                if (ch < L.cin_real) {
+                    float* o = L.mat_out + ((size_t)cimg * L.cin_real + ch) * hw + p0;
+                    if (p0 + 3 < hw) {  // (dword-aligned 16-byte store, like the epilogue's)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[i][0]), __float_as_uint(v[i][1]), __float_as_uint(v[i][2]), __float_as_uint(v[i][3])},
+                                                               rs_mat, w_voff, ch * hw * (int)sizeof(float), 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (p0 + e < hw) o[e] = v[i][e];
+                    }
+                }
+            }
+        }
     };
     // ---- A-operand rows of this lane: pixel slot p = pt * 16 + j -> image g of the group, pixel (py, px) ----
     int off[NPT];
@@ -183,14 +207,19 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     };
     constexpr int WD = (NPT <= 9) ? 9 : 3;
     float4 wr[WD];
+    // the first weights and the first slab are requested BEFORE the LDS fill below: their latency runs under it
 #pragma unroll
     for (int s0 = 0; s0 < WD - 1; s0++) wr[s0] = wload(s0);
 #pragma unroll
     for (int i = 0; i < 4; i++) fetch(0, i);
+    for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers, halo included
+    if (L.in_mode != IN_IDENT)
+        for (int i = tid; i < 3 * L.cpad_in; i += 256) s_coef[i] = L.coef[i];
+    __syncthreads();
     transform_store(0, 0);
     __syncthreads();
     float4 xr[3];
-    const int FL = L.in_mode == IN_BNBWD ? 2 : 1;  // staging loads per tap (taps 0..3)
+    const int FL = (L.in_mode == IN_BNBWD || L.in_mode == IN_BNRES) ? 2 : 1;  // staging loads per tap (taps 0..3)
     for (int cb = 0; cb < L.n_cb; cb++) {
         const float* sb = slab + (cb & 1) * bufsz;
         xr[0] = *reinterpret_cast<const float4*>(sb + off[0]);

@@ -137,7 +137,7 @@ def _f64_reference(net, tr, w, dev):
 # board, planes, blocks, observation planes, batch, int8 states
 GEOMETRIES = [(3, 16, 2, 9, 4, False), (5, 8, 1, 5, 7, False), (9, 8, 1, 9, 6, False), (9, 32, 3, 9, 64, True), (6, 128, 1, 2, 17, True), (7, 40, 1, 4, 33, False),
               (11, 8, 2, 9, 9, False), (13, 24, 1, 3, 5, False), (15, 16, 1, 9, 3, False), (15, 32, 2, 9, 10, True), (4, 16, 1, 3, 5, False), (8, 16, 1, 2, 6, False),
-              (10, 8, 1, 2, 4, False), (12, 16, 1, 2, 3, False), (14, 8, 1, 3, 2, False), (15, 8, 1, 2, 2, False)]
+              (10, 8, 1, 2, 4, False), (12, 16, 1, 2, 3, False), (14, 8, 1, 3, 2, False), (15, 8, 1, 2, 2, False), (5, 256, 1, 3, 6, False)]
 
 
 KINKS = {}
@@ -167,6 +167,31 @@ def test_gradient_matches_float64_autograd(board, planes, blocks, chan, B, int8_
     for k, v in sd_d.items():
         if 'running' in k:
             assert float((v - sd[k].double()).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+        if 'num_batches_tracked' in k:
+            assert int(v) == int(sd[k]), k
+
+
+@pytest.mark.parametrize('K', [1, 2, 3, 8])
+def test_other_unroll_lengths(K):
+    """Every reference configuration unrolls 5 steps; the kernels take any K <= 32 (the heads' grouping, the accumulate-in-step-order rule and the
+    0.5 / (1 / K) gradient scales all depend on it)."""
+    dev = torch.device('cuda', 0)
+    net, A = _net(5, 16, 1, 3, 300 + K, dev)
+    net.train()
+    rs = np.random.RandomState(K)
+    B = 5
+    tr = _batch(rs, B, (3, 5, 5), A, K=K)
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    hl = _hip(net, dev, B, K=K)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
+    tol = 8e-2 if closest < 2e-6 else 2e-3
+    for k, g in gd.items():
+        scale = max(1e-8, float(g.abs().max()))
+        assert float((g - hl.grad_views[k].double()).abs().max()) <= tol * scale, (k, K, closest)
+    sd = net.state_dict()
+    for k, v in sd_d.items():
         if 'num_batches_tracked' in k:
             assert int(v) == int(sd[k]), k
 
