@@ -68,6 +68,7 @@ struct mzlc_learner {
     int device = 0, num_cus = 256;
     int P = 0, C0 = 0, A = 0, R = 0, K = 0, h = 0, w = 0, hw = 0, maxB = 0;
     int npt = 15, G = 1, qstride = 0;
+    bool xcd_remap = true;   // k_lc_wgrad: the blocks of one image chunk on one XCD (MZLC_NO_XCD_REMAP=1 at create: launch order)
     bool fuse_apply = true;  // block outputs formed in the next conv's staging (MZLC_NO_FUSE_APPLY=1 at create: one k_lc_apply per block)
     bool side15 = false;  // the 15 x 15 build of the conv kernel (geometry as compile-time constants); MZLC_NO_SIDE=1 at create: the generic build
     int P4 = 0, nsteps = 0, SPY = 0, SPX = 0;
@@ -416,6 +417,9 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (b) pj.b = b->wg;
             int x = cdiv(a->wg.ci_tiles, 2);
             if (b && cdiv(b->wg.ci_tiles, 2) > x) x = cdiv(b->wg.ci_tiles, 2);
+            // a chunk's blocks on one XCD (k_lc_wgrad): needs the same block grid in both jobs and a group count the 8 XCDs divide
+            const int groups = (ya + yb) / a->wg.co_blocks;
+            pj.remap = (h->xcd_remap && (!b || (b->wg.co_blocks == a->wg.co_blocks && cdiv(b->wg.ci_tiles, 2) == cdiv(a->wg.ci_tiles, 2))) && groups % 8 == 0) ? 1 : 0;
             if (a->wg.action || (b && b->wg.action)) hipLaunchKernelGGL(k_lc_wgrad<true>, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
             else hipLaunchKernelGGL(k_lc_wgrad<false>, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
             break;
@@ -516,6 +520,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->h = cfg->board_h; h->w = cfg->board_w; h->hw = h->h * h->w; h->maxB = cfg->max_batch;
     h->paired = !getenv("MZLC_NO_PAIR");
     h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
+    h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
     if (h->C0 < 1 || h->h < 1 || h->w < 1 || h->R < 1 || h->P < 1) return bad("bad conv-net geometry (in_channels, board_h, board_w, num_res_blocks, num_planes)");
     if (cfg->in_dim != h->C0 * h->hw) return bad("in_dim must equal in_channels * board_h * board_w");

@@ -56,6 +56,7 @@ template <typename J>
 struct Pair {
     J a, b;
     int na;  // workgroup rows (blockIdx.y) of job a; rows of job b follow
+    int remap;  // k_lc_wgrad: XCD-aware placement of the workgroups (see there); 0: the launch order
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -363,9 +364,21 @@ struct LcWgrad {
 // transform and the LDS writes are VALU / LDS issue) runs under the other's MFMAs.
 template <bool ACT>
 __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
-    const bool second = (int)blockIdx.y >= PJ.na;
+    // XCD-aware placement.  The 8 XCDs take workgroups round-robin by linear id, each with its own 4 MB L2; the co_blocks x ci_blocks workgroups
+    // of one image chunk read the SAME dz / y / x planes (each plane is staged by every block of the other channel dimension).  In launch order
+    // they land on eight different XCDs and every one fetches its own copy from the MALL: 270 MB per paired launch against 88 MB algorithmic
+    // (PMC, profiles/round5/convlearner).  Remapped, a chunk's blocks share an XCD: id L -> xcd = L & 7, group = xcd + 8 * ((L >> 3) / blocks).
+    int bx = blockIdx.x, byy = blockIdx.y;
+    if (PJ.remap) {
+        const int X = gridDim.x, Yc = PJ.a.co_blocks, nblocks = X * Yc;
+        const int Lid = (int)blockIdx.x + X * (int)blockIdx.y, s = Lid >> 3;
+        const int g = (Lid & 7) + 8 * (s / nblocks), blk = s % nblocks;
+        bx = blk % X;
+        byy = g * Yc + blk / X;
+    }
+    const bool second = byy >= PJ.na;
     const LcWgrad L = second ? PJ.b : PJ.a;
-    const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
+    const int by = second ? byy - PJ.na : byy;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm = reinterpret_cast<float*>(smem);
     const int ybuf = 32 * L.SPY, xbuf = 32 * L.SPX;
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     float* s_xc = s_dc + 96;        // [2][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, i16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
-    const int cib = blockIdx.x, cob = by % L.co_blocks, chunk = by / L.co_blocks;
+    const int cib = bx, cob = by % L.co_blocks, chunk = by / L.co_blocks;
     if (cib * 2 >= L.ci_tiles) return;  // (a paired job with fewer input-channel blocks; workgroup-uniform, before any barrier)
     const int hw = L.h * L.w_img, QP = (hw + 3) >> 2;
     const float r_iw = 1.0f / (float)L.w_img;

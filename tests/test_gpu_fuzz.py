@@ -452,3 +452,81 @@ def test_random_net_inference_api_bit_exact_vs_oracle(oracle, i):
         np.testing.assert_array_equal(pi2[b], opi2, err_msg=str(case))
         assert reward[b] == np.float32(orw) and value2[b] == np.float32(ov2), case
     p.close()
+
+
+CONV_LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_CONV_LEARN_CASES', '8'))
+
+
+def _draw_conv_learn_case(i):
+    rs = np.random.RandomState(7700 + i + 100000 * OFFSET)
+    board = int(rs.choice([3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
+    planes = int(rs.choice([8, 16, 24, 32, 40, 64, 128]))
+    budget = 2_500_000  # elements of one activation tensor x layers: keeps a case (and its float64 autograd twin) under a second
+    blocks = int(rs.choice([1, 1, 2, 3]))
+    K = int(rs.choice([5, 5, 1, 2, 3, 6]))
+    B = int(rs.choice([1, 2, 5, 9, 16, 23, 40]))
+    while B > 1 and B * planes * board * board * (1 + 2 * blocks) * (1 + 2 * K) > budget * 8:
+        B = max(1, B // 2)
+    return dict(board=board, planes=planes, blocks=blocks, chan=int(rs.randint(1, 10)), K=K, B=B, int8=bool(rs.rand() < 0.5), weights=bool(rs.rand() < 0.6),
+                seed=int(rs.randint(1 << 30)), opt=dict(lr=float(rs.choice([1e-3, 2e-2])), wd=float(rs.choice([0.0, 1e-4])), clip=float(rs.choice([0.0, 0.5, 40.0]))))
+
+
+@pytest.mark.parametrize('i', range(CONV_LEARN_CASES_N))
+def test_random_conv_learner_configuration_matches_float64_autograd(i):
+    """Round 5: the conv learner's kernels (csrc/mz_learn_conv.h) over board sizes 3-15 (every pixel tiling, images per workgroup, pitch layout of the
+    weight gradient), plane counts on and off the 16-channel tile, 1-3 blocks, unroll 1-6, ragged batches, int8 / float states, int8 / int16 actions,
+    with / without importance weights: loss, priorities, every gradient and the BatchNorm running statistics against float64 PyTorch-ROCm autograd; then
+    one optimizer step with drawn Adam / clip settings against torch.optim.Adam.  Kinked batches (a float64 pre-activation within 2e-6 of a ReLU
+    boundary, tests/test_gpu_conv_learner.py) are held to 8e-2 instead of 2e-3."""
+    import copy
+
+    import torch
+
+    from muzero_amd import learner
+    from muzero_amd.hip_learner import HipLearner
+    from test_gpu_conv_learner import _batch, _f64_reference, _net, _ring
+
+    c = _draw_conv_learn_case(i)
+    dev = torch.device('cuda', 0)
+    net, A = _net(c['board'], c['planes'], c['blocks'], c['chan'], 4000 + i, dev)
+    net.train()
+    rs = np.random.RandomState(c['seed'])
+    B, K, shape = c['B'], c['K'], (c['chan'], c['board'], c['board'])
+    tr = _batch(rs, B, shape, A, K=K, int8_state=c['int8'])
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32) if c['weights'] else np.ones(B, np.float32)
+    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    o = c['opt']
+    hl = HipLearner(net, dev, K, B + int(rs.randint(0, 5)), lr=o['lr'], weight_decay=o['wd'], clip_grad=o['clip'] > 0, max_grad_norm=o['clip'] or 40.0)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev) if c['weights'] else None, B)
+    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d)), c
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=str(c))
+    kinked = closest < 2e-6
+    tol = 8e-2 if kinked else 2e-3
+    for k, g in gd.items():
+        scale = max(1e-8, float(g.abs().max()))
+        err = float((g - hl.grad_views[k].double()).abs().max())
+        assert err <= tol * scale, (c, k, err, scale, closest)
+    sd = net.state_dict()
+    for k, v in sd_d.items():
+        if 'running' in k:
+            assert float((v - sd[k].double()).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), (c, k)
+        if 'num_batches_tracked' in k:
+            assert int(v) == int(sd[k]), (c, k)
+    if kinked:
+        return  # (the optimizer step below compares against the float64 gradient)
+    # one Adam step from the float64 gradient with torch's own optimizer on a float64 twin of the weights
+    twin = copy.deepcopy(net).double()
+    for (k, p) in twin.named_parameters():
+        p.grad = gd[k].clone()
+    opt = torch.optim.Adam(twin.parameters(), lr=o['lr'], weight_decay=o['wd'])
+    if o['clip'] > 0:
+        torch.nn.utils.clip_grad_norm_(twin.parameters(), o['clip'])
+    opt.step()
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    hl.apply()
+    for (k, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+        moved = float((q - before[k].double()).abs().max())
+        # Adam's first step moves every weight by ~lr whatever the gradient's size: elements whose gradient is at rounding distance from 0 may go
+        # the other way in float32 -- a mean bar for the tensor, and a 2 lr bar for single elements
+        d = (p.double() - q).abs()
+        assert float(d.mean()) <= 0.02 * max(moved, 1e-12) + 1e-7 and float(d.max()) <= 2.2 * o['lr'] + 1e-6, (c, k, float(d.mean()), float(d.max()), moved)

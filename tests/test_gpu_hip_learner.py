@@ -360,3 +360,28 @@ def test_resume_from_a_checkpoint_continues_the_same_run():
     oa, oc = hl_a.optimizer.state_dict(), hl_c.optimizer.state_dict()
     for i in oa['state']:
         assert torch.equal(oa['state'][i]['exp_avg'], oc['state'][i]['exp_avg']) and torch.equal(oa['state'][i]['exp_avg_sq'], oc['state'][i]['exp_avg_sq'])
+
+
+def test_load_state_dict_through_the_learner_reaches_the_inference_engine():
+    """HipLearner.load_state_dict / adopt write the master weights through views of the flat vector, which bumps neither the
+    parameters' version counters nor -- until round 5 -- the module's weights epoch: initial_inference / uct_search on the adopted module kept
+    serving the previous weights.  Now commit() bumps the epoch: inference after load_state_dict equals a fresh net loaded with the same weights."""
+    dev = torch.device('cuda', 0)
+    net = build_mlp(mlp_case('cartpole')).to(dev)
+    other = build_mlp(('other', (4, 5), 2, 512, 31, 31, 64, 99)).to(dev)
+    x = torch.rand(1, 4, 5, device=dev)
+    before = net.initial_inference(x)  # binds the module's engine to the current weights
+    hl = _hip(net, dev, 8)
+    assert net.initial_inference(x).value == before.value
+    hl.load_state_dict(other.state_dict())
+    after, want = net.initial_inference(x), other.initial_inference(x)
+    assert after.value != before.value
+    assert after.value == want.value and np.array_equal(after.pi_probs, want.pi_probs) and np.array_equal(after.hidden_state, want.hidden_state)
+    # adopt() on a module whose engine is already bound: same rule
+    third = build_mlp(('third', (4, 5), 2, 512, 31, 31, 64, 123)).to(dev)
+    ref3 = third.initial_inference(x)
+    fresh = build_mlp(mlp_case('cartpole')).to(dev)
+    _ = fresh.initial_inference(x)
+    hl2 = _hip(fresh, dev, 8)
+    hl2.load_state_dict(third.state_dict())
+    assert fresh.initial_inference(x).value == ref3.value
