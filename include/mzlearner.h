@@ -1,6 +1,6 @@
 /*
  * mzlearner.h -- C ABI of the MI355X-native MuZero learner step (libmzlearner_hip.so): the MLP nets (MuZeroMLPNet, network.py:236-267)
- * and -- round 5 -- the board-game conv nets (MuZeroBoardGameNet, network.py:540-574: residual towers with train-mode BatchNorm).
+ * and -- round 5 -- the conv nets (MuZeroBoardGameNet, network.py:540-574, and MuZeroAtariNet, :501-537: residual towers with train-mode BatchNorm).
  *
  * Row f2 of SURVEY.md section 8: what the reference does per training step in `run_training` (pipeline.py:238-255) --
  * `calc_loss` (:541-612) + `loss.backward()` + optional `clip_grad_norm_` (:246-247) + `optimizer.step()` (torch.optim.Adam with
@@ -29,6 +29,7 @@ extern "C" {
 
 #define MZL_NET_MLP 0    /* MuZeroMLPNet (network.py:236-267); kernels: muzero_amd/csrc/mz_learn.h */
 #define MZL_NET_BOARD 1  /* MuZeroBoardGameNet (network.py:540-574); kernels: muzero_amd/csrc/mz_learn_conv.h */
+#define MZL_NET_ATARI 2  /* MuZeroAtariNet (network.py:501-537): the same kernels; the 96 x 96 representation (network.py:312-353) on 12 x 12 tiles */
 
 /* The network's constructor arguments (MuZeroMLPNet network.py:239-247 | MuZeroBoardGameNet :543-549) + the batch geometry of calc_loss
  * (pipeline.py:541-575). */
@@ -42,10 +43,10 @@ typedef struct {
     int32_t unroll_steps;         /* K, config.py:87 */
     int32_t max_batch;            /* capacity: mzl_grad accepts any batch <= max_batch */
     int32_t grad_slices;          /* >= 1: the weight-gradient kernel splits its reduction over this many workgroup rows (large batches); conv nets: 1 */
-    int32_t net_kind;             /* MZL_NET_MLP | MZL_NET_BOARD */
-    /* MZL_NET_BOARD only (hidden_dim is unused there; both support sizes are 1: squared-error heads, network.py:551): */
-    int32_t in_channels;          /* planes of the observation (network.py:549 input_shape[0]) */
-    int32_t board_h, board_w;     /* board_h * board_w <= 240 */
+    int32_t net_kind;             /* MZL_NET_MLP | MZL_NET_BOARD | MZL_NET_ATARI */
+    /* conv nets only (hidden_dim is unused there; the board net's support sizes are 1: squared-error heads, network.py:551): */
+    int32_t in_channels;          /* planes of the observation (network.py:549 / :508 input_shape[0]) */
+    int32_t board_h, board_w;     /* MZL_NET_BOARD: the board, board_h * board_w <= 240; MZL_NET_ATARI: the frame, 96 x 96 (hidden state 6 x 6) */
     int32_t num_res_blocks;       /* residual blocks of each of the three towers (network.py:546) */
 } mzl_config;
 

@@ -161,8 +161,9 @@ static void build_big_jobs(mz_learner* h) {
 
 extern "C" int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out) {
     if (!cfg || !out) return fail(MZL_E_INVALID, "null argument");
-    if (cfg->net_kind != MZL_NET_MLP && cfg->net_kind != MZL_NET_BOARD) return fail(MZL_E_INVALID, "net_kind must be MZL_NET_MLP or MZL_NET_BOARD");
-    if (cfg->net_kind == MZL_NET_BOARD) {
+    if (cfg->net_kind != MZL_NET_MLP && cfg->net_kind != MZL_NET_BOARD && cfg->net_kind != MZL_NET_ATARI)
+        return fail(MZL_E_INVALID, "net_kind must be MZL_NET_MLP, MZL_NET_BOARD or MZL_NET_ATARI");
+    if (cfg->net_kind != MZL_NET_MLP) {
         if (cfg->in_dim < 1 || cfg->num_actions < 1 || cfg->num_actions > 32767 || cfg->num_planes < 1 || cfg->unroll_steps < 1 || cfg->unroll_steps > 32 ||
             cfg->max_batch < 1)
             return fail(MZL_E_INVALID, "bad learner dimensions");

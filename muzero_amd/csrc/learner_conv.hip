@@ -38,6 +38,14 @@ struct LayerInfo {
 struct TowerInfo {
     std::vector<int> layers;  // [conv0], then 2 R block convs
     bool conv0 = false;
+    int R = 0;                // residual blocks
+};
+// launch geometry of the whole-image conv / weight-gradient kernels for h x w "images" (boards, hidden states, tiles with their halo)
+struct Geom {
+    int h = 0, w = 0, hw = 0;
+    int npt = 15, G = 1, qstride = 0;       // k_lc_conv: pixel tiles per workgroup, images per workgroup, LDS slot-plane stride
+    bool side15 = false;                     // the 15 x 15 build
+    int P4 = 0, nsteps = 0, SPY = 0, SPX = 0;  // k_lc_wgrad: row pitch, 16-position steps per image, plane strides
 };
 struct TensorInfo {
     std::string name;
@@ -50,6 +58,7 @@ struct AppBufs {  // saved tensors of ONE application of a tower (representation
 enum OpKind { OP_CONV, OP_WGRAD, OP_WREDUCE, OP_BNFWD, OP_BNBWD, OP_APPLY };
 struct Op {
     int kind;
+    int npt = 15, side15 = 0;  // OP_CONV: which build
     LcConv conv;
     LcWgrad wg;
     LcWreduce wr;
@@ -61,17 +70,40 @@ struct Op {
 int pad16(int x) { return (x + 15) & ~15; }
 int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// pixel tiling of the conv kernels (G whole images per workgroup in NPT tiles of 16 pixel slots; lane = pixel quad while staging) and the pitch
+// layout of the weight-gradient kernel for h x w images; false if the image does not fit
+bool make_geom(Geom& g, int hh, int ww, bool allow_side15) {
+    g.h = hh; g.w = ww; g.hw = hh * ww;
+    if (g.hw < 1 || g.hw > 240) return false;
+    const int QP = (g.hw + 3) / 4;
+    double best = -1.0;
+    const int cand[3] = {6, 9, 15};
+    for (int i = 0; i < 3; i++) {
+        int G = (16 * cand[i]) / g.hw;
+        if (64 / QP < G) G = 64 / QP;
+        if (G < 1) continue;
+        const double eff = (double)G * g.hw / (16.0 * cand[i]);
+        if (eff > best + 1e-9) { best = eff; g.npt = cand[i]; g.G = G; }  // (ties: the smaller tiling -- fewer accumulators per wave)
+    }
+    if (best < 0.0) return false;
+    g.qstride = (4 * g.G * (g.h + 2) * (g.w + 2) + 63) & ~63;
+    g.side15 = allow_side15 && g.h == 15 && g.w == 15 && g.G == 1 && g.npt == 15;
+    g.P4 = 4 * cdiv(g.w + 1, 4);
+    g.nsteps = cdiv(g.h * g.P4, 16);
+    g.SPY = 16 * g.nsteps + 4;
+    g.SPX = 2 * g.P4 + 16 * g.nsteps + 12;
+    return true;
+}
+
 }  // namespace
 
 struct mzlc_learner {
     mzl_config cfg{};
     int device = 0, num_cus = 256;
     int P = 0, C0 = 0, A = 0, R = 0, K = 0, h = 0, w = 0, hw = 0, maxB = 0;
-    int npt = 15, G = 1, qstride = 0;
+    Geom gm;                 // geometry of the hidden state (the board; 6 x 6 for the Atari net)
     bool xcd_remap = true;   // k_lc_wgrad: the blocks of one image chunk on one XCD (MZLC_NO_XCD_REMAP=1 at create: launch order)
     bool fuse_apply = true;  // block outputs formed in the next conv's staging (MZLC_NO_FUSE_APPLY=1 at create: one k_lc_apply per block)
-    bool side15 = false;  // the 15 x 15 build of the conv kernel (geometry as compile-time constants); MZLC_NO_SIDE=1 at create: the generic build
-    int P4 = 0, nsteps = 0, SPY = 0, SPX = 0;
     std::vector<LayerInfo> layers;
     TowerInfo tower[3];  // 0 representation, 1 dynamics, 2 prediction
     std::vector<TensorInfo> tensors;
@@ -112,6 +144,24 @@ struct mzlc_learner {
     float* d_sq = nullptr;
     int sq_blocks = 0;
     const void* checked_ptr[9] = {};
+    // ---- MuZeroAtariNet (net_kind == MZL_NET_ATARI): the representation net works on 96 x 96 -> 48 x 48 -> 24 x 24 planes before the hidden state's 6 x 6 ----
+    bool atari = false;
+    int obsH = 0, obsW = 0;
+    Geom gt, g12;                 // 14 x 14 tiles (12 x 12 + halo) of the large planes; the 12 x 12 stage as whole images
+    int l_c1 = -1, l_c2 = -1;     // conv_1 / conv_2 (stride 2, no BatchNorm)
+    std::vector<int> l_b1, l_b2;  // the 4 convs of res_blocks_1 (48 x 48, 128 planes) / res_blocks_2 (24 x 24, num_planes)
+    TowerInfo t12;                // res_blocks_3 (12 x 12): the fused whole-image path
+    AppBufs a12;
+    struct StageBufs { std::vector<float*> y, h1, x, fcoef, save, bcoef; float *dzA = nullptr, *dzB = nullptr, *gF = nullptr; };
+    StageBufs sb48, sb24;
+    float *y_c1 = nullptr, *a1 = nullptr, *y_c2 = nullptr, *a2 = nullptr, *p1 = nullptr, *hraw = nullptr, *g12in = nullptr, *dH = nullptr;
+    float *TA = nullptr, *TB = nullptr, *TC = nullptr;      // tile buffers
+    float* D12[3] = {nullptr, nullptr, nullptr};            // the gradient ping-pong buffers of the 12 x 12 stage
+    float *coef_relu = nullptr, *coef_ident = nullptr;      // [3][cpad]: (a, b) = (1, 0); (c1, c2, c3) = (1, 0, 0)
+    int par_f[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, par_d[4] = {0, 0, 0, 0};  // packed offsets of the parity copies: forward of conv_1 / conv_2, data gradient of conv_2
+    LcPackPar* d_pack_par = nullptr;
+    int n_pack_par = 0;
+    int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
 
 namespace {
@@ -163,6 +213,7 @@ int add_conv(mzlc_learner* h, const std::string& conv_name, const std::string& b
 void add_tower(mzlc_learner* h, int ti, const std::string& net, bool conv0, int cin0_real, int n_act, bool input_needs_grad) {
     TowerInfo& t = h->tower[ti];
     t.conv0 = conv0;
+    t.R = h->R;
     const int P = h->P;
     if (conv0) t.layers.push_back(add_conv(h, net + ".conv_block.0", net + ".conv_block.1", cin0_real, n_act, P, input_needs_grad ? cin0_real : 0));
     for (int r = 0; r < h->R; r++) {
@@ -182,32 +233,34 @@ void add_head(mzlc_learner* h, int hi, const std::string& name, int oc, int n_ou
     add_tensor(h, name + ".4.bias", n_out, 0, &H.lb_off);
 }
 
-bool alloc_app(mzlc_learner* h, const TowerInfo& t, AppBufs& a) {
+bool alloc_app(mzlc_learner* h, const TowerInfo& t, AppBufs& a, size_t elems) {
     bool ok = true;
-    const int nl = (int)t.layers.size(), nx = h->R + (t.conv0 ? 1 : 0);
+    const int nl = (int)t.layers.size(), nx = t.R + (t.conv0 ? 1 : 0);
     a.y.resize(nl); a.fcoef.resize(nl); a.save.resize(nl); a.bcoef.resize(nl); a.x.resize(nx);
-    const int cpad = pad16(h->P);
+    const int cpad = pad16(h->P > 128 ? h->P : 128);
     for (int i = 0; i < nl; i++) {
-        ok = ok && dalloc(h, &a.y[i], h->T) == hipSuccess && dalloc(h, &a.fcoef[i], (size_t)3 * cpad) == hipSuccess &&
+        ok = ok && dalloc(h, &a.y[i], elems) == hipSuccess && dalloc(h, &a.fcoef[i], (size_t)3 * cpad) == hipSuccess &&
              dalloc(h, &a.save[i], (size_t)2 * cpad) == hipSuccess && dalloc(h, &a.bcoef[i], (size_t)3 * cpad) == hipSuccess;
     }
-    for (int i = 0; i < nx; i++) ok = ok && dalloc(h, &a.x[i], h->T) == hipSuccess;
+    for (int i = 0; i < nx; i++) ok = ok && dalloc(h, &a.x[i], elems) == hipSuccess;
     return ok;
 }
 
-size_t conv_lds(const mzlc_learner* h, int cpad_in) { return ((size_t)8 * h->qstride + (size_t)3 * cpad_in) * sizeof(float); }
-size_t wgrad_lds(const mzlc_learner* h) { return ((size_t)32 * (h->SPY + h->SPX) + 160) * sizeof(float); }
+size_t conv_lds(int qstride, int cpad_in) { return ((size_t)8 * qstride + (size_t)3 * cpad_in) * sizeof(float); }
+size_t wgrad_lds(const Geom& g) { return ((size_t)32 * (g.SPY + g.SPX) + 160) * sizeof(float); }
 
 // ---- op builders -------------------------------------------------------------------------------------------------------------
 struct Sched {
     mzlc_learner* h;
-    int B, lane;
+    int B, lane;      // B: images of this geometry (batch, or batch x tiles)
     bool lane_pairs;  // this tower's launches are paired with another tower's
-    int groups() const { return cdiv(B, h->G); }
+    Geom g;           // geometry of the images these ops work on
+    int C;            // channels of the activation tensors (num_planes; 128 in the Atari net's first stage)
+    int groups() const { return cdiv(B, g.G); }
 
     LcConv conv_base(const LayerInfo& L, bool dgrad) const {
         LcConv c{};
-        c.B = B; c.G = h->G; c.h = h->h; c.w_img = h->w; c.qstride = h->qstride;
+        c.B = B; c.G = g.G; c.h = g.h; c.w_img = g.w; c.qstride = g.qstride;
         if (!dgrad) {
             c.cin_real = L.cin_real; c.cin = L.cin; c.n_cb = L.n_cb; c.cout = L.cout; c.co_tiles = L.co_tiles;
             c.w = h->packed + L.f_off;
@@ -219,7 +272,7 @@ struct Sched {
         c.num_actions = h->A;
         return c;
     }
-    Op op_conv(const LcConv& c) const { Op o{}; o.kind = OP_CONV; o.conv = c; return o; }
+    Op op_conv(const LcConv& c) const { Op o{}; o.kind = OP_CONV; o.conv = c; o.npt = g.npt; o.side15 = g.side15 ? 1 : 0; return o; }
     Op op_bnfwd(const LayerInfo& L, float* fcoef, float* save) const {
         Op o{};
         o.kind = OP_BNFWD;
@@ -227,7 +280,7 @@ struct Sched {
         f.part = h->stat[lane]; f.gamma = h->params + L.bn.gamma_off; f.beta = h->params + L.bn.beta_off; f.coef = fcoef; f.save = save;
         f.running_mean = h->running ? h->running + L.bn.rm_off : nullptr; f.running_var = h->running ? h->running + L.bn.rv_off : nullptr;
         f.num_batches = h->nbt ? h->nbt + L.bn.nbt : nullptr;
-        f.groups = groups(); f.C = L.bn.C; f.cpad = L.bn.cpad; f.count = (float)B * (float)h->hw;
+        f.groups = groups(); f.C = L.bn.C; f.cpad = L.bn.cpad; f.count = (float)B * (float)g.hw;
         return o;
     }
     Op op_bnbwd(const LayerInfo& L, const float* save, float* bcoef, int ngroups, int accumulate) const {
@@ -236,14 +289,14 @@ struct Sched {
         LcBnBwd& f = o.bb;
         f.part = h->stat[lane]; f.gamma = h->params + L.bn.gamma_off; f.save = save; f.coef = bcoef;
         f.dgamma = h->grads + L.bn.gamma_off; f.dbeta = h->grads + L.bn.beta_off;
-        f.groups = ngroups; f.C = L.bn.C; f.cpad = L.bn.cpad; f.accumulate = accumulate; f.count = (float)B * (float)h->hw;
+        f.groups = ngroups; f.C = L.bn.C; f.cpad = L.bn.cpad; f.accumulate = accumulate; f.count = (float)B * (float)g.hw;
         return o;
     }
     Op op_apply(const float* y, const float* res, const float* coef, float* out) const {
         Op o{};
         o.kind = OP_APPLY;
-        o.ap.y = y; o.ap.res = res; o.ap.coef = coef; o.ap.out = out; o.ap.C = h->P; o.ap.hw = h->hw; o.ap.cpad = pad16(h->P);
-        o.ap.n = (long long)B * h->P * h->hw;
+        o.ap.y = y; o.ap.res = res; o.ap.coef = coef; o.ap.out = out; o.ap.C = C; o.ap.hw = g.hw; o.ap.cpad = pad16(C);
+        o.ap.n = (long long)B * C * g.hw;
         return o;
     }
     void wgrad_ops(std::vector<Op>& ops, const LayerInfo& L, const float* dz, const float* y, const float* bcoef, const float* x0, int x_mode, const float* xcoef,
@@ -254,7 +307,7 @@ struct Sched {
         g.dz = dz; g.y = y; g.dcoef = bcoef; g.x0 = x0; g.xcoef = xcoef; g.x_mode = x_mode; g.action = action; g.num_actions = h->A;
         g.cin_real = L.cin_real; g.cin = L.cin; g.cout = L.cout; g.ci_tiles = cdiv(L.cin, 16); g.co_tiles = L.co_tiles;
         g.cpad_in = pad16(L.cin_real); g.cpad_out = pad16(L.cout);
-        g.B = B; g.h = h->h; g.w_img = h->w; g.P4 = h->P4; g.nsteps = h->nsteps; g.SPY = h->SPY; g.SPX = h->SPX;
+        g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX;
         g.co_blocks = cdiv(g.co_tiles, 2);
         const int ci_blocks = cdiv(g.ci_tiles, 2);
         // two workgroups per CU in all: a paired launch brings the other half; the first conv blocks (action planes: the dynamics tower's extra
@@ -293,7 +346,7 @@ struct Sched {
         const float* pend_coef = nullptr;
         const float* pend_res = nullptr;
         float* pend_out = nullptr;
-        for (int r = 0; r < h->R; r++) {
+        for (int r = 0; r < t.R; r++) {
             const int l1 = li + 2 * r, l2 = l1 + 1;
             const LayerInfo &L1 = h->layers[t.layers[l1]], &L2 = h->layers[t.layers[l2]];
             LcConv c = conv_base(L1, false);
@@ -311,7 +364,7 @@ struct Sched {
             d.in0 = a.y[l1]; d.in_mode = IN_BNRELU; d.coef = a.fcoef[l1]; d.out = a.y[l2]; d.stat_mode = ST_FWD; d.stat_part = h->stat[lane];
             ops.push_back(op_conv(d));
             ops.push_back(op_bnfwd(L2, a.fcoef[l2], a.save[l2]));
-            if (h->fuse_apply && r + 1 < h->R) {
+            if (h->fuse_apply && r + 1 < t.R) {
                 pend_y = a.y[l2]; pend_coef = a.fcoef[l2]; pend_res = cur; pend_out = a.x[xi + r];
             } else {
                 ops.push_back(op_apply(a.y[l2], cur, a.fcoef[l2], a.x[xi + r]));
@@ -328,7 +381,7 @@ struct Sched {
         float *Da = h->D[lane][0], *Db = h->D[lane][1], *Dc = h->D[lane][2];
         const int li = t.conv0 ? 1 : 0, xi = t.conv0 ? 1 : 0;
         int ng = entry_groups;
-        for (int r = h->R - 1; r >= 0; r--) {
+        for (int r = t.R - 1; r >= 0; r--) {
             const int l1 = li + 2 * r, l2 = l1 + 1;
             const LayerInfo &L1 = h->layers[t.layers[l1]], &L2 = h->layers[t.layers[l2]];
             const float* xin_blk = r > 0 ? a.x[xi + r - 1] : (t.conv0 ? a.x[0] : x_in);
@@ -389,7 +442,7 @@ hipError_t conv_attr() {
 int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
     switch (a->kind) {
         case OP_CONV: {
-            if (b && b->conv.in_mode != a->conv.in_mode) {  // (never the case for the zipped towers; kept correct anyway)
+            if (b && (b->conv.in_mode != a->conv.in_mode || b->npt != a->npt || b->side15 != a->side15)) {  // (never the case for the zipped towers; kept correct anyway)
                 launch_ops(h, a, nullptr, st);
                 return launch_ops(h, b, nullptr, st);
             }
@@ -401,11 +454,11 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             int z = cdiv(a->conv.co_tiles, 4), cp = a->conv.cpad_in;
             if (b) { z = cdiv(b->conv.co_tiles, 4) > z ? cdiv(b->conv.co_tiles, 4) : z; cp = b->conv.cpad_in > cp ? b->conv.cpad_in : cp; }
             const dim3 grid(1, ga + gb, z);
-            const size_t lds = conv_lds(h, cp);
+            const size_t lds = conv_lds(a->conv.qstride, cp);
             const int mode = a->conv.in_mode;
-            if (h->npt == 15 && h->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
-            else if (h->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
-            else if (h->npt == 9) launch_conv<9, 0>(mode, pj, grid, lds, st);
+            if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
+            else if (a->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
+            else if (a->npt == 9) launch_conv<9, 0>(mode, pj, grid, lds, st);
             else launch_conv<6, 0>(mode, pj, grid, lds, st);
             break;
         }
@@ -420,8 +473,10 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             // a chunk's blocks on one XCD (k_lc_wgrad): needs the same block grid in both jobs and a group count the 8 XCDs divide
             const int groups = (ya + yb) / a->wg.co_blocks;
             pj.remap = (h->xcd_remap && (!b || (b->wg.co_blocks == a->wg.co_blocks && cdiv(b->wg.ci_tiles, 2) == cdiv(a->wg.ci_tiles, 2))) && groups % 8 == 0) ? 1 : 0;
-            if (a->wg.action || (b && b->wg.action)) hipLaunchKernelGGL(k_lc_wgrad<true>, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
-            else hipLaunchKernelGGL(k_lc_wgrad<false>, dim3(x, ya + yb), dim3(256), wgrad_lds(h), st, pj);
+            const size_t wlds = ((size_t)32 * (a->wg.SPY + a->wg.SPX) + 160) * sizeof(float);
+            if (a->wg.ring_zero) hipLaunchKernelGGL((k_lc_wgrad<false, true>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
+            else if (a->wg.action || (b && b->wg.action)) hipLaunchKernelGGL((k_lc_wgrad<true, false>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
+            else hipLaunchKernelGGL((k_lc_wgrad<false, false>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
             break;
         }
         case OP_WREDUCE: {
@@ -510,6 +565,278 @@ void launch_normalize(mzlc_learner* h, const float* in, float* out, int B, hipSt
     else hipLaunchKernelGGL(k_lc_normalize<32>, grid, dim3(256), 0, st, in, out, B, h->P, h->hw);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// MuZeroAtariNet's representation net (network.py:312-353) on the tile path (mz_learn_conv.h, LcTileGather): x -> conv_1 (stride 2) -> relu ->
+// res_blocks_1 @ 48 x 48 x 128 -> conv_2 (stride 2) -> relu -> res_blocks_2 @ 24 x 24 -> avg pool -> res_blocks_3 @ 12 x 12 (whole images: the
+// fused path of the towers) -> avg pool -> 6 x 6.  Launched one job at a time (nothing to pair with); the planes are cut into 12 x 12 tiles.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int TILE = 12;
+
+struct AtariRun {
+    mzlc_learner* h;
+    int B;
+    hipStream_t st;
+
+    void run(const Op& o) const { launch_ops(h, &o, nullptr, st); }
+    // plane (H x W, a parity plane when sy == 2) of src [B][C][srcH][srcW] -> tiles with halo
+    void gather(const float* src0, const float* src1, const float* coef, int mode, int C, int H, int W, int srcH, int srcW, int sy, int sx, int py, int px,
+                int inner_only, float* dst) const {
+        LcTileGather g{};
+        g.src0 = src0; g.src1 = src1; g.coef = coef; g.dst = dst; g.mode = mode; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W;
+        g.srcH = srcH; g.srcW = srcW; g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.T = TILE; g.nty = H / TILE; g.ntx = W / TILE; g.inner_only = inner_only;
+        g.n = (long long)B * g.nty * g.ntx * C * (TILE + 2) * (TILE + 2);
+        hipLaunchKernelGGL(k_lc_tile_gather, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g);
+    }
+    // returns the number of statistic groups written (0 without stat_part)
+    int scatter(const float* src, int C, int H, int W, float* dst, int dstH, int dstW, int sy, int sx, int py, int px, const float* skip, float* stat_part) const {
+        LcTileScatter g{};
+        g.src = src; g.dst = dst; g.skip = skip; g.stat_part = stat_part; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W; g.dstH = dstH; g.dstW = dstW;
+        g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.T = TILE; g.nty = H / TILE; g.ntx = W / TILE;
+        const dim3 grid(cdiv(H * W, 32), B);
+        const int cpt = cdiv(C, 8);
+        if (cpt <= 2) hipLaunchKernelGGL(k_lc_tile_scatter<2>, grid, dim3(256), 0, st, g);
+        else if (cpt <= 8) hipLaunchKernelGGL(k_lc_tile_scatter<8>, grid, dim3(256), 0, st, g);
+        else if (cpt <= 16) hipLaunchKernelGGL(k_lc_tile_scatter<16>, grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(k_lc_tile_scatter<32>, grid, dim3(256), 0, st, g);
+        return B * cdiv(H * W, 32);
+    }
+    Sched tiles(int C, int nt) const { return Sched{h, B * nt, 0, false, h->gt, C}; }
+    // stride-1 conv of the tiles in `in` -> `out` (forward or data-gradient copy of layer L), identity staging, no epilogue extras
+    void conv_tiles(const LayerInfo& L, bool dgrad, int nt, const float* in, float* out) const {
+        const Sched s = tiles(dgrad ? L.cout : L.cin_real, nt);
+        LcConv c = s.conv_base(L, dgrad);
+        c.in0 = in; c.in_mode = IN_IDENT; c.out = out; c.stat_mode = ST_NONE;
+        run(s.op_conv(c));
+    }
+    // one parity plane's share of a stride-2 conv: the packed copy at `w_off`; accumulate: out += (the earlier planes' sum rides in `skip`)
+    void conv_par(int w_off, int cin, int cout, int nt, const float* in, float* out, bool accumulate) const {
+        const Sched s = tiles(cin, nt);
+        LcConv c{};
+        c.B = B * nt; c.G = h->gt.G; c.h = h->gt.h; c.w_img = h->gt.w; c.qstride = h->gt.qstride;
+        c.cin_real = cin; c.cin = cin; c.n_cb = cdiv(cin, 16); c.cout = cout; c.co_tiles = cdiv(cout, 16); c.w = h->packed + w_off;
+        c.cpad_in = pad16(cin); c.cpad_out = pad16(cout); c.num_actions = h->A;
+        c.in0 = in; c.in_mode = IN_IDENT; c.out = out; c.skip = accumulate ? out : nullptr; c.stat_mode = ST_NONE;
+        run(s.op_conv(c));
+    }
+    void bn_fwd(const LayerInfo& L, float* fcoef, float* save, int groups, float count) const {
+        const Sched s = tiles(L.cout, 1);
+        Op o = s.op_bnfwd(L, fcoef, save);
+        o.bf.groups = groups; o.bf.count = count;
+        run(o);
+    }
+    void bn_bwd(const LayerInfo& L, const float* save, float* bcoef, int groups, float count) const {
+        const Sched s = tiles(L.cout, 1);
+        Op o = s.op_bnbwd(L, save, bcoef, groups, 0);
+        o.bb.count = count;
+        run(o);
+    }
+    void apply(const float* y, const float* res, const float* coef, float* out, int C, int hw, int cpad = 0) const {
+        Op o{};
+        o.kind = OP_APPLY;
+        o.ap.y = y; o.ap.res = res; o.ap.coef = coef; o.ap.out = out; o.ap.C = C; o.ap.hw = hw; o.ap.cpad = cpad ? cpad : pad16(C); o.ap.n = (long long)B * C * hw;
+        run(o);
+    }
+    // dz = extra [x > 0] + the BatchNorm-backward partial sums against `partner`; returns the groups written to stat[0]
+    int entry(const float* x, const float* gs, float scale, const float* extra, const float* partner, float* dz, int C, int hw) const {
+        LcEntry e{};
+        e.x = x; e.gs = gs; e.extra = extra; e.partner = partner; e.dz = dz; e.stat_part = h->stat[0]; e.scale = scale; e.B = B; e.C = C; e.hw = hw; e.cpad = pad16(C);
+        const int nchunks = cdiv(hw, 32), split = nchunks < 64 ? nchunks : 64;
+        const dim3 grid(split, B);
+        const int cpt = cdiv(C, 8);
+        if (cpt <= 2) hipLaunchKernelGGL(k_lc_entry<2>, grid, dim3(256), 0, st, e);
+        else if (cpt <= 8) hipLaunchKernelGGL(k_lc_entry<8>, grid, dim3(256), 0, st, e);
+        else if (cpt <= 16) hipLaunchKernelGGL(k_lc_entry<16>, grid, dim3(256), 0, st, e);
+        else hipLaunchKernelGGL(k_lc_entry<32>, grid, dim3(256), 0, st, e);
+        return B * split;
+    }
+    // weight gradient of layer L from dy tiles (already BatchNorm-backward transformed, halo included: ring_zero) and x tiles
+    void wgrad_tiles(const LayerInfo& L, int cin, int nt, const float* dy_tiles, const float* x_tiles, const signed char* tapmap) const {
+        const Sched s = tiles(L.cout, nt);
+        LayerInfo Lw = L;
+        Lw.cin_real = cin; Lw.cin = cin;
+        std::vector<Op> ops;
+        s.wgrad_ops(ops, Lw, dy_tiles, dy_tiles, h->coef_ident, x_tiles, IN_IDENT, nullptr, nullptr, 0);
+        ops[0].wg.ring_zero = 1;
+        ops[0].wg.cpad_out = pad16(h->P > 128 ? h->P : 128);  // (the stride of coef_ident's rows)
+        if (tapmap) {
+            ops[1].wr.use_map = 1;
+            for (int t = 0; t < 9; t++) ops[1].wr.tapmap[t] = tapmap[t];
+        }
+        run(ops[0]);
+        run(ops[1]);
+    }
+
+    // ---- forward of two residual blocks on a tiled stage ----
+    float* stage_fwd(mzlc_learner::StageBufs& sb, const std::vector<int>& lay, const float* x_in, int C, int H, int W) const {
+        const int nt = (H / TILE) * (W / TILE), hw = H * W;
+        const float count = (float)B * (float)hw;
+        const float* cur = x_in;
+        for (int r = 0; r < 2; r++) {
+            const LayerInfo &L1 = h->layers[lay[2 * r]], &L2 = h->layers[lay[2 * r + 1]];
+            gather(cur, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
+            conv_tiles(L1, false, nt, h->TA, h->TB);
+            int ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0]);
+            bn_fwd(L1, sb.fcoef[2 * r], sb.save[2 * r], ng, count);
+            apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
+            gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
+            conv_tiles(L2, false, nt, h->TA, h->TB);
+            ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0]);
+            bn_fwd(L2, sb.fcoef[2 * r + 1], sb.save[2 * r + 1], ng, count);
+            apply(sb.y[2 * r + 1], cur, sb.fcoef[2 * r + 1], sb.x[r], C, hw);
+            cur = sb.x[r];
+        }
+        return const_cast<float*>(cur);
+    }
+    // ---- backward: sb.dzA holds dz of the stage's last BatchNorm, its partial sums (ng groups) are in stat[0]; leaves the gradient wrt x_in in sb.gF ----
+    void stage_bwd(mzlc_learner::StageBufs& sb, const std::vector<int>& lay, const float* x_in, int C, int H, int W, int ng) const {
+        const int nt = (H / TILE) * (W / TILE), hw = H * W;
+        const float count = (float)B * (float)hw;
+        for (int r = 1; r >= 0; r--) {
+            const LayerInfo &L1 = h->layers[lay[2 * r]], &L2 = h->layers[lay[2 * r + 1]];
+            const float* xin_blk = r > 0 ? sb.x[r - 1] : x_in;
+            bn_bwd(L2, sb.save[2 * r + 1], sb.bcoef[2 * r + 1], ng, count);
+            gather(sb.dzA, sb.y[2 * r + 1], sb.bcoef[2 * r + 1], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
+            gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
+            wgrad_tiles(L2, C, nt, h->TA, h->TC, nullptr);
+            conv_tiles(L2, true, nt, h->TA, h->TB);
+            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr);
+            ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
+            bn_bwd(L1, sb.save[2 * r], sb.bcoef[2 * r], ng, count);
+            gather(sb.dzB, sb.y[2 * r], sb.bcoef[2 * r], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
+            gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
+            wgrad_tiles(L1, C, nt, h->TA, h->TC, nullptr);
+            conv_tiles(L1, true, nt, h->TA, h->TB);
+            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr);  // + the block's skip gradient
+            if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
+        }
+    }
+};
+
+// tap maps of the parity planes (mz_learn_conv.h, LcTileGather).  Forward / weight gradient: stride-1 tap (sy, sx) of plane (p, q) is weight tap
+// (krow(p, sy), krow(q, sx)); data gradient of a stride-2 conv: output parity plane (p, q) of dx from dy.
+int par_row(int p, int s) { return p == 0 ? (s == 1 ? 1 : -1) : (s == 0 ? 0 : (s == 1 ? 2 : -1)); }
+int par_row_d(int p, int s) { return p == 0 ? (s == 1 ? 1 : -1) : (s == 2 ? 0 : (s == 1 ? 2 : -1)); }
+void par_tapmap(int p, int q, bool dgrad, signed char* m) {
+    for (int sy = 0; sy < 3; sy++)
+        for (int sx = 0; sx < 3; sx++) {
+            const int ky = dgrad ? par_row_d(p, sy) : par_row(p, sy), kx = dgrad ? par_row_d(q, sx) : par_row(q, sx);
+            m[sy * 3 + sx] = (signed char)((ky >= 0 && kx >= 0) ? ky * 3 + kx : -1);
+        }
+}
+
+// forward of the Atari representation; returns the 6 x 6 raw hidden state
+float* atari_rep_fwd(mzlc_learner* h, int B, hipStream_t st) {
+    const AtariRun R{h, B, st};
+    const int H1 = h->obsH / 2, W1 = h->obsW / 2, H2 = H1 / 2, W2 = W1 / 2, H3 = H2 / 2, W3 = W2 / 2;
+    const LayerInfo &C1 = h->layers[h->l_c1], &C2 = h->layers[h->l_c2];
+    // conv_1: four parity planes of the observation, accumulated on the tiles
+    for (int pq = 0; pq < 4; pq++) {
+        R.gather(h->obs, nullptr, nullptr, IN_IDENT, h->C0, H1, W1, h->obsH, h->obsW, 2, 2, pq >> 1, pq & 1, 0, h->TA);
+        R.conv_par(h->par_f[0][pq], h->C0, C1.cout, (H1 / TILE) * (W1 / TILE), h->TA, h->TB, pq > 0);
+    }
+    R.scatter(h->TB, C1.cout, H1, W1, h->y_c1, H1, W1, 1, 1, 0, 0, nullptr, nullptr);
+    const int big = pad16(h->P > 128 ? h->P : 128);  // the row stride of coef_relu / coef_ident
+    R.apply(h->y_c1, nullptr, h->coef_relu, h->a1, C1.cout, H1 * W1, big);
+    float* x48 = R.stage_fwd(h->sb48, h->l_b1, h->a1, 128, H1, W1);
+    for (int pq = 0; pq < 4; pq++) {
+        R.gather(x48, nullptr, nullptr, IN_IDENT, 128, H2, W2, H1, W1, 2, 2, pq >> 1, pq & 1, 0, h->TA);
+        R.conv_par(h->par_f[1][pq], 128, C2.cout, (H2 / TILE) * (W2 / TILE), h->TA, h->TB, pq > 0);
+    }
+    R.scatter(h->TB, h->P, H2, W2, h->y_c2, H2, W2, 1, 1, 0, 0, nullptr, nullptr);
+    R.apply(h->y_c2, nullptr, h->coef_relu, h->a2, h->P, H2 * W2, big);
+    float* x24 = R.stage_fwd(h->sb24, h->l_b2, h->a2, h->P, H2, W2);
+    {
+        const long long n = (long long)B * h->P * H3 * W3;
+        hipLaunchKernelGGL(k_lc_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x24, h->p1, n, H2, W2, H3, W3);
+    }
+    std::vector<Op> ops;
+    const Sched s12{h, B, 0, false, h->g12, h->P};
+    float* x12 = s12.tower_fwd(ops, h->t12, h->a12, h->p1, nullptr);
+    for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
+    {
+        const long long n = (long long)B * h->P * h->hw;
+        hipLaunchKernelGGL(k_lc_pool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x12, h->hraw, n, H3, W3, h->h, h->w);
+    }
+    return h->hraw;
+}
+
+// backward of the Atari representation from the gradient wrt the normalised hidden state s_0
+void atari_rep_bwd(mzlc_learner* h, int B, const float* gs0, hipStream_t st) {
+    const AtariRun R{h, B, st};
+    const int H1 = h->obsH / 2, W1 = h->obsW / 2, H2 = H1 / 2, W2 = W1 / 2, H3 = H2 / 2, W3 = W2 / 2;
+    const LayerInfo &C1 = h->layers[h->l_c1], &C2 = h->layers[h->l_c2];
+    const int P = h->P;
+    float* x12 = h->a12.x.back();
+    float* x24 = h->sb24.x[1];
+    float* x48 = h->sb48.x[1];
+    // normalize backward (the mask x > 0 of k_lc_entry is harmless on an average of ReLU outputs: where it is 0 every input of the window is 0 and masked
+    // below), average-pool backward, mask + partial sums of res_blocks_3's last BatchNorm
+    R.entry(h->hraw, gs0, 1.0f, nullptr, h->hraw, h->dH, P, h->hw);
+    {
+        const long long n = (long long)B * P * H3 * W3;
+        hipLaunchKernelGGL(k_lc_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->dH, h->g12in, n, H3, W3, h->h, h->w);
+    }
+    {
+        LcEntry e{};
+        float* keep[3] = {h->D[0][0], h->D[0][1], h->D[0][2]};
+        for (int i = 0; i < 3; i++) h->D[0][i] = h->D12[i];  // (the op builders read the buffers of lane 0; restored below)
+        e.x = x12; e.gs = nullptr; e.extra = h->g12in; e.partner = h->a12.y.back(); e.dz = h->D[0][0]; e.stat_part = h->stat[0]; e.scale = 1.0f;
+        e.B = B; e.C = P; e.hw = H3 * W3; e.cpad = pad16(P);
+        const int nchunks = cdiv(e.hw, 32), split = nchunks < ENTRY_SPLIT ? nchunks : ENTRY_SPLIT;
+        const dim3 grid(split, B);
+        const int cpt = cdiv(P, 8);
+        if (cpt <= 2) hipLaunchKernelGGL(k_lc_entry<2>, grid, dim3(256), 0, st, e);
+        else if (cpt <= 8) hipLaunchKernelGGL(k_lc_entry<8>, grid, dim3(256), 0, st, e);
+        else if (cpt <= 16) hipLaunchKernelGGL(k_lc_entry<16>, grid, dim3(256), 0, st, e);
+        else hipLaunchKernelGGL(k_lc_entry<32>, grid, dim3(256), 0, st, e);
+        std::vector<Op> ops;
+        const Sched s12{h, B, 0, false, h->g12, P};
+        s12.tower_bwd(ops, h->t12, h->a12, h->p1, nullptr, B * split, 0, h->g12in, nullptr);  // gradient wrt the pooled 12 x 12 input -> g12in
+        for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
+        for (int i = 0; i < 3; i++) h->D[0][i] = keep[i];
+    }
+    // 24 x 24 stage
+    {
+        const long long n = (long long)B * P * H2 * W2;
+        hipLaunchKernelGGL(k_lc_pool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->g12in, h->sb24.gF, n, H2, W2, H3, W3);
+    }
+    int ng = R.entry(x24, nullptr, 1.0f, h->sb24.gF, h->sb24.y[3], h->sb24.dzA, P, H2 * W2);
+    R.stage_bwd(h->sb24, h->l_b2, h->a2, P, H2, W2, ng);
+    // conv_2 (stride 2, relu without BatchNorm): dy = g [a2 > 0]
+    {
+        const long long n = (long long)B * P * H2 * W2;
+        hipLaunchKernelGGL(k_lc_relu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->sb24.gF, h->a2, h->sb24.dzB, n);
+    }
+    const int nt2 = (H2 / TILE) * (W2 / TILE);
+    R.gather(h->sb24.dzB, nullptr, nullptr, IN_IDENT, P, H2, W2, H2, W2, 1, 1, 0, 0, 0, h->TA);  // dy tiles with halo: both gradients read them
+    for (int pq = 0; pq < 4; pq++) {
+        signed char m[9];
+        par_tapmap(pq >> 1, pq & 1, false, m);
+        R.gather(x48, nullptr, nullptr, IN_IDENT, 128, H2, W2, H1, W1, 2, 2, pq >> 1, pq & 1, 0, h->TC);
+        R.wgrad_tiles(C2, 128, nt2, h->TA, h->TC, m);
+    }
+    for (int pq = 0; pq < 4; pq++) {  // data gradient: parity plane (p, q) of the 48 x 48 gradient from the dy tiles
+        R.conv_par(h->par_d[pq], P, 128, nt2, h->TA, h->TB, false);
+        R.scatter(h->TB, 128, H2, W2, h->sb48.gF, H1, W1, 2, 2, pq >> 1, pq & 1, nullptr, nullptr);
+    }
+    ng = R.entry(x48, nullptr, 1.0f, h->sb48.gF, h->sb48.y[3], h->sb48.dzA, 128, H1 * W1);
+    R.stage_bwd(h->sb48, h->l_b1, h->a1, 128, H1, W1, ng);
+    // conv_1: weight gradient only (its input is the observation)
+    {
+        const long long n = (long long)B * 128 * H1 * W1;
+        hipLaunchKernelGGL(k_lc_relu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->sb48.gF, h->a1, h->sb48.dzB, n);
+    }
+    const int nt1 = (H1 / TILE) * (W1 / TILE);
+    R.gather(h->sb48.dzB, nullptr, nullptr, IN_IDENT, 128, H1, W1, H1, W1, 1, 1, 0, 0, 0, h->TA);
+    for (int pq = 0; pq < 4; pq++) {
+        signed char m[9];
+        par_tapmap(pq >> 1, pq & 1, false, m);
+        R.gather(h->obs, nullptr, nullptr, IN_IDENT, h->C0, H1, W1, h->obsH, h->obsW, 2, 2, pq >> 1, pq & 1, 0, h->TC);
+        R.wgrad_tiles(C1, h->C0, nt1, h->TA, h->TC, m);
+    }
+}
+
 }  // namespace
 
 // =================================================================================================================================
@@ -517,44 +844,69 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     mzlc_learner* h = new mzlc_learner();
     h->cfg = *cfg; h->device = device_id; h->num_cus = num_cus > 0 ? num_cus : 256;
     h->P = cfg->num_planes; h->C0 = cfg->in_channels; h->A = cfg->num_actions; h->R = cfg->num_res_blocks; h->K = cfg->unroll_steps;
-    h->h = cfg->board_h; h->w = cfg->board_w; h->hw = h->h * h->w; h->maxB = cfg->max_batch;
+    h->atari = cfg->net_kind == MZL_NET_ATARI;
+    h->maxB = cfg->max_batch;
     h->paired = !getenv("MZLC_NO_PAIR");
     h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
     h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
-    if (h->C0 < 1 || h->h < 1 || h->w < 1 || h->R < 1 || h->P < 1) return bad("bad conv-net geometry (in_channels, board_h, board_w, num_res_blocks, num_planes)");
-    if (cfg->in_dim != h->C0 * h->hw) return bad("in_dim must equal in_channels * board_h * board_w");
-    if (cfg->value_support_size != 1 || cfg->reward_support_size != 1)
-        return bad("the conv learner covers MuZeroBoardGameNet (squared-error value / reward heads, network.py:540-574); categorical conv heads are not built");
-    if (h->hw > 240 || h->P > 1024) return bad("conv learner: boards up to 240 points and 1024 planes (larger nets train through muzero_amd.learner.train_step)");
-    {   // pixel tiling of the conv kernels: G whole images per workgroup in NPT tiles of 16 pixel slots; lane = pixel quad while staging
-        const int QP = (h->hw + 3) / 4;
-        double best = -1.0;
-        const int cand[3] = {6, 9, 15};
-        for (int i = 0; i < 3; i++) {
-            int G = (16 * cand[i]) / h->hw;
-            if (64 / QP < G) G = 64 / QP;
-            if (G < 1) continue;
-            const double eff = (double)G * h->hw / (16.0 * cand[i]);
-            if (eff > best + 1e-9) { best = eff; h->npt = cand[i]; h->G = G; }  // (ties: the smaller tiling -- fewer accumulators per wave)
-        }
-        if (best < 0.0) return bad("board does not fit the conv kernels' tiling");
-        h->qstride = (4 * h->G * (h->h + 2) * (h->w + 2) + 63) & ~63;
-        h->side15 = h->h == 15 && h->w == 15 && h->G == 1 && h->npt == 15 && !getenv("MZLC_NO_SIDE");
-        h->P4 = 4 * cdiv(h->w + 1, 4);
-        h->nsteps = cdiv(h->h * h->P4, 16);
-        h->SPY = 16 * h->nsteps + 4;
-        h->SPX = 2 * h->P4 + 16 * h->nsteps + 12;
-        if (wgrad_lds(h) > 160 * 1024 || conv_lds(h, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
+    if (h->atari) {  // the observation is board_h x board_w (96 x 96 in every reference configuration); the hidden state 1 / 16 of it
+        h->obsH = cfg->board_h; h->obsW = cfg->board_w;
+        if (h->obsH < 1 || h->obsH % (16 * TILE / 2) || h->obsW % (16 * TILE / 2) || h->obsH != h->obsW)
+            return bad("Atari net: square frames whose side is a multiple of 96 (the 48 x 48 and 24 x 24 stages are cut into 12 x 12 tiles)");
+        h->h = h->obsH / 16; h->w = h->obsW / 16;
+        if (h->obsH / 8 != TILE) return bad("Atari net: 96 x 96 frames (the 12 x 12 stage runs as whole images)");
+    } else {
+        h->h = cfg->board_h; h->w = cfg->board_w; h->obsH = h->h; h->obsW = h->w;
     }
-    // ---- parameter / buffer tables in state_dict order (network.py:356-498) ----
-    add_tower(h, 0, "represent_net", true, h->C0, 0, false);
+    h->hw = h->h * h->w;
+    h->max_imgs = h->maxB * (h->atari ? (h->obsH / 2 / TILE) * (h->obsW / 2 / TILE) : 1);
+    if (h->C0 < 1 || h->h < 1 || h->w < 1 || h->R < 1 || h->P < 1) return bad("bad conv-net geometry (in_channels, board_h, board_w, num_res_blocks, num_planes)");
+    if (cfg->in_dim != h->C0 * h->obsH * h->obsW) return bad("in_dim must equal in_channels * board_h * board_w");
+    if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1024 || cfg->reward_support_size > 1024) return bad("support sizes must be in [1, 1024]");
+    if (h->hw > 240 || h->P > 1024) return bad("conv learner: boards up to 240 points and 1024 planes (larger nets train through muzero_amd.learner.train_step)");
+    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"))) return bad("board does not fit the conv kernels' tiling");
+    if (wgrad_lds(h->gm) > 160 * 1024 || conv_lds(h->gm.qstride, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
+    if (h->atari && (!make_geom(h->gt, TILE + 2, TILE + 2, false) || !make_geom(h->g12, TILE, TILE, false))) return bad("internal: tile geometry");
+    // ---- parameter / buffer tables in state_dict order (network.py:312-498) ----
+    const int kv = cfg->value_support_size > 1 ? 2 : 0, kr = cfg->reward_support_size > 1 ? 2 : 0;  // head kinds: categorical (2-hot cross entropy) | squared error
+    if (h->atari) {
+        auto add_plain = [&](const std::string& name, int cin, int cout) {  // stride-2 conv without BatchNorm: parity copies instead of the standard ones
+            LayerInfo L;
+            L.cin_real = cin; L.cin = cin; L.cout = cout; L.cin_d = 0; L.co_tiles = cdiv(cout, 16); L.n_cb = cdiv(cin, 16); L.f_off = -1;
+            add_tensor(h, name + ".weight", cout, cin * 9, &L.w_off);
+            h->layers.push_back(L);
+            return (int)h->layers.size() - 1;
+        };
+        auto add_blocks = [&](const std::string& pre, int C, std::vector<int>& out) {
+            for (int r = 0; r < 2; r++) {
+                const std::string b = pre + "." + std::to_string(r);
+                out.push_back(add_conv(h, b + ".conv_block1.0", b + ".conv_block1.1", C, 0, C, C));
+                out.push_back(add_conv(h, b + ".conv_block2.0", b + ".conv_block2.1", C, 0, C, C));
+            }
+        };
+        h->l_c1 = add_plain("represent_net.conv_1", h->C0, 128);
+        add_blocks("represent_net.res_blocks_1", 128, h->l_b1);
+        h->l_c2 = add_plain("represent_net.conv_2", 128, h->P);
+        add_blocks("represent_net.res_blocks_2", h->P, h->l_b2);
+        add_blocks("represent_net.res_blocks_3", h->P, h->t12.layers);
+        h->t12.conv0 = false; h->t12.R = 2;
+        for (int k = 0; k < 2; k++) {  // parity copies: forward of conv_1 / conv_2, data gradient of conv_2
+            const LayerInfo& L = h->layers[k == 0 ? h->l_c1 : h->l_c2];
+            for (int pq = 0; pq < 4; pq++) { h->par_f[k][pq] = (int)h->packed_floats; h->packed_floats += (size_t)L.co_tiles * L.n_cb * 9 * 256; }
+        }
+        for (int pq = 0; pq < 4; pq++) { h->par_d[pq] = (int)h->packed_floats; h->packed_floats += (size_t)cdiv(128, 16) * cdiv(h->P, 16) * 9 * 256; }
+    } else {
+        add_tower(h, 0, "represent_net", true, h->C0, 0, false);
+    }
     add_tower(h, 1, "dynamics_net", true, h->P, h->A, true);
-    add_head(h, 0, "dynamics_net.reward_head", 1, cfg->reward_support_size, 0);
+    add_head(h, 0, "dynamics_net.reward_head", 1, cfg->reward_support_size, kr);
     add_tower(h, 2, "prediction_net", false, 0, 0, true);
     add_head(h, 1, "prediction_net.policy_net", 2, h->A, 1);
-    add_head(h, 2, "prediction_net.value_net", 1, cfg->value_support_size, 0);
-    h->n_max = h->A > 1 ? h->A : 1;
+    add_head(h, 2, "prediction_net.value_net", 1, cfg->value_support_size, kv);
+    h->n_max = h->A;
+    if (cfg->value_support_size > h->n_max) h->n_max = cfg->value_support_size;
+    if (cfg->reward_support_size > h->n_max) h->n_max = cfg->reward_support_size;
     // ---- device memory ----
     h->T = (size_t)h->maxB * h->P * h->hw;
     bool ok = true;
@@ -563,6 +915,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     {
         std::vector<LcPackJob> jobs;
         for (const LayerInfo& L : h->layers) {
+            if (L.f_off < 0) continue;  // (the Atari net's stride-2 convs: parity copies, below)
             LcPackJob j{};
             j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.cin_d = L.cin_d; j.f_off = L.f_off; j.d_off = L.d_off;
             j.n_cb = L.n_cb; j.co_tiles = L.co_tiles; j.n_cb_d = L.n_cb_d; j.co_tiles_d = L.co_tiles_d;
@@ -577,24 +930,28 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         for (int i = 0; i < 3; i++) { h->lwT_off[i] = (int)n; n += (size_t)h->head[i].n_out * h->head[i].oc * h->hw; }
         AL(&h->lwT, n);
     }
-    ok = ok && alloc_app(h, h->tower[0], h->app_rep);
+    if (!h->atari) ok = ok && alloc_app(h, h->tower[0], h->app_rep, h->T);
     h->app_dyn.resize(h->K); h->app_pred.resize(h->K);
-    for (int t = 0; t < h->K; t++) ok = ok && alloc_app(h, h->tower[1], h->app_dyn[t]) && alloc_app(h, h->tower[2], h->app_pred[t]);
+    for (int t = 0; t < h->K; t++) ok = ok && alloc_app(h, h->tower[1], h->app_dyn[t], h->T) && alloc_app(h, h->tower[2], h->app_pred[t], h->T);
     h->s.resize(h->K);
     for (int t = 0; t < h->K; t++) AL(&h->s[t], h->T);
-    AL(&h->obs, (size_t)h->maxB * h->C0 * h->hw);
+    AL(&h->obs, (size_t)h->maxB * h->C0 * h->obsH * h->obsW);
     ok = ok && dalloc(h, &h->act, (size_t)h->K * h->maxB) == hipSuccess;
     {
-        const int g_conv = cdiv(h->maxB, h->G), g_entry = h->maxB * cdiv(h->hw, 32);
+        const int g_conv = cdiv(h->maxB, h->gm.G), g_entry = h->maxB * cdiv(h->hw, 32);
         h->stat_groups_cap = g_conv > g_entry ? g_conv : g_entry;
-        const int cpad = pad16(h->P);
+        if (h->atari) {  // tile scatter / entry kernels of the 48 x 48 stage: one group per 32 positions, and the 12 x 12 stage's conv groups
+            const int g_big = h->maxB * cdiv((h->obsH / 2) * (h->obsW / 2), 32);
+            h->stat_groups_cap = g_big > h->stat_groups_cap ? g_big : h->stat_groups_cap;
+        }
+        const int cpad = pad16(h->P > 128 ? h->P : 128);
         for (int l = 0; l < 2; l++) AL(&h->stat[l], (size_t)h->stat_groups_cap * cpad * 2);
         // weight-gradient partials: chunks <= min(B, CUs / blocks); chunks * blocks <= max(CUs, blocks)
         size_t mx = 0;
         for (const LayerInfo& L : h->layers) {
             const int cot = L.co_tiles, cit = cdiv(L.cin, 16), blocks = cdiv(cot, 2) * cdiv(cit, 2);
             int chunks = 2 * h->num_cus / blocks;
-            chunks = chunks < 1 ? 1 : (chunks > h->maxB ? h->maxB : chunks);
+            chunks = chunks < 1 ? 1 : (chunks > h->max_imgs ? h->max_imgs : chunks);
             const size_t n = (size_t)chunks * 9 * cot * 16 * cit * 16;
             mx = n > mx ? n : mx;
         }
@@ -617,6 +974,56 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         }
         AL(&h->hwpart, (size_t)h->K * h->hp_total);
     }
+    if (h->atari) {
+        const int H1 = h->obsH / 2, W1 = h->obsW / 2, H2 = H1 / 2, W2 = W1 / 2, H3 = H2 / 2, W3 = W2 / 2, P = h->P;
+        const size_t n48 = (size_t)h->maxB * 128 * H1 * W1, n24 = (size_t)h->maxB * P * H2 * W2, n12 = (size_t)h->maxB * P * H3 * W3;
+        const int cpad = pad16(P > 128 ? P : 128);
+        auto stage = [&](mzlc_learner::StageBufs& sb, size_t n) {
+            sb.y.resize(4); sb.fcoef.resize(4); sb.save.resize(4); sb.bcoef.resize(4); sb.h1.resize(2); sb.x.resize(2);
+            for (int i = 0; i < 4; i++) { AL(&sb.y[i], n); AL(&sb.fcoef[i], (size_t)3 * cpad); AL(&sb.save[i], (size_t)2 * cpad); AL(&sb.bcoef[i], (size_t)3 * cpad); }
+            for (int i = 0; i < 2; i++) { AL(&sb.h1[i], n); AL(&sb.x[i], n); }
+            AL(&sb.dzA, n); AL(&sb.dzB, n); AL(&sb.gF, n);
+        };
+        stage(h->sb48, n48);
+        stage(h->sb24, n24);
+        AL(&h->y_c1, n48); AL(&h->a1, n48); AL(&h->y_c2, n24); AL(&h->a2, n24); AL(&h->p1, n12); AL(&h->g12in, n12); AL(&h->hraw, h->T); AL(&h->dH, h->T);
+        for (int i = 0; i < 3; i++) AL(&h->D12[i], n12);
+        ok = ok && alloc_app(h, h->t12, h->a12, n12);
+        const size_t ts2 = (size_t)(TILE + 2) * (TILE + 2);
+        size_t nt = (size_t)h->maxB * (H1 / TILE) * (W1 / TILE) * 128 * ts2;
+        const size_t nt24 = (size_t)h->maxB * (H2 / TILE) * (W2 / TILE) * P * ts2;
+        nt = nt24 > nt ? nt24 : nt;
+        AL(&h->TA, nt); AL(&h->TB, nt); AL(&h->TC, nt);
+        AL(&h->coef_relu, (size_t)3 * cpad); AL(&h->coef_ident, (size_t)3 * cpad);
+        if (ok) {
+            std::vector<float> one(3 * cpad, 0.0f);
+            for (int c = 0; c < cpad; c++) one[c] = 1.0f;  // row 0 = 1: (a, b) = (1, 0) and (c1, c2, c3) = (1, 0, 0)
+            ok = hipMemcpy(h->coef_relu, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(h->coef_ident, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        }
+        std::vector<LcPackPar> pj;
+        for (int k = 0; k < 2; k++) {
+            const LayerInfo& L = h->layers[k == 0 ? h->l_c1 : h->l_c2];
+            for (int pq = 0; pq < 4; pq++) {
+                LcPackPar j{};
+                j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.dst_off = h->par_f[k][pq]; j.n_cb = L.n_cb; j.co_tiles = L.co_tiles; j.transpose = 0;
+                par_tapmap(pq >> 1, pq & 1, false, j.tapmap);
+                pj.push_back(j);
+            }
+        }
+        {
+            const LayerInfo& L = h->layers[h->l_c2];
+            for (int pq = 0; pq < 4; pq++) {
+                LcPackPar j{};
+                j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.dst_off = h->par_d[pq]; j.n_cb = cdiv(L.cout, 16); j.co_tiles = cdiv(L.cin, 16); j.transpose = 1;
+                par_tapmap(pq >> 1, pq & 1, true, j.tapmap);
+                pj.push_back(j);
+            }
+        }
+        h->n_pack_par = (int)pj.size();
+        ok = ok && dalloc(h, &h->d_pack_par, pj.size()) == hipSuccess;
+        if (ok) ok = hipMemcpy(h->d_pack_par, pj.data(), pj.size() * sizeof(LcPackPar), hipMemcpyHostToDevice) == hipSuccess;
+    }
     h->sq_blocks = (int)((h->total + 1023) / 1024);
     AL(&h->d_sq, (size_t)h->sq_blocks);
     if (!ok) {
@@ -624,8 +1031,9 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         mzlc_destroy(h);
         return MZL_E_HIP;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = conv_attr<15, 15>();
     if (e == hipSuccess) e = conv_attr<15, 0>();
     if (e == hipSuccess) e = conv_attr<9, 0>();
@@ -682,6 +1090,7 @@ int mzlc_bind_buffers(mzlc_learner* h, float* running, int64_t* num_batches) {
 
 static int pack_all(mzlc_learner* h, hipStream_t st) {
     hipLaunchKernelGGL(k_lc_pack, dim3(64, h->n_pack), dim3(256), 0, st, h->d_pack, h->params, h->packed);
+    if (h->n_pack_par) hipLaunchKernelGGL(k_lc_pack_par, dim3(64, h->n_pack_par), dim3(256), 0, st, h->d_pack_par, h->params, h->packed);
     for (int i = 0; i < 3; i++) {
         const int nf = h->head[i].oc * h->hw, n = h->head[i].n_out * nf;
         hipLaunchKernelGGL(k_lc_pack_lin, dim3(cdiv(n, 256)), dim3(256), 0, st, h->params, h->lwT + h->lwT_off[i], h->head[i].lw_off, h->head[i].n_out, nf);
@@ -730,13 +1139,18 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     LcBatch bt{};
     bt.state = b->d_state; bt.action = b->d_action; bt.pi = b->d_pi_prob; bt.value = b->d_value; bt.reward = b->d_reward; bt.idx = b->d_index;
     bt.w = b->d_weights; bt.prio = b->d_priorities; bt.B = B; bt.state_i8 = b->state_is_int8; bt.action_bytes = b->action_bytes; bt.K = K; bt.A = h->A;
-    bt.in_dim = h->C0 * h->hw;
+    bt.in_dim = h->C0 * h->obsH * h->obsW;
     hipLaunchKernelGGL(k_lc_gather, dim3(cdiv(bt.in_dim, 256) > 8 ? 8 : cdiv(bt.in_dim, 256), B), dim3(256), 0, st, bt, h->obs, h->act);
-    Sched sr{h, B, 0, false}, s0{h, B, 0, paired}, s1{h, B, 1, paired};
+    Sched sr{h, B, 0, false, h->gm, h->P}, s0{h, B, 0, paired, h->gm, h->P}, s1{h, B, 1, paired, h->gm, h->P};
     // ---- forward ----
     std::vector<Op> ops, ops2;
-    float* hraw = sr.tower_fwd(ops, h->tower[0], h->app_rep, h->obs, nullptr);
-    for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
+    float* hraw;
+    if (h->atari) {
+        hraw = atari_rep_fwd(h, B, st);
+    } else {
+        hraw = sr.tower_fwd(ops, h->tower[0], h->app_rep, h->obs, nullptr);
+        for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
+    }
     launch_normalize(h, hraw, h->s[0], B, st);
     std::vector<float*> g_raw(K), f_out(K);
     for (int t = 0; t < K; t++) {
@@ -765,7 +1179,7 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     hipLaunchKernelGGL(k_lch_conv, dim3(B, ng), dim3(256), 0, st, HA);
     hipLaunchKernelGGL(k_lch_bn, dim3(1), dim3(64 * 3 * LCH_MAXOC), 0, st, HA);
     {
-        const size_t lds = ((size_t)LCH_MAXOC * h->hw + 2 * (size_t)h->n_max + 16) * sizeof(float);
+        const size_t lds = ((size_t)LCH_MAXOC * h->hw + 3 * (size_t)h->n_max + 32) * sizeof(float);
         hipLaunchKernelGGL(k_lch_loss, dim3(B, ng), dim3(256), lds, st, HA);
     }
     hipLaunchKernelGGL(k_lch_bnb, dim3(1), dim3(64 * (3 * LCH_MAXOC + 1)), 0, st, HA);
@@ -796,7 +1210,9 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
         if (run_zip(h, ops, ops2, false, st, paired)) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
         gs_next = gs_t;
     }
-    {
+    if (h->atari) {
+        atari_rep_bwd(h, B, gs_next, st);
+    } else {
         LcEntry er{};
         er.x = hraw; er.gs = gs_next; er.extra = nullptr; er.partner = h->app_rep.y.back(); er.dz = h->D[0][0]; er.stat_part = h->stat[0];
         er.scale = 1.0f; er.B = B; er.C = h->P; er.hw = h->hw; er.cpad = pad16(h->P);

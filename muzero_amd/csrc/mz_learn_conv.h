@@ -357,12 +357,13 @@ struct LcWgrad {
     int B, ipw;            // images per chunk
     int h, w_img, P4, nsteps, SPY, SPX;
     int co_blocks;         // blockIdx.y = chunk * co_blocks + cob
+    int ring_zero;         // 1: the outermost ring of every dy image is multiplied by 0 (tiles gathered with their halo: only the inner pixels are outputs)
 };
 
 // ACT: the layer has action-plane input channels (the dynamics net's first conv); the other builds carry none of that code.
 // LDS is single-buffered (67.6 KB at 15 x 15): TWO workgroups share a CU, one's staging (global -> registers is in flight during the MFMAs, but the
 // transform and the LDS writes are VALU / LDS issue) runs under the other's MFMAs.
-template <bool ACT>
+template <bool ACT, bool RING = false>
 __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     // XCD-aware placement.  The 8 XCDs take workgroups round-robin by linear id, each with its own 4 MB L2; the co_blocks x ci_blocks workgroups
     // of one image chunk read the SAME dz / y / x planes (each plane is staged by every block of the other channel dimension).  In launch order
@@ -408,11 +409,13 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const bool s_ok = lane < QP;
     const int p0 = (s_ok ? lane : 0) * 4;
     int spos[4], pm[4];
+    float ym[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
         spos[e] = (s_ok && pp < hw) ? py * L.P4 + px : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
         pm[e] = ACT ? pp % L.num_actions : 0;
+        ym[e] = (RING && (py == 0 || px == 0 || py == L.h - 1 || px == L.w_img - 1)) ? 0.0f : 1.0f;
     }
     float4 rdz[8], ry[8], rx[8];
     int r_act = -1;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
             const float c1 = s_dc[cl], c2 = s_dc[32 + cl], c3 = s_dc[64 + cl];
             const float a[4] = {rdz[k].x, rdz[k].y, rdz[k].z, rdz[k].w}, yy[4] = {ry[k].x, ry[k].y, ry[k].z, ry[k].w};
 #pragma unroll
-            for (int e = 0; e < 4; e++) vy[k][e] = fmaf(c1, a[e], fmaf(c2, yy[e], c3));
+            for (int e = 0; e < 4; e++) vy[k][e] = RING ? fmaf(c1, a[e], fmaf(c2, yy[e], c3)) * ym[e] : fmaf(c1, a[e], fmaf(c2, yy[e], c3));
         }
         const bool bnrelu = L.x_mode == IN_BNRELU;
 #pragma unroll
@@ -556,6 +559,8 @@ struct LcWreduce {
     const float* part;
     float* grad;
     int chunks, cout, cin, co_pad, ci_pad, accumulate;
+    int use_map;            // 1: accumulator tap t of the partials is weight tap tapmap[t] (-1: not a tap of this parity plane; see LcTileGather)
+    signed char tapmap[9];
 };
 __global__ __launch_bounds__(256) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
     const bool second = (int)blockIdx.y >= PJ.na;
@@ -564,8 +569,10 @@ __global__ __launch_bounds__(256) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
     const int n = 9 * L.cout * L.cin;
     const int i = by * 256 + threadIdx.x;  // (tap, co, ci), ci fastest: coalesced reads
     if (i >= n) return;
-    const int ci = i % L.cin, co = (i / L.cin) % L.cout, tap = i / (L.cin * L.cout);
-    const float* p = L.part + ((size_t)tap * L.co_pad + co) * L.ci_pad + ci;
+    const int ci = i % L.cin, co = (i / L.cin) % L.cout, tap_src = i / (L.cin * L.cout);
+    const int tap = L.use_map ? (int)L.tapmap[tap_src] : tap_src;
+    if (tap < 0) return;
+    const float* p = L.part + ((size_t)tap_src * L.co_pad + co) * L.ci_pad + ci;
     const size_t cs = (size_t)9 * L.co_pad * L.ci_pad;
     float s = 0.0f;
     for (int c = 0; c < L.chunks; c++) s += p[c * cs];
@@ -852,6 +859,122 @@ __global__ __launch_bounds__(256) void k_lc_entry(const LcEntry L) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Large images (the Atari representation, network.py:312-353: 96 x 96 -> 48 x 48 -> 24 x 24 before the hidden state's 6 x 6): the convolution
+// kernels above hold WHOLE images of at most 240 points.  A large plane is cut into T x T tiles, gathered WITH their one-pixel halo into
+// (T + 2) x (T + 2) "images" (zero outside the plane), convolved by the same kernels -- of every tile's output only the inner T x T is
+// meaningful -- and scattered back.  The staging transform (BatchNorm + ReLU, BatchNorm backward) is applied by the gather, which is the one
+// place that knows which halo positions lie outside the plane (the convolution pads the TRANSFORMED activation with zeros).  A stride-2
+// convolution (conv_1, conv_2) is four stride-1 convolutions over the parity planes of its input, x[2 y' + p][2 x' + q]: tap ky of output
+// row oy reads input row 2 oy + ky - 1, i.e. the even plane's row oy for ky = 1 and the odd plane's rows oy - 1 / oy for ky = 0 / 2 -- the
+// gather takes a stride and an origin, the packed weights of each plane hold its taps and zeros elsewhere.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LcTileGather {
+    const float* src0;   // [B][C][srcH][srcW]
+    const float* src1;   // IN_BNBWD: y
+    const float* coef;   // [3][cpad] or null (IN_IDENT)
+    float* dst;          // [B * nty * ntx][C][(T + 2)^2]
+    int mode;            // IN_IDENT | IN_BNRELU | IN_BNBWD
+    int B, C, cpad, H, W;            // the plane that is tiled (a parity plane: H = srcH / 2)
+    int srcH, srcW, sy, sx, py, px;  // plane position (y, x) is source element (y * sy + py, x * sx + px)
+    int T, nty, ntx;
+    int inner_only;      // 1: the halo ring is written as zeros (the dy operand of the weight gradient: only the tile's own pixels count)
+    long long n;         // elements of dst
+};
+__global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.n) return;
+    const int TS = L.T + 2, ts2 = TS * TS;
+    const int lx = (int)(i % TS), ly = (int)((i / TS) % TS), c = (int)((i / ts2) % L.C);
+    const long long ti = i / ((long long)ts2 * L.C);
+    const int nt = L.nty * L.ntx, b = (int)(ti / nt), t = (int)(ti % nt), tyi = t / L.ntx, txi = t % L.ntx;
+    const int y = tyi * L.T - 1 + ly, x = txi * L.T - 1 + lx;
+    float v = 0.0f;
+    const bool ring = ly == 0 || lx == 0 || ly == TS - 1 || lx == TS - 1;
+    if (y >= 0 && y < L.H && x >= 0 && x < L.W && !(L.inner_only && ring)) {
+        const size_t si = ((size_t)b * L.C + c) * L.srcH * L.srcW + (size_t)(y * L.sy + L.py) * L.srcW + (x * L.sx + L.px);
+        v = L.src0[si];
+        if (L.mode == IN_BNRELU) {
+            v = fmaf(L.coef[c], v, L.coef[L.cpad + c]);
+            v = v > 0.0f ? v : 0.0f;
+        } else if (L.mode == IN_BNBWD) {
+            v = fmaf(L.coef[c], v, fmaf(L.coef[L.cpad + c], L.src1[si], L.coef[2 * L.cpad + c]));
+        }
+    }
+    L.dst[i] = v;
+}
+
+// inner T x T of every tile -> the plane (a parity plane of dst when sy = 2), + skip; optional forward statistics (sum v, sum v^2) per
+// (workgroup, channel).  workgroup = one image x 32 plane positions; thread (position, channel group of 8)
+struct LcTileScatter {
+    const float* src;    // tiles [B * nty * ntx][C][(T + 2)^2]
+    float* dst;          // [B][C][dstH][dstW]
+    const float* skip;   // like dst, or null
+    float* stat_part;    // [B * chunks][cpad][2] or null
+    int B, C, cpad, H, W, dstH, dstW, sy, sx, py, px, T, nty, ntx;
+};
+template <int CPT>
+__global__ __launch_bounds__(256) void k_lc_tile_scatter(const LcTileScatter L) {
+    const int b = blockIdx.y, lp = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + lp;
+    const int cpt = (L.C + 7) >> 3, TS = L.T + 2;
+    const bool ok = p < L.H * L.W;
+    const int y = ok ? p / L.W : 0, x = ok ? p - (p / L.W) * L.W : 0;
+    const int tyi = y / L.T, txi = x / L.T, ly = y - tyi * L.T + 1, lx = x - txi * L.T + 1;
+    const size_t sbase = ((size_t)(b * L.nty + tyi) * L.ntx + txi) * L.C * TS * TS + (size_t)ly * TS + lx;
+    const size_t dbase = (size_t)b * L.C * L.dstH * L.dstW + (size_t)(y * L.sy + L.py) * L.dstW + (x * L.sx + L.px);
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg * cpt + i;
+        float v = 0.0f;
+        if (ok && i < cpt && c < L.C) {
+            v = L.src[sbase + (size_t)c * TS * TS];
+            const size_t di = dbase + (size_t)c * L.dstH * L.dstW;
+            if (L.skip) v += L.skip[di];
+            L.dst[di] = v;
+        }
+        if (L.stat_part) {
+            float a = mz::butterfly16(v), bb = mz::butterfly16(v * v);
+            a += __shfl_xor(a, 16);
+            bb += __shfl_xor(bb, 16);
+            if (lp == 0 && i < cpt && c < L.C) {
+                float* d = L.stat_part + (((size_t)b * gridDim.x + blockIdx.x) * L.cpad + c) * 2;
+                d[0] = a; d[1] = bb;
+            }
+        }
+    }
+}
+
+// nn.AvgPool2d(3, 2, 1), count_include_pad (network.py:337,342), and its backward (every input pixel collects 1 / 9 of the outputs whose window covers it)
+__global__ __launch_bounds__(256) void k_lc_pool_fwd(const float* in, float* out, long long n, int ih, int iw, int oh, int ow) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const float* p = in + (i / ((long long)ow * oh)) * ih * iw;
+    float acc = 0.0f;
+    for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) {
+            const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+            if (iy >= 0 && iy < ih && ix >= 0 && ix < iw) acc = acc + p[iy * iw + ix];
+        }
+    out[i] = acc / 9.0f;
+}
+__global__ __launch_bounds__(256) void k_lc_pool_bwd(const float* gout, float* gin, long long n, int ih, int iw, int oh, int ow) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over the INPUT pixels
+    if (i >= n) return;
+    const int ix = (int)(i % iw), iy = (int)((i / iw) % ih);
+    const float* g = gout + (i / ((long long)iw * ih)) * oh * ow;
+    float acc = 0.0f;
+    for (int oy = (iy + 0) / 2; oy <= (iy + 1) / 2; oy++)      // 2 oy - 1 <= iy <= 2 oy + 1
+        for (int ox = (ix + 0) / 2; ox <= (ix + 1) / 2; ox++)
+            if (oy < oh && ox < ow) acc = acc + g[oy * ow + ox];
+    gin[i] = acc / 9.0f;
+}
+// dz = g [x > 0] for a ReLU WITHOUT BatchNorm (conv_1 / conv_2 of the Atari representation, network.py:345,347); x = relu(y) materialised
+__global__ __launch_bounds__(256) void k_lc_relu_bwd(const float* g, const float* x, float* dz, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dz[i] = x[i] > 0.0f ? g[i] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Batch plumbing: replay rows -> dense observations and actions (replay.py:27-32 `Transition` storages addressed by row index)
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct LcBatch {
@@ -1049,30 +1172,59 @@ __global__ __launch_bounds__(256) void k_lch_loss(const LchArgs A) {
             s_dl[0] = 2.0f * d * gscale;
             if (G.head == 2 && G.t == 0) A.bt.prio[b] = fabsf(d);  // pipeline.py:603-609
         }
-    } else {            // cross entropy against soft targets (pipeline.py:629)
+    } else {            // cross entropy against soft targets (pipeline.py:629): the policy's visit distribution, or (kind 2) the 2-hot projection
+                        // of the transformed scalar target onto the support (util.py:48-59,96-116: signed_hyperbolic, clamp, two neighbouring bins)
+        float* s_tg = s_red + 16;  // [n_out] (kind 2)
         const float* pi = A.bt.pi + ((size_t)row * A.K + G.t) * A.A;
+        float tscalar = 0.0f;
+        if (H.kind == 2) {
+            tscalar = (G.head == 0 ? A.bt.reward : A.bt.value)[row * A.K + G.t];
+            for (int n = tid; n < H.n_out; n += 256) s_tg[n] = 0.0f;
+            __syncthreads();
+            if (tid == 0) {
+                const float half = (float)((H.n_out - 1) / 2);
+                const float ax = fabsf(tscalar), sg = tscalar > 0.0f ? 1.0f : (tscalar < 0.0f ? -1.0f : 0.0f);
+                float z = sg * (sqrtf(ax + 1.0f) - 1.0f) + 0.001f * tscalar;          // signed_hyperbolic, util.py:20-22
+                z = z < -half ? -half : (z > half ? half : z);
+                const float span = 2.0f * half, pos = (z + half) / span * (float)(H.n_out - 1);
+                const float lo = floorf(pos), hi = ceilf(pos);
+                const float slo = lo / ((float)H.n_out - 1.0f) * span - half, shi = hi / ((float)H.n_out - 1.0f) * span - half;
+                const float wlo = (shi - z) / (shi - slo + 1e-5f);
+                s_tg[(int)lo] += wlo;
+                s_tg[(int)hi] += 1.0f - wlo;
+            }
+            __syncthreads();
+            pi = s_tg;
+        }
         float mx = __uint_as_float(0xff800000u);
         for (int n = tid; n < H.n_out; n += 256) mx = s_lg[n] > mx ? s_lg[n] : mx;
         for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(mx, m); mx = o > mx ? o : mx; }
         if ((tid & 63) == 0) s_red[tid >> 6] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        float se = 0.0f, sp = 0.0f, spl = 0.0f;
+        float se = 0.0f, sp = 0.0f, spl = 0.0f, sev = 0.0f;
+        const float half_s = (float)((H.n_out - 1) / 2);
         for (int n = tid; n < H.n_out; n += 256) {
             const float e = expf(s_lg[n] - mx);
             se += e;
             sp += pi[n];
             spl = fmaf(pi[n], s_lg[n] - mx, spl);
+            sev = fmaf(e, (float)n - half_s, sev);  // (kind 2: expectation over the support, for the priority)
         }
-        for (int m = 32; m >= 1; m >>= 1) { se += __shfl_xor(se, m); sp += __shfl_xor(sp, m); spl += __shfl_xor(spl, m); }
+        for (int m = 32; m >= 1; m >>= 1) { se += __shfl_xor(se, m); sp += __shfl_xor(sp, m); spl += __shfl_xor(spl, m); sev += __shfl_xor(sev, m); }
         __syncthreads();
-        if ((tid & 63) == 0) { s_red[tid >> 6] = se; s_red[4 + (tid >> 6)] = sp; s_red[8 + (tid >> 6)] = spl; }
+        if ((tid & 63) == 0) { s_red[tid >> 6] = se; s_red[4 + (tid >> 6)] = sp; s_red[8 + (tid >> 6)] = spl; s_red[12 + (tid >> 6)] = sev; }
         __syncthreads();
         se = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
         sp = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
         spl = ((s_red[8] + s_red[9]) + s_red[10]) + s_red[11];
+        sev = ((s_red[12] + s_red[13]) + s_red[14]) + s_red[15];
         const float lse = logf(se);
-        if (tid == 0) A.lpart[(size_t)g * A.B + b] = (sp * lse - spl) * wgt;   // -sum pi (l - mx - lse)
+        if (tid == 0) {
+            A.lpart[(size_t)g * A.B + b] = (sp * lse - spl) * wgt;   // -sum pi (l - mx - lse)
+            // priority |v_0 - z_0| in scalar space (pipeline.py:603-609): logits_to_transformed_expected_value (util.py:70-93)
+            if (H.kind == 2 && G.head == 2 && G.t == 0) A.bt.prio[b] = fabsf(mz::signed_parabolic(sev / se) - tscalar);
+        }
         for (int n = tid; n < H.n_out; n += 256) s_dl[n] = (expf(s_lg[n] - mx) / se * sp - pi[n]) * gscale;
     }
     __syncthreads();
@@ -1298,6 +1450,26 @@ __global__ __launch_bounds__(256) void k_lc_pack(const LcPackJob* jobs, const fl
             if (co < J.cout && ci < J.cin_d) v = params[J.w_off + ((size_t)co * J.cin + ci) * 9 + (8 - tap)];
             packed[J.d_off + x] = v;
         }
+    }
+}
+// operand copy of one parity plane of a stride-2 conv (see LcTileGather): tap t of the stride-1 kernel the tiles are convolved with is weight tap
+// tapmap[t] (or 0 where the plane has no such tap).  transpose: the data gradient's copy ("output" channel = the layer's input channel)
+struct LcPackPar {
+    int w_off, cout, cin, dst_off, n_cb, co_tiles, transpose;
+    signed char tapmap[9];
+};
+__global__ __launch_bounds__(256) void k_lc_pack_par(const LcPackPar* jobs, const float* params, float* packed) {
+    const LcPackPar J = jobs[blockIdx.y];
+    const int n = J.co_tiles * J.n_cb * 9 * 256;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < n; x += gridDim.x * 256) {
+        const int i = x & 3, lane = (x >> 2) & 63, rest = x >> 8;
+        const int tap = rest % 9, cb = (rest / 9) % J.n_cb, ct = rest / (9 * J.n_cb);
+        const int q = lane >> 4, jj = lane & 15, src = J.tapmap[tap];
+        const int o = 16 * ct + jj, k = 16 * cb + 4 * i + q;   // output channel of this conv, reduction channel
+        const int co = J.transpose ? k : o, ci = J.transpose ? o : k;
+        float v = 0.0f;
+        if (src >= 0 && co < J.cout && ci < J.cin) v = params[J.w_off + ((size_t)co * J.cin + ci) * 9 + src];
+        packed[J.dst_off + x] = v;
     }
 }
 // transposed Linear weights of the heads: lwT[k][n] = lw[n][k]

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmzlearner_hip.so')
 ABI_SYMBOLS = ['mzl_last_error', 'mzl_create', 'mzl_destroy', 'mzl_num_params', 'mzl_grad_floats', 'mzl_num_tensors', 'mzl_tensor_info',
                'mzl_num_buffers', 'mzl_num_running', 'mzl_buffer_info', 'mzl_bind_buffers', 'mzl_bind', 'mzl_commit', 'mzl_grad', 'mzl_apply',
                'mzl_replay_scratch_doubles', 'mzl_replay_sample', 'mzl_replay_update_priorities']
-NET_MLP, NET_BOARD = 0, 1
+NET_MLP, NET_BOARD, NET_ATARI = 0, 1, 2
 
 
 class LearnerError(RuntimeError):
@@ -160,11 +160,11 @@ class HipLearner:
         if self.device.type == 'cuda' and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
         spec = network.planner_spec()
-        if spec['kind'] not in ('mlp', 'board'):
-            raise LearnerError('HipLearner covers MuZeroMLPNet and MuZeroBoardGameNet; the Atari net trains through muzero_amd.learner.train_step')
+        if spec['kind'] not in ('mlp', 'board', 'atari'):
+            raise LearnerError(f"HipLearner covers MuZeroMLPNet, MuZeroBoardGameNet and MuZeroAtariNet, not {spec['kind']!r}")
         self.kind = spec['kind']
         tiles = (max_batch + 15) // 16
-        if self.kind == 'board':
+        if self.kind in ('board', 'atari'):
             grad_slices = 1
         if grad_slices is None:
             # long reductions (large batches): the weight-gradient kernel runs one 8-wave workgroup per (layer, slice) -- 8 unrolled layers
@@ -172,9 +172,10 @@ class HipLearner:
             cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
             grad_slices = 1 if tiles * unroll_steps < 256 else max(2, min(64, int(cus / (8.0 + 2.0 / unroll_steps)), tiles * unroll_steps // 8))
         in_dim = int(np.prod(spec['input_shape']))
-        if self.kind == 'board':
+        if self.kind in ('board', 'atari'):
             c0, bh, bw = spec['input_shape']
-            cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], 1, 1, 1, unroll_steps, max_batch, 1, NET_BOARD, c0, bh, bw, spec['num_res_blocks'])
+            cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], 1, spec['value_support_size'], spec['reward_support_size'], unroll_steps, max_batch, 1,
+                            NET_BOARD if self.kind == 'board' else NET_ATARI, c0, bh, bw, spec['num_res_blocks'])
         else:
             cfg = MzlConfig(in_dim, spec['num_actions'], spec['num_planes'], spec['hidden_dim'], spec['value_support_size'], spec['reward_support_size'],
                             unroll_steps, max_batch, grad_slices, NET_MLP, 0, 0, 0, 0)

@@ -860,6 +860,7 @@ LEARN_CASES = [
     ('mlp_cat', 'mlp', 'tiny', 6),             # categorical value / reward heads
     ('mlp_mse', 'mlp', 'tiny_mse', 5),         # MSE heads
     ('conv_board3', 'conv', 'board3', 4),      # BatchNorm in train mode
+    ('conv_atari_s', 'conv', 'atari_s', 3),    # MuZeroAtariNet: strided 96 x 96 representation, average pools, categorical conv heads (round 5)
 ]
 
 

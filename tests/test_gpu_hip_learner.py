@@ -165,10 +165,11 @@ def test_errors_are_reported_not_swallowed():
                  idx.data_ptr(), w.data_ptr(), hl.loss.data_ptr(), hl.priorities.data_ptr(), 8, 0, 1)
     L = load_library()
     assert L.mzl_grad(hl._h, C.byref(b), None) == -1 and b'd_state is not memory' in L.mzl_last_error()
-    from helpers import build_conv, conv_case
+    # the Atari kernels cut the 48 x 48 and 24 x 24 stages into 12 x 12 tiles: frames other than the reference's 96 x 96 are refused, not mis-tiled
+    from muzero_amd.network import MuZeroAtariNet
 
-    with pytest.raises(LearnerError, match='MuZeroMLPNet'):  # (round 5: board nets have their own kernels; the Atari net still has none)
-        _hip(build_conv(conv_case('atari_s')).to(dev), dev, 8)
+    with pytest.raises(LearnerError, match='96'):
+        _hip(MuZeroAtariNet((4, 64, 64), 6, 1, 8, 11, 11).to(dev), dev, 8)
 
 
 def _closed_loop(seed, iters=6, envs=64):
