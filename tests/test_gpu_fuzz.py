@@ -530,3 +530,32 @@ def test_random_conv_learner_configuration_matches_float64_autograd(i):
         # the other way in float32 -- a mean bar for the tensor, and a 2 lr bar for single elements
         d = (p.double() - q).abs()
         assert float(d.mean()) <= 0.02 * max(moved, 1e-12) + 1e-7 and float(d.max()) <= 2.2 * o['lr'] + 1e-6, (c, k, float(d.mean()), float(d.max()), moved)
+
+
+ATARI_LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_ATARI_LEARN_CASES', '4'))
+
+
+@pytest.mark.parametrize('i', range(ATARI_LEARN_CASES_N))
+def test_random_atari_learner_configuration_matches_float64_autograd(i):
+    """Round 5: the conv learner's Atari path (tiles of the 48 x 48 / 24 x 24 stages, parity-plane strided convolutions, pools, categorical heads)
+    over frame stacks 1-32, planes 8-128, 1-3 blocks, 3-18 actions, supports 5-601 (value and reward drawn apart), unroll 1-6, batches 1-9, against
+    float64 PyTorch-ROCm autograd.  Twice per case (tests/test_gpu_atari_learner.py explains why): seeded random weights -- loss, priorities and
+    BatchNorm statistics at the board-net bars, gradients at the 0.25 mask-noise bar -- and kink-free weights -- every gradient tensor at 2e-3."""
+    import torch
+
+    from test_gpu_atari_learner import NOISY, TIGHT, _case
+
+    rs = np.random.RandomState(8800 + i + 100000 * OFFSET)
+    chan, planes, blocks = int(rs.choice([1, 2, 4, 4, 8, 32])), int(rs.choice([8, 16, 24, 40, 64, 128])), int(rs.choice([1, 1, 2, 3]))
+    A, vs, rsz, K = int(rs.randint(3, 19)), int(rs.choice([5, 11, 31, 61, 601])), int(rs.choice([5, 11, 31, 61, 601])), int(rs.choice([5, 5, 1, 2, 3, 6]))
+    B = int(rs.choice([1, 2, 3, 5, 9]))
+    if planes >= 64:
+        B = min(B, 3)
+    c = (chan, planes, blocks, A, vs, rsz, B, K, int(rs.randint(1 << 20)))
+    dev = torch.device('cuda', 0)
+    errs, probe = _case(*c, True, dev)
+    worst = max(errs, key=errs.get)
+    assert probe.closest_all > 1e-4 and errs[worst] <= TIGHT, (c, worst, errs[worst], probe.closest_all)
+    errs, probe = _case(*c, False, dev)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] <= (NOISY if B > 1 else 0.6), (c, worst, errs[worst], probe.closest_all)
