@@ -71,19 +71,25 @@ int pad16(int x) { return (x + 15) & ~15; }
 int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // pixel tiling of the conv kernels (G whole images per workgroup in NPT tiles of 16 pixel slots; lane = pixel quad while staging) and the pitch
-// layout of the weight-gradient kernel for h x w images; false if the image does not fit
-bool make_geom(Geom& g, int hh, int ww, bool allow_side15) {
+// layout of the weight-gradient kernel for h x w images; false if the image does not fit.  `images` > 0: the batch the learner is built for --
+// the tiling is then chosen by the time of one launch, (rounds of workgroups over the CUs) x (tiles per workgroup), `wg_per_group` workgroups
+// per image group (output-channel blocks x paired jobs): at batch 128 a 6 x 6 hidden state packs best as 4 images in 9 tiles, but that is 128
+// workgroups on 256 CUs, and 2 images in 6 tiles fills the chip in 2/3 of the time.  Ties / images == 0: the densest packing.
+bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256) {
     g.h = hh; g.w = ww; g.hw = hh * ww;
     if (g.hw < 1 || g.hw > 240) return false;
     const int QP = (g.hw + 3) / 4;
     double best = -1.0;
+    long best_cost = -1;
     const int cand[3] = {6, 9, 15};
     for (int i = 0; i < 3; i++) {
         int G = (16 * cand[i]) / g.hw;
         if (64 / QP < G) G = 64 / QP;
         if (G < 1) continue;
         const double eff = (double)G * g.hw / (16.0 * cand[i]);
-        if (eff > best + 1e-9) { best = eff; g.npt = cand[i]; g.G = G; }  // (ties: the smaller tiling -- fewer accumulators per wave)
+        const long cost = images > 0 ? (long)cdiv(cdiv(images, G) * wg_per_group, cus) * cand[i] : 0;
+        // (ties: the denser packing, then the smaller tiling -- fewer accumulators per wave)
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && eff > best + 1e-9)) { best = eff; best_cost = cost; g.npt = cand[i]; g.G = G; }
     }
     if (best < 0.0) return false;
     g.qstride = (4 * g.G * (g.h + 2) * (g.w + 2) + 63) & ~63;
@@ -586,7 +592,7 @@ struct AtariRun {
         g.src0 = src0; g.src1 = src1; g.coef = coef; g.dst = dst; g.mode = mode; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W;
         g.srcH = srcH; g.srcW = srcW; g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.T = TILE; g.nty = H / TILE; g.ntx = W / TILE; g.inner_only = inner_only;
         g.n = (long long)B * g.nty * g.ntx * C * (TILE + 2) * (TILE + 2);
-        hipLaunchKernelGGL(k_lc_tile_gather, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_lc_tile_gather<TILE + 2>, dim3((unsigned)(B * g.nty * g.ntx), (unsigned)cdiv(C * (TILE + 2) * (TILE + 2), 256)), dim3(256), 0, st, g);
     }
     // returns the number of statistic groups written (0 without stat_part)
     int scatter(const float* src, int C, int H, int W, float* dst, int dstH, int dstW, int sy, int sx, int py, int px, const float* skip, float* stat_part) const {
@@ -641,9 +647,18 @@ struct AtariRun {
     int entry(const float* x, const float* gs, float scale, const float* extra, const float* partner, float* dz, int C, int hw) const {
         LcEntry e{};
         e.x = x; e.gs = gs; e.extra = extra; e.partner = partner; e.dz = dz; e.stat_part = h->stat[0]; e.scale = scale; e.B = B; e.C = C; e.hw = hw; e.cpad = pad16(C);
+        const int cpt = cdiv(C, 8);
+        if (!gs && extra && hw % 4 == 0) {  // the tiled stages: four positions per lane
+            const int nchunks = cdiv(hw / 4, 32), split = nchunks < 32 ? nchunks : 32;
+            const dim3 grid(split, B);
+            if (cpt <= 2) hipLaunchKernelGGL(k_lc_entry_plain<2>, grid, dim3(256), 0, st, e);
+            else if (cpt <= 8) hipLaunchKernelGGL(k_lc_entry_plain<8>, grid, dim3(256), 0, st, e);
+            else if (cpt <= 16) hipLaunchKernelGGL(k_lc_entry_plain<16>, grid, dim3(256), 0, st, e);
+            else hipLaunchKernelGGL(k_lc_entry_plain<32>, grid, dim3(256), 0, st, e);
+            return B * split;
+        }
         const int nchunks = cdiv(hw, 32), split = nchunks < 64 ? nchunks : 64;
         const dim3 grid(split, B);
-        const int cpt = cdiv(C, 8);
         if (cpt <= 2) hipLaunchKernelGGL(k_lc_entry<2>, grid, dim3(256), 0, st, e);
         else if (cpt <= 8) hipLaunchKernelGGL(k_lc_entry<8>, grid, dim3(256), 0, st, e);
         else if (cpt <= 16) hipLaunchKernelGGL(k_lc_entry<16>, grid, dim3(256), 0, st, e);
@@ -865,7 +880,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (cfg->in_dim != h->C0 * h->obsH * h->obsW) return bad("in_dim must equal in_channels * board_h * board_w");
     if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1024 || cfg->reward_support_size > 1024) return bad("support sizes must be in [1, 1024]");
     if (h->hw > 240 || h->P > 1024) return bad("conv learner: boards up to 240 points and 1024 planes (larger nets train through muzero_amd.learner.train_step)");
-    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"))) return bad("board does not fit the conv kernels' tiling");
+    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"), getenv("MZLC_DENSE_TILING") ? 0 : h->maxB, cdiv(cdiv(h->P, 16), 4) * 2, h->num_cus)) return bad("board does not fit the conv kernels' tiling");
     if (wgrad_lds(h->gm) > 160 * 1024 || conv_lds(h->gm.qstride, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
     if (h->atari && (!make_geom(h->gt, TILE + 2, TILE + 2, false) || !make_geom(h->g12, TILE, TILE, false))) return bad("internal: tile geometry");
     // ---- parameter / buffer tables in state_dict order (network.py:312-498) ----

@@ -575,7 +575,15 @@ __global__ __launch_bounds__(256) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
     const float* p = L.part + ((size_t)tap_src * L.co_pad + co) * L.ci_pad + ci;
     const size_t cs = (size_t)9 * L.co_pad * L.ci_pad;
     float s = 0.0f;
-    for (int c = 0; c < L.chunks; c++) s += p[c * cs];
+    int c = 0;
+    for (; c + 8 <= L.chunks; c += 8) {  // eight loads in flight, added in chunk order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[(size_t)(c + k) * cs];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += v[k];
+    }
+    for (; c < L.chunks; c++) s += p[c * cs];
     float* g = L.grad + ((size_t)co * L.cin + ci) * 9 + tap;
     *g = L.accumulate ? *g + s : s;
 }
@@ -599,7 +607,15 @@ struct LcBnFwd {
 // workgroup = 16 channels x 16 group slices: slice j adds groups j, j + 16, .. in float64, the 16 slices meet in LDS in slice order
 __device__ __forceinline__ void lc_group_sums(const float* part, int groups, int cpad, int c, int slice, double (*s_acc)[16][2], double& s1, double& s2) {
     double a = 0.0, b = 0.0;
-    for (int g = slice; g < groups; g += 16) {
+    int g = slice;
+    for (; g + 7 * 16 < groups; g += 8 * 16) {  // (the tiled Atari stages have thousands of groups: eight loads in flight, added in group order)
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const float2*>(part + ((size_t)(g + 16 * k) * cpad + c) * 2);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a += (double)v[k].x; b += (double)v[k].y; }
+    }
+    for (; g < groups; g += 16) {
         const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)g * cpad + c) * 2);
         a += (double)v.x;
         b += (double)v.y;
@@ -858,6 +874,47 @@ __global__ __launch_bounds__(256) void k_lc_entry(const LcEntry L) {
     }
 }
 
+// k_lc_entry without the normalisation (gs == null) for planes of hw % 4 == 0 positions (the tiled stages of the Atari representation: 2304 / 576 /
+// 144): dz = extra [x > 0] + the partial sums, four positions per lane (b128 loads / stores).  grid (nsplit, B) as above, chunks of 128 positions.
+template <int CPT>
+__global__ __launch_bounds__(256) void k_lc_entry_plain(const LcEntry L) {
+    const int b = blockIdx.y, q = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int cpt = (L.C + 7) >> 3, nq = L.hw >> 2, nchunks = (nq + 31) >> 5;
+    float s1[CPT], s2[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; i++) { s1[i] = 0.0f; s2[i] = 0.0f; }
+    for (int ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
+        const int qi = ck * 32 + q;
+        if (qi >= nq) continue;
+        const size_t base = (size_t)b * L.C * L.hw + 4 * (size_t)qi;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg * cpt + i;
+            if (i < cpt && c < L.C) {
+                const size_t o = base + (size_t)c * L.hw;
+                const float4 x = *reinterpret_cast<const float4*>(L.x + o), e = *reinterpret_cast<const float4*>(L.extra + o);
+                const float4 y = *reinterpret_cast<const float4*>(L.partner + o);
+                float4 t;
+                t.x = x.x > 0.0f ? e.x : 0.0f; t.y = x.y > 0.0f ? e.y : 0.0f; t.z = x.z > 0.0f ? e.z : 0.0f; t.w = x.w > 0.0f ? e.w : 0.0f;
+                *reinterpret_cast<float4*>(L.dz + o) = t;
+                s1[i] += (t.x + t.y) + (t.z + t.w);
+                s2[i] += fmaf(t.x, y.x, t.y * y.y) + fmaf(t.z, y.z, t.w * y.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        float a = mz::butterfly16(s1[i]), bb = mz::butterfly16(s2[i]);
+        a += __shfl_xor(a, 16);
+        bb += __shfl_xor(bb, 16);
+        const int c = cg * cpt + i;
+        if (q == 0 && i < cpt && c < L.C) {
+            float* d = L.stat_part + (((size_t)b * gridDim.x + blockIdx.x) * L.cpad + c) * 2;
+            d[0] = a; d[1] = bb;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Large images (the Atari representation, network.py:312-353: 96 x 96 -> 48 x 48 -> 24 x 24 before the hidden state's 6 x 6): the convolution
 // kernels above hold WHOLE images of at most 240 points.  A large plane is cut into T x T tiles, gathered WITH their one-pixel halo into
@@ -880,13 +937,14 @@ struct LcTileGather {
     int inner_only;      // 1: the halo ring is written as zeros (the dy operand of the weight gradient: only the tile's own pixels count)
     long long n;         // elements of dst
 };
+// grid (tiles, channel chunks): the tile's coordinates are workgroup-uniform (scalar), the element's (c, ly, lx) divide by compile-time constants
+template <int TS>
 __global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= L.n) return;
-    const int TS = L.T + 2, ts2 = TS * TS;
-    const int lx = (int)(i % TS), ly = (int)((i / TS) % TS), c = (int)((i / ts2) % L.C);
-    const long long ti = i / ((long long)ts2 * L.C);
-    const int nt = L.nty * L.ntx, b = (int)(ti / nt), t = (int)(ti % nt), tyi = t / L.ntx, txi = t % L.ntx;
+    constexpr int ts2 = TS * TS;
+    const int ti = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= L.C * ts2) return;
+    const int c = j / ts2, r = j - c * ts2, ly = r / TS, lx = r - ly * TS;
+    const int nt = L.nty * L.ntx, b = ti / nt, t = ti - b * nt, tyi = t / L.ntx, txi = t - tyi * L.ntx;
     const int y = tyi * L.T - 1 + ly, x = txi * L.T - 1 + lx;
     float v = 0.0f;
     const bool ring = ly == 0 || lx == 0 || ly == TS - 1 || lx == TS - 1;
@@ -900,7 +958,7 @@ __global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
             v = fmaf(L.coef[c], v, fmaf(L.coef[L.cpad + c], L.src1[si], L.coef[2 * L.cpad + c]));
         }
     }
-    L.dst[i] = v;
+    L.dst[(size_t)ti * L.C * ts2 + j] = v;
 }
 
 // inner T x T of every tile -> the plane (a parity plane of dst when sy = 2), + skip; optional forward statistics (sum v, sum v^2) per

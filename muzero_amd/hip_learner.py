@@ -140,8 +140,23 @@ def conv_learner_flops(input_shape, num_actions: int, num_res_blocks: int, num_p
     return 2.0 * (2 * fwd + dgrad)
 
 
+def atari_learner_flops(input_shape, num_actions: int, num_res_blocks: int, num_planes: int, unroll_steps: int) -> float:
+    """conv_learner_flops for a MuZeroAtariNet (network.py:312-353 of the reference: conv_1 (stride 2) -> two 128-plane blocks at 48 x 48 ->
+    conv_2 (stride 2) -> two blocks at 24 x 24 -> pool -> two blocks at 12 x 12 -> pool; dynamics / prediction towers on 6 x 6).  Algorithmic:
+    the 14 x 14 halo tiles the kernels actually convolve (1.36 x the positions of the two large stages) are not counted."""
+    c0, h, w = input_shape
+    P, A, R, K = num_planes, num_actions, num_res_blocks, unroll_steps
+    s1, s2, s3, s4 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8), (h // 16) * (w // 16)
+    rep_first = c0 * 128 * 9 * s1  # forward + weight gradient only
+    rep_rest = 4 * 128 * 128 * 9 * s1 + 128 * P * 9 * s2 + 4 * P * P * 9 * s2 + 4 * P * P * 9 * s3
+    tower = 2 * R * P * P * 9 * s4
+    fwd = rep_first + rep_rest + K * ((P + A) * P * 9 * s4 + tower) + K * tower
+    dgrad = rep_rest + K * (P * P * 9 * s4 + tower) + K * tower
+    return 2.0 * (2 * fwd + dgrad)
+
+
 class HipLearner:
-    """The learner step of `run_training` (pipeline.py:238-255) for a `MuZeroMLPNet` or a `MuZeroBoardGameNet` on the GPU, as HIP kernels.
+    """The learner step of `run_training` (pipeline.py:238-255) for a `MuZeroMLPNet`, a `MuZeroBoardGameNet` or a `MuZeroAtariNet` on the GPU, as HIP kernels.
     (Conv nets: the BatchNorm layers run in TRAIN mode whatever `network.training` says -- a learner step is a training step -- and their
     running statistics, `num_batches_tracked` included, are module buffers re-pointed at the learner's flat buffer vectors.)
 
