@@ -372,7 +372,8 @@ def learner_leg(rank, local_rank, world, torch, dist, backend, batches=(128, 409
             assert bool(int(same)), 'data-parallel learner: ranks diverged after all-reduced updates'
         hl.close()
     return {'what': 'hip_learner.HipLearner: loss + backward + Adam + operand re-pack as gfx950 kernels, MuZeroMLPNet 512/64/31, unroll 5', 'rows': rows,
-            'flop_per_sample': 6.0 * mac, 'conv': conv_learner_leg(rank, local_rank, world, torch, dist, backend)}
+            'flop_per_sample': 6.0 * mac, 'conv': conv_learner_leg(rank, local_rank, world, torch, dist, backend),
+            'atari': atari_learner_leg(rank, local_rank, world, torch, dist, backend)}
 
 
 def conv_learner_leg(rank, local_rank, world, torch, dist, backend, batch=128, iters=10):
@@ -421,6 +422,46 @@ def conv_learner_leg(rank, local_rank, world, torch, dist, backend, batch=128, i
         same = torch.tensor([1 if torch.equal(mine, ref) else 0], device=dev)
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
         rec['ranks_hold_identical_weights'] = bool(int(same))
+    hl.close()
+    return rec
+
+
+def atari_learner_leg(rank, local_rank, world, torch, dist, backend, batch=128, iters=6):
+    """Row f2, the Atari net (round 5): one update of make_atari_config's network (config.py:132-141: 128 planes, 8 blocks, supports 61, batch 128,
+    unroll 5) on 4 x 96 x 96 frame stacks with 6 actions -- the tile path of csrc/mz_learn_conv.h.  Algorithmic FLOPs:
+    hip_learner.atari_learner_flops (the halo positions the tiles convolve are not counted)."""
+    from muzero_amd.config import make_atari_config
+    from muzero_amd.hip_learner import HipLearner, atari_learner_flops
+    from muzero_amd.network import MuZeroAtariNet
+
+    dev = torch.device('cuda', local_rank)
+    cfg = make_atari_config(use_tensorboard=False)
+    K, cap, A, shape = cfg.unroll_steps, 256, 6, (4, 96, 96)
+    g = torch.Generator(device='cpu').manual_seed(23 + rank)
+    ring = dict(state=torch.rand(cap, 4 * 96 * 96, generator=g).to(dev), action=torch.randint(0, A, (cap, K), generator=g).to(torch.int8).to(dev),
+                pi_prob=torch.full((cap, K, A), 1.0 / A, device=dev), value=(torch.rand(cap, K, generator=g) * 20 - 10).to(dev),
+                reward=(torch.rand(cap, K, generator=g) * 2 - 1).to(dev))
+    torch.manual_seed(0)
+    net = MuZeroAtariNet(shape, A, cfg.num_res_blocks, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size).to(dev)
+    hl = HipLearner(net, dev, K, batch, lr=cfg.lr_init, weight_decay=cfg.weight_decay, milestones=cfg.lr_milestones, gamma=cfg.lr_decay_rate)
+    idx = torch.randint(0, cap, (batch,), generator=g).to(dev)
+    ar = world > 1 and backend == 'nccl'
+    for _ in range(2):
+        hl.step(ring, idx, None, batch, allreduce=ar)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        hl.step(ring, idx, None, batch, allreduce=ar)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    flop = atari_learner_flops(shape, A, cfg.num_res_blocks, cfg.num_planes, K)
+    tf = flop * batch / (ms * 1e-3) / 1e12
+    rec = {'what': 'hip_learner.HipLearner on MuZeroAtariNet 4x96x96 / 128 planes / 8 blocks / A=6 / supports 61, unroll 5 (make_atari_config): loss + backward + Adam as gfx950 kernels',
+           'batch_per_gpu': batch, 'ms_per_update': ms, 'samples_per_sec': world * batch / (ms * 1e-3), 'flop_per_sample': flop, 'achieved_tflops_per_gpu': tf,
+           'mfma_frac': tf / PEAK_FP32_MFMA_TFLOPS, 'parameters': int(hl.total),
+           'pytorch_rocm_same_update_ms': {'eager_miopen': 45.8, 'hip_graph_miopen': 43.3, 'source': 'tools/conv_learner_bench.py --atari, round 5 (DESIGN 4c)'}}
     hl.close()
     return rec
 

@@ -65,6 +65,8 @@ def kinkfree_state_dict(net, seed):
             sd[name + '.weight'] = torch.from_numpy(rs.uniform(0.08, 0.15, n).astype(np.float32))
             sd[name + '.bias'] = torch.from_numpy((sign * rs.uniform(2.0, 3.0, n)).astype(np.float32))
     for name in ('represent_net.conv_1.weight', 'represent_net.conv_2.weight'):
+        if name not in sd:  # (board nets: every ReLU follows a BatchNorm)
+            continue
         wt = sd[name].abs()
         sign = torch.from_numpy(rs.choice([-1.0, 1.0, 1.0], size=wt.shape[0]).astype(np.float32))
         sd[name] = wt * sign.view(-1, 1, 1, 1)
@@ -195,16 +197,21 @@ def _case(chan, planes, blocks, A, vs, rs_, B, K, seed, kinkfree, dev):
             assert float((v - sd[k].double()).abs().max()) <= 3e-5 * max(1.0, float(v.abs().max())), k
         if 'num_batches_tracked' in k:
             assert int(v) == int(sd[k]), k
-    # Relative to the tensor's largest entry, but no finer than 1e-3 of the largest gradient entry of the whole network; BatchNorm shifts (sums of dz
-    # over every position: the most cancellation-prone tensors) count at a fifth.  With every channel live, the shift of a tower's LAST BatchNorm is
-    # cancelled by the batch statistics of the layers behind it -- exactly (float64 gradient ~1e-17 of the others) or up to border effects of the next
-    # convolution's zero padding -- and what a float32 pass leaves there is the rounding of that cancelling sum.
+    return grad_errors(gd, hl.grad_views), probe
+
+
+def grad_errors(gd, views):
+    """Per tensor: max |difference| relative to the tensor's largest entry, but no finer than 1e-3 of the largest gradient entry of the whole
+    network; BatchNorm shifts (sums of dz over every position: the most cancellation-prone tensors) count at a fifth.  With every channel live,
+    the shift of a tower's LAST BatchNorm is cancelled by the batch statistics of the layers behind it -- exactly (float64 gradient ~1e-17 of the
+    others) or up to border effects of the next convolution's zero padding -- and what a float32 pass leaves there is the rounding of that
+    cancelling sum."""
     gmax = max(float(g.abs().max()) for g in gd.values())
     errs = {}
     for k, g in gd.items():
-        e = float((g - hl.grad_views[k].double()).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
+        e = float((g - views[k].double()).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
         errs[k] = e / 5 if k.endswith('.1.bias') else e
-    return errs, probe
+    return errs
 
 
 IDS = [f'c{s[0]}-p{s[1]}-r{s[2]}-a{s[3]}-v{s[4]}-n{s[6]}-k{s[7]}-s{s[8]}' for s in SHAPES]

@@ -196,11 +196,44 @@ def test_other_unroll_lengths(K):
             assert int(v) == int(sd[k]), k
 
 
+# the geometries above that sit on a kink (and are held to 8e-2 only) are pinned -- a geometry outside this list that needs the
+# loose bar fails -- and every geometry has a kink-free twin below that is held to the tight bar with no allowance.
+KNOWN_KINKED_SET = {(5, 256, 1, 6), (7, 40, 1, 33), (9, 32, 3, 64), (11, 8, 2, 9), (15, 8, 1, 2), (15, 16, 1, 3), (15, 32, 2, 10)}  # (board, planes, blocks, batch)
+
+
 def test_most_small_geometries_were_kink_free():
-    """The loose tolerance must stay the exception: of the cases above at least eight ran under the 2e-3 bar."""
+    """The loose tolerance must stay the exception: of the cases above at least eight ran under the 2e-3 bar, and the kinked ones are the known ones."""
     if len(KINKS) < len(GEOMETRIES):
         pytest.skip('runs after the parametrised cases')
+    print('kinked:', sorted(k for k, v in KINKS.items() if v))
     assert sum(1 for v in KINKS.values() if not v) >= 8, KINKS
+    assert {k for k, v in KINKS.items() if v} <= KNOWN_KINKED_SET, KINKS
+
+
+@pytest.mark.parametrize('board,planes,blocks,chan,B,int8_state', GEOMETRIES, ids=[f'b{g[0]}-p{g[1]}-r{g[2]}-n{g[4]}' for g in GEOMETRIES])
+def test_gradient_matches_float64_autograd_kink_free(board, planes, blocks, chan, B, int8_state):
+    """The same geometries with weights that keep every ReLU channel on or off for the whole batch (tests/test_gpu_atari_learner.kinkfree_state_dict,
+    a mix of live and dead channels): every gradient tensor within 2e-3 of float64 autograd, no kink allowance."""
+    from muzero_amd.network import MuZeroBoardGameNet
+    from test_gpu_atari_learner import grad_errors, kinkfree_state_dict
+
+    dev = torch.device('cuda', 0)
+    A = board * board + 1
+    net = MuZeroBoardGameNet((chan, board, board), A, blocks, planes)
+    net.load_state_dict(kinkfree_state_dict(net, 100 + board))
+    net = net.to(dev)
+    net.train()
+    rs = np.random.RandomState(board * 7 + B)
+    tr = _batch(rs, B, (chan, board, board), A, int8_state=int8_state)
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    hl = _hip(net, dev, B)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    errs = grad_errors(gd, hl.grad_views)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] <= 2e-3, (worst, errs[worst], closest)
 
 
 def test_six_updates_follow_the_autograd_learner():

@@ -141,6 +141,25 @@ def test_random_board_conv_configuration_bit_exact_vs_oracle(oracle, i):
 
 
 LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_LEARN_CASES', '10'))
+# the learner comparisons below accept a looser bar next to a detected kink of the loss.  So that a real regression cannot hide
+# there, the cases that have ever NEEDED the looser bar are listed by generator index (seed offset 0, indices < 300: what tools/dev/deep_parity.sh
+# runs): a case outside the list that needs it fails.  MZ_FUZZ_RECORD_CARVED=<file>: append "kind index" lines instead (to rebuild the list).
+KNOWN_CARVED = {'mlp': set(),  # (none in 300)
+                'convkf': {174},  # kink-free weights: a normalisation tie (1 in 300)
+                'conv': {0, 1, 3, 6, 8, 10, 11, 13, 18, 23, 25, 27, 29, 34, 40, 46, 49, 51, 53, 56, 58, 60, 61, 62, 67, 70, 71, 72, 73, 74, 79, 81, 87,
+                         88, 89, 90, 96, 99, 100, 102, 103, 109, 110, 116, 117, 118, 120, 122, 124, 125, 126, 129, 132, 133, 134, 141, 143, 147, 155, 159,
+                         161, 168, 174, 176, 179, 181, 184, 185, 190, 192, 193, 194, 196, 198, 201, 203, 208, 211, 212, 216, 217, 219, 229, 230, 232, 241,
+                         245, 247, 255, 257, 258, 261, 263, 265, 271, 273, 274, 277, 278, 280, 284, 286, 287, 289, 290}}  # random weights: 105 of 300
+
+
+def _carved(kind, i, detail):
+    rec = os.environ.get('MZ_FUZZ_RECORD_CARVED')
+    if rec:
+        with open(rec, 'a') as f:
+            f.write(f'{kind} {i} {detail}\n')
+        return
+    if OFFSET == 0 and i < 300:
+        assert i in KNOWN_CARVED[kind], (kind, i, 'needs the kink tolerance but is not a known carved-out case', detail)
 
 
 def _draw_learn_case(i):
@@ -224,6 +243,7 @@ def test_random_learner_configuration_matches_autograd(i):
         if err <= 3e-3 * max(na, 1e-7) + 2e-7:  # (+ float32 rounding of the sums themselves: a two-action policy bias gradient cancels to ~5e-6)
             continue  # (the normal case, kink nearby or not)
         assert not smooth and err <= 5e-2 * max(na, 1e-7), (k, c, err, na, 'smooth' if smooth else 'near a kink', min(margins))
+        _carved('mlp', i, f'{k} {err / max(na, 1e-7):.2e}')
     # one optimizer step with the drawn hyper-parameters against torch.optim.Adam + clip_grad_norm_ -- on IDENTICAL gradients (the kernels'
     # gradient copied into the torch parameters: gradient parity is the comparison above; with each side on its own gradient an entry next
     # to zero takes -lr sign(g) with opposite signs, seen twice in 6 000 cases), so this checks the clip / Adam / weight-decay arithmetic alone
@@ -476,8 +496,9 @@ def test_random_conv_learner_configuration_matches_float64_autograd(i):
     """Round 5: the conv learner's kernels (csrc/mz_learn_conv.h) over board sizes 3-15 (every pixel tiling, images per workgroup, pitch layout of the
     weight gradient), plane counts on and off the 16-channel tile, 1-3 blocks, unroll 1-6, ragged batches, int8 / float states, int8 / int16 actions,
     with / without importance weights: loss, priorities, every gradient and the BatchNorm running statistics against float64 PyTorch-ROCm autograd; then
-    one optimizer step with drawn Adam / clip settings against torch.optim.Adam.  Kinked batches (a float64 pre-activation within 2e-6 of a ReLU
-    boundary, tests/test_gpu_conv_learner.py) are held to 8e-2 instead of 2e-3."""
+    one optimizer step with drawn Adam / clip settings against torch.optim.Adam.  Kinked batches (a float64 pre-activation within 5e-6 of a ReLU
+    boundary, tests/test_gpu_conv_learner.py) are held to 0.25 instead of 2e-3 and must be on the KNOWN_CARVED list; the kink-free twin of every
+    case (next test) has no such allowance."""
     import copy
 
     import torch
@@ -500,12 +521,16 @@ def test_random_conv_learner_configuration_matches_float64_autograd(i):
     loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev) if c['weights'] else None, B)
     assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d)), c
     np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=str(c))
-    kinked = closest < 2e-6
-    tol = 8e-2 if kinked else 2e-3
-    for k, g in gd.items():
-        scale = max(1e-8, float(g.abs().max()))
-        err = float((g - hl.grad_views[k].double()).abs().max())
-        assert err <= tol * scale, (c, k, err, scale, closest)
+    kinked = closest < 5e-6  # (unrolls of 6 steps amplify rounding: flips seen up to 2.8e-6)
+    from test_gpu_atari_learner import grad_errors
+
+    tol = 0.25 if kinked else 2e-3
+    errs = grad_errors(gd, hl.grad_views)  # (relative to each tensor's largest entry, floored at 1e-3 of the network's: see there)
+    wk = max(errs, key=errs.get)
+    worst = errs[wk]
+    assert worst <= tol, (c, wk, worst, closest)
+    if worst > 2e-3:
+        _carved('conv', i, f'{worst:.2e} closest {closest:.1e}')
     sd = net.state_dict()
     for k, v in sd_d.items():
         if 'running' in k:
@@ -530,6 +555,41 @@ def test_random_conv_learner_configuration_matches_float64_autograd(i):
         # the other way in float32 -- a mean bar for the tensor, and a 2 lr bar for single elements
         d = (p.double() - q).abs()
         assert float(d.mean()) <= 0.02 * max(moved, 1e-12) + 1e-7 and float(d.max()) <= 2.2 * o['lr'] + 1e-6, (c, k, float(d.mean()), float(d.max()), moved)
+
+
+@pytest.mark.parametrize('i', range(CONV_LEARN_CASES_N))
+def test_random_conv_learner_configuration_kink_free(i):
+    """The same generator with KINK-FREE weights (tests/test_gpu_atari_learner.kinkfree_state_dict: every ReLU channel on or off for the whole batch, a
+    mix of both; confirmed by the float64 probe): no carve-out -- every gradient tensor within 2e-3 of float64 autograd (a third of the random-weight
+    cases above sit within rounding of a ReLU boundary somewhere and are held to 8e-2 only)."""
+    import torch
+
+    from muzero_amd.hip_learner import HipLearner
+    from muzero_amd.network import MuZeroBoardGameNet
+    from test_gpu_atari_learner import TIGHT, grad_errors, kinkfree_state_dict
+    from test_gpu_conv_learner import _batch, _f64_reference, _ring
+
+    c = _draw_conv_learn_case(i)
+    dev = torch.device('cuda', 0)
+    A = c['board'] * c['board'] + 1
+    net = MuZeroBoardGameNet((c['chan'], c['board'], c['board']), A, c['blocks'], c['planes'])
+    net.load_state_dict(kinkfree_state_dict(net, 4000 + i))
+    net = net.to(dev)
+    net.train()
+    rs = np.random.RandomState(c['seed'])
+    B, K, shape = c['B'], c['K'], (c['chan'], c['board'], c['board'])
+    tr = _batch(rs, B, shape, A, K=K, int8_state=c['int8'])
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32) if c['weights'] else np.ones(B, np.float32)
+    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    hl = HipLearner(net, dev, K, B, lr=1e-3)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev) if c['weights'] else None, B)
+    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d)), c
+    errs = grad_errors(gd, hl.grad_views)
+    worst = max(errs, key=errs.get)
+    if errs[worst] > TIGHT:  # only next to a min / max tie of normalize_hidden_state (the weights take care of the ReLUs, not of those)
+        assert closest < 2e-6 and errs[worst] <= 8e-2, (c, worst, errs[worst], closest)
+        _carved('convkf', i, f'{errs[worst]:.2e} closest {closest:.1e}')
+    hl.close()
 
 
 ATARI_LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_ATARI_LEARN_CASES', '4'))
