@@ -45,7 +45,7 @@ struct Geom {
     int h = 0, w = 0, hw = 0;
     int npt = 15, G = 1, qstride = 0;       // k_lc_conv: pixel tiles per workgroup, images per workgroup, LDS slot-plane stride
     bool side15 = false;                     // the 15 x 15 build
-    int P4 = 0, nsteps = 0, SPY = 0, SPX = 0;  // k_lc_wgrad: row pitch, 16-position steps per image, plane strides
+    int P4 = 0, nsteps = 0, SPY = 0, SPX = 0, SG = 1;  // k_lc_wgrad: row pitch, 16-position steps per staging round, plane strides, images per round
 };
 struct TensorInfo {
     std::string name;
@@ -75,7 +75,7 @@ int cdiv(int a, int b) { return (a + b - 1) / b; }
 // the tiling is then chosen by the time of one launch, (rounds of workgroups over the CUs) x (tiles per workgroup), `wg_per_group` workgroups
 // per image group (output-channel blocks x paired jobs): at batch 128 a 6 x 6 hidden state packs best as 4 images in 9 tiles, but that is 128
 // workgroups on 256 CUs, and 2 images in 6 tiles fills the chip in 2/3 of the time.  Ties / images == 0: the densest packing.
-bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256) {
+bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256, bool stack_wgrad = true) {
     g.h = hh; g.w = ww; g.hw = hh * ww;
     if (g.hw < 1 || g.hw > 240) return false;
     const int QP = (g.hw + 3) / 4;
@@ -95,7 +95,16 @@ bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int w
     g.qstride = (4 * g.G * (g.h + 2) * (g.w + 2) + 63) & ~63;
     g.side15 = allow_side15 && g.h == 15 && g.w == 15 && g.G == 1 && g.npt == 15;
     g.P4 = 4 * cdiv(g.w + 1, 4);
-    g.nsteps = cdiv(g.h * g.P4, 16);
+    // k_lc_wgrad stages SG images per round, stacked with one zero row between them (one tall "image" of SG (h + 1) - 1 rows): a 6 x 6 plane is 9
+    // pixel quads -- 9 of a wave's 64 staging lanes and two barriers per image otherwise.  As many as the staging lanes hold and as leave two
+    // workgroups per CU their LDS (80 KB each)
+    g.SG = 1;
+    if (stack_wgrad)
+        for (int sg = 2; sg <= 16 && sg * QP <= 64; sg++) {
+            const int ns = cdiv((sg * (g.h + 1) - 1) * g.P4, 16);
+            if (((size_t)32 * (32 * ns + 2 * g.P4 + 16) + 160) * sizeof(float) <= 80 * 1024) g.SG = sg;
+        }
+    g.nsteps = cdiv((g.SG * (g.h + 1) - 1) * g.P4, 16);
     g.SPY = 16 * g.nsteps + 4;
     g.SPX = 2 * g.P4 + 16 * g.nsteps + 12;
     return true;
@@ -108,6 +117,7 @@ struct mzlc_learner {
     int device = 0, num_cus = 256;
     int P = 0, C0 = 0, A = 0, R = 0, K = 0, h = 0, w = 0, hw = 0, maxB = 0;
     Geom gm;                 // geometry of the hidden state (the board; 6 x 6 for the Atari net)
+    int wgrad_min_ipw = 1;   // k_lc_wgrad: least images per workgroup (small images: the partial tile's write-out amortised over more of them)
     bool xcd_remap = true;   // k_lc_wgrad: the blocks of one image chunk on one XCD (MZLC_NO_XCD_REMAP=1 at create: launch order)
     bool fuse_apply = true;  // block outputs formed in the next conv's staging (MZLC_NO_FUSE_APPLY=1 at create: one k_lc_apply per block)
     std::vector<LayerInfo> layers;
@@ -313,7 +323,7 @@ struct Sched {
         g.dz = dz; g.y = y; g.dcoef = bcoef; g.x0 = x0; g.xcoef = xcoef; g.x_mode = x_mode; g.action = action; g.num_actions = h->A;
         g.cin_real = L.cin_real; g.cin = L.cin; g.cout = L.cout; g.ci_tiles = cdiv(L.cin, 16); g.co_tiles = L.co_tiles;
         g.cpad_in = pad16(L.cin_real); g.cpad_out = pad16(L.cout);
-        g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX;
+        g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX; g.sg = this->g.SG;
         g.co_blocks = cdiv(g.co_tiles, 2);
         const int ci_blocks = cdiv(g.ci_tiles, 2);
         // two workgroups per CU in all: a paired launch brings the other half; the first conv blocks (action planes: the dynamics tower's extra
@@ -321,6 +331,8 @@ struct Sched {
         int chunks = ((lane_pairs && !action) ? 1 : 2) * h->num_cus / (g.co_blocks * ci_blocks);
         chunks = chunks < 1 ? 1 : (chunks > B ? B : chunks);
         g.ipw = cdiv(B, chunks);
+        if (g.ipw < h->wgrad_min_ipw) g.ipw = h->wgrad_min_ipw < B ? h->wgrad_min_ipw : B;
+        g.ipw = cdiv(g.ipw, g.sg) * g.sg;  // whole staging rounds
         chunks = cdiv(B, g.ipw);
         g.part = h->wpart[lane];
         ops.push_back(o);
@@ -592,7 +604,7 @@ struct AtariRun {
         g.src0 = src0; g.src1 = src1; g.coef = coef; g.dst = dst; g.mode = mode; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W;
         g.srcH = srcH; g.srcW = srcW; g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.T = TILE; g.nty = H / TILE; g.ntx = W / TILE; g.inner_only = inner_only;
         g.n = (long long)B * g.nty * g.ntx * C * (TILE + 2) * (TILE + 2);
-        hipLaunchKernelGGL(k_lc_tile_gather<TILE + 2>, dim3((unsigned)(B * g.nty * g.ntx), (unsigned)cdiv(C * (TILE + 2) * (TILE + 2), 256)), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_lc_tile_gather<TILE + 2>, dim3((unsigned)(B * g.nty * g.ntx), (unsigned)cdiv(C * (TILE + 2) * (TILE + 2), 1024)), dim3(256), 0, st, g);
     }
     // returns the number of statistic groups written (0 without stat_part)
     int scatter(const float* src, int C, int H, int W, float* dst, int dstH, int dstW, int sy, int sx, int py, int px, const float* skip, float* stat_part) const {
@@ -864,6 +876,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->paired = !getenv("MZLC_NO_PAIR");
     h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
     h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
+    if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
     if (h->atari) {  // the observation is board_h x board_w (96 x 96 in every reference configuration); the hidden state 1 / 16 of it
         h->obsH = cfg->board_h; h->obsW = cfg->board_w;
@@ -880,7 +893,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (cfg->in_dim != h->C0 * h->obsH * h->obsW) return bad("in_dim must equal in_channels * board_h * board_w");
     if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1024 || cfg->reward_support_size > 1024) return bad("support sizes must be in [1, 1024]");
     if (h->hw > 240 || h->P > 1024) return bad("conv learner: boards up to 240 points and 1024 planes (larger nets train through muzero_amd.learner.train_step)");
-    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"), getenv("MZLC_DENSE_TILING") ? 0 : h->maxB, cdiv(cdiv(h->P, 16), 4) * 2, h->num_cus)) return bad("board does not fit the conv kernels' tiling");
+    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"), getenv("MZLC_DENSE_TILING") ? 0 : h->maxB, cdiv(cdiv(h->P, 16), 4) * 2, h->num_cus, !getenv("MZLC_NO_WGRAD_STACK"))) return bad("board does not fit the conv kernels' tiling");
     if (wgrad_lds(h->gm) > 160 * 1024 || conv_lds(h->gm.qstride, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
     if (h->atari && (!make_geom(h->gt, TILE + 2, TILE + 2, false) || !make_geom(h->g12, TILE, TILE, false))) return bad("internal: tile geometry");
     // ---- parameter / buffer tables in state_dict order (network.py:312-498) ----

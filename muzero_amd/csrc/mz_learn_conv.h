@@ -357,6 +357,7 @@ struct LcWgrad {
     int B, ipw;            // images per chunk
     int h, w_img, P4, nsteps, SPY, SPX;
     int co_blocks;         // blockIdx.y = chunk * co_blocks + cob
+    int sg;                // images per staging round (stacked with one zero row between them; nsteps / SPY / SPX are the stack's)
     int ring_zero;         // 1: the outermost ring of every dy image is multiplied by 0 (tiles gathered with their halo: only the inner pixels are outputs)
 };
 
@@ -404,38 +405,42 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         s_xc[t] = (L.x_mode == IN_BNRELU && c < L.cin_real) ? L.xcoef[(t >> 5) * L.cpad_in + c] : 0.0f;
     }
     const __amdgpu_buffer_rsrc_t rs_dz = mkrs(L.dz), rs_y = mkrs(L.y), rs_x = mkrs(L.x0);
-    // staging plan: lane = pixel quad (lanes >= QP idle), wave w the channels w, 4 + w, .., 28 + w of each operand.  Elements past the image
-    // (the last quad) get their own exec-mask region per element index: 8 lane branches per image instead of one per store
-    const bool s_ok = lane < QP;
-    const int p0 = (s_ok ? lane : 0) * 4;
+    // staging plan: lane = (image of the round, pixel quad) (lanes >= sg QP idle), wave w the channels w, 4 + w, .., 28 + w of each operand.
+    // Elements past the image (the last quad) get their own exec-mask region per element index: 8 lane branches per round instead of one per store
+    const int gi = lc_idiv(lane, 1.0f / (float)QP), ql = lane - gi * QP;
+    const bool s_ok = gi < L.sg;
+    const int p0 = (s_ok ? ql : 0) * 4;
     int spos[4], pm[4];
     float ym[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
-        spos[e] = (s_ok && pp < hw) ? py * L.P4 + px : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
+        spos[e] = (s_ok && pp < hw) ? (gi * (L.h + 1) + py) * L.P4 + px : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
         pm[e] = ACT ? pp % L.num_actions : 0;
         ym[e] = (RING && (py == 0 || px == 0 || py == L.h - 1 || px == L.w_img - 1)) ? 0.0f : 1.0f;
     }
     float4 rdz[8], ry[8], rx[8];
     int r_act = -1;
+    bool r_ok = false;  // this lane's image of the round in flight belongs to the chunk (the last round may be short: its idle slots are staged as zeros)
     const int b_lo = chunk * L.ipw, b_hi = (b_lo + L.ipw < L.B) ? b_lo + L.ipw : L.B;
-    const unsigned vo = (unsigned)(p0 * sizeof(float));
-    auto fetch = [&](int b) {
-        const int bc = b < L.B ? b : L.B - 1;
+    auto fetch = [&](int b) {  // round of images b .. b + sg - 1
+        const int bi = b + (s_ok ? gi : 0);
+        r_ok = s_ok && bi < b_hi;
+        const int rel = r_ok ? bi - b : 0;
+        const unsigned vo_o = (unsigned)((rel * L.cout * hw + p0) * sizeof(float)), vo_i = (unsigned)((rel * L.cin_real * hw + p0) * sizeof(float));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int c = co0 + 4 * k + wave, cc = c < L.cout ? c : 0;
-            const int so = (int)(((size_t)bc * L.cout + cc) * hw * sizeof(float));
-            rdz[k] = ld4(rs_dz, vo, so);
-            ry[k] = ld4(rs_y, vo, so);
+            const int so = (int)(((size_t)b * L.cout + cc) * hw * sizeof(float));
+            rdz[k] = ld4(rs_dz, vo_o, so);
+            ry[k] = ld4(rs_y, vo_o, so);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int c = ci0 + 4 * k + wave, cc = c < L.cin_real ? c : 0;
-            rx[k] = ld4(rs_x, vo, (int)(((size_t)bc * L.cin_real + cc) * hw * sizeof(float)));
+            rx[k] = ld4(rs_x, vo_i, (int)(((size_t)b * L.cin_real + cc) * hw * sizeof(float)));
         }
-        if (ACT) r_act = L.action[bc];
+        if (ACT) r_act = L.action[b + rel];
     };
     auto stage = [&]() {
         float vy[8][4], vx[8][4];
@@ -446,6 +451,10 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
             const float a[4] = {rdz[k].x, rdz[k].y, rdz[k].z, rdz[k].w}, yy[4] = {ry[k].x, ry[k].y, ry[k].z, ry[k].w};
 #pragma unroll
             for (int e = 0; e < 4; e++) vy[k][e] = RING ? fmaf(c1, a[e], fmaf(c2, yy[e], c3)) * ym[e] : fmaf(c1, a[e], fmaf(c2, yy[e], c3));
+            if (!r_ok) {  // (an idle image slot of a short last round: zeros over what the previous round left there)
+#pragma unroll
+                for (int e = 0; e < 4; e++) vy[k][e] = 0.0f;
+            }
         }
         const bool bnrelu = L.x_mode == IN_BNRELU;
 #pragma unroll
@@ -495,14 +504,15 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (b_lo < b_hi) fetch(b_lo);
+    const int SGn = L.sg;
     const float* py_ = s_y + (wm * 16 + i16) * L.SPY + 4 * kq;             // + 16 g: the lane's dy quad
     const float* px_ = s_x + (wn * 16 + i16) * L.SPX + L.P4 + 4 + 4 * kq;   // + 16 g + dy P4: the centre quad of row dy
     const int P4 = L.P4;
-    for (int b = b_lo; b < b_hi; b++) {
-        __syncthreads();  // the previous image's MFMAs have read the planes (first pass: the zero fill is complete)
+    for (int b = b_lo; b < b_hi; b += SGn) {
+        __syncthreads();  // the previous round's MFMAs have read the planes (first pass: the zero fill is complete)
         stage();
         __syncthreads();
-        if (b + 1 < b_hi) fetch(b + 1);  // in flight during this image's MFMAs
+        if (b + SGn < b_hi) fetch(b + SGn);  // in flight during this round's MFMAs
         // operands of step g + 1 are requested before the MFMAs of step g: two register sets, the loop unrolled by two, scheduling barriers between
         // "request" and "multiply" (left alone the scheduler sinks the reads to their first use and every step waits for its own LDS round trip)
         struct OpSet { float4 a4; float4 c4[3]; float lf[3], rg[3]; };
@@ -937,28 +947,45 @@ struct LcTileGather {
     int inner_only;      // 1: the halo ring is written as zeros (the dy operand of the weight gradient: only the tile's own pixels count)
     long long n;         // elements of dst
 };
-// grid (tiles, channel chunks): the tile's coordinates are workgroup-uniform (scalar), the element's (c, ly, lx) divide by compile-time constants
+// grid (tiles, chunks of 1024 tile elements): the tile's coordinates are workgroup-uniform (scalar), the element's (c, ly, lx) divide by compile-time
+// constants; four elements per thread, their loads issued together (one 4-byte load per thread in flight left the kernel latency-bound at 1.5 TB/s)
 template <int TS>
 __global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
     constexpr int ts2 = TS * TS;
-    const int ti = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
-    if (j >= L.C * ts2) return;
-    const int c = j / ts2, r = j - c * ts2, ly = r / TS, lx = r - ly * TS;
+    const int ti = blockIdx.x, j0 = blockIdx.y * 1024 + threadIdx.x, nel = L.C * ts2;
     const int nt = L.nty * L.ntx, b = ti / nt, t = ti - b * nt, tyi = t / L.ntx, txi = t - tyi * L.ntx;
-    const int y = tyi * L.T - 1 + ly, x = txi * L.T - 1 + lx;
-    float v = 0.0f;
-    const bool ring = ly == 0 || lx == 0 || ly == TS - 1 || lx == TS - 1;
-    if (y >= 0 && y < L.H && x >= 0 && x < L.W && !(L.inner_only && ring)) {
-        const size_t si = ((size_t)b * L.C + c) * L.srcH * L.srcW + (size_t)(y * L.sy + L.py) * L.srcW + (x * L.sx + L.px);
-        v = L.src0[si];
-        if (L.mode == IN_BNRELU) {
-            v = fmaf(L.coef[c], v, L.coef[L.cpad + c]);
-            v = v > 0.0f ? v : 0.0f;
-        } else if (L.mode == IN_BNBWD) {
-            v = fmaf(L.coef[c], v, fmaf(L.coef[L.cpad + c], L.src1[si], L.coef[2 * L.cpad + c]));
-        }
+    const float* s0 = L.src0 + (size_t)b * L.C * L.srcH * L.srcW;
+    const float* s1 = L.mode == IN_BNBWD ? L.src1 + (size_t)b * L.C * L.srcH * L.srcW : s0;
+    float v[4], v1[4];
+    int cc[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = j0 + u * 256;
+        const int c = j / ts2, r = j - c * ts2, ly = r / TS, lx = r - ly * TS;
+        const int y = tyi * L.T - 1 + ly, x = txi * L.T - 1 + lx;
+        const bool ring = ly == 0 || lx == 0 || ly == TS - 1 || lx == TS - 1;
+        in[u] = j < nel && y >= 0 && y < L.H && x >= 0 && x < L.W && !(L.inner_only && ring);
+        cc[u] = c;
+        const size_t si = in[u] ? (size_t)c * L.srcH * L.srcW + (size_t)(y * L.sy + L.py) * L.srcW + (x * L.sx + L.px) : 0;
+        v[u] = s0[si];
+        v1[u] = L.mode == IN_BNBWD ? s1[si] : 0.0f;
     }
-    L.dst[(size_t)ti * L.C * ts2 + j] = v;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = j0 + u * 256;
+        float o = 0.0f;
+        if (in[u]) {
+            o = v[u];
+            if (L.mode == IN_BNRELU) {
+                o = fmaf(L.coef[cc[u]], o, L.coef[L.cpad + cc[u]]);
+                o = o > 0.0f ? o : 0.0f;
+            } else if (L.mode == IN_BNBWD) {
+                o = fmaf(L.coef[cc[u]], o, fmaf(L.coef[L.cpad + cc[u]], v1[u], L.coef[2 * L.cpad + cc[u]]));
+            }
+        }
+        if (j < nel) L.dst[(size_t)ti * nel + j] = o;
+    }
 }
 
 // inner T x T of every tile -> the plane (a parity plane of dst when sy = 2), + skip; optional forward statistics (sum v, sum v^2) per
