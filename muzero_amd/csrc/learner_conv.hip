@@ -500,10 +500,10 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
         case OP_WREDUCE: {
             Pair<LcWreduce> pj{};
             pj.a = a->wr;
-            const int ya = cdiv(9 * a->wr.cout * a->wr.cin, 256), yb = b ? cdiv(9 * b->wr.cout * b->wr.cin, 256) : 0;
+            const int ya = cdiv(a->wr.cout * a->wr.cin, 64), yb = b ? cdiv(b->wr.cout * b->wr.cin, 64) : 0;
             pj.na = ya;
             if (b) pj.b = b->wr;
-            hipLaunchKernelGGL(k_lc_wreduce, dim3(1, ya + yb), dim3(256), 0, st, pj);
+            hipLaunchKernelGGL(k_lc_wreduce, dim3(1, ya + yb), dim3(64), 0, st, pj);
             break;
         }
         case OP_BNFWD: {

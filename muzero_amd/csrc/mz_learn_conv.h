@@ -572,30 +572,42 @@ struct LcWreduce {
     int use_map;            // 1: accumulator tap t of the partials is weight tap tapmap[t] (-1: not a tap of this parity plane; see LcTileGather)
     signed char tapmap[9];
 };
-__global__ __launch_bounds__(256) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
+// thread = one (co, ci) pair, all nine taps: the partial planes are read coalesced over ci (four chunks x nine taps in flight), the nine
+// results are 36 contiguous bytes of the gradient (one thread per (tap, co, ci) wrote them 36 bytes apart).  Chunks are added in order.
+__global__ __launch_bounds__(64) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
     const bool second = (int)blockIdx.y >= PJ.na;
     const LcWreduce L = second ? PJ.b : PJ.a;
     const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
-    const int n = 9 * L.cout * L.cin;
-    const int i = by * 256 + threadIdx.x;  // (tap, co, ci), ci fastest: coalesced reads
-    if (i >= n) return;
-    const int ci = i % L.cin, co = (i / L.cin) % L.cout, tap_src = i / (L.cin * L.cout);
-    const int tap = L.use_map ? (int)L.tapmap[tap_src] : tap_src;
-    if (tap < 0) return;
-    const float* p = L.part + ((size_t)tap_src * L.co_pad + co) * L.ci_pad + ci;
-    const size_t cs = (size_t)9 * L.co_pad * L.ci_pad;
-    float s = 0.0f;
-    int c = 0;
-    for (; c + 8 <= L.chunks; c += 8) {  // eight loads in flight, added in chunk order
-        float v[8];
+    const int i = by * 64 + threadIdx.x;  // (co, ci), ci fastest
+    if (i >= L.cout * L.cin) return;
+    const int ci = i % L.cin, co = i / L.cin;
+    const size_t ts = (size_t)L.co_pad * L.ci_pad, cs = 9 * ts;
+    const float* p = L.part + (size_t)co * L.ci_pad + ci;
+    float s[9];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = p[(size_t)(c + k) * cs];
+    for (int t = 0; t < 9; t++) s[t] = 0.0f;
+    for (int c = 0; c < L.chunks; c += 4) {
+        float v[4][9];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s += v[k];
+        for (int k = 0; k < 4; k++) {
+            const int cc = c + k < L.chunks ? c + k : L.chunks - 1;
+#pragma unroll
+            for (int t = 0; t < 9; t++) v[k][t] = p[cc * cs + t * ts];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (c + k < L.chunks) {
+#pragma unroll
+                for (int t = 0; t < 9; t++) s[t] += v[k][t];
+            }
+        }
     }
-    for (; c < L.chunks; c++) s += p[c * cs];
-    float* g = L.grad + ((size_t)co * L.cin + ci) * 9 + tap;
-    *g = L.accumulate ? *g + s : s;
+    float* g = L.grad + (size_t)i * 9;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int tap = L.use_map ? (int)L.tapmap[t] : t;
+        if (tap >= 0) g[tap] = L.accumulate ? g[tap] + s[t] : s[t];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
