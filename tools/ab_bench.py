@@ -28,6 +28,18 @@ for g in ('cartpole', 'tictactoe'):
         best = min(best, prof['search_kernel_ms'] / prof['search_kernel_launches'])
     print(f'  {g}: {best * 1e3:.1f} us per search launch')
     p.close()
+net = build_mlp(mlp_case('lunar'))  # the LunarLander-shaped leg of bench.py (four actions, synthetic env)
+p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=4096, seed=2000, num_simulations=50, discount=0.997, root_dirichlet_alpha=0.25,
+                                 root_exploration_eps=0.25), 0)
+p.load_state_dict(net.state_dict())
+p.selfplay_reset(pl.ENV_SYNTHETIC)
+p.selfplay_step(1.0, 30)
+best = 1e9
+for rep in range(3):
+    p.profile_begin(); p.selfplay_step(1.0, 100); prof = p.profile_end()
+    best = min(best, prof['search_kernel_ms'] / prof['search_kernel_launches'])
+print(f'  lunar: {best * 1e3:.1f} us per search launch')
+p.close()
 ''' % (REPO, REPO)
 
 for lib in sys.argv[1:]:
