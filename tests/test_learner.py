@@ -75,7 +75,7 @@ def test_target_projection_matches_reference(S):
     np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
 
 
-CASES = [('mlp_cat', 'mlp', 'tiny'), ('mlp_mse', 'mlp', 'tiny_mse'), ('conv_board3', 'conv', 'board3')]
+CASES = [('mlp_cat', 'mlp', 'tiny'), ('mlp_mse', 'mlp', 'tiny_mse'), ('conv_board3', 'conv', 'board3'), ('conv_atari_s', 'conv', 'atari_s')]
 
 
 def _net(kind, cname):
@@ -88,6 +88,7 @@ def _net(kind, cname):
 def test_calc_loss_and_updates_match_reference(name, kind, cname):
     pre = f'learn_{name}'
     net = _net(kind, cname)
+    big = 1e-5 if cname == 'atari_s' else 0
     tr = Transition(*[G[f'{pre}_{f}'] for f in Transition._fields])
     weights = torch.from_numpy(G[f'{pre}_weights'])
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
@@ -100,15 +101,18 @@ def test_calc_loss_and_updates_match_reference(name, kind, cname):
         if step == 0:
             np.testing.assert_allclose(prio, G[f'{pre}_prio'], **TOL)
             for pn, pp in net.named_parameters():
-                np.testing.assert_allclose(pp.grad.numpy(), G[f'{pre}_grad_{pn}'], rtol=2e-4, atol=2e-7, err_msg=pn)
+                ref = G[f'{pre}_grad_{pn}']
+                # (the Atari net sums 2304-position planes: float32 rounding of differently blocked sums, relative to the tensor's size)
+                np.testing.assert_allclose(pp.grad.numpy(), ref, rtol=2e-4, atol=2e-7 if big == 0 else big * float(np.abs(ref).max()), err_msg=pn)
         if step == 1:
             torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
         opt.step()
         sched.step()
         losses.append(float(loss.detach()))
-    np.testing.assert_allclose(losses, G[f'{pre}_losses'], rtol=2e-5)
+    np.testing.assert_allclose(losses, G[f'{pre}_losses'], rtol=2e-5 if big == 0 else 5e-4)
     for pn, pp in net.state_dict().items():
-        np.testing.assert_allclose(pp.numpy(), G[f'{pre}_final_{pn}'], rtol=2e-4, atol=2e-6, err_msg=pn)
+        # (Atari: Adam's first steps are lr * sign(g) -- an entry whose gradient is at rounding distance from zero may step the other way)
+        np.testing.assert_allclose(pp.numpy(), G[f'{pre}_final_{pn}'], rtol=2e-4, atol=2e-6 if big == 0 else 1e-3, err_msg=pn)
 
 
 def test_run_training_loop_with_collector_thread(tmp_path):
