@@ -177,6 +177,7 @@ struct mzlc_learner {
     int par_f[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, par_d[4] = {0, 0, 0, 0};  // packed offsets of the parity copies: forward of conv_1 / conv_2, data gradient of conv_2
     LcPackPar* d_pack_par = nullptr;
     int n_pack_par = 0;
+    bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
 
@@ -448,6 +449,27 @@ void launch_conv(int mode, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStr
     else if (mode == IN_BNRES) hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNRES, SIDE>), grid, dim3(256), lds, st, pj);
     else hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNBWD, SIDE>), grid, dim3(256), lds, st, pj);
 }
+// the tap sets of the parity planes (par_tapmap): forward rows {1} | {0, 1}, data-gradient rows {1} | {1, 2}, squared
+template <int MASK>
+void launch_conv_taps(const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_lc_conv<15, IN_IDENT, 0, MASK>), grid, dim3(256), lds, st, pj);
+}
+bool launch_conv_tapmask(int mask, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
+    switch (mask) {
+        case 0x010: launch_conv_taps<0x010>(pj, grid, lds, st); return true;
+        case 0x018: launch_conv_taps<0x018>(pj, grid, lds, st); return true;
+        case 0x012: launch_conv_taps<0x012>(pj, grid, lds, st); return true;
+        case 0x01b: launch_conv_taps<0x01b>(pj, grid, lds, st); return true;
+        case 0x030: launch_conv_taps<0x030>(pj, grid, lds, st); return true;
+        case 0x090: launch_conv_taps<0x090>(pj, grid, lds, st); return true;
+        case 0x1b0: launch_conv_taps<0x1b0>(pj, grid, lds, st); return true;
+    }
+    return false;
+}
+template <int MASK>
+hipError_t conv_taps_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<15, IN_IDENT, 0, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 template <int NPT, int SIDE>
 hipError_t conv_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_IDENT, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -474,6 +496,9 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             const dim3 grid(1, ga + gb, z);
             const size_t lds = conv_lds(a->conv.qstride, cp);
             const int mode = a->conv.in_mode;
+            if (a->conv.tapmask && a->conv.tapmask != 0x1ff) {  // (a parity plane: built as whole-tile, identity-mode, unpaired launches only)
+                if (b || a->npt != 15 || a->side15 || mode != IN_IDENT || !launch_conv_tapmask(a->conv.tapmask, pj, grid, lds, st)) return MZL_E_INVALID;
+            } else
             if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
             else if (a->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
             else if (a->npt == 9) launch_conv<9, 0>(mode, pj, grid, lds, st);
@@ -492,6 +517,17 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             const int groups = (ya + yb) / a->wg.co_blocks;
             pj.remap = (h->xcd_remap && (!b || (b->wg.co_blocks == a->wg.co_blocks && cdiv(b->wg.ci_tiles, 2) == cdiv(a->wg.ci_tiles, 2))) && groups % 8 == 0) ? 1 : 0;
             const size_t wlds = ((size_t)32 * (a->wg.SPY + a->wg.SPX) + 160) * sizeof(float);
+            const dim3 wgrid(x, ya + yb);
+            if (a->wg.tapmask && a->wg.tapmask != 0x1ff) {  // a parity plane (tile path: ring_zero, no action planes, unpaired)
+                if (b || !a->wg.ring_zero || a->wg.action) return MZL_E_INVALID;
+                switch (a->wg.tapmask) {
+                    case 0x010: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x010>), wgrid, dim3(256), wlds, st, pj); break;
+                    case 0x018: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x018>), wgrid, dim3(256), wlds, st, pj); break;
+                    case 0x012: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x012>), wgrid, dim3(256), wlds, st, pj); break;
+                    case 0x01b: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x01b>), wgrid, dim3(256), wlds, st, pj); break;
+                    default: return MZL_E_INVALID;
+                }
+            } else
             if (a->wg.ring_zero) hipLaunchKernelGGL((k_lc_wgrad<false, true>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
             else if (a->wg.action || (b && b->wg.action)) hipLaunchKernelGGL((k_lc_wgrad<true, false>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
             else hipLaunchKernelGGL((k_lc_wgrad<false, false>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
@@ -628,13 +664,14 @@ struct AtariRun {
         run(s.op_conv(c));
     }
     // one parity plane's share of a stride-2 conv: the packed copy at `w_off`; accumulate: out += (the earlier planes' sum rides in `skip`)
-    void conv_par(int w_off, int cin, int cout, int nt, const float* in, float* out, bool accumulate) const {
+    void conv_par(int w_off, int cin, int cout, int nt, const float* in, float* out, bool accumulate, int tapmask) const {
         const Sched s = tiles(cin, nt);
         LcConv c{};
         c.B = B * nt; c.G = h->gt.G; c.h = h->gt.h; c.w_img = h->gt.w; c.qstride = h->gt.qstride;
         c.cin_real = cin; c.cin = cin; c.n_cb = cdiv(cin, 16); c.cout = cout; c.co_tiles = cdiv(cout, 16); c.w = h->packed + w_off;
         c.cpad_in = pad16(cin); c.cpad_out = pad16(cout); c.num_actions = h->A;
         c.in0 = in; c.in_mode = IN_IDENT; c.out = out; c.skip = accumulate ? out : nullptr; c.stat_mode = ST_NONE;
+        c.tapmask = h->par_compact ? tapmask : 0;
         run(s.op_conv(c));
     }
     void bn_fwd(const LayerInfo& L, float* fcoef, float* save, int groups, float count) const {
@@ -688,7 +725,12 @@ struct AtariRun {
         ops[0].wg.cpad_out = pad16(h->P > 128 ? h->P : 128);  // (the stride of coef_ident's rows)
         if (tapmap) {
             ops[1].wr.use_map = 1;
-            for (int t = 0; t < 9; t++) ops[1].wr.tapmap[t] = tapmap[t];
+            int mask = 0;
+            for (int t = 0; t < 9; t++) {
+                ops[1].wr.tapmap[t] = tapmap[t];
+                if (tapmap[t] >= 0) mask |= 1 << t;
+            }
+            if (h->par_compact) ops[0].wg.tapmask = mask;
         }
         run(ops[0]);
         run(ops[1]);
@@ -752,6 +794,15 @@ void par_tapmap(int p, int q, bool dgrad, signed char* m) {
         }
 }
 
+int par_tapmask(int p, int q, bool dgrad) {
+    signed char m[9];
+    par_tapmap(p, q, dgrad, m);
+    int mask = 0;
+    for (int t = 0; t < 9; t++)
+        if (m[t] >= 0) mask |= 1 << t;
+    return mask;
+}
+
 // forward of the Atari representation; returns the 6 x 6 raw hidden state
 float* atari_rep_fwd(mzlc_learner* h, int B, hipStream_t st) {
     const AtariRun R{h, B, st};
@@ -760,7 +811,7 @@ float* atari_rep_fwd(mzlc_learner* h, int B, hipStream_t st) {
     // conv_1: four parity planes of the observation, accumulated on the tiles
     for (int pq = 0; pq < 4; pq++) {
         R.gather(h->obs, nullptr, nullptr, IN_IDENT, h->C0, H1, W1, h->obsH, h->obsW, 2, 2, pq >> 1, pq & 1, 0, h->TA);
-        R.conv_par(h->par_f[0][pq], h->C0, C1.cout, (H1 / TILE) * (W1 / TILE), h->TA, h->TB, pq > 0);
+        R.conv_par(h->par_f[0][pq], h->C0, C1.cout, (H1 / TILE) * (W1 / TILE), h->TA, h->TB, pq > 0, par_tapmask(pq >> 1, pq & 1, false));
     }
     R.scatter(h->TB, C1.cout, H1, W1, h->y_c1, H1, W1, 1, 1, 0, 0, nullptr, nullptr);
     const int big = pad16(h->P > 128 ? h->P : 128);  // the row stride of coef_relu / coef_ident
@@ -768,7 +819,7 @@ float* atari_rep_fwd(mzlc_learner* h, int B, hipStream_t st) {
     float* x48 = R.stage_fwd(h->sb48, h->l_b1, h->a1, 128, H1, W1);
     for (int pq = 0; pq < 4; pq++) {
         R.gather(x48, nullptr, nullptr, IN_IDENT, 128, H2, W2, H1, W1, 2, 2, pq >> 1, pq & 1, 0, h->TA);
-        R.conv_par(h->par_f[1][pq], 128, C2.cout, (H2 / TILE) * (W2 / TILE), h->TA, h->TB, pq > 0);
+        R.conv_par(h->par_f[1][pq], 128, C2.cout, (H2 / TILE) * (W2 / TILE), h->TA, h->TB, pq > 0, par_tapmask(pq >> 1, pq & 1, false));
     }
     R.scatter(h->TB, h->P, H2, W2, h->y_c2, H2, W2, 1, 1, 0, 0, nullptr, nullptr);
     R.apply(h->y_c2, nullptr, h->coef_relu, h->a2, h->P, H2 * W2, big);
@@ -844,7 +895,7 @@ void atari_rep_bwd(mzlc_learner* h, int B, const float* gs0, hipStream_t st) {
         R.wgrad_tiles(C2, 128, nt2, h->TA, h->TC, m);
     }
     for (int pq = 0; pq < 4; pq++) {  // data gradient: parity plane (p, q) of the 48 x 48 gradient from the dy tiles
-        R.conv_par(h->par_d[pq], P, 128, nt2, h->TA, h->TB, false);
+        R.conv_par(h->par_d[pq], P, 128, nt2, h->TA, h->TB, false, par_tapmask(pq >> 1, pq & 1, true));
         R.scatter(h->TB, 128, H2, W2, h->sb48.gF, H1, W1, 2, 2, pq >> 1, pq & 1, nullptr, nullptr);
     }
     ng = R.entry(x48, nullptr, 1.0f, h->sb48.gF, h->sb48.y[3], h->sb48.dzA, 128, H1 * W1);
@@ -876,6 +927,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->paired = !getenv("MZLC_NO_PAIR");
     h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
     h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
+    h->par_compact = !getenv("MZLC_NO_TAPSETS");
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
     if (h->atari) {  // the observation is board_h x board_w (96 x 96 in every reference configuration); the hidden state 1 / 16 of it
@@ -1034,7 +1086,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
             const LayerInfo& L = h->layers[k == 0 ? h->l_c1 : h->l_c2];
             for (int pq = 0; pq < 4; pq++) {
                 LcPackPar j{};
-                j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.dst_off = h->par_f[k][pq]; j.n_cb = L.n_cb; j.co_tiles = L.co_tiles; j.transpose = 0;
+                j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.dst_off = h->par_f[k][pq]; j.n_cb = L.n_cb; j.co_tiles = L.co_tiles; j.transpose = 0; j.compact = h->par_compact ? 1 : 0;
                 par_tapmap(pq >> 1, pq & 1, false, j.tapmap);
                 pj.push_back(j);
             }
@@ -1043,7 +1095,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
             const LayerInfo& L = h->layers[h->l_c2];
             for (int pq = 0; pq < 4; pq++) {
                 LcPackPar j{};
-                j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.dst_off = h->par_d[pq]; j.n_cb = cdiv(L.cout, 16); j.co_tiles = cdiv(L.cin, 16); j.transpose = 1;
+                j.w_off = L.w_off; j.cout = L.cout; j.cin = L.cin; j.dst_off = h->par_d[pq]; j.n_cb = cdiv(L.cout, 16); j.co_tiles = cdiv(L.cin, 16); j.transpose = 1; j.compact = h->par_compact ? 1 : 0;
                 par_tapmap(pq >> 1, pq & 1, true, j.tapmap);
                 pj.push_back(j);
             }
@@ -1062,10 +1114,21 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, true, 0x010>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, true, 0x018>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, true, 0x012>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_wgrad<false, true, 0x01b>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = conv_attr<15, 15>();
     if (e == hipSuccess) e = conv_attr<15, 0>();
     if (e == hipSuccess) e = conv_attr<9, 0>();
     if (e == hipSuccess) e = conv_attr<6, 0>();
+    if (e == hipSuccess) e = conv_taps_attr<0x010>();
+    if (e == hipSuccess) e = conv_taps_attr<0x018>();
+    if (e == hipSuccess) e = conv_taps_attr<0x012>();
+    if (e == hipSuccess) e = conv_taps_attr<0x01b>();
+    if (e == hipSuccess) e = conv_taps_attr<0x030>();
+    if (e == hipSuccess) e = conv_taps_attr<0x090>();
+    if (e == hipSuccess) e = conv_taps_attr<0x1b0>();
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (dalloc's fills run on the NULL stream)
     if (e != hipSuccess) {
         err = std::string("conv learner init: ") + hipGetErrorString(e);

@@ -84,11 +84,19 @@ struct LcConv {
     int cout, co_tiles, cpad_out;
     int B, G, h, w_img;
     int qstride;           // LDS floats per slot plane (>= 4 * G * (h + 2) * (w + 2), multiple of 64)
+    int tapmask;           // 0 / 0x1ff: all nine taps; else the taps this conv has (a parity plane of a stride-2 conv: 1, 2 or 4 of them), weights packed compactly
 };
+
+// taps of a TAPMASK build: their number and the k-th one (compile-time)
+constexpr int tm_count(int m) { int c = 0; for (int i = 0; i < 9; i++) c += (m >> i) & 1; return c; }
+constexpr int tm_tap(int m, int k) { for (int i = 0; i < 9; i++) if ((m >> i) & 1) { if (k == 0) return i; k--; } return 0; }
 
 // MODE: the staging transform (IN_*) as a compile-time fact; SIDE > 0: a SIDE x SIDE board, one image per workgroup, as compile-time constants
 // (the launcher checks them) -- index arithmetic, tap offsets and predicates become immediates.
-template <int NPT, int MODE, int SIDE>
+// TAPMASK != 0x1ff: only the taps of the mask exist (the parity planes of the Atari representation's stride-2 convs have 1, 2, 2 and 4 of the
+// nine: run with all nine and zero weights they cost four convolutions for one); their weights are packed [co tile][block][tap of the mask] and
+// come one block ahead through two register sets instead of the ring.
+template <int NPT, int MODE, int SIDE, int TAPMASK = 0x1ff>
 __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const bool second = (int)blockIdx.y >= PJ.na;
     LcConv L = second ? PJ.b : PJ.a;
@@ -201,16 +209,23 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     for (int pt = 0; pt < NPT; pt++) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int cot = blockIdx.z * 4 + wave, ctc = cot < L.co_tiles ? cot : L.co_tiles - 1;
     const __amdgpu_buffer_rsrc_t rs_w = mkrs(L.w);
-    const int wbase = ctc * L.n_cb * 9 * 1024, n_steps = L.n_cb * 9;
+    constexpr int NTAP = TAPMASK == 0x1ff ? 9 : tm_count(TAPMASK);
+    const int wbase = ctc * L.n_cb * NTAP * 1024, n_steps = L.n_cb * NTAP;
     auto wload = [&](int step) {
         const int sc = step < n_steps ? step : n_steps - 1;
         return ld4(rs_w, lane * 16, wbase + sc * 1024);
     };
     constexpr int WD = (NPT <= 9) ? 9 : 3;
     float4 wr[WD];
+    float4 wc[NTAP < 9 ? NTAP : 1], wn[NTAP < 9 ? NTAP : 1];  // TAPMASK builds: this block's and the next block's weights
     // the first weights and the first slab are requested BEFORE the LDS fill below: their latency runs under it
+    if constexpr (NTAP == 9) {
 #pragma unroll
-    for (int s0 = 0; s0 < WD - 1; s0++) wr[s0] = wload(s0);
+        for (int s0 = 0; s0 < WD - 1; s0++) wr[s0] = wload(s0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NTAP; i++) wc[i] = wload(i);
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) fetch(0, i);
     for (int i = tid; i < bufsz / 2; i += 256) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // both buffers, halo included
@@ -223,6 +238,34 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const int FL = (L.in_mode == IN_BNBWD || L.in_mode == IN_BNRES) ? 2 : 1;  // staging loads per tap (taps 0..3)
     for (int cb = 0; cb < L.n_cb; cb++) {
         const float* sb = slab + (cb & 1) * bufsz;
+        if constexpr (NTAP < 9) {
+            const int cbn = cb + 1 < L.n_cb ? cb + 1 : cb;
+#pragma unroll
+            for (int i = 0; i < NTAP; i++) wn[i] = wload(cbn * NTAP + i);
+#pragma unroll
+            for (int i = 0; i < 4; i++) fetch(cbn, i);
+            constexpr int t0 = tm_tap(TAPMASK, 0), t1 = tm_tap(TAPMASK, NPT > 1 ? 0 : (NTAP > 1 ? 1 : 0));
+            xr[0] = *reinterpret_cast<const float4*>(sb + off[0] + ((t0 / 3) * siw + (t0 % 3)) * 4);
+            xr[1] = *reinterpret_cast<const float4*>(sb + off[NPT > 1 ? 1 : 0] + ((t1 / 3) * siw + (t1 % 3)) * 4);
+#pragma unroll
+            for (int ti = 0; ti < NTAP; ti++) {
+#pragma unroll
+                for (int pt = 0; pt < NPT; pt++) {
+                    const int n = ti * NPT + pt, n2 = n + 2;
+                    if (n2 < NTAP * NPT) {
+                        const int ti2 = n2 / NPT, pt2 = n2 - ti2 * NPT, tap2 = tm_tap(TAPMASK, ti2);
+                        xr[n2 % 3] = *reinterpret_cast<const float4*>(sb + off[pt2] + ((tap2 / 3) * siw + (tap2 % 3)) * 4);
+                    }
+                    const float4 x4 = xr[n % 3], w4 = wc[ti];
+                    acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x, w4.x, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y, w4.y, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.z, w4.z, acc[pt], 0, 0, 0);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.w, w4.w, acc[pt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NTAP; i++) wc[i] = wn[i];
+        } else {
         xr[0] = *reinterpret_cast<const float4*>(sb + off[0]);
         xr[1] = *reinterpret_cast<const float4*>(sb + off[NPT > 1 ? 1 : 0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -252,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         (void)FL;
         if (cb + 1 < L.n_cb) transform_store(cb + 1, (cb + 1) & 1);
@@ -358,13 +402,14 @@ struct LcWgrad {
     int h, w_img, P4, nsteps, SPY, SPX;
     int co_blocks;         // blockIdx.y = chunk * co_blocks + cob
     int sg;                // images per staging round (stacked with one zero row between them; nsteps / SPY / SPX are the stack's)
+    int tapmask;           // 0 / 0x1ff: all nine taps; else only these accumulators exist (a parity plane of a stride-2 conv; see k_lc_conv's TAPMASK)
     int ring_zero;         // 1: the outermost ring of every dy image is multiplied by 0 (tiles gathered with their halo: only the inner pixels are outputs)
 };
 
 // ACT: the layer has action-plane input channels (the dynamics net's first conv); the other builds carry none of that code.
 // LDS is single-buffered (67.6 KB at 15 x 15): TWO workgroups share a CU, one's staging (global -> registers is in flight during the MFMAs, but the
 // transform and the LDS writes are VALU / LDS issue) runs under the other's MFMAs.
-template <bool ACT, bool RING = false>
+template <bool ACT, bool RING = false, int TAPMASK = 0x1ff>
 __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     // XCD-aware placement.  The 8 XCDs take workgroups round-robin by linear id, each with its own 4 MB L2; the co_blocks x ci_blocks workgroups
     // of one image chunk read the SAME dz / y / x planes (each plane is staged by every block of the other channel dimension).  In launch order
@@ -521,21 +566,30 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
             o.a4 = *reinterpret_cast<const float4*>(py_ + 16 * gc);
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
-                const float* r = px_ + 16 * gc + (dy - 1) * P4;
-                o.c4[dy] = *reinterpret_cast<const float4*>(r);
-                o.lf[dy] = r[-1];
-                o.rg[dy] = r[4];
+                if (((TAPMASK >> (3 * dy)) & 7) != 0) {  // (a row none of whose taps exists is not read)
+                    const float* r = px_ + 16 * gc + (dy - 1) * P4;
+                    o.c4[dy] = *reinterpret_cast<const float4*>(r);
+                    if ((TAPMASK >> (3 * dy)) & 1) o.lf[dy] = r[-1];
+                    if ((TAPMASK >> (3 * dy + 2)) & 1) o.rg[dy] = r[4];
+                }
             }
         };
         auto multiply = [&](const OpSet& o) {
             const float a[4] = {o.a4.x, o.a4.y, o.a4.z, o.a4.w};
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
-                const float xs[6] = {o.lf[dy], o.c4[dy].x, o.c4[dy].y, o.c4[dy].z, o.c4[dy].w, o.rg[dy]};
+                float xs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (((TAPMASK >> (3 * dy)) & 7) != 0) {
+                    xs[1] = o.c4[dy].x; xs[2] = o.c4[dy].y; xs[3] = o.c4[dy].z; xs[4] = o.c4[dy].w;
+                    if ((TAPMASK >> (3 * dy)) & 1) xs[0] = o.lf[dy];
+                    if ((TAPMASK >> (3 * dy + 2)) & 1) xs[5] = o.rg[dy];
+                }
 #pragma unroll
                 for (int dx = 0; dx < 3; dx++) {
+                    if ((TAPMASK >> (dy * 3 + dx)) & 1) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs[s + dx], acc[dy * 3 + dx], 0, 0, 0);
+                        for (int s = 0; s < 4; s++) acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs[s + dx], acc[dy * 3 + dx], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -558,9 +612,11 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const int co_pad = L.co_tiles * 16, ci_pad = L.ci_tiles * 16;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        float* d = L.part + (((size_t)chunk * 9 + t) * co_pad + cot * 16 + 4 * kq) * ci_pad + cit * 16 + i16;
+        if ((TAPMASK >> t) & 1) {  // (the other tap planes of the partials are never read as values: k_lc_wreduce's tap map drops them)
+            float* d = L.part + (((size_t)chunk * 9 + t) * co_pad + cot * 16 + 4 * kq) * ci_pad + cit * 16 + i16;
 #pragma unroll
-        for (int r = 0; r < 4; r++) d[(size_t)r * ci_pad] = acc[t][r];
+            for (int r = 0; r < 4; r++) d[(size_t)r * ci_pad] = acc[t][r];
+        }
     }
 }
 
@@ -1553,14 +1609,21 @@ __global__ __launch_bounds__(256) void k_lc_pack(const LcPackJob* jobs, const fl
 // tapmap[t] (or 0 where the plane has no such tap).  transpose: the data gradient's copy ("output" channel = the layer's input channel)
 struct LcPackPar {
     int w_off, cout, cin, dst_off, n_cb, co_tiles, transpose;
+    int compact;  // 1: only the plane's own taps are stored, [co tile][block][k-th tap of the plane] (k_lc_conv's TAPMASK builds); 0: nine taps, zeros elsewhere
     signed char tapmap[9];
 };
 __global__ __launch_bounds__(256) void k_lc_pack_par(const LcPackPar* jobs, const float* params, float* packed) {
     const LcPackPar J = jobs[blockIdx.y];
-    const int n = J.co_tiles * J.n_cb * 9 * 256;
+    int nt = 9, taps[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+    if (J.compact) {
+        nt = 0;
+        for (int t = 0; t < 9; t++)
+            if (J.tapmap[t] >= 0) taps[nt++] = t;
+    }
+    const int n = J.co_tiles * J.n_cb * nt * 256;
     for (int x = blockIdx.x * 256 + threadIdx.x; x < n; x += gridDim.x * 256) {
         const int i = x & 3, lane = (x >> 2) & 63, rest = x >> 8;
-        const int tap = rest % 9, cb = (rest / 9) % J.n_cb, ct = rest / (9 * J.n_cb);
+        const int tap = taps[rest % nt], cb = (rest / nt) % J.n_cb, ct = rest / (nt * J.n_cb);
         const int q = lane >> 4, jj = lane & 15, src = J.tapmap[tap];
         const int o = 16 * ct + jj, k = 16 * cb + 4 * i + q;   // output channel of this conv, reduction channel
         const int co = J.transpose ? k : o, ci = J.transpose ? o : k;
