@@ -75,14 +75,14 @@ int cdiv(int a, int b) { return (a + b - 1) / b; }
 // the tiling is then chosen by the time of one launch, (rounds of workgroups over the CUs) x (tiles per workgroup), `wg_per_group` workgroups
 // per image group (output-channel blocks x paired jobs): at batch 128 a 6 x 6 hidden state packs best as 4 images in 9 tiles, but that is 128
 // workgroups on 256 CUs, and 2 images in 6 tiles fills the chip in 2/3 of the time.  Ties / images == 0: the densest packing.
-bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256, bool stack_wgrad = true) {
+bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256, bool stack_wgrad = true, bool allow16 = false) {
     g.h = hh; g.w = ww; g.hw = hh * ww;
-    if (g.hw < 1 || g.hw > 240) return false;
+    if (g.hw < 1 || g.hw > (allow16 ? 256 : 240)) return false;
     const int QP = (g.hw + 3) / 4;
     double best = -1.0;
     long best_cost = -1;
-    const int cand[3] = {6, 9, 15};
-    for (int i = 0; i < 3; i++) {
+    const int cand[4] = {6, 9, 15, 16};  // (16: the wide tiles of the Atari net's 48 x 48 stage only -- 14 x 18 positions)
+    for (int i = 0; i < (allow16 ? 4 : 3); i++) {
         int G = (16 * cand[i]) / g.hw;
         if (64 / QP < G) G = 64 / QP;
         if (G < 1) continue;
@@ -177,6 +177,8 @@ struct mzlc_learner {
     int par_f[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, par_d[4] = {0, 0, 0, 0};  // packed offsets of the parity copies: forward of conv_1 / conv_2, data gradient of conv_2
     LcPackPar* d_pack_par = nullptr;
     int n_pack_par = 0;
+    Geom gt16;                // 12 x 16 tiles with their halo (14 x 18): planes whose width 16 divides into at least three (the 48 x 48 stage)
+    bool wide_tiles = true;   // MZLC_NO_WIDE_TILES=1 at create: 12 x 12 tiles everywhere
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
@@ -450,25 +452,36 @@ void launch_conv(int mode, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStr
     else hipLaunchKernelGGL((k_lc_conv<NPT, IN_BNBWD, SIDE>), grid, dim3(256), lds, st, pj);
 }
 // the tap sets of the parity planes (par_tapmap): forward rows {1} | {0, 1}, data-gradient rows {1} | {1, 2}, squared
-template <int MASK>
+template <int NPT, int MASK>
 void launch_conv_taps(const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_lc_conv<15, IN_IDENT, 0, MASK>), grid, dim3(256), lds, st, pj);
+    hipLaunchKernelGGL((k_lc_conv<NPT, IN_IDENT, 0, MASK>), grid, dim3(256), lds, st, pj);
 }
-bool launch_conv_tapmask(int mask, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
+// (the data-gradient planes exist for conv_2 only: 24 x 24 planes, 12 x 12 tiles, NPT 15)
+bool launch_conv_tapmask(int npt, int mask, const Pair<LcConv>& pj, dim3 grid, size_t lds, hipStream_t st) {
+    if (npt == 16) {
+        switch (mask) {
+            case 0x010: launch_conv_taps<16, 0x010>(pj, grid, lds, st); return true;
+            case 0x018: launch_conv_taps<16, 0x018>(pj, grid, lds, st); return true;
+            case 0x012: launch_conv_taps<16, 0x012>(pj, grid, lds, st); return true;
+            case 0x01b: launch_conv_taps<16, 0x01b>(pj, grid, lds, st); return true;
+        }
+        return false;
+    }
+    if (npt != 15) return false;
     switch (mask) {
-        case 0x010: launch_conv_taps<0x010>(pj, grid, lds, st); return true;
-        case 0x018: launch_conv_taps<0x018>(pj, grid, lds, st); return true;
-        case 0x012: launch_conv_taps<0x012>(pj, grid, lds, st); return true;
-        case 0x01b: launch_conv_taps<0x01b>(pj, grid, lds, st); return true;
-        case 0x030: launch_conv_taps<0x030>(pj, grid, lds, st); return true;
-        case 0x090: launch_conv_taps<0x090>(pj, grid, lds, st); return true;
-        case 0x1b0: launch_conv_taps<0x1b0>(pj, grid, lds, st); return true;
+        case 0x010: launch_conv_taps<15, 0x010>(pj, grid, lds, st); return true;
+        case 0x018: launch_conv_taps<15, 0x018>(pj, grid, lds, st); return true;
+        case 0x012: launch_conv_taps<15, 0x012>(pj, grid, lds, st); return true;
+        case 0x01b: launch_conv_taps<15, 0x01b>(pj, grid, lds, st); return true;
+        case 0x030: launch_conv_taps<15, 0x030>(pj, grid, lds, st); return true;
+        case 0x090: launch_conv_taps<15, 0x090>(pj, grid, lds, st); return true;
+        case 0x1b0: launch_conv_taps<15, 0x1b0>(pj, grid, lds, st); return true;
     }
     return false;
 }
-template <int MASK>
+template <int NPT, int MASK>
 hipError_t conv_taps_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<15, IN_IDENT, 0, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<NPT, IN_IDENT, 0, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <int NPT, int SIDE>
 hipError_t conv_attr() {
@@ -497,7 +510,11 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             const size_t lds = conv_lds(a->conv.qstride, cp);
             const int mode = a->conv.in_mode;
             if (a->conv.tapmask && a->conv.tapmask != 0x1ff) {  // (a parity plane: built as whole-tile, identity-mode, unpaired launches only)
-                if (b || a->npt != 15 || a->side15 || mode != IN_IDENT || !launch_conv_tapmask(a->conv.tapmask, pj, grid, lds, st)) return MZL_E_INVALID;
+                if (b || a->side15 || mode != IN_IDENT || !launch_conv_tapmask(a->npt, a->conv.tapmask, pj, grid, lds, st)) return MZL_E_INVALID;
+            } else
+            if (a->npt == 16) {  // the wide tiles of the Atari net (gathered: identity staging)
+                if (mode != IN_IDENT) return MZL_E_INVALID;
+                hipLaunchKernelGGL((k_lc_conv<16, IN_IDENT, 0>), grid, dim3(256), lds, st, pj);
             } else
             if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
             else if (a->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
@@ -633,20 +650,28 @@ struct AtariRun {
     hipStream_t st;
 
     void run(const Op& o) const { launch_ops(h, &o, nullptr, st); }
+    // tiles are 12 rows x 12 or 16 columns of plane positions: 16 where the plane's width allows (48: three columns of tiles; 24 does not divide)
+    int tile_w(int W) const { return (h->wide_tiles && W % 16 == 0 && W / 16 >= 3) ? 16 : TILE; }
+    const Geom& tgeom(int W) const { return tile_w(W) == 16 ? h->gt16 : h->gt; }
+    int ntiles(int H, int W) const { return (H / TILE) * (W / tile_w(W)); }
     // plane (H x W, a parity plane when sy == 2) of src [B][C][srcH][srcW] -> tiles with halo
     void gather(const float* src0, const float* src1, const float* coef, int mode, int C, int H, int W, int srcH, int srcW, int sy, int sx, int py, int px,
                 int inner_only, float* dst) const {
         LcTileGather g{};
+        const int tw = tile_w(W), ts2 = (TILE + 2) * (tw + 2);
         g.src0 = src0; g.src1 = src1; g.coef = coef; g.dst = dst; g.mode = mode; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W;
-        g.srcH = srcH; g.srcW = srcW; g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.T = TILE; g.nty = H / TILE; g.ntx = W / TILE; g.inner_only = inner_only;
-        g.n = (long long)B * g.nty * g.ntx * C * (TILE + 2) * (TILE + 2);
-        hipLaunchKernelGGL(k_lc_tile_gather<TILE + 2>, dim3((unsigned)(B * g.nty * g.ntx), (unsigned)cdiv(C * (TILE + 2) * (TILE + 2), 1024)), dim3(256), 0, st, g);
+        g.srcH = srcH; g.srcW = srcW; g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.Ty = TILE; g.Tx = tw; g.nty = H / TILE; g.ntx = W / tw; g.inner_only = inner_only;
+        g.n = (long long)B * g.nty * g.ntx * C * ts2;
+        const dim3 grid((unsigned)(B * g.nty * g.ntx), (unsigned)cdiv(C * ts2, 1024));
+        if (tw == 16) hipLaunchKernelGGL((k_lc_tile_gather<TILE + 2, 18>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_lc_tile_gather<TILE + 2, TILE + 2>), grid, dim3(256), 0, st, g);
     }
     // returns the number of statistic groups written (0 without stat_part)
     int scatter(const float* src, int C, int H, int W, float* dst, int dstH, int dstW, int sy, int sx, int py, int px, const float* skip, float* stat_part) const {
         LcTileScatter g{};
+        const int tw = tile_w(W);
         g.src = src; g.dst = dst; g.skip = skip; g.stat_part = stat_part; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W; g.dstH = dstH; g.dstW = dstW;
-        g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.T = TILE; g.nty = H / TILE; g.ntx = W / TILE;
+        g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.Ty = TILE; g.Tx = tw; g.nty = H / TILE; g.ntx = W / tw;
         const dim3 grid(cdiv(H * W, 32), B);
         const int cpt = cdiv(C, 8);
         if (cpt <= 2) hipLaunchKernelGGL(k_lc_tile_scatter<2>, grid, dim3(256), 0, st, g);
@@ -655,19 +680,21 @@ struct AtariRun {
         else hipLaunchKernelGGL(k_lc_tile_scatter<32>, grid, dim3(256), 0, st, g);
         return B * cdiv(H * W, 32);
     }
-    Sched tiles(int C, int nt) const { return Sched{h, B * nt, 0, false, h->gt, C}; }
+    Sched tiles(int C, int H, int W) const { return Sched{h, B * ntiles(H, W), 0, false, tgeom(W), C}; }
+    Sched plain(int C) const { return Sched{h, B, 0, false, h->gt, C}; }  // (finalize kernels: the geometry is not used)
     // stride-1 conv of the tiles in `in` -> `out` (forward or data-gradient copy of layer L), identity staging, no epilogue extras
-    void conv_tiles(const LayerInfo& L, bool dgrad, int nt, const float* in, float* out) const {
-        const Sched s = tiles(dgrad ? L.cout : L.cin_real, nt);
+    void conv_tiles(const LayerInfo& L, bool dgrad, int H, int W, const float* in, float* out) const {
+        const Sched s = tiles(dgrad ? L.cout : L.cin_real, H, W);
         LcConv c = s.conv_base(L, dgrad);
         c.in0 = in; c.in_mode = IN_IDENT; c.out = out; c.stat_mode = ST_NONE;
         run(s.op_conv(c));
     }
     // one parity plane's share of a stride-2 conv: the packed copy at `w_off`; accumulate: out += (the earlier planes' sum rides in `skip`)
-    void conv_par(int w_off, int cin, int cout, int nt, const float* in, float* out, bool accumulate, int tapmask) const {
-        const Sched s = tiles(cin, nt);
+    void conv_par(int w_off, int cin, int cout, int H, int W, const float* in, float* out, bool accumulate, int tapmask) const {
+        const Sched s = tiles(cin, H, W);
+        const Geom& tg = tgeom(W);
         LcConv c{};
-        c.B = B * nt; c.G = h->gt.G; c.h = h->gt.h; c.w_img = h->gt.w; c.qstride = h->gt.qstride;
+        c.B = B * ntiles(H, W); c.G = tg.G; c.h = tg.h; c.w_img = tg.w; c.qstride = tg.qstride;
         c.cin_real = cin; c.cin = cin; c.n_cb = cdiv(cin, 16); c.cout = cout; c.co_tiles = cdiv(cout, 16); c.w = h->packed + w_off;
         c.cpad_in = pad16(cin); c.cpad_out = pad16(cout); c.num_actions = h->A;
         c.in0 = in; c.in_mode = IN_IDENT; c.out = out; c.skip = accumulate ? out : nullptr; c.stat_mode = ST_NONE;
@@ -675,13 +702,13 @@ struct AtariRun {
         run(s.op_conv(c));
     }
     void bn_fwd(const LayerInfo& L, float* fcoef, float* save, int groups, float count) const {
-        const Sched s = tiles(L.cout, 1);
+        const Sched s = plain(L.cout);
         Op o = s.op_bnfwd(L, fcoef, save);
         o.bf.groups = groups; o.bf.count = count;
         run(o);
     }
     void bn_bwd(const LayerInfo& L, const float* save, float* bcoef, int groups, float count) const {
-        const Sched s = tiles(L.cout, 1);
+        const Sched s = plain(L.cout);
         Op o = s.op_bnbwd(L, save, bcoef, groups, 0);
         o.bb.count = count;
         run(o);
@@ -715,8 +742,8 @@ struct AtariRun {
         return B * split;
     }
     // weight gradient of layer L from dy tiles (already BatchNorm-backward transformed, halo included: ring_zero) and x tiles
-    void wgrad_tiles(const LayerInfo& L, int cin, int nt, const float* dy_tiles, const float* x_tiles, const signed char* tapmap) const {
-        const Sched s = tiles(L.cout, nt);
+    void wgrad_tiles(const LayerInfo& L, int cin, int H, int W, const float* dy_tiles, const float* x_tiles, const signed char* tapmap) const {
+        const Sched s = tiles(L.cout, H, W);
         LayerInfo Lw = L;
         Lw.cin_real = cin; Lw.cin = cin;
         std::vector<Op> ops;
@@ -738,18 +765,18 @@ struct AtariRun {
 
     // ---- forward of two residual blocks on a tiled stage ----
     float* stage_fwd(mzlc_learner::StageBufs& sb, const std::vector<int>& lay, const float* x_in, int C, int H, int W) const {
-        const int nt = (H / TILE) * (W / TILE), hw = H * W;
+        const int hw = H * W;
         const float count = (float)B * (float)hw;
         const float* cur = x_in;
         for (int r = 0; r < 2; r++) {
             const LayerInfo &L1 = h->layers[lay[2 * r]], &L2 = h->layers[lay[2 * r + 1]];
             gather(cur, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
-            conv_tiles(L1, false, nt, h->TA, h->TB);
+            conv_tiles(L1, false, H, W, h->TA, h->TB);
             int ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0]);
             bn_fwd(L1, sb.fcoef[2 * r], sb.save[2 * r], ng, count);
             apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
             gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
-            conv_tiles(L2, false, nt, h->TA, h->TB);
+            conv_tiles(L2, false, H, W, h->TA, h->TB);
             ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0]);
             bn_fwd(L2, sb.fcoef[2 * r + 1], sb.save[2 * r + 1], ng, count);
             apply(sb.y[2 * r + 1], cur, sb.fcoef[2 * r + 1], sb.x[r], C, hw);
@@ -759,7 +786,7 @@ struct AtariRun {
     }
     // ---- backward: sb.dzA holds dz of the stage's last BatchNorm, its partial sums (ng groups) are in stat[0]; leaves the gradient wrt x_in in sb.gF ----
     void stage_bwd(mzlc_learner::StageBufs& sb, const std::vector<int>& lay, const float* x_in, int C, int H, int W, int ng) const {
-        const int nt = (H / TILE) * (W / TILE), hw = H * W;
+        const int hw = H * W;
         const float count = (float)B * (float)hw;
         for (int r = 1; r >= 0; r--) {
             const LayerInfo &L1 = h->layers[lay[2 * r]], &L2 = h->layers[lay[2 * r + 1]];
@@ -767,15 +794,15 @@ struct AtariRun {
             bn_bwd(L2, sb.save[2 * r + 1], sb.bcoef[2 * r + 1], ng, count);
             gather(sb.dzA, sb.y[2 * r + 1], sb.bcoef[2 * r + 1], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
-            wgrad_tiles(L2, C, nt, h->TA, h->TC, nullptr);
-            conv_tiles(L2, true, nt, h->TA, h->TB);
+            wgrad_tiles(L2, C, H, W, h->TA, h->TC, nullptr);
+            conv_tiles(L2, true, H, W, h->TA, h->TB);
             scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr);
             ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
             bn_bwd(L1, sb.save[2 * r], sb.bcoef[2 * r], ng, count);
             gather(sb.dzB, sb.y[2 * r], sb.bcoef[2 * r], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
-            wgrad_tiles(L1, C, nt, h->TA, h->TC, nullptr);
-            conv_tiles(L1, true, nt, h->TA, h->TB);
+            wgrad_tiles(L1, C, H, W, h->TA, h->TC, nullptr);
+            conv_tiles(L1, true, H, W, h->TA, h->TB);
             scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr);  // + the block's skip gradient
             if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
         }
@@ -811,7 +838,7 @@ float* atari_rep_fwd(mzlc_learner* h, int B, hipStream_t st) {
     // conv_1: four parity planes of the observation, accumulated on the tiles
     for (int pq = 0; pq < 4; pq++) {
         R.gather(h->obs, nullptr, nullptr, IN_IDENT, h->C0, H1, W1, h->obsH, h->obsW, 2, 2, pq >> 1, pq & 1, 0, h->TA);
-        R.conv_par(h->par_f[0][pq], h->C0, C1.cout, (H1 / TILE) * (W1 / TILE), h->TA, h->TB, pq > 0, par_tapmask(pq >> 1, pq & 1, false));
+        R.conv_par(h->par_f[0][pq], h->C0, C1.cout, H1, W1, h->TA, h->TB, pq > 0, par_tapmask(pq >> 1, pq & 1, false));
     }
     R.scatter(h->TB, C1.cout, H1, W1, h->y_c1, H1, W1, 1, 1, 0, 0, nullptr, nullptr);
     const int big = pad16(h->P > 128 ? h->P : 128);  // the row stride of coef_relu / coef_ident
@@ -819,7 +846,7 @@ float* atari_rep_fwd(mzlc_learner* h, int B, hipStream_t st) {
     float* x48 = R.stage_fwd(h->sb48, h->l_b1, h->a1, 128, H1, W1);
     for (int pq = 0; pq < 4; pq++) {
         R.gather(x48, nullptr, nullptr, IN_IDENT, 128, H2, W2, H1, W1, 2, 2, pq >> 1, pq & 1, 0, h->TA);
-        R.conv_par(h->par_f[1][pq], 128, C2.cout, (H2 / TILE) * (W2 / TILE), h->TA, h->TB, pq > 0, par_tapmask(pq >> 1, pq & 1, false));
+        R.conv_par(h->par_f[1][pq], 128, C2.cout, H2, W2, h->TA, h->TB, pq > 0, par_tapmask(pq >> 1, pq & 1, false));
     }
     R.scatter(h->TB, h->P, H2, W2, h->y_c2, H2, W2, 1, 1, 0, 0, nullptr, nullptr);
     R.apply(h->y_c2, nullptr, h->coef_relu, h->a2, h->P, H2 * W2, big);
@@ -886,16 +913,15 @@ void atari_rep_bwd(mzlc_learner* h, int B, const float* gs0, hipStream_t st) {
         const long long n = (long long)B * P * H2 * W2;
         hipLaunchKernelGGL(k_lc_relu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->sb24.gF, h->a2, h->sb24.dzB, n);
     }
-    const int nt2 = (H2 / TILE) * (W2 / TILE);
     R.gather(h->sb24.dzB, nullptr, nullptr, IN_IDENT, P, H2, W2, H2, W2, 1, 1, 0, 0, 0, h->TA);  // dy tiles with halo: both gradients read them
     for (int pq = 0; pq < 4; pq++) {
         signed char m[9];
         par_tapmap(pq >> 1, pq & 1, false, m);
         R.gather(x48, nullptr, nullptr, IN_IDENT, 128, H2, W2, H1, W1, 2, 2, pq >> 1, pq & 1, 0, h->TC);
-        R.wgrad_tiles(C2, 128, nt2, h->TA, h->TC, m);
+        R.wgrad_tiles(C2, 128, H2, W2, h->TA, h->TC, m);
     }
     for (int pq = 0; pq < 4; pq++) {  // data gradient: parity plane (p, q) of the 48 x 48 gradient from the dy tiles
-        R.conv_par(h->par_d[pq], P, 128, nt2, h->TA, h->TB, false, par_tapmask(pq >> 1, pq & 1, true));
+        R.conv_par(h->par_d[pq], P, 128, H2, W2, h->TA, h->TB, false, par_tapmask(pq >> 1, pq & 1, true));
         R.scatter(h->TB, 128, H2, W2, h->sb48.gF, H1, W1, 2, 2, pq >> 1, pq & 1, nullptr, nullptr);
     }
     ng = R.entry(x48, nullptr, 1.0f, h->sb48.gF, h->sb48.y[3], h->sb48.dzA, 128, H1 * W1);
@@ -905,13 +931,12 @@ void atari_rep_bwd(mzlc_learner* h, int B, const float* gs0, hipStream_t st) {
         const long long n = (long long)B * 128 * H1 * W1;
         hipLaunchKernelGGL(k_lc_relu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->sb48.gF, h->a1, h->sb48.dzB, n);
     }
-    const int nt1 = (H1 / TILE) * (W1 / TILE);
     R.gather(h->sb48.dzB, nullptr, nullptr, IN_IDENT, 128, H1, W1, H1, W1, 1, 1, 0, 0, 0, h->TA);
     for (int pq = 0; pq < 4; pq++) {
         signed char m[9];
         par_tapmap(pq >> 1, pq & 1, false, m);
         R.gather(h->obs, nullptr, nullptr, IN_IDENT, h->C0, H1, W1, h->obsH, h->obsW, 2, 2, pq >> 1, pq & 1, 0, h->TC);
-        R.wgrad_tiles(C1, h->C0, nt1, h->TA, h->TC, m);
+        R.wgrad_tiles(C1, h->C0, H1, W1, h->TA, h->TC, m);
     }
 }
 
@@ -947,7 +972,11 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (h->hw > 240 || h->P > 1024) return bad("conv learner: boards up to 240 points and 1024 planes (larger nets train through muzero_amd.learner.train_step)");
     if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"), getenv("MZLC_DENSE_TILING") ? 0 : h->maxB, cdiv(cdiv(h->P, 16), 4) * 2, h->num_cus, !getenv("MZLC_NO_WGRAD_STACK"))) return bad("board does not fit the conv kernels' tiling");
     if (wgrad_lds(h->gm) > 160 * 1024 || conv_lds(h->gm.qstride, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
-    if (h->atari && (!make_geom(h->gt, TILE + 2, TILE + 2, false) || !make_geom(h->g12, TILE, TILE, false))) return bad("internal: tile geometry");
+    h->wide_tiles = !getenv("MZLC_NO_WIDE_TILES");
+    if (h->atari && (!make_geom(h->gt, TILE + 2, TILE + 2, false) || !make_geom(h->g12, TILE, TILE, false) ||
+                     !make_geom(h->gt16, TILE + 2, 18, false, 0, 1, 256, true, true)))
+        return bad("internal: tile geometry");
+    if (h->atari && (wgrad_lds(h->gt16) > 80 * 1024 || h->gt16.npt != 16)) h->wide_tiles = false;  // (two weight-gradient workgroups per CU need their LDS)
     // ---- parameter / buffer tables in state_dict order (network.py:312-498) ----
     const int kv = cfg->value_support_size > 1 ? 2 : 0, kr = cfg->reward_support_size > 1 ? 2 : 0;  // head kinds: categorical (2-hot cross entropy) | squared error
     if (h->atari) {
@@ -1122,13 +1151,18 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (e == hipSuccess) e = conv_attr<15, 0>();
     if (e == hipSuccess) e = conv_attr<9, 0>();
     if (e == hipSuccess) e = conv_attr<6, 0>();
-    if (e == hipSuccess) e = conv_taps_attr<0x010>();
-    if (e == hipSuccess) e = conv_taps_attr<0x018>();
-    if (e == hipSuccess) e = conv_taps_attr<0x012>();
-    if (e == hipSuccess) e = conv_taps_attr<0x01b>();
-    if (e == hipSuccess) e = conv_taps_attr<0x030>();
-    if (e == hipSuccess) e = conv_taps_attr<0x090>();
-    if (e == hipSuccess) e = conv_taps_attr<0x1b0>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x010>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x018>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x012>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x01b>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x030>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x090>();
+    if (e == hipSuccess) e = conv_taps_attr<15, 0x1b0>();
+    if (e == hipSuccess) e = conv_taps_attr<16, 0x1ff>();
+    if (e == hipSuccess) e = conv_taps_attr<16, 0x010>();
+    if (e == hipSuccess) e = conv_taps_attr<16, 0x018>();
+    if (e == hipSuccess) e = conv_taps_attr<16, 0x012>();
+    if (e == hipSuccess) e = conv_taps_attr<16, 0x01b>();
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (dalloc's fills run on the NULL stream)
     if (e != hipSuccess) {
         err = std::string("conv learner init: ") + hipGetErrorString(e);

@@ -1007,19 +1007,19 @@ struct LcTileGather {
     const float* src0;   // [B][C][srcH][srcW]
     const float* src1;   // IN_BNBWD: y
     const float* coef;   // [3][cpad] or null (IN_IDENT)
-    float* dst;          // [B * nty * ntx][C][(T + 2)^2]
+    float* dst;          // [B * nty * ntx][C][(Ty + 2) (Tx + 2)]
     int mode;            // IN_IDENT | IN_BNRELU | IN_BNBWD
     int B, C, cpad, H, W;            // the plane that is tiled (a parity plane: H = srcH / 2)
     int srcH, srcW, sy, sx, py, px;  // plane position (y, x) is source element (y * sy + py, x * sx + px)
-    int T, nty, ntx;
+    int Ty, Tx, nty, ntx;            // tile size (rows x columns of plane positions) and count
     int inner_only;      // 1: the halo ring is written as zeros (the dy operand of the weight gradient: only the tile's own pixels count)
     long long n;         // elements of dst
 };
 // grid (tiles, chunks of 1024 tile elements): the tile's coordinates are workgroup-uniform (scalar), the element's (c, ly, lx) divide by compile-time
 // constants; four elements per thread, their loads issued together (one 4-byte load per thread in flight left the kernel latency-bound at 1.5 TB/s)
-template <int TS>
+template <int TSY, int TSX>
 __global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
-    constexpr int ts2 = TS * TS;
+    constexpr int ts2 = TSY * TSX;
     const int ti = blockIdx.x, j0 = blockIdx.y * 1024 + threadIdx.x, nel = L.C * ts2;
     const int nt = L.nty * L.ntx, b = ti / nt, t = ti - b * nt, tyi = t / L.ntx, txi = t - tyi * L.ntx;
     const float* s0 = L.src0 + (size_t)b * L.C * L.srcH * L.srcW;
@@ -1030,9 +1030,9 @@ __global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int j = j0 + u * 256;
-        const int c = j / ts2, r = j - c * ts2, ly = r / TS, lx = r - ly * TS;
-        const int y = tyi * L.T - 1 + ly, x = txi * L.T - 1 + lx;
-        const bool ring = ly == 0 || lx == 0 || ly == TS - 1 || lx == TS - 1;
+        const int c = j / ts2, r = j - c * ts2, ly = r / TSX, lx = r - ly * TSX;
+        const int y = tyi * L.Ty - 1 + ly, x = txi * L.Tx - 1 + lx;
+        const bool ring = ly == 0 || lx == 0 || ly == TSY - 1 || lx == TSX - 1;
         in[u] = j < nel && y >= 0 && y < L.H && x >= 0 && x < L.W && !(L.inner_only && ring);
         cc[u] = c;
         const size_t si = in[u] ? (size_t)c * L.srcH * L.srcW + (size_t)(y * L.sy + L.py) * L.srcW + (x * L.sx + L.px) : 0;
@@ -1063,23 +1063,23 @@ struct LcTileScatter {
     float* dst;          // [B][C][dstH][dstW]
     const float* skip;   // like dst, or null
     float* stat_part;    // [B * chunks][cpad][2] or null
-    int B, C, cpad, H, W, dstH, dstW, sy, sx, py, px, T, nty, ntx;
+    int B, C, cpad, H, W, dstH, dstW, sy, sx, py, px, Ty, Tx, nty, ntx;
 };
 template <int CPT>
 __global__ __launch_bounds__(256) void k_lc_tile_scatter(const LcTileScatter L) {
     const int b = blockIdx.y, lp = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + lp;
-    const int cpt = (L.C + 7) >> 3, TS = L.T + 2;
+    const int cpt = (L.C + 7) >> 3, TSX = L.Tx + 2, ts2 = (L.Ty + 2) * TSX;
     const bool ok = p < L.H * L.W;
     const int y = ok ? p / L.W : 0, x = ok ? p - (p / L.W) * L.W : 0;
-    const int tyi = y / L.T, txi = x / L.T, ly = y - tyi * L.T + 1, lx = x - txi * L.T + 1;
-    const size_t sbase = ((size_t)(b * L.nty + tyi) * L.ntx + txi) * L.C * TS * TS + (size_t)ly * TS + lx;
+    const int tyi = y / L.Ty, txi = x / L.Tx, ly = y - tyi * L.Ty + 1, lx = x - txi * L.Tx + 1;
+    const size_t sbase = ((size_t)(b * L.nty + tyi) * L.ntx + txi) * L.C * ts2 + (size_t)ly * TSX + lx;
     const size_t dbase = (size_t)b * L.C * L.dstH * L.dstW + (size_t)(y * L.sy + L.py) * L.dstW + (x * L.sx + L.px);
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
         const int c = cg * cpt + i;
         float v = 0.0f;
         if (ok && i < cpt && c < L.C) {
-            v = L.src[sbase + (size_t)c * TS * TS];
+            v = L.src[sbase + (size_t)c * ts2];
             const size_t di = dbase + (size_t)c * L.dstH * L.dstW;
             if (L.skip) v += L.skip[di];
             L.dst[di] = v;
