@@ -29,7 +29,7 @@ extern "C" {
 
 #define MZL_NET_MLP 0    /* MuZeroMLPNet (network.py:236-267); kernels: muzero_amd/csrc/mz_learn.h */
 #define MZL_NET_BOARD 1  /* MuZeroBoardGameNet (network.py:540-574); kernels: muzero_amd/csrc/mz_learn_conv.h */
-#define MZL_NET_ATARI 2  /* MuZeroAtariNet (network.py:501-537): the same kernels; the 96 x 96 representation (network.py:312-353) on 12 x 12 tiles */
+#define MZL_NET_ATARI 2  /* MuZeroAtariNet (network.py:501-537): the same kernels; the 96 x 96 representation (network.py:312-353) on 12 x 12 / 12 x 16 tiles */
 
 /* The network's constructor arguments (MuZeroMLPNet network.py:239-247 | MuZeroBoardGameNet :543-549) + the batch geometry of calc_loss
  * (pipeline.py:541-575). */
