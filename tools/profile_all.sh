@@ -28,6 +28,7 @@ for W in "$@"; do
     c4) run c4 "--workload c4 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c4 --steps 1 --warmup 0 --sims 3 --no-cpu-baseline --no-sustained" ;;
     learner) run learner "--batches 128,4096 --no-torch --iters 100" "--batches 128,4096 --no-torch --iters 10" tools/learner_bench.py ;;
     convlearner) run convlearner "--hip-only --iters 5" "--hip-only --iters 1" tools/conv_learner_bench.py ;;
+    atarilearner) run atarilearner "--atari --chan 4 --planes 128 --blocks 8 --batch 128 --hip-only --iters 5" "--atari --chan 4 --planes 128 --blocks 8 --batch 128 --hip-only --iters 1" tools/conv_learner_bench.py ;;
     lunar) run lunar "--workload lunar --steps 10 --warmup 2 --no-cpu-baseline" "--workload lunar --steps 4 --warmup 1 --preheat 0 --no-cpu-baseline" ;;
     c5) run c5 "--workload c5 --steps 1 --warmup 0 --no-cpu-baseline --no-sustained" "--workload c5 --steps 1 --warmup 0 --sims 2 --no-cpu-baseline --no-sustained" ;;
   esac

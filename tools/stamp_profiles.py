@@ -26,7 +26,7 @@ def main():
     for w in workloads:
         src = os.path.join(REPO, 'gpurun_out', 'profiles', w)
         doc = json.load(open(os.path.join(src, 'summary.json')))
-        if w in ('learner', 'convlearner'):
+        if w in ('learner', 'convlearner', 'atarilearner'):
             if doc.get('_learner_fingerprint') != mz_build.learner_fingerprint():
                 sys.exit(f'learner: measured on other learner sources: re-run tools/profile_all.sh learner')
         elif doc.get('_source_fingerprint') != fp:
