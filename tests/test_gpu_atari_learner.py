@@ -333,3 +333,59 @@ def test_checkpoint_round_trip_and_planner_epoch():
     hl2.step_transitions(tr)
     for k, v in net.state_dict().items():
         assert torch.equal(v, net2.state_dict()[k]), k
+
+
+def _atari_closed_loop(seed, iters=3, envs=16):
+    """device self-play on the synthetic Atari stand-in (C4's kernels on a small net) -> device epilogue -> HBM replay -> HipLearner updates on
+    the Atari net -> planner reload, in event order."""
+    from muzero_amd import learner as L
+    from muzero_amd import planner as pl
+    from muzero_amd.config import make_atari_config
+    from muzero_amd.network import MuZeroAtariNet
+    from muzero_amd.replay import PrioritizedReplay
+
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(seed)
+    cfg = make_atari_config(batch_size=8, min_replay_size=8, use_tensorboard=False)
+    cfg.num_simulations, cfg.num_planes, cfg.num_res_blocks, cfg.value_support_size, cfg.reward_support_size = 6, 8, 1, 11, 11
+    cfg.acc_seq_length, cfg.lr_init = 12, 1e-3
+    net = MuZeroAtariNet((4, 96, 96), 6, cfg.num_res_blocks, cfg.num_planes, cfg.value_support_size, cfg.reward_support_size).to(dev)
+    hl = L.make_hip_learner(cfg, net, dev)
+    replay = PrioritizedReplay(512, 0.0, 0.0, np.random.RandomState(seed), device='cuda')
+    p = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=envs, seed=seed), 0)
+    p.load_state_dict(net.state_dict())
+    p.attach_replay(replay, cfg, obs_shape=(4, 96, 96))
+    p.selfplay_reset(pl.ENV_SYNTHETIC)
+    losses = []
+    for _ in range(iters):
+        p.selfplay_step(1.0, 14)
+        p.synchronize()
+        if replay.size < cfg.min_replay_size:
+            continue
+        for _ in range(2):
+            idx, _, ring = replay.sample_indices(cfg.batch_size)
+            loss, _ = hl.step(ring, torch.from_numpy(idx).to(dev), None, cfg.batch_size)
+            losses.append(loss.clone())
+        p.load_state_dict(net.state_dict())
+    # the planner now answers with the LEARNER's weights: a fresh planner loaded from the module agrees bit for bit
+    obs = np.random.RandomState(1).uniform(0, 1, (3, 4, 96, 96)).astype(np.float32)
+    h1, pi1, v1 = p.initial_inference(obs)
+    q = pl.Planner(pl.make_mz_config(net.planner_spec(), cfg, num_envs=envs, seed=seed), 0)
+    q.load_state_dict(net.state_dict())
+    h2, pi2, v2 = q.initial_inference(obs)
+    same = np.array_equal(np.asarray(h1), np.asarray(h2)) and np.array_equal(pi1, pi2) and np.array_equal(v1, v2)
+    out = ([float(x) for x in losses], {k: v.cpu().numpy().copy() for k, v in net.state_dict().items()}, replay.size, same)
+    p.close()
+    q.close()
+    hl.close()
+    return out
+
+
+def test_atari_closed_loop_runs_and_repeats():
+    """Self-play -> replay -> Atari learner -> planner reload on one GPU: finite losses, weights that move, a planner that serves the learner's
+    weights, and the same run from the same seed (no atomics anywhere on the path)."""
+    a, b = _atari_closed_loop(3), _atari_closed_loop(3)
+    assert len(a[0]) >= 4 and np.isfinite(a[0]).all() and a[3]
+    assert a[0] == b[0] and a[2] == b[2]
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
