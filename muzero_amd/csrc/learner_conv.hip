@@ -179,6 +179,7 @@ struct mzlc_learner {
     int n_pack_par = 0;
     Geom gt16;                // 12 x 16 tiles with their halo (14 x 18): planes whose width 16 divides into at least three (the 48 x 48 stage)
     bool wide_tiles = true;   // MZLC_NO_WIDE_TILES=1 at create: 12 x 12 tiles everywhere
+    bool bad_dispatch = false;  // a launch found no kernel build for its job (reported by mzlc_grad: never silently skipped)
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
@@ -510,10 +511,10 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             const size_t lds = conv_lds(a->conv.qstride, cp);
             const int mode = a->conv.in_mode;
             if (a->conv.tapmask && a->conv.tapmask != 0x1ff) {  // (a parity plane: built as whole-tile, identity-mode, unpaired launches only)
-                if (b || a->side15 || mode != IN_IDENT || !launch_conv_tapmask(a->npt, a->conv.tapmask, pj, grid, lds, st)) return MZL_E_INVALID;
+                if (b || a->side15 || mode != IN_IDENT || !launch_conv_tapmask(a->npt, a->conv.tapmask, pj, grid, lds, st)) { h->bad_dispatch = true; return MZL_E_INVALID; }
             } else
             if (a->npt == 16) {  // the wide tiles of the Atari net (gathered: identity staging)
-                if (mode != IN_IDENT) return MZL_E_INVALID;
+                if (mode != IN_IDENT) { h->bad_dispatch = true; return MZL_E_INVALID; }
                 hipLaunchKernelGGL((k_lc_conv<16, IN_IDENT, 0>), grid, dim3(256), lds, st, pj);
             } else
             if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
@@ -536,13 +537,13 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             const size_t wlds = ((size_t)32 * (a->wg.SPY + a->wg.SPX) + 160) * sizeof(float);
             const dim3 wgrid(x, ya + yb);
             if (a->wg.tapmask && a->wg.tapmask != 0x1ff) {  // a parity plane (tile path: ring_zero, no action planes, unpaired)
-                if (b || !a->wg.ring_zero || a->wg.action) return MZL_E_INVALID;
+                if (b || !a->wg.ring_zero || a->wg.action) { h->bad_dispatch = true; return MZL_E_INVALID; }
                 switch (a->wg.tapmask) {
                     case 0x010: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x010>), wgrid, dim3(256), wlds, st, pj); break;
                     case 0x018: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x018>), wgrid, dim3(256), wlds, st, pj); break;
                     case 0x012: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x012>), wgrid, dim3(256), wlds, st, pj); break;
                     case 0x01b: hipLaunchKernelGGL((k_lc_wgrad<false, true, 0x01b>), wgrid, dim3(256), wlds, st, pj); break;
-                    default: return MZL_E_INVALID;
+                    default: h->bad_dispatch = true; return MZL_E_INVALID;
                 }
             } else
             if (a->wg.ring_zero) hipLaunchKernelGGL((k_lc_wgrad<false, true>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
@@ -1346,6 +1347,7 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
         sr.tower_bwd(ops, h->tower[0], h->app_rep, h->obs, nullptr, eg, 0, nullptr, nullptr);
         for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
     }
+    if (h->bad_dispatch) { err = "internal: a launch of the conv learner had no kernel build for its job (tap set / tile geometry)"; return MZL_E_INVALID; }
     if (hipGetLastError() != hipSuccess) { err = "a conv-learner kernel failed to launch"; return MZL_E_HIP; }
     return MZL_OK;
 }
