@@ -189,7 +189,7 @@ SHAPES = [(4, 8, 1, 6, 11, 11, 3, 5, 3), (4, 8, 1, 6, 11, 11, 3, 5, 5), (4, 8, 1
 REP_ERR = {}
 
 
-def _case(chan, planes, blocks, A, vs, rs_, B, K, seed, kinkfree, dev):
+def _case(chan, planes, blocks, A, vs, rs_, B, K, seed, kinkfree, dev, int8_state=False):
     from muzero_amd.network import MuZeroAtariNet
 
     net = MuZeroAtariNet((chan, 96, 96), A, blocks, planes, vs, rs_)
@@ -200,6 +200,8 @@ def _case(chan, planes, blocks, A, vs, rs_, B, K, seed, kinkfree, dev):
     tr = Transition(rs.uniform(0, 1, (B, chan, 96, 96)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
                     rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), (rs.uniform(-1, 1, (B, K)) * 8.0).astype(np.float32),
                     rs.uniform(-1, 1, (B, K)).astype(np.float32))
+    if int8_state:  # (the replay ring's int8 state storage: the gather kernel converts)
+        tr = tr._replace(state=(tr.state * 4.0).astype(np.int8))
     w = rs.uniform(0.3, 1.0, B).astype(np.float32)
     loss_d, prio_d, gd, sd_d, probe = _f64(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
     probe.err32 = f32_errors(net, tr, w, dev, gd) if kinkfree else None
@@ -208,9 +210,12 @@ def _case(chan, planes, blocks, A, vs, rs_, B, K, seed, kinkfree, dev):
     assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
     np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=2e-4 * max(1.0, float(prio_d.abs().max())))
     sd = net.state_dict()  # the train-mode pass has updated the running statistics, one momentum step per application of a layer
+    # (one-pass batch variance from float32 partial sums: relative error ~1e-7 (1 + mean^2 / var) -- DESIGN 4c.  The reference's nets sit at
+    # mean^2 / var < 10; the kink-free weights push the heads' 1 x 1 convolutions of all-positive features to ~3 500: 3e-4)
+    stat_tol = 1e-3 if kinkfree else 3e-5
     for k, v in sd_d.items():
         if 'running' in k:
-            assert float((v - sd[k].double()).abs().max()) <= 3e-5 * max(1.0, float(v.abs().max())), k
+            assert float((v - sd[k].double()).abs().max()) <= stat_tol * max(1.0, float(v.abs().max())), k
         if 'num_batches_tracked' in k:
             assert int(v) == int(sd[k]), k
     return grad_errors(gd, hl.grad_views), probe

@@ -619,10 +619,11 @@ def test_random_atari_learner_configuration_matches_float64_autograd(i):
     if planes >= 64:
         B = min(B, 3)
     c = (chan, planes, blocks, A, vs, rsz, B, K, int(rs.randint(1 << 20)))
+    i8 = bool(rs.rand() < 0.25)  # int8 state storage (drawn after everything else: the earlier cases keep their shapes)
     dev = torch.device('cuda', 0)
-    errs, probe = _case(*c, True, dev)
+    errs, probe = _case(*c, True, dev, i8)
     k, e, bar = kinkfree_worst(errs, probe.err32, probe.closest_tie)  # (TIGHT; 4 x PyTorch-ROCm's float32 error on an ill-conditioned batch; NOISY next to a normalisation tie)
     assert probe.closest_all > 1e-4 and e <= bar, (c, k, e, bar, probe.closest_all, probe.closest_tie)
-    errs, probe = _case(*c, False, dev)
+    errs, probe = _case(*c, False, dev, i8)
     worst = max(errs, key=errs.get)
     assert errs[worst] <= 0.6, (c, worst, errs[worst], probe.closest_all)  # (seen: 0.31 once in 900 cases; NOISY = 0.25 holds for the committed shapes)
