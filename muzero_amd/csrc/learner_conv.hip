@@ -154,7 +154,7 @@ struct mzlc_learner {
     // heads
     LchGroup* d_groups = nullptr;
     std::vector<LchGroup> groups_host;
-    float *hu = nullptr, *hdz = nullptr, *hfeat = nullptr, *hdl = nullptr, *hspart = nullptr, *hcoef = nullptr, *hsave = nullptr, *hlpart = nullptr, *hwpart = nullptr;
+    float *hu = nullptr, *hdz = nullptr, *hfeat = nullptr, *hdl = nullptr, *hspart = nullptr, *hspiv = nullptr, *hcoef = nullptr, *hsave = nullptr, *hlpart = nullptr, *hwpart = nullptr;
     int hp_off[3] = {0, 0, 0}, hp_total = 0;
     int n_max = 1;
     float* d_sq = nullptr;
@@ -499,6 +499,11 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (b && (b->conv.in_mode != a->conv.in_mode || b->npt != a->npt || b->side15 != a->side15)) {  // (never the case for the zipped towers; kept correct anyway)
                 launch_ops(h, a, nullptr, st);
                 return launch_ops(h, b, nullptr, st);
+            }
+            // (the forward statistics are taken from the accumulators themselves: a conv that leaves them carries no skip and no mask)
+            if ((a->conv.stat_mode == ST_FWD && (a->conv.skip || a->conv.mask)) || (b && b->conv.stat_mode == ST_FWD && (b->conv.skip || b->conv.mask))) {
+                h->bad_dispatch = true;
+                return MZL_E_INVALID;
             }
             Pair<LcConv> pj{};
             pj.a = a->conv;
@@ -1055,7 +1060,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
             h->stat_groups_cap = g_big > h->stat_groups_cap ? g_big : h->stat_groups_cap;
         }
         const int cpad = pad16(h->P > 128 ? h->P : 128);
-        for (int l = 0; l < 2; l++) AL(&h->stat[l], (size_t)h->stat_groups_cap * cpad * 2);
+        for (int l = 0; l < 2; l++) AL(&h->stat[l], (size_t)h->stat_groups_cap * cpad * 4);  // (forward partials: four floats per group and channel)
         // weight-gradient partials: chunks <= min(B, CUs / blocks); chunks * blocks <= max(CUs, blocks)
         size_t mx = 0;
         for (const LayerInfo& L : h->layers) {
@@ -1076,7 +1081,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         ok = ok && dalloc(h, &h->d_groups, (size_t)ng) == hipSuccess;
         const size_t gb = (size_t)ng * h->maxB;
         AL(&h->hu, gb * LCH_MAXOC * h->hw); AL(&h->hdz, gb * LCH_MAXOC * h->hw); AL(&h->hfeat, gb * LCH_MAXOC * h->hw);
-        AL(&h->hdl, gb * h->n_max); AL(&h->hspart, gb * LCH_MAXOC * 2); AL(&h->hcoef, (size_t)ng * LCH_MAXOC * 5); AL(&h->hsave, (size_t)ng * LCH_MAXOC * 2);
+        AL(&h->hdl, gb * h->n_max); AL(&h->hspart, gb * LCH_MAXOC * 2); AL(&h->hspiv, gb * LCH_MAXOC); AL(&h->hcoef, (size_t)ng * LCH_MAXOC * 5); AL(&h->hsave, (size_t)ng * LCH_MAXOC * 2);
         AL(&h->hlpart, gb);
         for (int i = 0; i < 3; i++) {
             h->hp_off[i] = h->hp_total;
@@ -1299,7 +1304,7 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     for (int i = 0; i < 3; i++) { HA.head[i] = h->head[i]; HA.lwT_off[i] = h->lwT_off[i]; }
     HA.groups = h->d_groups; HA.ngroups = ng; HA.K = K; HA.B = B; HA.P = h->P; HA.hw = h->hw; HA.A = h->A;
     HA.params = h->params; HA.grads = h->grads; HA.running = h->running; HA.nbt = h->nbt; HA.lwT = h->lwT;
-    HA.u = h->hu; HA.dzb = h->hdz; HA.feat = h->hfeat; HA.dlogit = h->hdl; HA.spart = h->hspart; HA.coef = h->hcoef; HA.save = h->hsave; HA.lpart = h->hlpart;
+    HA.u = h->hu; HA.dzb = h->hdz; HA.feat = h->hfeat; HA.dlogit = h->hdl; HA.spart = h->hspart; HA.spiv = h->hspiv; HA.coef = h->hcoef; HA.save = h->hsave; HA.lpart = h->hlpart;
     HA.n_max = h->n_max; HA.bt = bt; HA.loss = b->d_loss; HA.wpart = h->hwpart; HA.hp_total = h->hp_total;
     for (int i = 0; i < 3; i++) HA.hp_off[i] = h->hp_off[i];
     hipLaunchKernelGGL(k_lch_conv, dim3(B, ng), dim3(256), 0, st, HA);

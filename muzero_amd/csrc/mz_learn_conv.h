@@ -312,6 +312,33 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     if (L.mask && L.mcoef && co_ok) { ma = L.mcoef[co]; mb = L.mcoef[L.cpad_out + co]; }
     const bool part_is_mask = L.partner == L.mask;
     float s1 = 0.0f, s2 = 0.0f;
+    // ST_FWD: the batch statistics are summed around a PIVOT -- the workgroup's first output of the channel (pixel 0 of its first image, lane
+    // group 0) -- so that sum (y - p)^2 carries the variance, not mean^2 (E[y^2] - mean^2 from float32 partial sums loses log10(mean^2 / var) of
+    // its seven digits).  The finalize kernel gets (p, sum (y - p), sum (y - p)^2, n) per workgroup and channel.
+    const bool st_fwd = L.stat_mode == ST_FWD;
+    const float pvt = st_fwd ? __shfl(acc[0][0], j) : 0.0f;
+    const int nimg = (img0 + L.G <= L.B) ? L.G : (L.B - img0 > 0 ? L.B - img0 : 0);
+    if (st_fwd) {  // (a forward conv carries no skip and no mask: its outputs ARE the accumulators; slot p is a real output iff p < nimg * hw)
+        const int nvalid = nimg * hw;  // (workgroup-uniform; the padding channels' sums are never read: the finalize kernel zeroes their coefficients)
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) {
+            if ((pt + 1) * 16 <= nvalid) {  // a whole tile of real outputs (all but the last one or two): no per-element test
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float u = acc[pt][r] - pvt;
+                    s1 += u;
+                    s2 = fmaf(u, u, s2);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float u = (pt * 16 + 4 * q + r) < nvalid ? acc[pt][r] - pvt : 0.0f;
+                    s1 += u;
+                    s2 = fmaf(u, u, s2);
+                }
+            }
+        }
+    }
     constexpr int EC = NPT < 3 ? NPT : 3;
 #pragma unroll
     for (int pb = 0; pb < NPT; pb += EC) {
@@ -356,8 +383,10 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
                 if (L.mask && !(fmaf(ma, mv[e][r], mb) > 0.0f)) t = 0.0f;
                 if (!ok[e][r]) t = 0.0f;
                 const float pv = part_is_mask ? mv[e][r] : yv[e][r];
-                s1 += t;
-                s2 = L.stat_mode == ST_BWD ? fmaf(t, pv, s2) : fmaf(t, t, s2);
+                if (L.stat_mode == ST_BWD) {
+                    s1 += t;
+                    s2 = fmaf(t, pv, s2);
+                }
                 v[r] = t;
             }
             if (vec[e]) {
@@ -374,8 +403,12 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
         s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         if (q == 0 && co < L.cpad_out) {
-            float* d = L.stat_part + ((size_t)by * L.cpad_out + co) * 2;
-            d[0] = s1; d[1] = s2;
+            if (st_fwd) {
+                *reinterpret_cast<float4*>(L.stat_part + ((size_t)by * L.cpad_out + co) * 4) = make_float4(co_ok ? pvt : 0.0f, s1, s2, co_ok ? (float)(nimg * hw) : 0.0f);
+            } else {
+                float* d = L.stat_part + ((size_t)by * L.cpad_out + co) * 2;
+                d[0] = s1; d[1] = s2;
+            }
         }
     }
 }
@@ -671,7 +704,7 @@ __global__ __launch_bounds__(64) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
 // in order in float64 (the partials are float32 sums of <= a few hundred values).
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct LcBnFwd {
-    const float* part;     // [groups][cpad][2]
+    const float* part;     // [groups][cpad][4]: pivot p, sum (y - p), sum (y - p)^2, n (k_lc_conv ST_FWD, k_lc_tile_scatter)
     const float* gamma;    // [C]
     const float* beta;
     float* coef;           // [3][cpad]: a, b, (unused)    -- what the next conv's staging applies
@@ -705,23 +738,60 @@ __device__ __forceinline__ void lc_group_sums(const float* part, int groups, int
     for (int k = 0; k < 16; k++) { s1 += s_acc[threadIdx.x & 15][k][0]; s2 += s_acc[threadIdx.x & 15][k][1]; }
 }
 
+// forward statistics from the pivoted partials: with T1 = sum S1, T2 = sum S2, U1 = sum n p, U2 = sum n p^2, V = sum p S1 over the groups,
+//   N mean = U1 + T1,   N var = T2 + 2 V - 2 mean T1 + U2 - 2 mean U1 + mean^2 N     (sum (y - mean)^2 with y - mean = (y - p) + (p - mean))
+// every sum in float64, slices and groups in a fixed order
+__device__ __forceinline__ void lc_pivot_sums(const float* part, int groups, int cpad, int c, int slice, double (*s_acc)[16][6], double& nmean, double& nvar,
+                                              double& ntot) {
+    double T0 = 0.0, T1 = 0.0, T2 = 0.0, U1 = 0.0, U2 = 0.0, V = 0.0;
+    int g = slice;
+    for (; g + 3 * 16 < groups; g += 4 * 16) {  // four loads in flight, added in group order
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const float4*>(part + ((size_t)(g + 16 * k) * cpad + c) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double p = v[k].x, a = v[k].y, b = v[k].z, n = v[k].w;
+            T0 += n; T1 += a; T2 += b; U1 += n * p; U2 += n * p * p; V += p * a;
+        }
+    }
+    for (; g < groups; g += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)g * cpad + c) * 4);
+        const double p = v.x, a = v.y, b = v.z, n = v.w;
+        T0 += n; T1 += a; T2 += b; U1 += n * p; U2 += n * p * p; V += p * a;
+    }
+    double* mine = s_acc[threadIdx.x & 15][slice];
+    mine[0] = T0; mine[1] = T1; mine[2] = T2; mine[3] = U1; mine[4] = U2; mine[5] = V;
+    __syncthreads();
+    T0 = T1 = T2 = U1 = U2 = V = 0.0;
+    for (int k = 0; k < 16; k++) {
+        const double* o = s_acc[threadIdx.x & 15][k];
+        T0 += o[0]; T1 += o[1]; T2 += o[2]; U1 += o[3]; U2 += o[4]; V += o[5];
+    }
+    ntot = T0;
+    nmean = U1 + T1;
+    const double mean = T0 > 0.0 ? nmean / T0 : 0.0;
+    nvar = T2 + 2.0 * V - 2.0 * mean * T1 + U2 - 2.0 * mean * U1 + mean * mean * T0;
+}
+
 __global__ __launch_bounds__(256) void k_lc_bn_fwd(const Pair<LcBnFwd> PJ) {
-    __shared__ double s_acc[16][16][2];
+    __shared__ double s_acc[16][16][6];
     const bool second = (int)blockIdx.y >= PJ.na;
     const LcBnFwd L = second ? PJ.b : PJ.a;
     const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
     const int c = by * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
     const int cc = c < L.cpad ? c : L.cpad - 1;
-    double s1, s2;
-    lc_group_sums(L.part, L.groups, L.cpad, cc, slice, s_acc, s1, s2);
+    double nmean, nvar, ntot;
+    lc_pivot_sums(L.part, L.groups, L.cpad, cc, slice, s_acc, nmean, nvar, ntot);
     if (slice != 0 || c >= L.cpad) return;
     if (c >= L.C) {
         L.coef[c] = 0.0f; L.coef[L.cpad + c] = 0.0f; L.coef[2 * L.cpad + c] = 0.0f;
         L.save[c] = 0.0f; L.save[L.cpad + c] = 0.0f;
         return;
     }
-    const double mean = s1 / (double)L.count;
-    double var = s2 / (double)L.count - mean * mean;
+    // (ntot == L.count: every valid output position is in exactly one partial)
+    const double mean = nmean / (double)L.count;
+    double var = nvar / (double)L.count;
     var = var < 0.0 ? 0.0 : var;
     const float invstd = (float)(1.0 / sqrt(var + 1e-5));
     const float a = L.gamma[c] * invstd;
@@ -1084,13 +1154,16 @@ __global__ __launch_bounds__(256) void k_lc_tile_scatter(const LcTileScatter L) 
             if (L.skip) v += L.skip[di];
             L.dst[di] = v;
         }
-        if (L.stat_part) {
-            float a = mz::butterfly16(v), bb = mz::butterfly16(v * v);
+        if (L.stat_part) {  // pivoted (see k_lc_conv's ST_FWD): the chunk's first position is the pivot (always a valid one)
+            const float pvt = __shfl(v, threadIdx.x & 32);
+            const float u = ok ? v - pvt : 0.0f;
+            float a = mz::butterfly16(u), bb = mz::butterfly16(u * u);
             a += __shfl_xor(a, 16);
             bb += __shfl_xor(bb, 16);
             if (lp == 0 && i < cpt && c < L.C) {
-                float* d = L.stat_part + (((size_t)b * gridDim.x + blockIdx.x) * L.cpad + c) * 2;
-                d[0] = a; d[1] = bb;
+                const int left = L.H * L.W - (int)blockIdx.x * 32;
+                *reinterpret_cast<float4*>(L.stat_part + (((size_t)b * gridDim.x + blockIdx.x) * L.cpad + c) * 4) =
+                    make_float4(pvt, a, bb, (float)(left < 32 ? left : 32));
             }
         }
     }
@@ -1190,7 +1263,8 @@ struct LchArgs {
     float* dzb;            // [ngroups][B][2][hw]
     float* feat;           // [ngroups][B][2 * hw]
     float* dlogit;         // [ngroups][B][n_max]
-    float* spart;          // [ngroups][B][2 oc][2] forward partials, then backward partials
+    float* spart;          // [ngroups][B][2 oc][2] forward partials (pivoted: sum (u - p), sum (u - p)^2), then backward partials
+    float* spiv;           // [ngroups][B][2 oc] the forward partials' pivots
     float* coef;           // [ngroups][2 oc][5]: a, b (forward); c1, c2, c3 (backward)
     float* save;           // [ngroups][2 oc][2]: mean, invstd
     float* lpart;          // [ngroups][B] weighted loss terms
@@ -1210,9 +1284,12 @@ __global__ __launch_bounds__(256) void k_lch_conv(const LchArgs A) {
     for (int i = tid; i < H.oc * A.P; i += 256) s_w[i / A.P][i % A.P] = A.params[H.w1_off + i];
     __syncthreads();
     const float* F = G.F + (size_t)b * A.P * A.hw;
-    float s1[LCH_MAXOC] = {0.f, 0.f}, s2[LCH_MAXOC] = {0.f, 0.f};
-    for (int p = tid; p < A.hw; p += 256) {
-        float acc[LCH_MAXOC] = {0.f, 0.f};
+    // one position per thread (hw <= 240 < 256 threads: mzlc_create's limit); the image's statistics are summed around a pivot -- u at position 0,
+    // published by thread 0 -- see k_lc_conv's ST_FWD
+    __shared__ float s_piv[LCH_MAXOC];
+    const int p = tid;
+    float acc[LCH_MAXOC] = {0.f, 0.f};
+    if (p < A.hw) {
         for (int c = 0; c < A.P; c++) {
             const float f = F[(size_t)c * A.hw + p];
 #pragma unroll
@@ -1221,11 +1298,20 @@ __global__ __launch_bounds__(256) void k_lch_conv(const LchArgs A) {
         }
 #pragma unroll
         for (int o = 0; o < LCH_MAXOC; o++)
-            if (o < H.oc) {
-                A.u[(((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p] = acc[o];
-                s1[o] += acc[o];
-                s2[o] = fmaf(acc[o], acc[o], s2[o]);
-            }
+            if (o < H.oc) A.u[(((size_t)g * A.B + b) * LCH_MAXOC + o) * A.hw + p] = acc[o];
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int o = 0; o < LCH_MAXOC; o++) s_piv[o] = acc[o];
+    }
+    __syncthreads();
+    float pvt[LCH_MAXOC], s1[LCH_MAXOC], s2[LCH_MAXOC];
+#pragma unroll
+    for (int o = 0; o < LCH_MAXOC; o++) {
+        pvt[o] = s_piv[o];
+        const float d = (p < A.hw && o < H.oc) ? acc[o] - pvt[o] : 0.0f;
+        s1[o] = d;
+        s2[o] = d * d;
     }
     // block sums in a fixed order: wave butterflies, then the four waves in order
 #pragma unroll
@@ -1237,7 +1323,24 @@ __global__ __launch_bounds__(256) void k_lch_conv(const LchArgs A) {
     if (tid < 2 * H.oc) {
         const float s = ((s_red[tid][0] + s_red[tid][1]) + s_red[tid][2]) + s_red[tid][3];
         A.spart[(((size_t)g * A.B + b) * LCH_MAXOC + (tid >> 1)) * 2 + (tid & 1)] = s;
+        if ((tid & 1) == 0) A.spiv[((size_t)g * A.B + b) * LCH_MAXOC + (tid >> 1)] = pvt[tid >> 1];
     }
+}
+
+// forward statistics of a head from its pivoted per-image partials (n = hw positions each): see lc_pivot_sums
+__device__ __forceinline__ void lch_wave_pivot_sums(const float* spart, const float* spiv, int g, int B, int o, double n, double& nmean, double& nvar) {
+    const int lane = threadIdx.x & 63;
+    double T1 = 0.0, T2 = 0.0, U1 = 0.0, U2 = 0.0, V = 0.0;
+    for (int i = lane; i < B; i += 64) {
+        const size_t e = ((size_t)g * B + i) * LCH_MAXOC + o;
+        const double a = spart[e * 2], b = spart[e * 2 + 1], p = spiv[e];
+        T1 += a; T2 += b; U1 += n * p; U2 += n * p * p; V += p * a;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { T1 += __shfl_xor(T1, m); T2 += __shfl_xor(T2, m); U1 += __shfl_xor(U1, m); U2 += __shfl_xor(U2, m); V += __shfl_xor(V, m); }
+    const double N = n * (double)B;
+    nmean = U1 + T1;
+    const double mean = nmean / N;
+    nvar = T2 + 2.0 * V - 2.0 * mean * T1 + U2 - 2.0 * mean * U1 + mean * mean * N;
 }
 
 // one WAVE per (head, plane): the K applications of a head in step order (their running-statistics updates are sequential); the batch sum is
@@ -1267,11 +1370,11 @@ __global__ __launch_bounds__(64 * 3 * LCH_MAXOC) void k_lch_bn(const LchArgs A) 
     for (int t = 0; t < A.K; t++) {
         const int g = lch_group_of(A, hd, t);
         if (g < 0) continue;
-        double s1, s2;
-        lch_wave_sums(A.spart, g, A.B, o, s1, s2);
+        double nmean, nvar;
+        lch_wave_pivot_sums(A.spart, A.spiv, g, A.B, o, (double)A.hw, nmean, nvar);
         if (lane != 0) continue;
-        const double mean = s1 / M;
-        double var = s2 / M - mean * mean;
+        const double mean = nmean / M;
+        double var = nvar / M;
         var = var < 0.0 ? 0.0 : var;
         const float invstd = (float)(1.0 / sqrt(var + 1e-5));
         const float a = A.params[H.gamma_off + o] * invstd;
