@@ -8,7 +8,7 @@
 //                        forward   y = conv(f(x))         f applied while staging: identity | relu(a x + b) (the previous layer's BatchNorm + ReLU,
 //                                                          never materialised) | relu(a y2 + b + x) (the previous BLOCK's output, written through once) |
 //                                                          action planes generated on the fly (network.py:440-444)
-//                                  epilogue: per-channel partial sums (sum y, sum y^2) of the batch statistics
+//                                  epilogue: per-channel partial sums of the batch statistics, taken around a pivot: (p, sum (y - p), sum (y - p)^2, n)
 //                        dgrad     g = convT(dy)          dy = c1 dz + c2 y + c3 (BatchNorm backward, applied while staging from TWO tensors),
 //                                                          weights = the transposed / tap-flipped packed copy
 //                                  epilogue: + skip gradient, ReLU mask of the layer below, partial sums (sum dz, sum dz y) of ITS BatchNorm backward
