@@ -45,6 +45,7 @@ struct Geom {
     int h = 0, w = 0, hw = 0;
     int npt = 15, G = 1, qstride = 0;       // k_lc_conv: pixel tiles per workgroup, images per workgroup, LDS slot-plane stride
     bool side15 = false;                     // the 15 x 15 build
+    bool stack_rows = false;
     int P4 = 0, nsteps = 0, SPY = 0, SPX = 0, SG = 1;  // k_lc_wgrad: row pitch, 16-position steps per staging round, plane strides, images per round
 };
 struct TensorInfo {
@@ -95,16 +96,20 @@ bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int w
     g.qstride = (4 * g.G * (g.h + 2) * (g.w + 2) + 63) & ~63;
     g.side15 = allow_side15 && g.h == 15 && g.w == 15 && g.G == 1 && g.npt == 15;
     g.P4 = 4 * cdiv(g.w + 1, 4);
-    // k_lc_wgrad stages SG images per round, stacked with one zero row between them (one tall "image" of SG (h + 1) - 1 rows): a 6 x 6 plane is 9
-    // pixel quads -- 9 of a wave's 64 staging lanes and two barriers per image otherwise.  As many as the staging lanes hold and as leave two
-    // workgroups per CU their LDS (80 KB each)
+    // k_lc_wgrad stages SG images per round, SIDE BY SIDE in one wide "image" of SG (w + 1) columns (the zero column behind every image's rows is the
+    // pitch layout's own row separator; the zero rows above and below are shared): a 6 x 6 plane is 9 pixel quads -- 9 of a wave's 64 staging lanes and
+    // two barriers per image otherwise.  As many as the staging lanes hold and as leave two workgroups per CU their LDS (80 KB each).
+    // MZLC_STACK_ROWS=1 at create: the first form of this -- images stacked vertically with a zero row between them (more padding: kept for A/B)
     g.SG = 1;
+    g.stack_rows = getenv("MZLC_STACK_ROWS") != nullptr;
     if (stack_wgrad)
         for (int sg = 2; sg <= 16 && sg * QP <= 64; sg++) {
-            const int ns = cdiv((sg * (g.h + 1) - 1) * g.P4, 16);
-            if (((size_t)32 * (32 * ns + 2 * g.P4 + 16) + 160) * sizeof(float) <= 80 * 1024) g.SG = sg;
+            const int p4 = g.stack_rows ? g.P4 : 4 * cdiv(sg * (g.w + 1), 4);
+            const int ns = g.stack_rows ? cdiv((sg * (g.h + 1) - 1) * p4, 16) : cdiv(g.h * p4, 16);
+            if (((size_t)32 * (32 * ns + 2 * p4 + 16) + 160) * sizeof(float) <= 80 * 1024) g.SG = sg;
         }
-    g.nsteps = cdiv((g.SG * (g.h + 1) - 1) * g.P4, 16);
+    if (g.SG > 1 && !g.stack_rows) g.P4 = 4 * cdiv(g.SG * (g.w + 1), 4);
+    g.nsteps = (g.SG > 1 && g.stack_rows) ? cdiv((g.SG * (g.h + 1) - 1) * g.P4, 16) : cdiv(g.h * g.P4, 16);
     g.SPY = 16 * g.nsteps + 4;
     g.SPX = 2 * g.P4 + 16 * g.nsteps + 12;
     return true;
@@ -327,7 +332,7 @@ struct Sched {
         g.dz = dz; g.y = y; g.dcoef = bcoef; g.x0 = x0; g.xcoef = xcoef; g.x_mode = x_mode; g.action = action; g.num_actions = h->A;
         g.cin_real = L.cin_real; g.cin = L.cin; g.cout = L.cout; g.ci_tiles = cdiv(L.cin, 16); g.co_tiles = L.co_tiles;
         g.cpad_in = pad16(L.cin_real); g.cpad_out = pad16(L.cout);
-        g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX; g.sg = this->g.SG;
+        g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX; g.sg = this->g.SG; g.sg_cols = (this->g.SG > 1 && !this->g.stack_rows) ? 1 : 0;
         g.co_blocks = cdiv(g.co_tiles, 2);
         const int ci_blocks = cdiv(g.ci_tiles, 2);
         // two workgroups per CU in all: a paired launch brings the other half; the first conv blocks (action planes: the dynamics tower's extra

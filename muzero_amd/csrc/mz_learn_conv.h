@@ -434,7 +434,8 @@ struct LcWgrad {
     int B, ipw;            // images per chunk
     int h, w_img, P4, nsteps, SPY, SPX;
     int co_blocks;         // blockIdx.y = chunk * co_blocks + cob
-    int sg;                // images per staging round (stacked with one zero row between them; nsteps / SPY / SPX are the stack's)
+    int sg;                // images per staging round (nsteps / SPY / SPX / P4 are the round's)
+    int sg_cols;           // 1: the round's images side by side (column offset gi (w + 1)); 0: stacked vertically (row offset gi (h + 1))
     int tapmask;           // 0 / 0x1ff: all nine taps; else only these accumulators exist (a parity plane of a stride-2 conv; see k_lc_conv's TAPMASK)
     int ring_zero;         // 1: the outermost ring of every dy image is multiplied by 0 (tiles gathered with their halo: only the inner pixels are outputs)
 };
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
-        spos[e] = (s_ok && pp < hw) ? (gi * (L.h + 1) + py) * L.P4 + px : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
+        spos[e] = (s_ok && pp < hw) ? (L.sg_cols ? py * L.P4 + gi * (L.w_img + 1) + px : (gi * (L.h + 1) + py) * L.P4 + px) : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
         pm[e] = ACT ? pp % L.num_actions : 0;
         ym[e] = (RING && (py == 0 || px == 0 || py == L.h - 1 || px == L.w_img - 1)) ? 0.0f : 1.0f;
     }

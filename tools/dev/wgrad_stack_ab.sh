@@ -1,6 +1,9 @@
+# same-box A/B of the weight gradient's small-image staging: side by side (default) | stacked rows (MZLC_STACK_ROWS=1) | one image per round (MZLC_NO_WGRAD_STACK=1)
 for rep in 1 2; do
-for v in stack nostack; do
-  if [ $v = nostack ]; then export MZLC_NO_WGRAD_STACK=1; else unset MZLC_NO_WGRAD_STACK; fi
+for v in cols rows nostack; do
+  unset MZLC_NO_WGRAD_STACK MZLC_STACK_ROWS
+  if [ $v = nostack ]; then export MZLC_NO_WGRAD_STACK=1; fi
+  if [ $v = rows ]; then export MZLC_STACK_ROWS=1; fi
   a=$(timeout 300 python tools/conv_learner_bench.py --atari --chan 4 --planes 128 --blocks 8 --batch 128 --iters 10 --hip-only 2>&1 | tail -1 | grep -o '"ms_hip": [0-9.]*')
   b=$(timeout 300 python tools/conv_learner_bench.py --board 5 --planes 64 --blocks 4 --batch 256 --iters 30 --hip-only 2>&1 | tail -1 | grep -o '"ms_hip": [0-9.]*')
   c=$(timeout 300 python tools/conv_learner_bench.py --board 9 --planes 128 --blocks 4 --batch 128 --iters 30 --hip-only 2>&1 | tail -1 | grep -o '"ms_hip": [0-9.]*')
