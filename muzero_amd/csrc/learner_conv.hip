@@ -82,8 +82,8 @@ bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int w
     const int QP = (g.hw + 3) / 4;
     double best = -1.0;
     long best_cost = -1;
-    const int cand[4] = {6, 9, 15, 16};  // (16: the wide tiles of the Atari net's 48 x 48 stage only -- 14 x 18 positions)
-    for (int i = 0; i < (allow16 ? 4 : 3); i++) {
+    const int cand[5] = {5, 6, 9, 15, 16};  // (5: two 6 x 6 images in 80 slots; 16: the wide tiles of the Atari net's 48 x 48 stage only -- 14 x 18 positions)
+    for (int i = 0; i < (allow16 ? 5 : 4); i++) {
         int G = (16 * cand[i]) / g.hw;
         if (64 / QP < G) G = 64 / QP;
         if (G < 1) continue;
@@ -530,7 +530,8 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
             else if (a->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
             else if (a->npt == 9) launch_conv<9, 0>(mode, pj, grid, lds, st);
-            else launch_conv<6, 0>(mode, pj, grid, lds, st);
+            else if (a->npt == 6) launch_conv<6, 0>(mode, pj, grid, lds, st);
+            else launch_conv<5, 0>(mode, pj, grid, lds, st);
             break;
         }
         case OP_WGRAD: {
@@ -1162,6 +1163,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (e == hipSuccess) e = conv_attr<15, 0>();
     if (e == hipSuccess) e = conv_attr<9, 0>();
     if (e == hipSuccess) e = conv_attr<6, 0>();
+    if (e == hipSuccess) e = conv_attr<5, 0>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x010>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x018>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x012>();
