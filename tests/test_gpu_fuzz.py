@@ -143,13 +143,14 @@ def test_random_board_conv_configuration_bit_exact_vs_oracle(oracle, i):
 LEARN_CASES_N = int(os.environ.get('MZ_FUZZ_LEARN_CASES', '10'))
 # the learner comparisons below accept a looser bar next to a detected kink of the loss.  So that a real regression cannot hide
 # there, the cases that have ever NEEDED the looser bar are listed by generator index (seed offset 0, indices < 300: what tools/dev/deep_parity.sh
-# runs): a case outside the list that needs it fails.  MZ_FUZZ_RECORD_CARVED=<file>: append "kind index" lines instead (to rebuild the list).
+# runs): a case outside the list that needs it fails.  MZ_FUZZ_RECORD_CARVED=<file>: append "kind index" lines instead (to rebuild the list: which
+# of two branches a float32 pass takes at a kink depends on the kernels' summation orders, so a change of tiling moves a few cases in or out).
 KNOWN_CARVED = {'mlp': set(),  # (none in 300)
                 'convkf': set(),  # kink-free weights (none in 300)
-                'conv': {0, 1, 3, 8, 11, 13, 18, 20, 23, 25, 34, 39, 40, 49, 51, 53, 56, 58, 60, 61, 62, 67, 71, 72, 73, 74, 81, 87, 89, 90, 96, 99, 100,
-                         102, 109, 110, 112, 114, 116, 117, 118, 122, 124, 125, 126, 132, 133, 134, 139, 141, 143, 147, 151, 155, 159, 161, 168, 174, 176,
-                         179, 181, 184, 189, 190, 191, 192, 193, 195, 196, 198, 201, 203, 208, 211, 212, 216, 219, 229, 230, 232, 245, 247, 252, 254, 255,
-                         257, 258, 260, 261, 263, 265, 266, 271, 273, 274, 277, 280, 286, 287, 289, 290, 292, 295}}  # random weights: 103 of 300
+                'conv': {0, 1, 3, 8, 11, 13, 18, 20, 23, 25, 34, 39, 40, 49, 51, 53, 56, 57, 58, 60, 61, 62, 67, 71, 72, 73, 74, 81, 87, 89, 90, 96, 99,
+                         100, 102, 109, 110, 112, 114, 116, 117, 118, 122, 124, 125, 126, 132, 133, 134, 139, 141, 143, 147, 151, 155, 159, 161, 168, 174,
+                         176, 179, 181, 184, 189, 190, 191, 192, 193, 195, 196, 198, 201, 203, 208, 211, 212, 216, 219, 229, 230, 232, 245, 247, 252, 254,
+                         255, 258, 260, 261, 263, 265, 266, 271, 273, 274, 277, 280, 286, 287, 289, 290, 292, 295}}  # random weights: 103 of 300
 
 
 def _carved(kind, i, detail):
