@@ -392,3 +392,13 @@ def test_atari_closed_loop_runs_and_repeats():
     assert a[0] == b[0] and a[2] == b[2]
     for k in a[1]:
         assert np.array_equal(a[1][k], b[1][k]), k
+
+
+def test_full_size_atari_config_at_batch_128_kink_free():
+    """make_atari_config's network (128 planes, 8 blocks, supports 61, unroll 5) at ITS batch size -- the configuration bench.py times, where the
+    launch-time-aware tilings and chunk counts differ from the small cases above -- against float64 autograd with kink-free weights."""
+    dev = torch.device('cuda', 0)
+    errs, probe = _case(4, 128, 8, 6, 61, 61, 128, 5, 11, True, dev)
+    assert probe.closest_all > 1e-4
+    k, e, bar = kinkfree_worst(errs, probe.err32, probe.closest_tie)
+    assert e <= bar, (k, e, bar, probe.closest_tie)

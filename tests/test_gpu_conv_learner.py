@@ -338,3 +338,33 @@ def test_errors_are_loud():
         hl.grad({k: v.cpu() for k, v in _ring(tr, dev).items()}, None, None, 4)
     with pytest.raises(LearnerError):
         hl.grad(_ring(tr, dev), None, None, 5)  # > max_batch
+
+
+def test_full_size_c5_net_at_batch_128_kink_free():
+    """The C5 network (15 x 15, 128 planes, 8 blocks, 226 actions, unroll 5) at make_gomoku_config's batch size -- the configuration bench.py times --
+    against float64 autograd with kink-free weights: every gradient tensor within the tight bar."""
+    from muzero_amd.network import MuZeroBoardGameNet
+    from test_gpu_atari_learner import f32_errors, grad_errors, kinkfree_state_dict, kinkfree_worst
+
+    dev = torch.device('cuda', 0)
+    board, planes, blocks, chan, B = 15, 128, 8, 9, 128
+    A = board * board + 1
+    net = MuZeroBoardGameNet((chan, board, board), A, blocks, planes)
+    net.load_state_dict(kinkfree_state_dict(net, 77))
+    net = net.to(dev)
+    net.train()
+    rs = np.random.RandomState(5)
+    tr = _batch(rs, B, (chan, board, board), A, int8_state=True)
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    err32 = f32_errors(net, tr._replace(state=tr.state.astype(np.float32)), w, dev, gd)
+    hl = _hip(net, dev, B)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    k, e, bar = kinkfree_worst(grad_errors(gd, hl.grad_views), err32, closest if closest < 1e-6 else float('inf'))
+    assert e <= bar, (k, e, bar, closest)
+    sd = net.state_dict()
+    for kk, v in sd_d.items():
+        if 'running' in kk:
+            assert float((v - sd[kk].double()).abs().max()) <= 3e-5 * max(1.0, float(v.abs().max())), kk
