@@ -82,8 +82,9 @@ bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int w
     const int QP = (g.hw + 3) / 4;
     double best = -1.0;
     long best_cost = -1;
-    const int cand[5] = {5, 6, 9, 15, 16};  // (5: two 6 x 6 images in 80 slots; 16: the wide tiles of the Atari net's 48 x 48 stage only -- 14 x 18 positions)
-    for (int i = 0; i < (allow16 ? 5 : 4); i++) {
+    const int cand[6] = {5, 6, 9, 13, 15, 16};  // (5: two 6 x 6 images in 80 slots; 13: a 14 x 14 image -- a 12 x 12 tile with its halo -- in 208 slots;
+                                               //  16: the wide tiles of the Atari net's 48 x 48 stage only -- 14 x 18 positions)
+    for (int i = 0; i < (allow16 ? 6 : 5); i++) {
         int G = (16 * cand[i]) / g.hw;
         if (64 / QP < G) G = 64 / QP;
         if (G < 1) continue;
@@ -473,6 +474,18 @@ bool launch_conv_tapmask(int npt, int mask, const Pair<LcConv>& pj, dim3 grid, s
         }
         return false;
     }
+    if (npt == 13) {
+        switch (mask) {
+            case 0x010: launch_conv_taps<13, 0x010>(pj, grid, lds, st); return true;
+            case 0x018: launch_conv_taps<13, 0x018>(pj, grid, lds, st); return true;
+            case 0x012: launch_conv_taps<13, 0x012>(pj, grid, lds, st); return true;
+            case 0x01b: launch_conv_taps<13, 0x01b>(pj, grid, lds, st); return true;
+            case 0x030: launch_conv_taps<13, 0x030>(pj, grid, lds, st); return true;
+            case 0x090: launch_conv_taps<13, 0x090>(pj, grid, lds, st); return true;
+            case 0x1b0: launch_conv_taps<13, 0x1b0>(pj, grid, lds, st); return true;
+        }
+        return false;
+    }
     if (npt != 15) return false;
     switch (mask) {
         case 0x010: launch_conv_taps<15, 0x010>(pj, grid, lds, st); return true;
@@ -529,6 +542,7 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             } else
             if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
             else if (a->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
+            else if (a->npt == 13) launch_conv<13, 0>(mode, pj, grid, lds, st);
             else if (a->npt == 9) launch_conv<9, 0>(mode, pj, grid, lds, st);
             else if (a->npt == 6) launch_conv<6, 0>(mode, pj, grid, lds, st);
             else launch_conv<5, 0>(mode, pj, grid, lds, st);
@@ -1164,6 +1178,14 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (e == hipSuccess) e = conv_attr<9, 0>();
     if (e == hipSuccess) e = conv_attr<6, 0>();
     if (e == hipSuccess) e = conv_attr<5, 0>();
+    if (e == hipSuccess) e = conv_attr<13, 0>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x010>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x018>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x012>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x01b>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x030>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x090>();
+    if (e == hipSuccess) e = conv_taps_attr<13, 0x1b0>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x010>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x018>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x012>();
