@@ -56,18 +56,20 @@ struct TensorInfo {
 struct AppBufs {  // saved tensors of ONE application of a tower (representation: 1, dynamics / prediction: K)
     std::vector<float*> y, x, fcoef, save, bcoef;
 };
-enum OpKind { OP_CONV, OP_WGRAD, OP_WREDUCE, OP_BNFWD, OP_BNBWD, OP_APPLY };
+enum OpKind { OP_CONV, OP_WGRAD, OP_WREDUCE, OP_BNFWD, OP_BNBWD, OP_APPLY, OP_WGRAD_ACT };
 struct Op {
     int kind;
     int npt = 15, side15 = 0;  // OP_CONV: which build
     LcConv conv;
     LcWgrad wg;
     LcWreduce wr;
+    LcWgradAct wa;
     LcBnFwd bf;
     LcBnBwd bb;
     LcApply ap;
 };
 
+constexpr int ACT_CHUNKS = 8;  // batch chunks of k_lc_wgrad_act
 int pad16(int x) { return (x + 15) & ~15; }
 int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -154,6 +156,8 @@ struct mzlc_learner {
     float* stat[2] = {nullptr, nullptr};
     int stat_groups_cap = 0;
     float* wpart[2] = {nullptr, nullptr};
+    float* wpart_act = nullptr;  // k_lc_wgrad_act: [ACT_CHUNKS][P][A][9]
+    bool act_sparse = true;      // the action planes' weight gradient as a gather (MZLC_ACT_MFMA=1 at create: inside the MFMA kernel, the first form)
     float* D[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     float *GsA = nullptr, *GsB = nullptr, *GsP = nullptr;
     float *dF_pred = nullptr, *dF_rew = nullptr;
@@ -327,11 +331,14 @@ struct Sched {
     }
     void wgrad_ops(std::vector<Op>& ops, const LayerInfo& L, const float* dz, const float* y, const float* bcoef, const float* x0, int x_mode, const float* xcoef,
                    const int* action, int accumulate) const {
+        // hidden channels here, action planes by k_lc_wgrad_act -- where that removes at least four 16-channel tiles from the MFMA work (board games:
+        // A = hw + 1 planes; the Atari net's 6-18 planes ride in the hidden channels' last tile and stay)
+        const bool split = action && h->act_sparse && cdiv(L.cin, 16) - cdiv(L.cin_real, 16) >= 4;
         Op o{};
         o.kind = OP_WGRAD;
         LcWgrad& g = o.wg;
-        g.dz = dz; g.y = y; g.dcoef = bcoef; g.x0 = x0; g.xcoef = xcoef; g.x_mode = x_mode; g.action = action; g.num_actions = h->A;
-        g.cin_real = L.cin_real; g.cin = L.cin; g.cout = L.cout; g.ci_tiles = cdiv(L.cin, 16); g.co_tiles = L.co_tiles;
+        g.dz = dz; g.y = y; g.dcoef = bcoef; g.x0 = x0; g.xcoef = xcoef; g.x_mode = x_mode; g.action = split ? nullptr : action; g.num_actions = h->A;
+        g.cin_real = L.cin_real; g.cin = split ? L.cin_real : L.cin; g.cout = L.cout; g.ci_tiles = cdiv(g.cin, 16); g.co_tiles = L.co_tiles;
         g.cpad_in = pad16(L.cin_real); g.cpad_out = pad16(L.cout);
         g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX; g.sg = this->g.SG; g.sg_cols = (this->g.SG > 1 && !this->g.stack_rows) ? 1 : 0;
         g.co_blocks = cdiv(g.co_tiles, 2);
@@ -350,7 +357,17 @@ struct Sched {
         r.kind = OP_WREDUCE;
         r.wr.part = g.part; r.wr.grad = h->grads + L.w_off; r.wr.chunks = chunks; r.wr.cout = L.cout; r.wr.cin = L.cin;
         r.wr.co_pad = g.co_tiles * 16; r.wr.ci_pad = g.ci_tiles * 16; r.wr.accumulate = accumulate;
+        r.wr.cin_loop = split ? L.cin_real : 0;
         ops.push_back(r);
+        if (split) {
+            Op a{};
+            a.kind = OP_WGRAD_ACT;
+            LcWgradAct& w = a.wa;
+            w.dz = dz; w.y = y; w.dcoef = bcoef; w.action = action; w.part = h->wpart_act; w.grad = h->grads + L.w_off;
+            w.B = B; w.cout = L.cout; w.cpad_out = pad16(L.cout); w.cin = L.cin; w.cin_real = L.cin_real; w.A = h->A; w.h = this->g.h; w.w = this->g.w;
+            w.nchunk = B < ACT_CHUNKS ? B : ACT_CHUNKS; w.bchunk = cdiv(B, w.nchunk); w.nchunk = cdiv(B, w.bchunk); w.accumulate = accumulate;
+            ops.push_back(a);
+        }
     }
 
     // forward of one tower application; returns the tower's output tensor
@@ -574,6 +591,12 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (a->wg.ring_zero) hipLaunchKernelGGL((k_lc_wgrad<false, true>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
             else if (a->wg.action || (b && b->wg.action)) hipLaunchKernelGGL((k_lc_wgrad<true, false>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
             else hipLaunchKernelGGL((k_lc_wgrad<false, false>), dim3(x, ya + yb), dim3(256), wlds, st, pj);
+            break;
+        }
+        case OP_WGRAD_ACT: {
+            if (b) { h->bad_dispatch = true; return MZL_E_INVALID; }
+            hipLaunchKernelGGL(k_lc_wgrad_act, dim3(a->wa.cout, a->wa.nchunk), dim3(256), 0, st, a->wa);
+            hipLaunchKernelGGL(k_lc_wgrad_act_reduce, dim3(cdiv(a->wa.cout * a->wa.A * 9, 256)), dim3(256), 0, st, a->wa);
             break;
         }
         case OP_WREDUCE: {
@@ -979,6 +1002,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
     h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
     h->par_compact = !getenv("MZLC_NO_TAPSETS");
+    h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
     if (h->atari) {  // the observation is board_h x board_w (96 x 96 in every reference configuration); the hidden state 1 / 16 of it
@@ -1091,6 +1115,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
             mx = n > mx ? n : mx;
         }
         for (int l = 0; l < 2; l++) AL(&h->wpart[l], mx);
+        AL(&h->wpart_act, (size_t)ACT_CHUNKS * h->P * h->A * 9);
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < 3; i++) AL(&h->D[l][i], h->T);
     }

@@ -14,6 +14,7 @@
 //                                  epilogue: + skip gradient, ReLU mask of the layer below, partial sums (sum dz, sum dz y) of ITS BatchNorm backward
 //   k_lc_wgrad         dW[co][ci][tap] = sum_{b,p} dy[b][co][p] x[b][ci][p + tap]: MFMA with the reduction over PIXELS; both operands staged through
 //                      LDS in a zero-padded row-pitch layout so that a tap is a register choice, never a re-read; partials per image chunk
+//   k_lc_wgrad_act     the same for the action planes of the dynamics net's first conv (one-hot-like planes: a gather of dy), board games
 //   k_lc_wreduce       chunk partials -> gradient (torch layout), fixed order
 //   k_lc_bn_fwd / k_lc_bn_bwd   finalize the partial sums -> per-channel coefficients (a, b | c1, c2, c3), running statistics, dgamma / dbeta
 //   k_lc_apply         block output x' = relu(a y + b + x) (the residual needs it materialised)
@@ -659,6 +660,7 @@ struct LcWreduce {
     const float* part;
     float* grad;
     int chunks, cout, cin, co_pad, ci_pad, accumulate;
+    int cin_loop;           // input channels the partials cover (0: all `cin`; the dynamics net's first conv: its hidden channels -- k_lc_wgrad_act does the action planes)
     int use_map;            // 1: accumulator tap t of the partials is weight tap tapmap[t] (-1: not a tap of this parity plane; see LcTileGather)
     signed char tapmap[9];
 };
@@ -669,8 +671,9 @@ __global__ __launch_bounds__(64) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
     const LcWreduce L = second ? PJ.b : PJ.a;
     const int by = second ? (int)blockIdx.y - PJ.na : (int)blockIdx.y;
     const int i = by * 64 + threadIdx.x;  // (co, ci), ci fastest
-    if (i >= L.cout * L.cin) return;
-    const int ci = i % L.cin, co = i / L.cin;
+    const int cl = L.cin_loop ? L.cin_loop : L.cin;
+    if (i >= L.cout * cl) return;
+    const int ci = i % cl, co = i / cl;
     const size_t ts = (size_t)L.co_pad * L.ci_pad, cs = 9 * ts;
     const float* p = L.part + (size_t)co * L.ci_pad + ci;
     float s[9];
@@ -692,12 +695,69 @@ __global__ __launch_bounds__(64) void k_lc_wreduce(const Pair<LcWreduce> PJ) {
             }
         }
     }
-    float* g = L.grad + (size_t)i * 9;
+    float* g = L.grad + ((size_t)co * L.cin + ci) * 9;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int tap = L.use_map ? (int)L.tapmap[t] : t;
         if (tap >= 0) g[tap] = L.accumulate ? g[tap] + s[t] : s[t];
     }
+}
+
+// Weight gradient of the ACTION planes of the dynamics net's first conv (network.py:440-444).  Plane c' of image b is one where
+// (p + c' hw) mod A == action_b and zero elsewhere -- hw / A positions (at most one for the board games, A = hw + 1) -- so
+//     dW[co][cin_real + c'][ky][kx] = sum_b sum_{those q} dy[b][co][q - (ky - 1, kx - 1)]        (inside the image)
+// is a gather of dy, not a matrix product: as MFMA work the 226 planes of the C5 net were 65 % of that layer's weight gradient.
+// grid (cout, batch chunks), thread = plane c'; consecutive planes read consecutive positions.  Partials per chunk, reduced in chunk order.
+struct LcWgradAct {
+    const float* dz;       // [B][cout][hw]
+    const float* y;        // [B][cout][hw]
+    const float* dcoef;    // [3][cpad_out]: dy = c1 dz + c2 y + c3
+    const int* action;     // [B]
+    float* part;           // [nchunk][cout][A][9]
+    float* grad;           // the layer's weight gradient [cout][cin][9]
+    int B, cout, cpad_out, cin, cin_real, A, h, w, bchunk, nchunk, accumulate;
+};
+__global__ __launch_bounds__(256) void k_lc_wgrad_act(const LcWgradAct L) {
+    const int co = blockIdx.x, ck = blockIdx.y, cp = threadIdx.x;
+    if (cp >= L.A) return;
+    const float c1 = L.dcoef[co], c2 = L.dcoef[L.cpad_out + co], c3 = L.dcoef[2 * L.cpad_out + co];
+    const int hw = L.h * L.w, shift = (int)(((long long)cp * hw) % L.A);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = 0.0f;
+    const int b_lo = ck * L.bchunk, b_hi = b_lo + L.bchunk < L.B ? b_lo + L.bchunk : L.B;
+    for (int b = b_lo; b < b_hi; b++) {
+        int p0 = L.action[b] - shift;
+        p0 = p0 < 0 ? p0 + L.A : p0;
+        const float* dzb = L.dz + ((size_t)b * L.cout + co) * hw;
+        const float* yb = L.y + ((size_t)b * L.cout + co) * hw;
+        for (int q = p0; q < hw; q += L.A) {
+            const int yq = q / L.w, xq = q - yq * L.w;
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const int py = yq - ky + 1, px = xq - kx + 1;
+                    if (py >= 0 && py < L.h && px >= 0 && px < L.w) {
+                        const int pp = py * L.w + px;
+                        acc[ky * 3 + kx] += fmaf(c1, dzb[pp], fmaf(c2, yb[pp], c3));
+                    }
+                }
+            }
+        }
+    }
+    float* d = L.part + (((size_t)ck * L.cout + co) * L.A + cp) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; t++) d[t] = acc[t];
+}
+__global__ __launch_bounds__(256) void k_lc_wgrad_act_reduce(const LcWgradAct L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (co, c', tap)
+    if (i >= L.cout * L.A * 9) return;
+    const int t = i % 9, cp = (i / 9) % L.A, co = i / (9 * L.A);
+    float s = 0.0f;
+    for (int ck = 0; ck < L.nchunk; ck++) s += L.part[(size_t)ck * L.cout * L.A * 9 + i];
+    float* g = L.grad + ((size_t)co * L.cin + L.cin_real + cp) * 9 + t;
+    *g = L.accumulate ? *g + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
