@@ -624,7 +624,8 @@ def test_random_atari_learner_configuration_matches_float64_autograd(i):
     dev = torch.device('cuda', 0)
     errs, probe = _case(*c, True, dev, i8)
     k, e, bar = kinkfree_worst(errs, probe.err32, probe.closest_tie)  # (TIGHT; 4 x PyTorch-ROCm's float32 error on an ill-conditioned batch; NOISY next to a normalisation tie)
-    assert probe.closest_all > 1e-4 and e <= bar, (c, k, e, bar, probe.closest_all, probe.closest_tie)
+    # (closest_all: the construction's own check -- no ReLU pre-activation anywhere near float32 resolution of zero; seen down to 5e-5 once in 900 cases)
+    assert probe.closest_all > 1e-5 and e <= bar, (c, k, e, bar, probe.closest_all, probe.closest_tie)
     errs, probe = _case(*c, False, dev, i8)
     worst = max(errs, key=errs.get)
     assert errs[worst] <= 0.6, (c, worst, errs[worst], probe.closest_all)  # (seen: 0.31 once in 900 cases; NOISY = 0.25 holds for the committed shapes)
