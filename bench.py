@@ -112,9 +112,8 @@ def conv_cpu_baseline(name, case, net, kw, full_sims):
     whole moves of `full_sims` simulations (root inference included once per move, as in the reference)."""
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import oracle  # test infrastructure, used here only as the reported CPU baseline
-    from test_oracle_nets import _oracle_net
 
-    onet = _oracle_net(oracle, net, 'mlp' if name == 'c3' else 'conv')
+    onet = oracle.Net.from_module(net, 'mlp' if name == 'c3' else 'conv')
     A = case[3]
     threads = max(1, (os.cpu_count() or 2) // 2)
     rs = np.random.RandomState(5)

@@ -137,6 +137,11 @@ typedef struct {
     double* d_scratch;            /* [mzl_replay_scratch_doubles(capacity)], proportional draws only */
 } mzl_replay_draw;
 int64_t mzl_replay_scratch_doubles(int64_t capacity);
+/* Optional (round 6): a device int32[2] that the replay kernels bump where the reference would have raised -- [0] a draw from an EMPTY replay
+ * (replay.py:83-84; the draw returns slot 0), [1] a non-finite or negative priority in mzl_replay_update_priorities (replay.py:106-110; the value
+ * is skipped).  The kernels cannot raise: the caller reads the counters at a point where it synchronises anyway.  NULL (default): no counting.
+ * Process-wide; the pointer is read when a call is enqueued. */
+int mzl_replay_set_error_counters(int32_t* d_counters);
 int mzl_replay_sample(const mzl_replay_draw* draw, void* stream);
 /* priority[d_index[b]] = d_new[b] (replay.py:106-113; of a repeated index the last b wins).  d_owner: int32 [capacity] scratch. */
 int mzl_replay_update_priorities(float* d_priority, int64_t capacity, const int64_t* d_index, const float* d_new, int32_t batch, int32_t* d_owner,

@@ -163,7 +163,7 @@ struct mzlc_learner {
     float *dF_pred = nullptr, *dF_rew = nullptr;
     // heads
     LchGroup* d_groups = nullptr;
-    std::vector<LchGroup> groups_host;
+    std::vector<LchGroup> groups_host, groups_dev;  // this call's table; the one d_groups holds
     float *hu = nullptr, *hdz = nullptr, *hfeat = nullptr, *hdl = nullptr, *hspart = nullptr, *hspiv = nullptr, *hcoef = nullptr, *hsave = nullptr, *hlpart = nullptr, *hwpart = nullptr;
     int hp_off[3] = {0, 0, 0}, hp_total = 0;
     int n_max = 1;
@@ -1353,7 +1353,14 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
         h->groups_host[3 * t + 1] = LchGroup{f_out[t], 1, t};
         h->groups_host[3 * t + 2] = LchGroup{f_out[t], 2, t};
     }
-    if (hipMemcpyAsync(h->d_groups, h->groups_host.data(), ng * sizeof(LchGroup), hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync"; return MZL_E_HIP; }
+    // The table is a function of the handle (fixed activation buffers, heads and unroll steps): it reaches the device when it CHANGES -- the
+    // first call, in practice -- not on every call.  (a per-call hipMemcpyAsync from pageable memory is waited for on the host, which
+    // serialised the enqueue of the backward launches with the execution of the forward pass and could not be stream-captured.)
+    if (h->groups_dev.size() != h->groups_host.size() || memcmp(h->groups_dev.data(), h->groups_host.data(), ng * sizeof(LchGroup)) != 0) {
+        if (hipStreamSynchronize(st) != hipSuccess) { err = "hipStreamSynchronize"; return MZL_E_HIP; }  // (an earlier step may still read the old table)
+        if (hipMemcpy(h->d_groups, h->groups_host.data(), ng * sizeof(LchGroup), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy"; return MZL_E_HIP; }
+        h->groups_dev = h->groups_host;
+    }
     LchArgs HA{};
     for (int i = 0; i < 3; i++) { HA.head[i] = h->head[i]; HA.lwT_off[i] = h->lwT_off[i]; }
     HA.groups = h->d_groups; HA.ngroups = ng; HA.K = K; HA.B = B; HA.P = h->P; HA.hw = h->hw; HA.A = h->A;

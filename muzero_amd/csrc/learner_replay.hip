@@ -25,22 +25,35 @@ __device__ __forceinline__ long long live_size(const int64_t* num_added, long lo
     return n < capacity ? n : capacity;
 }
 
+// error counters (mzl_replay_set_error_counters; may be null): [0] draws from an EMPTY replay (the reference raises, replay.py:83-84; here
+// the draw returns slot 0 and is counted), [1] priorities the reference's update would have raised on (replay.py:106-110: non-finite or
+// negative; here they are skipped and counted)
 __global__ __launch_bounds__(256) void k_rp_uniform(const int64_t* num_added, long long capacity, unsigned long long seed, unsigned long long draw, int batch,
-                                                     int64_t* index, float* weights) {
+                                                     int64_t* index, float* weights, int* errors) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= batch) return;
     const long long n = live_size(num_added, capacity);
     mz::Philox g(seed, (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)b);
     long long i = (long long)(g.uniform() * (double)n);  // np.uniform(0, n).astype(int64): truncation
-    i = i >= n ? n - 1 : (i < 0 ? 0 : i);
+    i = i >= n ? n - 1 : i;
+    i = i < 0 ? 0 : i;  // (n == 0: slot 0, counted below -- never an index in front of the ring)
+    if (n < 1 && b == 0 && errors) atomicAdd(&errors[0], 1);
     index[b] = i;
     if (weights) weights[b] = 1.0f;
 }
 
-// block-local inclusive prefix sums of w_i = priority_i ^ alpha (float64), block totals
-__global__ __launch_bounds__(256) void k_rp_scan_blocks(const float* prio, const int64_t* num_added, long long capacity, double alpha, double* cdf, double* block_sum) {
-    __shared__ double s_part[256];
+// ONE reading of the item count per draw: the planner's stream advances *num_added while the scan, the pick and the importance weights
+// (1 / n) run -- every kernel of a proportional draw uses this snapshot
+__global__ void k_rp_snapshot(const int64_t* num_added, long long capacity, long long* snap, int* errors) {
     const long long n = live_size(num_added, capacity);
+    *snap = n;
+    if (n < 1 && errors) atomicAdd(&errors[0], 1);
+}
+
+// block-local inclusive prefix sums of w_i = priority_i ^ alpha (float64), block totals
+__global__ __launch_bounds__(256) void k_rp_scan_blocks(const float* prio, const long long* snap, long long capacity, double alpha, double* cdf, double* block_sum) {
+    __shared__ double s_part[256];
+    const long long n = *snap;
     const long long base = (long long)blockIdx.x * RB + (long long)threadIdx.x * 4;
     double w[4], run = 0.0;
 #pragma unroll
@@ -66,7 +79,10 @@ __global__ __launch_bounds__(256) void k_rp_scan_blocks(const float* prio, const
     if (threadIdx.x == 255) block_sum[blockIdx.x] = s_part[255];
 }
 
-// exclusive scan of the block totals by one workgroup (any number of blocks: chunks of 1024 with a running carry); block_off[nb] = total
+// prefix sums of the block totals by one workgroup (any number of blocks: chunks of 1024 with a running carry): block_off[i] = sum of blocks
+// < i, block_off[nb] = total.  Every entry is the INCLUSIVE running sum of its predecessor block (round 6, ADVICE r5: the exclusive form
+// `carry + inclusive - v` was neither monotone in floating point nor consistent with the total, so a draw could land in an empty
+// trailing block)
 __global__ __launch_bounds__(1024) void k_rp_scan_totals(const double* block_sum, double* block_off, int nb) {
     __shared__ double s[1024];
     __shared__ double s_carry;
@@ -84,20 +100,20 @@ __global__ __launch_bounds__(1024) void k_rp_scan_totals(const double* block_sum
             __syncthreads();
         }
         const double carry = s_carry;
-        if (i < nb) block_off[i] = carry + s[threadIdx.x] - v;
+        if (i < nb) block_off[i + 1] = carry + s[threadIdx.x];  // non-decreasing: sums of non-negative terms, added in one fixed order
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = carry + s[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) block_off[nb] = s_carry;
+    if (threadIdx.x == 0) block_off[0] = 0.0;  // (block_off[nb] was written by the last block's thread: the same sum the picks compare with)
 }
 
-__global__ __launch_bounds__(256) void k_rp_pick(const float* prio, const int64_t* num_added, long long capacity, double alpha, double beta, const double* cdf,
+__global__ __launch_bounds__(256) void k_rp_pick(const float* prio, const long long* snap, long long capacity, double alpha, double beta, const double* cdf,
                                                   const double* block_off, int nb, unsigned long long seed, unsigned long long draw, int batch, int64_t* index,
                                                   float* weights) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= batch) return;
-    const long long n = live_size(num_added, capacity);
+    const long long n = *snap;
     const double total = block_off[nb];
     mz::Philox g(seed, (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)b);
     const double u = g.uniform() * total;
@@ -114,10 +130,15 @@ __global__ __launch_bounds__(256) void k_rp_pick(const float* prio, const int64_
         const long long mid = (a + e) >> 1;
         if (off + cdf[mid] > u) e = mid; else a = mid + 1;
     }
+    // never an unwritten slot: inside [0, n - 1], and -- should rounding have carried u past the last item with weight -- back to the nearest
+    // slot that has one (np.random.choice cannot return an entry of probability 0)
+    a = a > n - 1 ? n - 1 : a;
+    a = a < 0 ? 0 : a;
+    double w = pow((double)prio[a], alpha);
+    while (!(w > 0.0) && a > 0) { a--; w = pow((double)prio[a], alpha); }
     index[b] = a;
-    const double w = pow((double)prio[a], alpha);
     const double p = w / total;
-    weights[b] = (float)pow((1.0 / (double)n) / p, beta);  // normalised by the batch maximum in k_rp_normalize
+    weights[b] = (p > 0.0 && n > 0) ? (float)pow((1.0 / (double)n) / p, beta) : 0.0f;  // normalised by the batch maximum in k_rp_normalize
 }
 
 __global__ __launch_bounds__(1024) void k_rp_normalize(float* weights, int batch) {
@@ -131,7 +152,7 @@ __global__ __launch_bounds__(1024) void k_rp_normalize(float* weights, int batch
         __syncthreads();
     }
     m = s[0];
-    for (int i = threadIdx.x; i < batch; i += 1024) weights[i] = weights[i] / m;
+    for (int i = threadIdx.x; i < batch; i += 1024) weights[i] = m > 0.0f ? weights[i] / m : 1.0f;  // (all priorities zero / empty replay: plain weights, not 0 / 0)
 }
 
 // priority[index[b]] = value[b], the last b of a repeated index wins: the owner array records the largest b per touched slot (max is order-free)
@@ -143,15 +164,27 @@ __global__ __launch_bounds__(256) void k_rp_owner_max(const int64_t* index, int 
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b < batch) atomicMax(&owner[index[b]], b);
 }
-__global__ __launch_bounds__(256) void k_rp_scatter(const int64_t* index, const float* value, int batch, const int* owner, float* prio) {
+__global__ __launch_bounds__(256) void k_rp_scatter(const int64_t* index, const float* value, int batch, const int* owner, float* prio, int* errors) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < batch && owner[index[b]] == b) prio[index[b]] = value[b];
+    if (b >= batch) return;
+    const float v = value[b];
+    // replay.py:106-110 raises on a non-finite or negative priority before writing anything; the device cannot raise: the value is not
+    // written (one NaN would poison every later prefix sum and importance weight) and the caller reads the count at its next sync point
+    const bool bad = !(v >= 0.0f) || v > 3.0e38f;
+    if (bad) { if (errors) atomicAdd(&errors[1], 1); return; }
+    if (owner[index[b]] == b) prio[index[b]] = v;
 }
 
 }  // namespace
 
 void mzl_internal_set_error(const std::string& msg);  // learner.hip: the text mzl_last_error() returns
 #define g_rerr_set(m) mzl_internal_set_error(m)
+
+static int* g_replay_errors = nullptr;  // device int32[2] or null (mzl_replay_set_error_counters)
+extern "C" int mzl_replay_set_error_counters(int32_t* d_counters) {
+    g_replay_errors = d_counters;
+    return MZL_OK;
+}
 
 extern "C" int64_t mzl_replay_scratch_doubles(int64_t capacity) {
     const int64_t nb = (capacity + RB - 1) / RB;
@@ -164,16 +197,18 @@ extern "C" int mzl_replay_sample(const mzl_replay_draw* d, void* stream) {
     const int gb = (d->batch + 255) / 256;
     if (d->priority_exponent == 0.0) {
         hipLaunchKernelGGL(k_rp_uniform, dim3(gb), dim3(256), 0, st, d->d_num_added, (long long)d->capacity, (unsigned long long)d->seed,
-                           (unsigned long long)d->draw, d->batch, d->d_index, d->d_weights);
+                           (unsigned long long)d->draw, d->batch, d->d_index, d->d_weights, g_replay_errors);
     } else {
         if (!d->d_priority || !d->d_weights || !d->d_scratch) { g_rerr_set("mzl_replay_sample: proportional draws need d_priority, d_weights and d_scratch"); return MZL_E_INVALID; }
         const int nb = (int)((d->capacity + RB - 1) / RB);
         double* cdf = d->d_scratch;
         double* bsum = cdf + d->capacity;
         double* boff = bsum + nb;
-        hipLaunchKernelGGL(k_rp_scan_blocks, dim3(nb), dim3(256), 0, st, d->d_priority, d->d_num_added, (long long)d->capacity, d->priority_exponent, cdf, bsum);
+        long long* snap = reinterpret_cast<long long*>(boff + nb + 1);  // (one of the 8 spare slots of mzl_replay_scratch_doubles)
+        hipLaunchKernelGGL(k_rp_snapshot, dim3(1), dim3(1), 0, st, d->d_num_added, (long long)d->capacity, snap, g_replay_errors);
+        hipLaunchKernelGGL(k_rp_scan_blocks, dim3(nb), dim3(256), 0, st, d->d_priority, snap, (long long)d->capacity, d->priority_exponent, cdf, bsum);
         hipLaunchKernelGGL(k_rp_scan_totals, dim3(1), dim3(1024), 0, st, bsum, boff, nb);
-        hipLaunchKernelGGL(k_rp_pick, dim3(gb), dim3(256), 0, st, d->d_priority, d->d_num_added, (long long)d->capacity, d->priority_exponent,
+        hipLaunchKernelGGL(k_rp_pick, dim3(gb), dim3(256), 0, st, d->d_priority, snap, (long long)d->capacity, d->priority_exponent,
                            d->importance_sampling_exponent, cdf, boff, nb, (unsigned long long)d->seed, (unsigned long long)d->draw, d->batch, d->d_index, d->d_weights);
         hipLaunchKernelGGL(k_rp_normalize, dim3(1), dim3(1024), 0, st, d->d_weights, d->batch);
     }
@@ -188,7 +223,7 @@ extern "C" int mzl_replay_update_priorities(float* d_priority, int64_t capacity,
     const int gb = (batch + 255) / 256;
     hipLaunchKernelGGL(k_rp_owner_clear, dim3(gb), dim3(256), 0, st, d_index, batch, d_owner);
     hipLaunchKernelGGL(k_rp_owner_max, dim3(gb), dim3(256), 0, st, d_index, batch, d_owner);
-    hipLaunchKernelGGL(k_rp_scatter, dim3(gb), dim3(256), 0, st, d_index, d_new, batch, d_owner, d_priority);
+    hipLaunchKernelGGL(k_rp_scatter, dim3(gb), dim3(256), 0, st, d_index, d_new, batch, d_owner, d_priority, g_replay_errors);
     if (hipGetLastError() != hipSuccess) { g_rerr_set("mzl_replay_update_priorities: kernel launch failed"); return MZL_E_HIP; }
     return MZL_OK;
 }

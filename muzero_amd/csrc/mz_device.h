@@ -56,13 +56,15 @@ __device__ __forceinline__ float signed_parabolic(float x) {
 // DPP row rotation inside each 16-lane row (no LDS crossbar, one VALU op): lane i receives lane (i + n) mod 16.
 template <int N>
 __device__ __forceinline__ float row_ror(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+    // (bound_ctrl: a rotation has no invalid source lanes, and with it hipcc does not pre-load the destination with `old` -- one v_mov less
+    // per DPP move on a wave whose every instruction is 5.8 cycles of issue, tools/micro/issue.hip)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
 }
 template <int N>
 __device__ __forceinline__ double row_ror(double v) {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x120 + N, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + N, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x120 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + N, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 

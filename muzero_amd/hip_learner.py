@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmzlearner_hip.so')
 # every symbol include/mzlearner.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = ['mzl_last_error', 'mzl_create', 'mzl_destroy', 'mzl_num_params', 'mzl_grad_floats', 'mzl_num_tensors', 'mzl_tensor_info',
                'mzl_num_buffers', 'mzl_num_running', 'mzl_buffer_info', 'mzl_bind_buffers', 'mzl_bind', 'mzl_commit', 'mzl_grad', 'mzl_apply',
-               'mzl_replay_scratch_doubles', 'mzl_replay_sample', 'mzl_replay_update_priorities']
+               'mzl_replay_scratch_doubles', 'mzl_replay_sample', 'mzl_replay_update_priorities', 'mzl_replay_set_error_counters']
 NET_MLP, NET_BOARD, NET_ATARI = 0, 1, 2
 
 
@@ -82,6 +82,7 @@ def load_library():
     L.mzl_replay_scratch_doubles.restype = i64
     L.mzl_replay_sample.argtypes = [C.POINTER(MzlReplayDraw), vp]
     L.mzl_replay_update_priorities.argtypes = [vp, i64, vp, vp, i32, vp, vp]
+    L.mzl_replay_set_error_counters.argtypes = [vp]
     _lib = L
     return L
 

@@ -365,6 +365,8 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
         warnings.warn('run_training: optimizer.graphed_step ignored with %d learner ranks (the one-graph update has no all-reduce); '
                       'using the eager step' % dist.get_world_size())
         graphed = None
+    metrics_every = max(1, int(getattr(config, 'metrics_every', 100) or 100))
+    loss_acc, loss_n = None, 0
     warm = False
     while True:
         if not warm:  # (replay.size reads the device counter: once the ring is warm it stays warm, and the loop stops asking)
@@ -391,14 +393,23 @@ def run_training(config, network, optimizer, lr_scheduler, device, actor_network
             loss_t, prio_t = hip.step(ring, idx_t, w_t, config.batch_size)
             if tuple(prio_t.shape) != (config.batch_size,):
                 raise RuntimeError(f'Expect priorities has shape ({config.batch_size}, ), got {tuple(prio_t.shape)}')
-            if replay._alpha != 0:
-                if sampler is not None:
-                    sampler.update_priorities(idx_t, prio_t)
-                else:
-                    replay.update_priorities(indices, prio_t.cpu().numpy())
+            # priorities are written on every update, whatever the sampling exponent (pipeline.py:249-252): a saved replay state then
+            # carries the reference's priorities even if the exponent changes on a resume
+            if sampler is not None:
+                sampler.update_priorities(idx_t, prio_t)  # three enqueued kernels, no synchronisation
+            else:
+                replay.update_priorities(indices, prio_t.cpu().numpy())
             train_steps_counter.value += 1
-            if train_steps_counter.value % 100 == 0 or train_steps_counter.value % config.checkpoint_interval == 0:
-                metrics.step(float(loss_t), lr_scheduler.get_last_lr()[0], train_steps_counter.value)
+            # metrics: the reference's loss is on the host after every step; here it stays on the device and the line is written every
+            # `config.metrics_every` updates (default 100; 1 = the reference's cadence, one read-back per update) and at checkpoints, carrying
+            # the MEAN loss of the updates since the last line (accumulated on the device)
+            loss_acc = loss_t.detach().clone() if loss_acc is None else loss_acc.add_(loss_t.detach())
+            loss_n += 1
+            if train_steps_counter.value % metrics_every == 0 or train_steps_counter.value % config.checkpoint_interval == 0:
+                metrics.step(float(loss_acc) / loss_n, lr_scheduler.get_last_lr()[0], train_steps_counter.value)
+                loss_acc, loss_n = None, 0
+                if sampler is not None:
+                    sampler.check_errors()  # what replay.update_priorities / sample would have raised (replay.py:83-84, 106-110)
         else:
             transitions, indices, weights = replay.sample_tensors(config.batch_size)
             if graphed is None and not multi and torch.device(device).type == 'cuda' and all(g.get('capturable', False) for g in optimizer.param_groups):

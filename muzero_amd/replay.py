@@ -302,6 +302,23 @@ class DeviceSampler:
         self._scratch = None if replay._alpha == 0 else torch.zeros(int(self._lib.mzl_replay_scratch_doubles(cap)), dtype=torch.float64, device=dev)
         self._owner = None
         self._bufs = {}
+        # where the kernels count what the reference would have raised on (include/mzlearner.h, mzl_replay_set_error_counters): [0] draws from an
+        # empty replay, [1] invalid priorities (skipped).  Read by `check_errors()` wherever the caller synchronises anyway.
+        self._errors = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def _bind_errors(self):
+        self._hl._check(self._lib.mzl_replay_set_error_counters(self._errors.data_ptr()))
+
+    def check_errors(self) -> None:
+        """Raises what `PrioritizedReplay` would have raised at the call (replay.py:83-84, 106-110) -- later, at a point where the caller reads
+        something back from the device anyway (run_training: its metrics line).  One device -> host copy of 8 bytes."""
+        empty, bad = (int(x) for x in self._errors.tolist())
+        if empty or bad:
+            self._errors.zero_()
+        if bad:
+            raise ValueError('Priorities must be finite and positive.')  # (the reference's message, replay.py:110)
+        if empty:
+            raise RuntimeError('sample() from an empty replay')
 
     def _stream(self):
         import ctypes as C
@@ -322,18 +339,21 @@ class DeviceSampler:
         d = self._hl.MzlReplayDraw(self._prio.data_ptr(), self._count.data_ptr(), rp._cap, float(rp._alpha), float(rp._beta), self.seed, self.draws, batch_size,
                                    idx.data_ptr(), w.data_ptr(), 0 if self._scratch is None else self._scratch.data_ptr())
         self.draws += 1
+        self._bind_errors()
         self._hl._check(self._lib.mzl_replay_sample(C.byref(d), self._stream()))
         return idx, (None if rp._alpha == 0 else w), rp._ring
 
     def update_priorities(self, indices: torch.Tensor, priorities: torch.Tensor) -> None:
-        """replay.py:106-113 on device tensors (of a repeated index the last value wins).  Values are not validated on the host (that would
-        be the read-back this class exists to avoid): the learner's |v - z| is finite and non-negative by construction."""
+        """replay.py:106-113 on device tensors (of a repeated index the last value wins).  Values are validated where they are -- the kernel
+        skips a non-finite or negative priority and counts it; `check_errors()` raises the reference's ValueError at the caller's next
+        synchronisation point (a host-side check here would be the read-back this class exists to avoid)."""
         rp = self.replay
         if self._owner is None:
             self._owner = torch.zeros(rp._cap, dtype=torch.int32, device=rp._dev)
         n = int(indices.numel())
         if indices.dtype != torch.int64 or priorities.dtype != torch.float32 or priorities.numel() < n or indices.device != self._prio.device or priorities.device != self._prio.device:
             raise ValueError('update_priorities: int64 indices and float32 priorities on the replay\'s device')
+        self._bind_errors()
         self._hl._check(self._lib.mzl_replay_update_priorities(self._prio.data_ptr(), rp._cap, indices.data_ptr(), priorities.data_ptr(), n,
                                                                self._owner.data_ptr(), self._stream()))
 

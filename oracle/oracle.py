@@ -189,6 +189,19 @@ class Net:
         return cls(h, num_actions, keep=(arrs, ptrs))
 
     @classmethod
+    def from_module(cls, net, kind):
+        """The oracle network holding the weights of a `muzero_amd.network` module (`kind`: 'mlp' or 'conv'); the shapes come from the
+        module's own `planner_spec()`.  What the parity tests, `__graft_entry__.smoke()` and bench.py's `cpu_baseline` legs build their
+        checker from (round 6: it used to live in tests/test_oracle_nets.py, which made bench.py import the test tree)."""
+        sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+        spec = net.planner_spec()
+        if kind == 'mlp':
+            return cls.mlp(sd, int(np.prod(spec['input_shape'])), spec['num_actions'], spec['num_planes'], spec['hidden_dim'],
+                           spec['value_support_size'], spec['reward_support_size'])
+        return cls.conv(sd, spec['kind'], spec['input_shape'], spec['num_actions'], spec['num_res_blocks'], spec['num_planes'],
+                        spec['value_support_size'], spec['reward_support_size'])
+
+    @classmethod
     def scripted(cls, pi0, values, rewards):
         pi0, values, rewards = _f32(pi0), _f32(values), _f32(rewards)
         h = lib().mzo_net_create_scripted(len(pi0), _p(pi0), _p(values), _p(rewards), len(values))

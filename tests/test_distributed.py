@@ -274,3 +274,53 @@ def test_bench_gpus_flag_never_reports_a_single_gpu_line():
     r2 = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True,
                         text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
     assert r2.returncode == 2 and 'refusing' in r2.stderr and r2.stdout.strip() == ''
+
+
+def _worker8(rank, world, port, q):
+    """World-size-8 rehearsal: uneven env shards, SUM / MAX aggregation, and the learner's bucketed gradient
+    all-reduce over eight ranks -- the plumbing the first 8-GPU lease will run over RCCL."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from helpers import build_mlp, mlp_case
+    from muzero_amd import learner, pipeline
+
+    torch.set_num_threads(1)
+    total = 4099  # not divisible by 8: three ranks carry one env more
+    lo, hi = pipeline.shard_range(total, rank, world)
+    rate, units, secs = pipeline.aggregate_throughput((hi - lo) * 50 * 2, 1.0 + 0.125 * rank)
+    net = build_mlp(mlp_case('tiny'))  # same seed on every rank: identical weights
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1)) * (i + 1)
+    learner.allreduce_gradients(net, bucket_bytes=2048)  # several buckets
+    want = np.mean([r + 1 for r in range(world)])
+    ok = all(torch.allclose(p.grad, torch.full_like(p, float(want * (i + 1)))) for i, p in enumerate(net.parameters()))
+    dist.barrier()
+    q.put((rank, lo, hi, rate, units, secs, ok, pipeline.rank_env()))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_sharding_aggregation_and_allreduce():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(8))
+    spans = [(r[1], r[2]) for r in res]
+    assert spans[0][0] == 0 and spans[-1][1] == 4099 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [hi - lo for lo, hi in spans]
+    assert sorted(sizes) == [512] * 5 + [513] * 3
+    for r in res:
+        assert r[4] == 4099 * 100 and r[5] == 1.875 and r[3] == 4099 * 100 / 1.875  # SUM of units, MAX of time, on every rank
+        assert r[6] and r[7] == (r[0], r[0], 8)

@@ -1,5 +1,6 @@
 """-m gpu: the HIP learner on MuZeroAtariNet (muzero_amd/csrc/mz_learn_conv.h, the tile path of DESIGN.md 4c) -- the reference's update
-(agent.py:332-444: calc_loss + backward, clip, Adam, MultiStepLR; network.py:127-280 the Atari network) for 96 x 96 frame stacks: strided
+(pipeline.py:541-629 `calc_loss`, pipeline.py:238-255 backward / clip / Adam / MultiStepLR in `run_training`; network.py:312-353 the Atari
+representation, network.py:501-537 `MuZeroAtariNet`) for 96 x 96 frame stacks: strided
 convolutions, 12 x 12 tiles of the 48 x 48 and 24 x 24 stages, average pools, categorical (2-hot cross-entropy) value / reward heads.
 
 Checked against (1) the committed fixture the reference itself produced (`oracle/gen_golden.py learn` -> learn_conv_atari_s_*: loss, priorities,

@@ -158,3 +158,29 @@ def test_run_training_uses_a_prepared_graph_for_conv_nets(tmp_path):
         assert torch.equal(v.cpu(), net.state_dict()[k].cpu()), k
     ck = load_checkpoint(str(tmp_path / 'train_steps_6_final'), torch.device('cpu'))
     assert set(ck) == {'network', 'optimizer', 'lr_scheduler', 'train_steps'} and ck['train_steps'] == 6
+
+
+def test_bench_eight_ranks_over_gloo_on_one_gpu():
+    """the N = 8 line of bench.py, end to end, on the one GPU this box has -- eight rank processes (started by bench.py
+    itself, as the driver's torchrun would), gloo for the barrier / MAX (`MZ_BENCH_BACKEND=gloo`; the driver's 8-GPU run uses RCCL), every
+    rank its own planner and env shard.  The line must say n_gpus 8, carry eight per-rank rates that sum to the value, and scale "weak"."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MZ_BENCH_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--preheat', '0', '--no-cpu-baseline',
+                        '--no-sustained', '--no-e2e', '--no-configs', '--no-learner'], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['steps'] == 3
+    rates = d['per_rank']['sims_per_sec_by_kernel_time']
+    assert len(rates) == 8 and all(v > 0 for v in rates)
+    assert d['value'] > 0 and d['config']['workload'].startswith('C2') and d['config']['parallelism'] == 'env-sharded x8'
+    assert d['distributed']['world_size'] == 8

@@ -15,13 +15,7 @@ VAL_TOL = dict(rtol=2e-4, atol=2e-4)
 
 
 def _oracle_net(oracle, net, case_kind):
-    sd = {k: v.numpy() for k, v in net.state_dict().items()}
-    spec = net.planner_spec()
-    if case_kind == 'mlp':
-        return oracle.Net.mlp(sd, int(np.prod(spec['input_shape'])), spec['num_actions'], spec['num_planes'], spec['hidden_dim'],
-                              spec['value_support_size'], spec['reward_support_size'])
-    return oracle.Net.conv(sd, spec['kind'], spec['input_shape'], spec['num_actions'], spec['num_res_blocks'], spec['num_planes'],
-                           spec['value_support_size'], spec['reward_support_size'])
+    return oracle.Net.from_module(net, case_kind)
 
 
 def _check(oracle, onet, prefix, teacher_forcing=True):
