@@ -1436,21 +1436,39 @@ int mzlc_apply(mzlc_learner* h, double lr, double beta1, double beta2, double ep
     return MZL_OK;
 }
 
-// diagnostic (tests): device pointers of saved tensors.  what: "y" (a = application: 0 representation, 1 + t dynamics_t, 1 + K + t prediction_t;
-// b = layer of the tower), "x" (materialised outputs), "s" (a = t), "dF_pred" / "dF_rew" (a = t)
+// diagnostic (tests): device pointers of saved tensors.  what: "y" (a = application: 0 representation, 1 + t dynamics_t, 1 + K + t prediction_t,
+// 1 + 2 K the Atari net's res_blocks_3; b = layer of the tower), "x" (materialised post-ReLU outputs), "fcoef" (the layer's BatchNorm as applied:
+// [3][pad16(C)], rows a, b), "s" (a = t), "dF_pred" / "dF_rew" (a = t).  Round 6 (tests/forced_masks.py: the decisions of THIS forward pass -- ReLU
+// masks, normalisation arg-min / arg-max -- for a float64 reference that takes the same branches): "feat" the heads' post-ReLU features
+// [3 K groups][B][2 hw]; the Atari representation's plane tensors "a1" / "a2" (post-ReLU conv_1 / conv_2), "s48_h1" / "s48_x" / "s24_h1" / "s24_x"
+// (b = block: the block's inner post-ReLU tensor / its output), "hraw" (the pooled 6 x 6 state before normalisation).  *count: floats of the
+// tensor at the last batch where the shape is known here, else the allocation's.
 int mzlc_debug_tensor(const mzlc_learner* h, const char* what, int a, int b, void** ptr, int64_t* count) {
     const std::string w = what;
     const AppBufs* ap = nullptr;
     if (a == 0) ap = &h->app_rep;
     else if (a >= 1 && a <= h->K) ap = &h->app_dyn[a - 1];
     else if (a > h->K && a <= 2 * h->K) ap = &h->app_pred[a - 1 - h->K];
+    else if (a == 2 * h->K + 1 && h->atari) ap = &h->a12;
     *count = (int64_t)h->T;
+    if (ap == &h->a12) *count = (int64_t)h->maxB * h->P * (h->obsH / 8) * (h->obsW / 8);  // (the 12 x 12 stage of the Atari representation)
     if (w == "y" && ap && b >= 0 && b < (int)ap->y.size()) { *ptr = ap->y[b]; return MZL_OK; }
     if (w == "x" && ap && b >= 0 && b < (int)ap->x.size()) { *ptr = ap->x[b]; return MZL_OK; }
+    if (w == "fcoef" && ap && b >= 0 && b < (int)ap->fcoef.size()) { *ptr = ap->fcoef[b]; *count = 3 * (int64_t)pad16(h->P); return MZL_OK; }
     if (w == "s" && a >= 0 && a < h->K) { *ptr = h->s[a]; return MZL_OK; }
-    const size_t tb = (size_t)h->lastB * h->P * h->hw;
-    if (w == "dF_pred" && a >= 0 && a < h->K) { *ptr = h->dF_pred + (size_t)a * tb; return MZL_OK; }
-    if (w == "dF_rew" && a >= 0 && a < h->K) { *ptr = h->dF_rew + (size_t)a * tb; return MZL_OK; }
+    if (w == "feat") { *ptr = h->hfeat; *count = (int64_t)3 * h->K * h->lastB * LCH_MAXOC * h->hw; return MZL_OK; }
+    if (h->atari) {
+        const int64_t n48 = (int64_t)h->lastB * 128 * (h->obsH / 2) * (h->obsW / 2), n24 = (int64_t)h->lastB * h->P * (h->obsH / 4) * (h->obsW / 4);
+        if (w == "a1") { *ptr = h->a1; *count = n48; return MZL_OK; }
+        if (w == "a2") { *ptr = h->a2; *count = n24; return MZL_OK; }
+        if (w == "hraw") { *ptr = h->hraw; *count = (int64_t)h->lastB * h->P * h->hw; return MZL_OK; }
+        if (b >= 0 && b < 2) {
+            if (w == "s48_h1") { *ptr = h->sb48.h1[b]; *count = n48; return MZL_OK; }
+            if (w == "s48_x") { *ptr = h->sb48.x[b]; *count = n48; return MZL_OK; }
+            if (w == "s24_h1") { *ptr = h->sb24.h1[b]; *count = n24; return MZL_OK; }
+            if (w == "s24_x") { *ptr = h->sb24.x[b]; *count = n24; return MZL_OK; }
+        }
+    }
     if (w == "gs") { *ptr = a ? h->GsB : h->GsA; return MZL_OK; }
     return MZL_E_INVALID;
 }

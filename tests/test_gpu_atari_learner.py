@@ -6,22 +6,20 @@ convolutions, 12 x 12 tiles of the 48 x 48 and 24 x 24 stages, average pools, ca
 Checked against (1) the committed fixture the reference itself produced (`oracle/gen_golden.py learn` -> learn_conv_atari_s_*: loss, priorities,
 every gradient tensor, three updates) and (2) PyTorch float64 autograd of this repo's network module on seeded batches of other shapes.
 
-Tolerances.  Loss, priorities and BatchNorm statistics are continuous in the weights and held to the board-net bars everywhere.  GRADIENTS of this
-network sit on ReLU kinks on practically every batch: one layer of the 48 x 48 stage applies ReLU to 128 x 2304 values per frame stack, some
-pre-activation lies within float32 rounding of zero (tools/dev/conv_learner_check.py --atari prints the closest ones: < 4e-7 on 5 of 8 seeded
-batches), a float32 pass -- this one, PyTorch-ROCm's or the reference's own -- takes the other branch there, and every upstream tensor moves by
-that element's contribution: a few 1e-2 of the tensor's largest entry for bias-like sums, more at batch 1.  tools/dev/atari_fuzz_probe.py shows
-PyTorch-ROCm's float32 autograd scattering against its own float64 run exactly as the HIP step does (1e-5 on clean batches, up to 1e-1 on the
-others, independently of each other).  So gradients are checked twice:
-  * KINK-FREE weights (`kinkfree_state_dict`): BatchNorm scales / shifts and the signs of conv_1 / conv_2 chosen so that every ReLU channel is
-    either on or off for the whole batch (a mix of both), which the float64 probe confirms (no pre-activation within 1e-4 of zero).  Every
-    gradient tensor must then match float64 autograd to 3e-3 of its largest entry (measured: 1e-5) -- every kernel of the path, the mask logic
-    included, with no noise to hide behind.  (Ill-conditioned batches -- a BatchNorm channel with a tiny batch variance amplifies the rounding of
-    y - mean by up to 316 in ANY float32 pass -- are recognised by PyTorch-ROCm's own float32 autograd on the same batch: the bar is then 4 x its
-    error on that tensor.  None of the committed shapes is one; about 1 % of the fuzz cases are.)
-  * seeded RANDOM weights (full-strength element-wise masks): every tensor within 0.25, and at least two of the ten batches within 1e-3
-    everywhere -- an indexing or scaling error is systematic and would fail all of them.
-The fixture of the reference's own run (random weights) is held to 8e-2 on the representation and 2e-3 on the two 6 x 6 networks."""
+Tolerances (round 6).  GRADIENTS of this network sit on ReLU kinks on practically every batch: one layer of the 48 x 48 stage applies ReLU to
+128 x 2304 values per frame stack, some pre-activation lies within float32 rounding of zero, a float32 pass -- this one, PyTorch-ROCm's or the
+reference's own -- takes the other branch there, and every upstream tensor moves by that element's contribution (up to 1e-1 of a tensor's largest
+entry).  Rounds 4-5 answered with loose bars (0.25 on random weights).  Now the float64 reference is TOLD what the HIP forward pass decided --
+every ReLU mask and every arg-min / arg-max of normalize_hidden_state, read back through the library's diagnostic hook (tests/forced_masks.py) --
+and takes the same branches; a float32 and a float64 pass are then compared on one piecewise-linear function, where an error of the tile path
+(halo positions, 12 x 16 tiles, parity planes, pooling) is a full-size error and rounding is 1e-5:
+  * seeded RANDOM weights, every shape: every gradient tensor within 1e-4 of its largest entry (measured 2e-5) -- at the Atari config's full size
+    (128 planes, 8 blocks, batch 128) within 4 x what PyTorch-ROCm's own float32 autograd reaches on the same branch (4.6e-4 there; the kernels 6.2e-4);
+  * the reference's own fixture batch: the kernels against float64 on their own branch at 1e-4 on EVERY network part -- and against the fixture's
+    gradients (the reference's float32 run, which took ITS branches) at 8e-2 on the representation net, 3e-3 elsewhere, as before;
+  * KINK-FREE weights (`kinkfree_state_dict`) remain as an independent second check that involves no read-back of the library's tensors: every ReLU
+    channel on or off for the whole batch, plain float64 autograd, 3e-3 (measured 1e-5).
+Loss, priorities and BatchNorm statistics are continuous in the weights and held to the board-net bars everywhere."""
 import copy
 
 import numpy as np
@@ -34,7 +32,7 @@ from muzero_amd.replay import Transition
 
 pytestmark = pytest.mark.gpu
 G = load_golden('learn_cases.npz')
-REP_TOL, TIGHT, NOISY = 8e-2, 3e-3, 0.25  # (TIGHT: typical agreement is 1e-5; 2-3e-3 is where float32 conditioning of single-image / near-constant-plane batches ends)
+REP_TOL, TIGHT = 8e-2, 3e-3  # (REP_TOL: against the REFERENCE's float32 run, which took its own ReLU branches; TIGHT: kink-free weights, typical agreement 1e-5)
 
 
 def _hip(net, dev, max_batch, K=5, **kw):
@@ -99,6 +97,12 @@ def test_loss_gradients_and_three_updates_match_the_reference():
                 net_name = pn.split('.')[0]
                 worst[net_name] = max(worst.get(net_name, 0.0), e)
                 assert e <= (REP_TOL if net_name == 'represent_net' else TIGHT), (pn, e)
+            # ... and the same batch against float64 autograd on THIS pass's branches (tests/forced_masks.py): every part of the network, 1e-4
+            from test_gpu_conv_learner import _same_branch, same_branch_bar
+
+            errs, err32, _, _, flipped = _same_branch(hl, net, tr, G[f'{pre}_weights'], B, 5, dev)
+            k, e, bar = same_branch_bar(errs, err32)
+            assert e <= bar and bar <= 3e-3, (k, e, bar, flipped)  # (this batch of 2 frame stacks: PyTorch-ROCm float32 4.2e-4 on the same branch, the kernels 5.2e-4)
         hl.apply(clip=(step == 1))
         losses.append(float(loss))
     print('worst relative gradient difference per network:', worst)
@@ -187,7 +191,7 @@ def _f64(net, tr, w, dev):
 SHAPES = [(4, 8, 1, 6, 11, 11, 3, 5, 3), (4, 8, 1, 6, 11, 11, 3, 5, 5), (4, 8, 1, 6, 11, 11, 3, 5, 7), (4, 8, 1, 6, 11, 11, 3, 5, 2),
           (4, 16, 2, 18, 61, 31, 5, 5, 1), (32, 24, 1, 4, 601, 601, 2, 2, 2), (4, 128, 1, 6, 61, 61, 2, 3, 3), (1, 8, 3, 3, 5, 7, 1, 1, 4),
           (2, 40, 1, 9, 21, 21, 4, 4, 6), (4, 8, 1, 6, 11, 11, 9, 5, 9)]
-REP_ERR = {}
+SAME_BRANCH = {}
 
 
 def _case(chan, planes, blocks, A, vs, rs_, B, K, seed, kinkfree, dev, int8_state=False):
@@ -242,7 +246,7 @@ def kinkfree_worst(errs, err32, tie=float('inf')):
     mask-noise bar.  Returns (tensor, error, bar) of the worst offender relative to its bar."""
     worst = None
     for k, e in errs.items():
-        bar = NOISY if tie < 1e-6 else min(8e-2, max(TIGHT, 4.0 * (err32[k] if err32 else 0.0)))
+        bar = 0.25 if tie < 1e-6 else min(8e-2, max(TIGHT, 4.0 * (err32[k] if err32 else 0.0)))
         if worst is None or e / bar > worst[1] / worst[2]:
             worst = (k, e, bar)
     return worst
@@ -274,21 +278,60 @@ def test_gradient_matches_float64_autograd_kink_free(chan, planes, blocks, A, vs
     assert any(e > 0 for e in errs.values())
 
 
+def _random_case(chan, planes, blocks, A, vs, rs_, B, K, seed, dev, int8_state=False):
+    from muzero_amd.network import MuZeroAtariNet
+    from test_gpu_conv_learner import _same_branch
+
+    net = MuZeroAtariNet((chan, 96, 96), A, blocks, planes, vs, rs_)
+    net.load_state_dict(seeded_state_dict(net, 100 + seed))
+    net = net.to(dev)
+    net.train()
+    rs = np.random.RandomState(seed)
+    tr = Transition(rs.uniform(0, 1, (B, chan, 96, 96)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
+                    rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), (rs.uniform(-1, 1, (B, K)) * 8.0).astype(np.float32),
+                    rs.uniform(-1, 1, (B, K)).astype(np.float32))
+    if int8_state:  # (the replay ring's int8 state storage: the gather kernel converts)
+        tr = tr._replace(state=(tr.state * 4.0).astype(np.int8))
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    hl = _hip(net, dev, B, K=K)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    errs, err32, loss_d, prio_d, flipped = _same_branch(hl, net, tr, w, B, K, dev)
+    assert abs(float(loss) - loss_d) <= 3e-5 * max(1.0, abs(loss_d))
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=2e-4 * max(1.0, float(prio_d.abs().max())))
+    return errs, err32, flipped
+
+
 @pytest.mark.parametrize('chan,planes,blocks,A,vs,rs_,B,K,seed', SHAPES, ids=IDS)
 def test_gradient_matches_float64_autograd_random_weights(chan, planes, blocks, A, vs, rs_, B, K, seed):
-    errs, probe = _case(chan, planes, blocks, A, vs, rs_, B, K, seed, False, torch.device('cuda', 0))
-    worst = max(errs, key=errs.get)
-    assert errs[worst] <= NOISY, (worst, errs[worst], probe.closest_all)
-    REP_ERR[(chan, planes, blocks, B, seed)] = (errs[worst], probe.closest_all)
+    """Seeded random weights, full-strength element-wise masks in the strided, tiled and pooled stages, against float64 autograd on the HIP pass's
+    own branches: every tensor within 1e-4 of its largest entry (VERDICT r5 #2: the 0.25 bar is gone)."""
+    from test_gpu_conv_learner import same_branch_bar
+
+    errs, err32, flipped = _random_case(chan, planes, blocks, A, vs, rs_, B, K, seed, torch.device('cuda', 0))
+    k, e, bar = same_branch_bar(errs, err32)
+    assert e <= bar and bar <= 3e-3, (k, e, bar, flipped)  # (bar: 1e-4, or 4 x PyTorch-ROCm's float32 error on the same branch for the single-image / tiny-batch shapes)
+    SAME_BRANCH[(chan, planes, blocks, B, seed)] = (e, bar)
 
 
-def test_some_random_weight_batches_had_no_flipped_mask():
-    """See the module docstring: at least two of the seeded random-weight batches above must agree with float64 autograd to 1e-3 of each
-    tensor's largest entry in EVERY tensor -- the bar a systematic error cannot pass on any batch."""
-    if len(REP_ERR) < len(SHAPES):
+def test_most_random_weight_shapes_meet_the_flat_bar():
+    """The yardstick clause (3 x PyTorch-ROCm float32) must stay the exception: most committed shapes agree to the flat 1e-4."""
+    if len(SAME_BRANCH) < len(SHAPES):
         pytest.skip('runs after the parametrised cases')
-    print({k: (f'{v[0]:.1e}', f'{v[1]:.1e}') for k, v in REP_ERR.items()})
-    assert sum(1 for e, _ in REP_ERR.values() if e <= 1e-3) >= 2, REP_ERR
+    print({k: (f'{v[0]:.1e}', f'{v[1]:.1e}') for k, v in SAME_BRANCH.items()})
+    assert sum(1 for e, _ in SAME_BRANCH.values() if e <= 1e-4) >= 7, SAME_BRANCH
+
+
+def test_full_size_atari_config_at_batch_128_random_weights():
+    """make_atari_config's network (128 planes, 8 blocks, supports 61, unroll 5) at ITS batch size with seeded RANDOM weights: the NPT = 16 tile builds,
+    the launch-time-aware tilings and chunk counts of batch 128 under element-wise masks."""
+    from test_gpu_conv_learner import same_branch_bar
+
+    errs, err32, flipped = _random_case(4, 128, 8, 6, 61, 61, 128, 5, 11, torch.device('cuda', 0))
+    k, e, bar = same_branch_bar(errs, err32)
+    print('Atari config net, batch 128, random weights: worst tensor', k, '%.2e' % e, 'bar %.2e' % bar, '(PyTorch-ROCm float32 on the same branch: %.2e);' % max(err32.values()),
+          flipped, 'ReLU decisions differ from float64\'s own')
+    assert e <= bar and bar <= 5e-3, (k, e, bar)
+    assert flipped > 0
 
 
 def test_ring_by_index_and_repeat_are_bit_identical():

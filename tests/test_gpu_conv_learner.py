@@ -6,11 +6,14 @@
 (2) PyTorch-ROCm autograd (muzero_amd.learner, pinned to the same vectors by tests/test_learner.py) in float64 on the same batch over the
     geometries that pick different kernel builds (pixel tilings NPT 6 / 9 / 15, images per workgroup, plane counts off the 16-tile, wide
     action-plane convs, int8 states, int16 actions).
-Tolerance: every gradient tensor within 2e-3 of its largest element (fp32, different summation orders) -- unless the float64 run itself sits
-on a KINK of the loss: a ReLU pre-activation or a min / max gap of normalize_hidden_state within 2e-6 of a tie (`_KinkProbe`).  There a float32
-evaluation may take the other branch, and everything upstream of that element differs by its contribution: PyTorch-ROCm's own float32 autograd
-differs from its float64 run by 1e-2 .. 7e-2 on such batches (tools/dev/conv_learner_check.py prints both next to the HIP step's error; on
-kink-free batches all three agree to 1e-5).  Kinked cases are held to 8e-2 and counted: most of the small geometries below must be kink-free."""
+Tolerance (round 6): the float64 reference is told what the HIP forward pass DECIDED -- every ReLU mask, every arg-min / arg-max of
+normalize_hidden_state, read back through the library's diagnostic hook (tests/forced_masks.py) -- and takes the same branches, so a float32
+pass and a float64 pass are compared on ONE piecewise-linear function: every gradient tensor of every geometry, seeded RANDOM weights, within
+1e-4 of its largest entry (measured 4e-5 and below; plain float64 autograd, which decides for itself, differs by 1e-2 .. 1.5e-1 wherever a
+pre-activation lies within float32 rounding of zero -- the 8e-2 "kinked" bar and the KNOWN_KINKED_SET of rounds 4-5 are gone).  At full size
+(the C5 net, batch 128: 8-block train-mode BatchNorm towers) float32 rounding itself reaches 1.6e-3 in PyTorch-ROCm's own float32 autograd
+on the same branch; the kernels are held to 4 x that yardstick there (the factor the kink-free tests use) (measured 2.3e-3).  The kink-free weight construction is kept as an
+independent second check (no read-back of the library's tensors involved)."""
 import copy
 import os
 
@@ -140,29 +143,51 @@ GEOMETRIES = [(3, 16, 2, 9, 4, False), (5, 8, 1, 5, 7, False), (9, 8, 1, 9, 6, F
               (10, 8, 1, 2, 4, False), (12, 16, 1, 2, 3, False), (14, 8, 1, 3, 2, False), (15, 8, 1, 2, 2, False), (5, 256, 1, 3, 6, False)]
 
 
-KINKS = {}
+SAME_BRANCH_TOL = 1e-4  # of each gradient tensor's largest entry, random weights, against float64 on the HIP pass's own branch (measured: 4e-5 and below)
+
+
+def _same_branch(hl, net, tr, w, B, K, dev, want_grads=False):
+    """float64 autograd told what the HIP forward pass decided at every ReLU and every normalisation (tests/forced_masks.py), PyTorch-ROCm's
+    float32 on the same branch as the yardstick of what float32 reaches; returns (errors per tensor, torch-float32 errors per tensor, loss,
+    priorities, ReLU decisions that the float64 pass would have taken differently)."""
+    from forced_masks import forced_f64, hip_decisions, tensor_errors
+
+    masks, norms = hip_decisions(hl, net, B, K)
+    loss_d, prio_d, gd, flipped = forced_f64(net, tr._replace(state=tr.state.astype(np.float64)), w, dev, masks, norms)
+    _, _, g32, _ = forced_f64(net, tr._replace(state=tr.state.astype(np.float32)), w, dev, masks, norms, dtype=torch.float32)
+    out = (tensor_errors(gd, hl.grad_views), tensor_errors(gd, g32), loss_d, prio_d, flipped)
+    return out + (gd,) if want_grads else out
+
+
+def same_branch_bar(errs, err32, flat=SAME_BRANCH_TOL):
+    """(tensor, error, bar) of the worst offender: every tensor within `flat` of its largest entry -- or, where deep train-mode BatchNorm towers
+    at a large batch amplify float32 rounding beyond that, within 4 x the worst error PyTorch-ROCm's own float32 autograd shows ON THE SAME
+    BRANCH (C5 net at batch 128: PyTorch 1.6e-3, the kernels 2.3e-3; small geometries: both below 5e-5)."""
+    bar = max(flat, 4.0 * max(err32.values()))
+    k = max(errs, key=errs.get)
+    return k, errs[k], bar
 
 
 @pytest.mark.parametrize('board,planes,blocks,chan,B,int8_state', GEOMETRIES, ids=[f'b{g[0]}-p{g[1]}-r{g[2]}-n{g[4]}' for g in GEOMETRIES])
 def test_gradient_matches_float64_autograd(board, planes, blocks, chan, B, int8_state):
+    """Seeded RANDOM weights (full-strength element-wise ReLU masks), every geometry, no kink allowance (round 6): the float64 reference takes the
+    branches the HIP forward pass took, so what is left is rounding -- every gradient tensor within 1e-4 of its largest entry."""
     dev = torch.device('cuda', 0)
     net, A = _net(board, planes, blocks, chan, 100 + board, dev)
     net.train()
     rs = np.random.RandomState(board * 7 + B)
     tr = _batch(rs, B, (chan, board, board), A, int8_state=int8_state)
     w = rs.uniform(0.3, 1.0, B).astype(np.float32)
-    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    # the running statistics and the loss do not depend on the branch to first order: plain float64 autograd
+    loss_p, prio_p, _, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
     hl = _hip(net, dev, B)
     loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
-    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
-    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4)
-    kinked = closest < 2e-6
-    KINKS[(board, planes, blocks, B)] = kinked
-    tol = 8e-2 if kinked else 2e-3
-    for k, g in gd.items():
-        scale = max(1e-8, float(g.abs().max()))
-        err = float((g - hl.grad_views[k].double()).abs().max())
-        assert err <= tol * scale, (k, err, scale, 'closest pre-activation / gap to a tie', closest)
+    assert abs(float(loss) - loss_p) <= 1e-4 * max(1.0, abs(loss_p))
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_p.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    errs, err32, loss_d, prio_d, flipped = _same_branch(hl, net, tr, w, B, 5, dev)
+    assert abs(float(loss) - loss_d) <= 2e-6 * max(1.0, abs(loss_d))
+    k, e, bar = same_branch_bar(errs, err32)
+    assert e <= bar, (k, e, bar, 'decisions float64 would have taken differently:', flipped, 'closest pre-activation / gap to a tie', closest)
     sd = net.state_dict()  # the train-mode forward pass has updated the running statistics (network.py:283-291), one step per application
     for k, v in sd_d.items():
         if 'running' in k:
@@ -182,32 +207,17 @@ def test_other_unroll_lengths(K):
     B = 5
     tr = _batch(rs, B, (3, 5, 5), A, K=K)
     w = rs.uniform(0.3, 1.0, B).astype(np.float32)
-    loss_d, prio_d, gd, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
+    loss_p, _, _, sd_d, closest = _f64_reference(net, tr._replace(state=tr.state.astype(np.float64)), w, dev)
     hl = _hip(net, dev, B, K=K)
     loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
-    assert abs(float(loss) - loss_d) <= 1e-4 * max(1.0, abs(loss_d))
-    tol = 8e-2 if closest < 2e-6 else 2e-3
-    for k, g in gd.items():
-        scale = max(1e-8, float(g.abs().max()))
-        assert float((g - hl.grad_views[k].double()).abs().max()) <= tol * scale, (k, K, closest)
+    assert abs(float(loss) - loss_p) <= 1e-4 * max(1.0, abs(loss_p))
+    errs, err32, _, _, flipped = _same_branch(hl, net, tr, w, B, K, dev)
+    k, e, bar = same_branch_bar(errs, err32)
+    assert e <= bar, (k, e, bar, K, flipped)
     sd = net.state_dict()
     for k, v in sd_d.items():
         if 'num_batches_tracked' in k:
             assert int(v) == int(sd[k]), k
-
-
-# the geometries above that sit on a kink (and are held to 8e-2 only) are pinned -- a geometry outside this list that needs the
-# loose bar fails -- and every geometry has a kink-free twin below that is held to the tight bar with no allowance.
-KNOWN_KINKED_SET = {(5, 256, 1, 6), (7, 40, 1, 33), (9, 32, 3, 64), (11, 8, 2, 9), (15, 8, 1, 2), (15, 16, 1, 3), (15, 32, 2, 10)}  # (board, planes, blocks, batch)
-
-
-def test_most_small_geometries_were_kink_free():
-    """The loose tolerance must stay the exception: of the cases above at least eight ran under the 2e-3 bar, and the kinked ones are the known ones."""
-    if len(KINKS) < len(GEOMETRIES):
-        pytest.skip('runs after the parametrised cases')
-    print('kinked:', sorted(k for k, v in KINKS.items() if v))
-    assert sum(1 for v in KINKS.values() if not v) >= 8, KINKS
-    assert {k for k, v in KINKS.items() if v} <= KNOWN_KINKED_SET, KINKS
 
 
 @pytest.mark.parametrize('board,planes,blocks,chan,B,int8_state', GEOMETRIES, ids=[f'b{g[0]}-p{g[1]}-r{g[2]}-n{g[4]}' for g in GEOMETRIES])
@@ -338,6 +348,46 @@ def test_errors_are_loud():
         hl.grad({k: v.cpu() for k, v in _ring(tr, dev).items()}, None, None, 4)
     with pytest.raises(LearnerError):
         hl.grad(_ring(tr, dev), None, None, 5)  # > max_batch
+
+
+def test_full_size_c5_net_at_batch_128_random_weights():
+    """VERDICT r5 #2: the C5 network at make_gomoku_config's batch size with seeded RANDOM weights -- the NPT = 15 build, 16 weight-gradient chunks,
+    XCD remap and paired launches under full-strength element-wise masks -- against float64 autograd on the HIP pass's own branch
+    (tests/forced_masks.py)."""
+    dev = torch.device('cuda', 0)
+    board, planes, blocks, chan, B = 15, 128, 8, 9, 128
+    net, A = _net(board, planes, blocks, chan, 177, dev)
+    net.train()
+    rs = np.random.RandomState(6)
+    tr = _batch(rs, B, (chan, board, board), A, int8_state=True)
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    hl = _hip(net, dev, B)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    errs, err32, loss_d, prio_d, flipped = _same_branch(hl, net, tr, w, B, 5, dev)
+    assert abs(float(loss) - loss_d) <= 3e-5 * max(1.0, abs(loss_d))
+    np.testing.assert_allclose(prio.cpu().numpy(), prio_d.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    k, e, bar = same_branch_bar(errs, err32)
+    print('C5 net, batch 128, random weights: worst tensor', k, '%.2e' % e, 'bar %.2e' % bar, '(PyTorch-ROCm float32 on the same branch: %.2e);' % max(err32.values()),
+          flipped, 'ReLU decisions differ from float64\'s own')
+    assert e <= bar and bar <= 1e-2, (k, e, bar)
+    assert flipped > 0  # (at this size some pre-activation always sits on a kink: the case the plain comparison could not hold tightly)
+
+
+@pytest.mark.parametrize('board,planes,blocks,chan,B', [(15, 128, 2, 9, 64), (15, 128, 4, 9, 96), (9, 128, 3, 9, 128)], ids=['b15-p128-r2-n64', 'b15-p128-r4-n96', 'b9-p128-r3-n128'])
+def test_wide_nets_at_large_batches_random_weights(board, planes, blocks, chan, B):
+    """VERDICT r5 #5: random-weight board-net cases at 128 planes and batches >= 64 (the small geometries stop at 32 planes / batch 64)."""
+    dev = torch.device('cuda', 0)
+    net, A = _net(board, planes, blocks, chan, 500 + board + blocks, dev)
+    net.train()
+    rs = np.random.RandomState(board + B)
+    tr = _batch(rs, B, (chan, board, board), A)
+    w = rs.uniform(0.3, 1.0, B).astype(np.float32)
+    hl = _hip(net, dev, B)
+    loss, prio = hl.grad(_ring(tr, dev), None, torch.from_numpy(w).to(dev), B)
+    errs, err32, loss_d, prio_d, flipped = _same_branch(hl, net, tr, w, B, 5, dev)
+    assert abs(float(loss) - loss_d) <= 3e-5 * max(1.0, abs(loss_d))
+    k, e, bar = same_branch_bar(errs, err32)
+    assert e <= bar and bar <= 5e-3, (k, e, bar, flipped)
 
 
 def test_full_size_c5_net_at_batch_128_kink_free():

@@ -25,11 +25,13 @@ def main():
     net = build_mlp(mlp_case(g))
     B, S = 4096, 25 if board else 50
     kw = dict(num_simulations=S, discount=1.0 if board else 0.997, is_board_game=board, known_bounds=(-1.0, 1.0) if board else None)
+    if g == 'lunar':  # the LunarLander-shaped leg of bench.py: four actions, the classic-control net, synthetic env
+        kw.update(root_dirichlet_alpha=0.25, root_exploration_eps=0.25)
     if len(sys.argv) > 2 and sys.argv[2] == 'nonoise':
         kw['root_dirichlet_alpha'] = 0.0  # root prior without Dirichlet sampling: isolates its cost in the root phase
     p = pl.Planner(pl.make_mz_config(net.planner_spec(), None, num_envs=B, **kw), 0)
     p.load_state_dict(net.state_dict())
-    p.selfplay_reset(pl.ENV_TICTACTOE if board else pl.ENV_CARTPOLE)
+    p.selfplay_reset(pl.ENV_TICTACTOE if board else (pl.ENV_SYNTHETIC if g == 'lunar' else pl.ENV_CARTPOLE))
     p.selfplay_step(-1.0 if board else 1.0, 5)
     p.lib.mz_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     tot = np.zeros(16)
