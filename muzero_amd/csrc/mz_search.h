@@ -127,10 +127,14 @@ __device__ __forceinline__ long long ts_now() {
 // (phase sums accumulate in global memory with return-less atomics, not in registers: 16 64-bit accumulators per thread pushed the
 // 8-wave kernels -- 256 registers per wave -- into VGPR spills that distorted exactly the phases being timed)
 __device__ long long g_stamp_acc[16];
-#define MZ_STAMP_DECL long long _t0 = 0;
+// round 6: every workgroup's own duration (cycles from its first to its last instruction) and start offset, last launch: how far apart do the 256
+// workgroups of a move finish?  (a kernel ends with its slowest workgroup)
+__device__ long long g_wg_cyc[2048];
+#define MZ_STAMP_DECL long long _t0 = 0; const long long _wg0 = (long long)__builtin_readcyclecounter();
 #define MZ_STAMP_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) _t0 = __builtin_readcyclecounter(); } while (0)
 #define MZ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t1 = __builtin_readcyclecounter(); atomicAdd(reinterpret_cast<unsigned long long*>(&g_stamp_acc[i]), (unsigned long long)(_t1 - _t0)); _t0 = _t1; } } while (0)
-#define MZ_STAMP_FLUSH(P) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) { __threadfence(); for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = (long long)atomicExch(reinterpret_cast<unsigned long long*>(&g_stamp_acc[_i]), 0ULL); } } while (0)
+#define MZ_STAMP_FLUSH(P) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_wg_cyc[blockIdx.x] = (long long)__builtin_readcyclecounter() - _wg0; g_wg_cyc[1024 + blockIdx.x] = _wg0; } \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (P).stamps) { __threadfence(); for (int _i = 0; _i < 16; _i++) (P).stamps[_i] = (long long)atomicExch(reinterpret_cast<unsigned long long*>(&g_stamp_acc[_i]), 0ULL); } } while (0)
 #else
 #define MZ_COUNT(i, v) do {} while (0)
 #define MZ_SUB_DECL

@@ -46,9 +46,6 @@
 //     of every path node (each lane loops over its node's actions) are lane-parallel.
 #pragma once
 
-#ifndef MZ_CHAIN_BCAST
-#define MZ_CHAIN_BCAST 1  // tree2_backup's value recurrence: every lane runs the chain on row-broadcast terms (0: round 5's DPP shift chain)
-#endif
 
 struct __attribute__((aligned(16))) Node2 {  // 16 bytes: one ds_read_b128
     double W;
@@ -478,42 +475,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
         // (the term a lane adds is fixed: fold the sign choice once; exit test every 4 levels only -- a wave-level branch per
         // level costs as much as the level's arithmetic)
         const double sprw = (board && psame) ? -prw : prw;
-#if MZ_CHAIN_BCAST
-        // round 6: EVERY lane of the env runs the whole recurrence -- the term of level t comes from lane t by a row broadcast
-        // (v_mov_b64_dpp row_newbcast: one instruction for the 64-bit value, no wait states behind a VALU result because the source is
-        // the fixed term, not the running value) -- and lane t keeps the value after level t: broadcast, multiply, add, two selects
-        // per level, where the shift chain paid two destination pre-loads, a wait state, two 32-bit DPP moves, multiply, add and
-        // two selects (9 issue slots of 5.8 cycles on a wave that runs alone).  Same operations on the same operands in the same
-        // order: the values are the reference's (mcts.py:152-155).
-        {
-            double x = val_in;  // the running value: identical in the env's 16 lanes
-            auto levels4 = [&](auto t0_tag) {
-                constexpr int T0 = decltype(t0_tag)::value;
-                double b0, b1, b2, b3;
-                asm("s_nop 1\n\t"
-                    "v_mov_b64_dpp %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                    "v_mov_b64_dpp %1, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                    "v_mov_b64_dpp %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
-                    "v_mov_b64_dpp %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
-                    : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
-                    : "v"(sprw), "n"(T0), "n"(T0 + 1), "n"(T0 + 2), "n"(T0 + 3 < 16 ? T0 + 3 : 15));
-                x = b0 + g * x; val = (a0 == T0) ? x : val;
-                x = b1 + g * x; val = (a0 == T0 + 1) ? x : val;
-                x = b2 + g * x; val = (a0 == T0 + 2) ? x : val;
-                if constexpr (T0 + 3 < 16) { x = b3 + g * x; val = (a0 == T0 + 3) ? x : val; }
-            };
-            if (__any(1 <= steps)) {
-                levels4(std::integral_constant<int, 1>{});
-                if (__any(5 <= steps)) {
-                    levels4(std::integral_constant<int, 5>{});
-                    if (__any(9 <= steps)) {
-                        levels4(std::integral_constant<int, 9>{});
-                        if (__any(13 <= steps)) levels4(std::integral_constant<int, 13>{});
-                    }
-                }
-            }
-        }
-#else
         for (int t0 = 1; t0 < 16 && __any(t0 <= steps); t0 += 4) {
 #pragma unroll
             for (int t = t0; t < t0 + 4; t++) {
@@ -522,7 +483,6 @@ __device__ __forceinline__ int tree2_backup(unsigned char* smem, const SearchPar
                 val = (a0 == t) ? cand : val;
             }
         }
-#endif
         MZ_TS(1);  // [1] backup: value chain
         if (valid) {
             const double W = W0 + (same ? val : -val);

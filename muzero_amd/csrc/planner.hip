@@ -1175,6 +1175,18 @@ extern "C" int mz_debug_read_stamps(mz_planner* p, long long out[16]) {
 }
 
 // diagnostic builds only (-DMZ_STAMPS): register-accumulated segment stamps of tree2_select [0..11] and tree2_backup [12..23]
+// diagnostic (stamps build): every workgroup's duration [0..1023] and start stamp [1024..2047] of the last search launch
+extern "C" int mz_debug_read_wg_cycles(mz_planner* p, long long out[2048]) {
+    if (!p || !out) return fail(MZ_E_INVALID, "null argument");
+    for (int i = 0; i < 2048; i++) out[i] = 0;
+#ifdef MZ_STAMPS
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(mz::g_wg_cyc), 2048 * sizeof(long long)));
+#endif
+    return MZ_OK;
+}
+
 extern "C" int mz_debug_read_tree_stamps(mz_planner* p, long long out[32]) {
     if (!p || !out) return fail(MZ_E_INVALID, "null argument");
     for (int i = 0; i < 32; i++) out[i] = 0;

@@ -164,16 +164,17 @@ def forced_f64(net, tr, w, dev, masks, norms, dtype=torch.float64):
 
 
 def tensor_errors(gd, views):
-    """Per gradient tensor: max |difference| over the tensor's largest entry (no floor but the float64 gradient's own scale: a tensor whose exact
-    gradient is zero up to rounding -- a tower's last BatchNorm shift, cancelled by the next layer's batch statistics -- is measured against the
-    largest entry of its own network part instead)."""
+    """Per gradient tensor: max |difference| over the tensor's largest entry -- but no finer than 1e-2 of the largest entry of its network part
+    (representation / dynamics / prediction): a tensor whose exact gradient nearly cancels (a tower's last BatchNorm shift, cancelled by the
+    next layer's batch statistics; the one-element bias of an MSE head on a balanced batch: 2e-5 beside entries of 0.2) is measured against the
+    gradients around it -- 1e-4 of that floor is 1e-6 of the part's largest gradient, a dozen float32 ulps."""
     part_max = {}
     for k, g in gd.items():
         part = k.split('.')[0]
         part_max[part] = max(part_max.get(part, 0.0), float(g.abs().max()))
     errs = {}
     for k, g in gd.items():
-        own = float(g.abs().max())
-        scale = own if own > 1e-6 * part_max[k.split('.')[0]] else part_max[k.split('.')[0]]
+        pm = part_max[k.split('.')[0]]
+        scale = pm if g.numel() == 1 else max(float(g.abs().max()), 1e-2 * pm)  # (a one-element tensor -- an MSE head's bias -- has no 'largest entry' of its own)
         errs[k] = float((g - views[k].double()).abs().max()) / max(scale, 1e-300)
     return errs

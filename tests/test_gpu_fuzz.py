@@ -546,7 +546,14 @@ def test_random_conv_learner_configuration_matches_float64_autograd(i):
         # Adam's first step moves every weight by ~lr whatever the gradient's size: elements whose gradient is at rounding distance from 0 may go
         # the other way in float32 -- a mean bar for the tensor, and a 2 lr bar for single elements
         d = (p.double() - q).abs()
-        assert float(d.mean()) <= 0.02 * max(moved, 1e-12) + 1e-7 and float(d.max()) <= 2.2 * o['lr'] + 1e-6, (c, k, float(d.mean()), float(d.max()), moved)
+        assert float(d.max()) <= 2.2 * o['lr'] + 1e-6, (c, k, float(d.max()), moved)
+        # (the mean bar over the elements whose gradient has a SIGN in float32: a tensor whose exact gradient cancels -- the BatchNorm shift in
+        # front of a train-mode BatchNorm, entries 1e-8 of their neighbours -- steps by +- lr at random in any float32 pass; rounds 4-5 never got
+        # here on the third of the cases they called kinked)
+        part_max = max(float(g.abs().max()) for kk, g in gd.items() if kk.split('.')[0] == k.split('.')[0])
+        sure = gd[k].abs() > 1e-5 * part_max
+        if bool(sure.any()):
+            assert float(d[sure].mean()) <= 0.02 * max(moved, 1e-12) + 1e-7, (c, k, float(d[sure].mean()), moved, int(sure.sum()), sure.numel())
 
 
 @pytest.mark.parametrize('i', range(CONV_LEARN_CASES_N))
