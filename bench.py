@@ -271,7 +271,7 @@ def configs_leg(args, rank, local_rank, world, torch, dist, red_dev):
     return out
 
 
-PROFILE_ROUND = 'round5'
+PROFILE_ROUND = 'round6'
 
 
 def lunar_leg(rank, local_rank, world, torch, dist, red_dev, steps=100, warm=20, preheat=100):
