@@ -57,21 +57,22 @@ def run(net, tr, w, B, K, tag):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'board'
+SEEDS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]  # extra seeds for the full-size cases
 if which in ('board', 'c5'):
     from muzero_amd.network import MuZeroBoardGameNet
-    cases = [(9, 32, 3, 9, 64, 5), (15, 32, 2, 9, 10, 5), (5, 8, 1, 5, 7, 5)] if which == 'board' else [(15, 128, 8, 9, 128, 5)]
-    for board, planes, blocks, chan, B, K in cases:
+    cases = [(9, 32, 3, 9, 64, 5, 0), (15, 32, 2, 9, 10, 5, 0), (5, 8, 1, 5, 7, 5, 0)] if which == 'board' else [(15, 128, 8, 9, 128, 5, sd) for sd in SEEDS]
+    for board, planes, blocks, chan, B, K, sd in cases:
         A = board * board + 1
         net = MuZeroBoardGameNet((chan, board, board), A, blocks, planes)
-        net.load_state_dict(seeded_state_dict(net, 300 + board))
-        rs = np.random.RandomState(board)
+        net.load_state_dict(seeded_state_dict(net, 300 + board + 1000 * sd))
+        rs = np.random.RandomState(board + 1000 * sd)
         tr = Transition(rs.uniform(0, 1, (B, chan, board, board)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int16 if A > 128 else np.int8),
                         rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
         w = rs.uniform(0.3, 1.0, B).astype(np.float32)
-        run(net, tr, w, B, K, f'board {board} planes {planes} blocks {blocks} batch {B}')
+        run(net, tr, w, B, K, f'board {board} planes {planes} blocks {blocks} batch {B} seed {sd}')
 else:
     from muzero_amd.network import MuZeroAtariNet
-    cases = [(4, 8, 1, 6, 11, 11, 3, 5, 3), (4, 16, 2, 18, 61, 31, 5, 5, 1), (2, 40, 1, 9, 21, 21, 4, 4, 6)] if which == 'atari' else [(4, 128, 8, 6, 61, 61, 128, 5, 11)]
+    cases = [(4, 8, 1, 6, 11, 11, 3, 5, 3), (4, 16, 2, 18, 61, 31, 5, 5, 1), (2, 40, 1, 9, 21, 21, 4, 4, 6)] if which == 'atari' else [(4, 128, 8, 6, 61, 61, 128, 5, 11 + 100 * sd) for sd in SEEDS]
     for chan, planes, blocks, A, vs, rs_, B, K, seed in cases:
         net = MuZeroAtariNet((chan, 96, 96), A, blocks, planes, vs, rs_)
         net.load_state_dict(seeded_state_dict(net, 100 + seed))
@@ -79,4 +80,4 @@ else:
         tr = Transition(rs.uniform(0, 1, (B, chan, 96, 96)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8),
                         rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32), (rs.uniform(-1, 1, (B, K)) * 8.0).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
         w = rs.uniform(0.3, 1.0, B).astype(np.float32)
-        run(net, tr, w, B, K, f'atari planes {planes} blocks {blocks} batch {B}')
+        run(net, tr, w, B, K, f'atari planes {planes} blocks {blocks} batch {B} seed {seed}')
