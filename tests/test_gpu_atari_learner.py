@@ -355,6 +355,34 @@ def test_ring_by_index_and_repeat_are_bit_identical():
     assert torch.equal(g1, hl.grad_flat) and torch.equal(l1, l3)
 
 
+def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
+    """Round 6: the tiled stages' stride-1 convolutions stage the tile WITH its halo and compute the inner 12 x 12 / 12 x 16 outputs only (`halo_in`,
+    a quarter fewer MFMAs); every output is the same chain in the same order as in round 5's whole-tile form (`MZLC_NO_HALO_IN=1`), so loss,
+    priorities and the whole gradient vector are the same BITS."""
+    import os
+
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(21)
+    B, K, A = 3, 5, 4  # (conv_case('atari_m'): 8 x 96 x 96 frames, 4 actions, 16 planes, 2 blocks)
+    tr = Transition(rs.uniform(0, 1, (B, 8, 96, 96)).astype(np.float32), rs.randint(0, A, (B, K)).astype(np.int8), rs.dirichlet(np.ones(A), size=(B, K)).astype(np.float32),
+                    rs.uniform(-5, 5, (B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(0.3, 1, B).astype(np.float32)).to(dev)
+    out = []
+    for flag in (None, '1'):
+        if flag:
+            os.environ['MZLC_NO_HALO_IN'] = flag
+        try:
+            net = build_conv(conv_case('atari_m')).to(dev)
+            net.train()
+            hl = _hip(net, dev, 4)
+            loss, prio = hl.grad(_ring(tr, dev), None, w, B)
+            out.append((loss.clone(), prio.clone(), hl.grad_flat.clone()))
+            hl.close()
+        finally:
+            os.environ.pop('MZLC_NO_HALO_IN', None)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
 def test_checkpoint_round_trip_and_planner_epoch():
     """state_dict() / optimizer_state_dict() of a stepped Atari learner restore into a fresh one that then takes bit-identical steps; every
     commit bumps the weights epoch the planner's cache keys on."""
