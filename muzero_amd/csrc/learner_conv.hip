@@ -192,6 +192,7 @@ struct mzlc_learner {
     bool bad_dispatch = false;  // a launch found no kernel build for its job (reported by mzlc_grad: never silently skipped)
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     bool halo_in = true;      // the tiled stages' stride-1 convs compute the inner positions of a tile only (MZLC_NO_HALO_IN=1 at create: whole haloed tiles)
+    bool ring_rows = true;    // the tiled stages' weight gradients reduce over the inner rows of a tile only (MZLC_NO_RING_ROWS=1 at create: all rows, ring zeroed)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
 
@@ -816,6 +817,13 @@ struct AtariRun {
         s.wgrad_ops(ops, Lw, dy_tiles, dy_tiles, h->coef_ident, x_tiles, IN_IDENT, nullptr, nullptr, 0);
         ops[0].wg.ring_zero = 1;
         ops[0].wg.cpad_out = pad16(h->P > 128 ? h->P : 128);  // (the stride of coef_ident's rows)
+        if (h->ring_rows && ops[0].wg.sg == 1) {  // the dy plane without the tile's first and last row (all ring): h - 2 rows of positions to reduce over
+            LcWgrad& g = ops[0].wg;
+            g.ring_rows = 1;
+            g.nsteps = cdiv((g.h - 2) * g.P4, 16);
+            g.SPY = 16 * g.nsteps + 4;
+            g.SPX = 2 * g.P4 + 16 * g.nsteps + 12;
+        }
         if (tapmap) {
             ops[1].wr.use_map = 1;
             int mask = 0;
@@ -1020,6 +1028,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->xcd_remap = !getenv("MZLC_NO_XCD_REMAP");
     h->par_compact = !getenv("MZLC_NO_TAPSETS");
     h->halo_in = !getenv("MZLC_NO_HALO_IN");
+    h->ring_rows = !getenv("MZLC_NO_RING_ROWS");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };

@@ -450,6 +450,9 @@ struct LcWgrad {
     int sg_cols;           // 1: the round's images side by side (column offset gi (w + 1)); 0: stacked vertically (row offset gi (h + 1))
     int tapmask;           // 0 / 0x1ff: all nine taps; else only these accumulators exist (a parity plane of a stride-2 conv; see k_lc_conv's TAPMASK)
     int ring_zero;         // 1: the outermost ring of every dy image is multiplied by 0 (tiles gathered with their halo: only the inner pixels are outputs)
+    int ring_rows;         // round 6, with ring_zero: 1: the dy plane holds rows 1 .. h - 2 only -- the first and last row of a haloed tile are all ring, i.e. all
+                           // zeros, and were 2 P4 of the reduction's positions (18 -> 15 steps of 16 positions for a 14 x 18 tile, 14 -> 12 for 14 x 14) --
+                           // and the x plane's "zero row above / below" slots carry the tile's real rows 0 and h - 1.  nsteps / SPY / SPX are those of h - 2 rows.
 };
 
 // ACT: the layer has action-plane input channels (the dynamics net's first conv); the other builds carry none of that code.
@@ -503,12 +506,19 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const int p0 = (s_ok ? ql : 0) * 4;
     int spos[4], pm[4];
     float ym[4];
+    bool sx_ok[4], sy_ok[4];  // this element is stored in the x / dy planes
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
         spos[e] = (s_ok && pp < hw) ? (L.sg_cols ? py * L.P4 + gi * (L.w_img + 1) + px : (gi * (L.h + 1) + py) * L.P4 + px) : -1;  // + P4 + 4 in the x planes (one zero row above, the margin)
         pm[e] = ACT ? pp % L.num_actions : 0;
         ym[e] = (RING && (py == 0 || px == 0 || py == L.h - 1 || px == L.w_img - 1)) ? 0.0f : 1.0f;
+        sx_ok[e] = spos[e] >= 0;
+        sy_ok[e] = sx_ok[e];
+        if (RING && L.ring_rows) {  // (one image per round: the launcher checks) row py of the tile is row py - 1 of the planes; rows 0 and h - 1 exist in x only
+            sy_ok[e] = sx_ok[e] && py >= 1 && py <= L.h - 2;
+            spos[e] -= L.P4;
+        }
     }
     float4 rdz[8], ry[8], rx[8];
     int r_act = -1;
@@ -580,14 +590,15 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         float* dx_ = s_x + L.P4 + 4;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            if (spos[e] >= 0) {
+            if (sx_ok[e]) {
                 float* py = s_y + spos[e] + wave * L.SPY;
                 float* px = dx_ + spos[e] + wave * L.SPX;
+                if (!RING || sy_ok[e]) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    py[4 * k * L.SPY] = vy[k][e];
-                    px[4 * k * L.SPX] = vx[k][e];
+                    for (int k = 0; k < 8; k++) py[4 * k * L.SPY] = vy[k][e];
                 }
+#pragma unroll
+                for (int k = 0; k < 8; k++) px[4 * k * L.SPX] = vx[k][e];
             }
         }
     };
