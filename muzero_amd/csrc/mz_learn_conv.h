@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const int p0 = (s_ok ? ql : 0) * 4;
     int spos[4], pm[4];
     float ym[4];
-    bool sx_ok[4], sy_ok[4];  // this element is stored in the x / dy planes
+    bool sx_ok[4];  // this element is staged
+    int sposy[4];   // its position in the dy plane (ring_rows: the plane's spare tail for the rows that have none)
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int pp = p0 + e, py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
@@ -514,10 +515,10 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         pm[e] = ACT ? pp % L.num_actions : 0;
         ym[e] = (RING && (py == 0 || px == 0 || py == L.h - 1 || px == L.w_img - 1)) ? 0.0f : 1.0f;
         sx_ok[e] = spos[e] >= 0;
-        sy_ok[e] = sx_ok[e];
+        sposy[e] = spos[e];
         if (RING && L.ring_rows) {  // (one image per round: the launcher checks) row py of the tile is row py - 1 of the planes; rows 0 and h - 1 exist in x only
-            sy_ok[e] = sx_ok[e] && py >= 1 && py <= L.h - 2;
             spos[e] -= L.P4;
+            sposy[e] = (py >= 1 && py <= L.h - 2) ? spos[e] : 16 * L.nsteps;
         }
     }
     float4 rdz[8], ry[8], rx[8];
@@ -590,15 +591,16 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         float* dx_ = s_x + L.P4 + 4;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
+            // (the loop of round 5, unconditional stores: a per-store predicate here cost the board net's update 6 % when it was tried.  ring_rows: the
+            // tile's rows 0 and h - 1 have no dy slot -- their dy values, zeros, go to the plane's unused 4-float tail at 16 nsteps)
             if (sx_ok[e]) {
-                float* py = s_y + spos[e] + wave * L.SPY;
+                float* py = s_y + sposy[e] + wave * L.SPY;
                 float* px = dx_ + spos[e] + wave * L.SPX;
-                if (!RING || sy_ok[e]) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) py[4 * k * L.SPY] = vy[k][e];
+                for (int k = 0; k < 8; k++) {
+                    py[4 * k * L.SPY] = vy[k][e];
+                    px[4 * k * L.SPX] = vx[k][e];
                 }
-#pragma unroll
-                for (int k = 0; k < 8; k++) px[4 * k * L.SPX] = vx[k][e];
             }
         }
     };

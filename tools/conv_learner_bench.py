@@ -62,6 +62,9 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / n
 
+    from muzero_amd import hip_learner as _hl
+    if os.environ.get('MZL_LIB_PATH'):  # A/B runs: another build of the learner library (tools/dev/halo_ab.sh)
+        _hl.LIB_PATH = os.environ['MZL_LIB_PATH']
     from muzero_amd.hip_learner import HipLearner, atari_learner_flops, conv_learner_flops
 
     net_h = copy.deepcopy(net_a)
