@@ -178,7 +178,7 @@ struct mzlc_learner {
     std::vector<int> l_b1, l_b2;  // the 4 convs of res_blocks_1 (48 x 48, 128 planes) / res_blocks_2 (24 x 24, num_planes)
     TowerInfo t12;                // res_blocks_3 (12 x 12): the fused whole-image path
     AppBufs a12;
-    struct StageBufs { std::vector<float*> y, h1, x, fcoef, save, bcoef; float *dzA = nullptr, *dzB = nullptr, *gF = nullptr; };
+    struct StageBufs { std::vector<float*> y, h1, x, fcoef, save, bcoef, xt; float *dzA = nullptr, *dzB = nullptr, *gF = nullptr; };  // xt: the forward convs' gathered input tiles, kept for the weight gradient (round 6)
     StageBufs sb48, sb24;
     float *y_c1 = nullptr, *a1 = nullptr, *y_c2 = nullptr, *a2 = nullptr, *p1 = nullptr, *hraw = nullptr, *g12in = nullptr, *dH = nullptr;
     float *TA = nullptr, *TB = nullptr, *TC = nullptr;      // tile buffers
@@ -193,6 +193,8 @@ struct mzlc_learner {
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     bool halo_in = true;      // the tiled stages' stride-1 convs compute the inner positions of a tile only (MZLC_NO_HALO_IN=1 at create: whole haloed tiles)
     bool ring_rows = true;    // the tiled stages' weight gradients reduce over the inner rows of a tile only (MZLC_NO_RING_ROWS=1 at create: all rows, ring zeroed)
+    bool keep_tiles = true;   // the forward pass's gathered input tiles stay in HBM (0.8 GB at batch 128) and ARE the weight gradient's x operand
+                              // (MZLC_NO_KEEP_TILES=1 at create: gathered again in the backward pass, round 5's form; same bits)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
 };
 
@@ -844,13 +846,15 @@ struct AtariRun {
         const float* cur = x_in;
         for (int r = 0; r < 2; r++) {
             const LayerInfo &L1 = h->layers[lay[2 * r]], &L2 = h->layers[lay[2 * r + 1]];
-            gather(cur, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
-            conv_tiles(L1, false, H, W, h->TA, h->TB);
+            float* xa = h->keep_tiles ? sb.xt[2 * r] : h->TA;      // (kept: the backward pass's weight gradient multiplies these very tiles)
+            float* xb = h->keep_tiles ? sb.xt[2 * r + 1] : h->TA;
+            gather(cur, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, xa);
+            conv_tiles(L1, false, H, W, xa, h->TB);
             int ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
             bn_fwd(L1, sb.fcoef[2 * r], sb.save[2 * r], ng, count);
             apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
-            gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
-            conv_tiles(L2, false, H, W, h->TA, h->TB);
+            gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, xb);
+            conv_tiles(L2, false, H, W, xb, h->TB);
             ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
             bn_fwd(L2, sb.fcoef[2 * r + 1], sb.save[2 * r + 1], ng, count);
             apply(sb.y[2 * r + 1], cur, sb.fcoef[2 * r + 1], sb.x[r], C, hw);
@@ -867,15 +871,15 @@ struct AtariRun {
             const float* xin_blk = r > 0 ? sb.x[r - 1] : x_in;
             bn_bwd(L2, sb.save[2 * r + 1], sb.bcoef[2 * r + 1], ng, count);
             gather(sb.dzA, sb.y[2 * r + 1], sb.bcoef[2 * r + 1], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
-            gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
-            wgrad_tiles(L2, C, H, W, h->TA, h->TC, nullptr);
+            if (!h->keep_tiles) gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
+            wgrad_tiles(L2, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r + 1] : h->TC, nullptr);
             conv_tiles(L2, true, H, W, h->TA, h->TB);
             scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr, halo_in());
             ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
             bn_bwd(L1, sb.save[2 * r], sb.bcoef[2 * r], ng, count);
             gather(sb.dzB, sb.y[2 * r], sb.bcoef[2 * r], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
-            gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
-            wgrad_tiles(L1, C, H, W, h->TA, h->TC, nullptr);
+            if (!h->keep_tiles) gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
+            wgrad_tiles(L1, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r] : h->TC, nullptr);
             conv_tiles(L1, true, H, W, h->TA, h->TB);
             scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr, halo_in());  // + the block's skip gradient
             if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
@@ -1029,6 +1033,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->par_compact = !getenv("MZLC_NO_TAPSETS");
     h->halo_in = !getenv("MZLC_NO_HALO_IN");
     h->ring_rows = !getenv("MZLC_NO_RING_ROWS");
+    h->keep_tiles = !getenv("MZLC_NO_KEEP_TILES");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
@@ -1173,6 +1178,12 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         };
         stage(h->sb48, n48);
         stage(h->sb24, n24);
+        if (h->keep_tiles) {  // (288 GB of HBM: the 1.2 GB of tiles per update are re-read once instead of re-gathered)
+            const size_t ts2k = (size_t)(TILE + 2) * (TILE + 2);
+            const size_t t48 = (size_t)h->maxB * (H1 / TILE) * (W1 / TILE) * 128 * ts2k, t24 = (size_t)h->maxB * (H2 / TILE) * (W2 / TILE) * P * ts2k;
+            h->sb48.xt.resize(4); h->sb24.xt.resize(4);
+            for (int i = 0; i < 4; i++) { AL(&h->sb48.xt[i], t48); AL(&h->sb24.xt[i], t24); }
+        }
         AL(&h->y_c1, n48); AL(&h->a1, n48); AL(&h->y_c2, n24); AL(&h->a2, n24); AL(&h->p1, n12); AL(&h->g12in, n12); AL(&h->hraw, h->T); AL(&h->dH, h->T);
         for (int i = 0; i < 3; i++) AL(&h->D12[i], n12);
         ok = ok && alloc_app(h, h->t12, h->a12, n12);

@@ -372,9 +372,9 @@ def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
                     rs.uniform(-5, 5, (B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
     w = torch.from_numpy(rs.uniform(0.3, 1, B).astype(np.float32)).to(dev)
     out = []
-    for flag in (None, '1'):
+    for flag in (None, 'MZLC_NO_HALO_IN', 'MZLC_NO_KEEP_TILES'):  # (NO_KEEP_TILES: the weight gradient's x tiles gathered again instead of kept from the forward pass)
         if flag:
-            os.environ['MZLC_NO_HALO_IN'] = flag
+            os.environ[flag] = '1'
         try:
             net = build_conv(conv_case('atari_m')).to(dev)
             net.train()
@@ -383,8 +383,10 @@ def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
             out.append((loss.clone(), prio.clone(), hl.grad_flat.clone()))
             hl.close()
         finally:
-            os.environ.pop('MZLC_NO_HALO_IN', None)
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+            if flag:
+                os.environ.pop(flag, None)
+    for o in out[1:]:
+        assert torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1]) and torch.equal(out[0][2], o[2])
 
 
 def test_checkpoint_round_trip_and_planner_epoch():
