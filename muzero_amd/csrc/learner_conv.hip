@@ -193,6 +193,8 @@ struct mzlc_learner {
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     bool halo_in = true;      // the tiled stages' stride-1 convs compute the inner positions of a tile only (MZLC_NO_HALO_IN=1 at create: whole haloed tiles)
     bool ring_rows = true;    // the tiled stages' weight gradients reduce over the inner rows of a tile only (MZLC_NO_RING_ROWS=1 at create: all rows, ring zeroed)
+    bool out_plane = true;    // (with halo_in) the tiled stages' stride-1 convs write their outputs straight into the plane, add the skip from there and sum the
+                              // BatchNorm statistics per tile (MZLC_NO_OUT_PLANE=1 at create: inner-only tiles + k_lc_tile_scatter)
     bool keep_tiles = true;   // the forward pass's gathered input tiles stay in HBM (0.8 GB at batch 128) and ARE the weight gradient's x operand
                               // (MZLC_NO_KEEP_TILES=1 at create: gathered again in the backward pass, round 5's form; same bits)
     int max_imgs = 0;             // images a conv / weight-gradient launch may see (batch x 16 tiles for the Atari net)
@@ -557,6 +559,11 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
             if (a->conv.tapmask && a->conv.tapmask != 0x1ff) {  // (a parity plane: built as whole-tile, identity-mode, unpaired launches only)
                 if (b || a->side15 || mode != IN_IDENT || !launch_conv_tapmask(a->npt, a->conv.tapmask, pj, grid, lds, st)) { h->bad_dispatch = true; return MZL_E_INVALID; }
             } else
+            if (a->conv.out_plane) {  // the tile path's stride-1 convs writing planes (halo_in; 12 x 12 or 12 x 16 inner positions)
+                if (mode != IN_IDENT || b || !a->conv.halo_in || (a->npt != 9 && a->npt != 12)) { h->bad_dispatch = true; return MZL_E_INVALID; }
+                if (a->npt == 12) hipLaunchKernelGGL((k_lc_conv<12, IN_IDENT, 0, 0x1ff, true>), grid, dim3(256), lds, st, pj);
+                else hipLaunchKernelGGL((k_lc_conv<9, IN_IDENT, 0, 0x1ff, true>), grid, dim3(256), lds, st, pj);
+            } else
             if (a->npt == 16) {  // the wide tiles of the Atari net (gathered: identity staging)
                 if (mode != IN_IDENT) { h->bad_dispatch = true; return MZL_E_INVALID; }
                 hipLaunchKernelGGL((k_lc_conv<16, IN_IDENT, 0>), grid, dim3(256), lds, st, pj);
@@ -758,6 +765,24 @@ struct AtariRun {
         }
         run(o);
     }
+    // (round 6: out_plane) the same conv with the scatter folded into its epilogue: the tile's inner outputs go straight to their place in `plane`
+    // [B][C][H][W] (+ `skip`, a plane of the same shape), and with `stat_part` the BatchNorm forward partial sums are taken per tile (pivoted, the
+    // format k_lc_bn_fwd reads).  Returns the statistic groups written, or -1 when this build / shape does not take the route (the caller scatters).
+    bool plane_route(int C, int H, int W) const { return h->out_plane && (size_t)B * C * H * W * sizeof(float) < ((size_t)1 << 32); }
+    int conv_tiles_plane(const LayerInfo& L, bool dgrad, int H, int W, const float* in, float* plane, const float* skip, float* stat_part) const {
+        const Sched s = tiles(dgrad ? L.cout : L.cin_real, H, W);
+        LcConv c = s.conv_base(L, dgrad);
+        c.in0 = in; c.in_mode = IN_IDENT; c.out = plane; c.skip = skip;
+        c.stat_mode = stat_part ? ST_FWD : ST_NONE; c.stat_part = stat_part;
+        Op o = s.op_conv(c);
+        const int tw = tile_w(W);
+        o.conv.halo_in = 1; o.conv.G = 1; o.conv.h = TILE; o.conv.w_img = tw; o.conv.qstride = (4 * (TILE + 2) * (tw + 2) + 63) & ~63;
+        o.conv.out_plane = 1; o.conv.pl_h = H; o.conv.pl_w = W; o.conv.pl_nty = H / TILE; o.conv.pl_ntx = W / tw;
+        o.npt = (TILE * tw) / 16;
+        o.side15 = 0;
+        run(o);
+        return B * ntiles(H, W);
+    }
     // one parity plane's share of a stride-2 conv: the packed copy at `w_off`; accumulate: out += (the earlier planes' sum rides in `skip`)
     void conv_par(int w_off, int cin, int cout, int H, int W, const float* in, float* out, bool accumulate, int tapmask) const {
         const Sched s = tiles(cin, H, W);
@@ -849,13 +874,20 @@ struct AtariRun {
             float* xa = h->keep_tiles ? sb.xt[2 * r] : h->TA;      // (kept: the backward pass's weight gradient multiplies these very tiles)
             float* xb = h->keep_tiles ? sb.xt[2 * r + 1] : h->TA;
             gather(cur, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, xa);
-            conv_tiles(L1, false, H, W, xa, h->TB);
-            int ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
+            int ng;
+            if (plane_route(C, H, W)) ng = conv_tiles_plane(L1, false, H, W, xa, sb.y[2 * r], nullptr, h->stat[0]);
+            else {
+                conv_tiles(L1, false, H, W, xa, h->TB);
+                ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
+            }
             bn_fwd(L1, sb.fcoef[2 * r], sb.save[2 * r], ng, count);
             apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
             gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, xb);
-            conv_tiles(L2, false, H, W, xb, h->TB);
-            ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
+            if (plane_route(C, H, W)) ng = conv_tiles_plane(L2, false, H, W, xb, sb.y[2 * r + 1], nullptr, h->stat[0]);
+            else {
+                conv_tiles(L2, false, H, W, xb, h->TB);
+                ng = scatter(h->TB, C, H, W, sb.y[2 * r + 1], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
+            }
             bn_fwd(L2, sb.fcoef[2 * r + 1], sb.save[2 * r + 1], ng, count);
             apply(sb.y[2 * r + 1], cur, sb.fcoef[2 * r + 1], sb.x[r], C, hw);
             cur = sb.x[r];
@@ -873,15 +905,21 @@ struct AtariRun {
             gather(sb.dzA, sb.y[2 * r + 1], sb.bcoef[2 * r + 1], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             if (!h->keep_tiles) gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L2, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r + 1] : h->TC, nullptr);
-            conv_tiles(L2, true, H, W, h->TA, h->TB);
-            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr, halo_in());
+            if (plane_route(C, H, W)) conv_tiles_plane(L2, true, H, W, h->TA, sb.gF, nullptr, nullptr);
+            else {
+                conv_tiles(L2, true, H, W, h->TA, h->TB);
+                scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr, halo_in());
+            }
             ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
             bn_bwd(L1, sb.save[2 * r], sb.bcoef[2 * r], ng, count);
             gather(sb.dzB, sb.y[2 * r], sb.bcoef[2 * r], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             if (!h->keep_tiles) gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L1, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r] : h->TC, nullptr);
-            conv_tiles(L1, true, H, W, h->TA, h->TB);
-            scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr, halo_in());  // + the block's skip gradient
+            if (plane_route(C, H, W)) conv_tiles_plane(L1, true, H, W, h->TA, sb.gF, sb.dzA, nullptr);  // + the block's skip gradient
+            else {
+                conv_tiles(L1, true, H, W, h->TA, h->TB);
+                scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr, halo_in());  // + the block's skip gradient
+            }
             if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
         }
     }
@@ -1034,6 +1072,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->halo_in = !getenv("MZLC_NO_HALO_IN");
     h->ring_rows = !getenv("MZLC_NO_RING_ROWS");
     h->keep_tiles = !getenv("MZLC_NO_KEEP_TILES");
+    h->out_plane = h->halo_in && !getenv("MZLC_NO_OUT_PLANE");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
@@ -1242,6 +1281,8 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (e == hipSuccess) e = conv_attr<6, 0>();
     if (e == hipSuccess) e = conv_attr<5, 0>();
     if (e == hipSuccess) e = conv_attr<13, 0>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<9, IN_IDENT, 0, 0x1ff, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lc_conv<12, IN_IDENT, 0, 0x1ff, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = conv_taps_attr<13, 0x010>();
     if (e == hipSuccess) e = conv_taps_attr<13, 0x018>();
     if (e == hipSuccess) e = conv_taps_attr<13, 0x012>();

@@ -91,6 +91,9 @@ struct LcConv {
                            // positions only.  (Before: the haloed tile was convolved as an image of its own, (h + 2) x (w + 2) outputs of which the
                            // scatter kept h x w -- 252 of 192 at the 48 x 48 stage, 196 of 144 at 24 x 24: a quarter of the MFMAs thrown away.)
                            // IN_IDENT staging, G == 1, no action planes.
+    int out_plane;         // round 6, with halo_in: 1: the "images" are the tiles of planes [B][cout][pl_h][pl_w] cut pl_nty x pl_ntx (tile = h x w_img inner
+    int pl_h, pl_w, pl_nty, pl_ntx;  // positions) and `out` / `skip` ARE those planes: the epilogue writes the tile's outputs where they belong (and adds the
+                           // skip from there) -- k_lc_tile_scatter's job, without the pass over the tiles; ST_FWD statistics per tile as for any image.
 };
 
 // taps of a TAPMASK build: their number and the k-th one (compile-time)
@@ -102,7 +105,9 @@ constexpr int tm_tap(int m, int k) { for (int i = 0; i < 9; i++) if ((m >> i) & 
 // TAPMASK != 0x1ff: only the taps of the mask exist (the parity planes of the Atari representation's stride-2 convs have 1, 2, 2 and 4 of the
 // nine: run with all nine and zero weights they cost four convolutions for one); their weights are packed [co tile][block][tap of the mask] and
 // come one block ahead through two register sets instead of the ring.
-template <int NPT, int MODE, int SIDE, int TAPMASK = 0x1ff>
+// PLANE: the out_plane epilogue (the tile path's stride-1 convs) as a build of its own -- the towers' builds do not carry its address arithmetic
+// (measured: as a run-time branch it cost the 19 x 19 net's update 0.3 ms of 45.5).
+template <int NPT, int MODE, int SIDE, int TAPMASK = 0x1ff, bool PLANE = false>
 __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const bool second = (int)blockIdx.y >= PJ.na;
     LcConv L = second ? PJ.b : PJ.a;
@@ -319,7 +324,13 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
     const bool co_ok = co < L.cout;
     const __amdgpu_buffer_rsrc_t rs_out = mkrs(L.out), rs_skip = mkrs(L.skip ? L.skip : L.out), rs_mask = mkrs(L.mask ? L.mask : L.out),
                                  rs_part = mkrs(L.partner ? L.partner : L.out);
-    const unsigned soff = (unsigned)((size_t)img0 * L.cout * hw * sizeof(float));
+    // (out_plane: G == 1, the workgroup's image is tile (tyi, txi) of plane image pb; offsets stay below 4 GiB: the launcher checks the plane tensor's size)
+    constexpr bool oplane = PLANE;
+    const int pl_nt = oplane ? L.pl_nty * L.pl_ntx : 1;
+    const int pimg = oplane ? img0 / pl_nt : 0, ptl = oplane ? img0 - pimg * pl_nt : 0, tyi = oplane ? ptl / L.pl_ntx : 0, txi = oplane ? ptl - tyi * L.pl_ntx : 0;
+    const int pl_hw = L.pl_h * L.pl_w;
+    const unsigned soff = oplane ? (unsigned)(((size_t)pimg * L.cout * pl_hw + (size_t)(tyi * L.h) * L.pl_w + (size_t)txi * L.w_img) * sizeof(float))
+                                 : (unsigned)((size_t)img0 * L.cout * hw * sizeof(float));
     float ma = 1.0f, mb = 0.0f;
     if (L.mask && L.mcoef && co_ok) { ma = L.mcoef[co]; mb = L.mcoef[L.cpad_out + co]; }
     const bool part_is_mask = L.partner == L.mask;
@@ -365,6 +376,10 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 ok[e][r] = co_ok && (pb + e < NPT) && (g < L.G) && (img0 + g < L.B);
+                if (oplane) {
+                    const int py = lc_idiv(pp, r_iw), px = pp - py * L.w_img;
+                    vo[e][r] = (unsigned)(co * pl_hw + py * L.pl_w + px) * (unsigned)sizeof(float);
+                } else
                 vo[e][r] = (unsigned)((g * L.cout + co) * hw + pp) * (unsigned)sizeof(float);
                 pp++;
                 if (pp == hw) { pp = 0; g++; }

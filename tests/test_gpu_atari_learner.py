@@ -372,9 +372,12 @@ def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
                     rs.uniform(-5, 5, (B, K)).astype(np.float32), rs.uniform(-1, 1, (B, K)).astype(np.float32))
     w = torch.from_numpy(rs.uniform(0.3, 1, B).astype(np.float32)).to(dev)
     out = []
-    for flag in (None, 'MZLC_NO_HALO_IN', 'MZLC_NO_KEEP_TILES'):  # (NO_KEEP_TILES: the weight gradient's x tiles gathered again instead of kept from the forward pass)
-        if flag:
-            os.environ[flag] = '1'
+    # (every form with MZLC_NO_OUT_PLANE: the plane-writing epilogue sums the BatchNorm statistics per TILE, the scatter per 32 positions --
+    # the same numbers in another order; it is held to rounding against these below.  NO_KEEP_TILES: the weight gradient's x tiles gathered
+    # again instead of kept from the forward pass)
+    for flags in (('MZLC_NO_OUT_PLANE',), ('MZLC_NO_OUT_PLANE', 'MZLC_NO_HALO_IN'), ('MZLC_NO_OUT_PLANE', 'MZLC_NO_KEEP_TILES'), ()):
+        for f in flags:
+            os.environ[f] = '1'
         try:
             net = build_conv(conv_case('atari_m')).to(dev)
             net.train()
@@ -383,10 +386,17 @@ def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
             out.append((loss.clone(), prio.clone(), hl.grad_flat.clone()))
             hl.close()
         finally:
-            if flag:
-                os.environ.pop(flag, None)
-    for o in out[1:]:
+            for f in flags:
+                os.environ.pop(f, None)
+    for o in out[1:3]:
         assert torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1]) and torch.equal(out[0][2], o[2])
+    # the default build (outputs written straight into the plane by the conv's epilogue, statistics per tile): same arithmetic but for the order
+    # of the BatchNorm partial sums
+    l0, p0, g0 = out[0]
+    l1, p1, g1 = out[3]
+    assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0))
+    assert float((p1 - p0).abs().max()) <= 1e-5 * float(p0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 2e-4 * float(g0.abs().max())
 
 
 def test_checkpoint_round_trip_and_planner_epoch():
