@@ -193,6 +193,7 @@ struct mzlc_learner {
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     bool halo_in = true;      // the tiled stages' stride-1 convs compute the inner positions of a tile only (MZLC_NO_HALO_IN=1 at create: whole haloed tiles)
     bool ring_rows = true;    // the tiled stages' weight gradients reduce over the inner rows of a tile only (MZLC_NO_RING_ROWS=1 at create: all rows, ring zeroed)
+    bool row_steps = true;    // (with ring_rows) a reduction step of those weight gradients is one row of a wide tile's 16 inner columns (MZLC_NO_ROW_STEPS=1: 16 flat positions)
     bool out_plane = true;    // (with halo_in) the tiled stages' stride-1 convs write their outputs straight into the plane, add the skip from there and sum the
                               // BatchNorm statistics per tile (MZLC_NO_OUT_PLANE=1 at create: inner-only tiles + k_lc_tile_scatter)
     bool keep_tiles = true;   // the forward pass's gathered input tiles stay in HBM (0.8 GB at batch 128) and ARE the weight gradient's x operand
@@ -850,6 +851,10 @@ struct AtariRun {
             g.nsteps = cdiv((g.h - 2) * g.P4, 16);
             g.SPY = 16 * g.nsteps + 4;
             g.SPX = 2 * g.P4 + 16 * g.nsteps + 12;
+            if (h->row_steps && g.P4 > 16 && g.w_img - 2 <= 16 && (g.h - 2) * g.P4 + 4 <= g.SPY) {  // one step per tile row (the planes keep their size)
+                g.ring_rows = 2;
+                g.nsteps = g.h - 2;
+            }
         }
         if (tapmap) {
             ops[1].wr.use_map = 1;
@@ -1073,6 +1078,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->ring_rows = !getenv("MZLC_NO_RING_ROWS");
     h->keep_tiles = !getenv("MZLC_NO_KEEP_TILES");
     h->out_plane = h->halo_in && !getenv("MZLC_NO_OUT_PLANE");
+    h->row_steps = h->ring_rows && !getenv("MZLC_NO_ROW_STEPS");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };

@@ -468,6 +468,10 @@ struct LcWgrad {
     int ring_rows;         // round 6, with ring_zero: 1: the dy plane holds rows 1 .. h - 2 only -- the first and last row of a haloed tile are all ring, i.e. all
                            // zeros, and were 2 P4 of the reduction's positions (18 -> 15 steps of 16 positions for a 14 x 18 tile, 14 -> 12 for 14 x 14) --
                            // and the x plane's "zero row above / below" slots carry the tile's real rows 0 and h - 1.  nsteps / SPY / SPX are those of h - 2 rows.
+                           // 2: and a reduction step is one ROW of the tile's inner columns (w - 2 <= 16 of them) instead of 16 consecutive flat positions:
+                           // both planes are stored one position to the left, so that the inner columns 1 .. w - 2 are slots 0 .. of their pitch row and
+                           // step g reads the aligned quads of row g; the ring columns' dy (zeros) have no slot, the pad slots are never multiplied:
+                           // nsteps = h - 2 (a 14 x 18 tile, pitch 20: 12 steps for 15 -- a fifth of the MFMAs were pad and ring columns).
 };
 
 // ACT: the layer has action-plane input channels (the dynamics net's first conv); the other builds carry none of that code.
@@ -532,8 +536,9 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         sx_ok[e] = spos[e] >= 0;
         sposy[e] = spos[e];
         if (RING && L.ring_rows) {  // (one image per round: the launcher checks) row py of the tile is row py - 1 of the planes; rows 0 and h - 1 exist in x only
-            spos[e] -= L.P4;
-            sposy[e] = (py >= 1 && py <= L.h - 2) ? spos[e] : 16 * L.nsteps;
+            const bool rows2 = L.ring_rows == 2;
+            spos[e] -= rows2 ? L.P4 + 1 : L.P4;
+            sposy[e] = (py >= 1 && py <= L.h - 2 && (!rows2 || (px >= 1 && px <= L.w_img - 2))) ? spos[e] : L.SPY - 4;
         }
     }
     float4 rdz[8], ry[8], rx[8];
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             // (the loop of round 5, unconditional stores: a per-store predicate here cost the board net's update 6 % when it was tried.  ring_rows: the
-            // tile's rows 0 and h - 1 have no dy slot -- their dy values, zeros, go to the plane's unused 4-float tail at 16 nsteps)
+            // tile's rows 0 and h - 1 have no dy slot -- their dy values, zeros, go to the plane's unused 4-float tail at SPY - 4)
             if (sx_ok[e]) {
                 float* py = s_y + sposy[e] + wave * L.SPY;
                 float* px = dx_ + spos[e] + wave * L.SPX;
@@ -627,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const float* py_ = s_y + (wm * 16 + i16) * L.SPY + 4 * kq;             // + 16 g: the lane's dy quad
     const float* px_ = s_x + (wn * 16 + i16) * L.SPX + L.P4 + 4 + 4 * kq;   // + 16 g + dy P4: the centre quad of row dy
     const int P4 = L.P4;
+    const int GS = (RING && L.ring_rows == 2) ? P4 : 16;  // floats from one reduction step's quads to the next one's
     for (int b = b_lo; b < b_hi; b += SGn) {
         __syncthreads();  // the previous round's MFMAs have read the planes (first pass: the zero fill is complete)
         stage();
@@ -637,11 +643,11 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         struct OpSet { float4 a4; float4 c4[3]; float lf[3], rg[3]; };
         auto request = [&](int g, OpSet& o) {
             const int gc = g < L.nsteps ? g : L.nsteps - 1;
-            o.a4 = *reinterpret_cast<const float4*>(py_ + 16 * gc);
+            o.a4 = *reinterpret_cast<const float4*>(py_ + GS * gc);
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
                 if (((TAPMASK >> (3 * dy)) & 7) != 0) {  // (a row none of whose taps exists is not read)
-                    const float* r = px_ + 16 * gc + (dy - 1) * P4;
+                    const float* r = px_ + GS * gc + (dy - 1) * P4;
                     o.c4[dy] = *reinterpret_cast<const float4*>(r);
                     if ((TAPMASK >> (3 * dy)) & 1) o.lf[dy] = r[-1];
                     if ((TAPMASK >> (3 * dy + 2)) & 1) o.rg[dy] = r[4];
