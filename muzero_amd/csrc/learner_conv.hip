@@ -78,7 +78,8 @@ int cdiv(int a, int b) { return (a + b - 1) / b; }
 // the tiling is then chosen by the time of one launch, (rounds of workgroups over the CUs) x (tiles per workgroup), `wg_per_group` workgroups
 // per image group (output-channel blocks x paired jobs): at batch 128 a 6 x 6 hidden state packs best as 4 images in 9 tiles, but that is 128
 // workgroups on 256 CUs, and 2 images in 6 tiles fills the chip in 2/3 of the time.  Ties / images == 0: the densest packing.
-bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256, bool stack_wgrad = true, bool allow16 = false) {
+bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int wg_per_group = 1, int cus = 256, bool stack_wgrad = true, bool allow16 = false,
+               int wgrad_blocks = 0) {
     g.h = hh; g.w = ww; g.hw = hh * ww;
     if (g.hw < 1 || g.hw > (allow16 ? 256 : 240)) return false;
     const int QP = (g.hw + 3) / 4;
@@ -103,14 +104,29 @@ bool make_geom(Geom& g, int hh, int ww, bool allow_side15, int images = 0, int w
     // pitch layout's own row separator; the zero rows above and below are shared): a 6 x 6 plane is 9 pixel quads -- 9 of a wave's 64 staging lanes and
     // two barriers per image otherwise.  As many as the staging lanes hold and as leave two workgroups per CU their LDS (80 KB each).
     // MZLC_STACK_ROWS=1 at create: the first form of this -- images stacked vertically with a zero row between them (more padding: kept for A/B)
+    // Among the counts that fit, the one with the shortest launch at the batch the learner is built for (round 6): workgroup rounds over the CUs' two slots x
+    // staging rounds per workgroup x steps per round, with wgrad_ops' own chunking -- a 6 x 6 plane takes 5 per round, but at batch 128 that is 13 chunks
+    // of 10 images = 416 workgroups of a paired launch on 512 slots; 4 per round is 16 chunks of 8 = 512, and 11 steps for 14 (Atari update: 29.0 -> 28.55 ms).
     g.SG = 1;
     g.stack_rows = getenv("MZLC_STACK_ROWS") != nullptr;
-    if (stack_wgrad)
-        for (int sg = 2; sg <= 16 && sg * QP <= 64; sg++) {
-            const int p4 = g.stack_rows ? g.P4 : 4 * cdiv(sg * (g.w + 1), 4);
-            const int ns = g.stack_rows ? cdiv((sg * (g.h + 1) - 1) * p4, 16) : cdiv(g.h * p4, 16);
-            if (((size_t)32 * (32 * ns + 2 * p4 + 16) + 160) * sizeof(float) <= 80 * 1024) g.SG = sg;
+    const int sg_cap = getenv("MZLC_WGRAD_SG") ? atoi(getenv("MZLC_WGRAD_SG")) : 16;
+    if (stack_wgrad) {
+        long best_c = 0;
+        bool have = false;
+        for (int sg = 1; sg <= sg_cap && sg * QP <= 64; sg++) {
+            const int p4 = (g.stack_rows || sg == 1) ? g.P4 : 4 * cdiv(sg * (g.w + 1), 4);
+            const int ns = (g.stack_rows && sg > 1) ? cdiv((sg * (g.h + 1) - 1) * p4, 16) : cdiv(g.h * p4, 16);
+            if (sg > 1 && ((size_t)32 * (32 * ns + 2 * p4 + 16) + 160) * sizeof(float) > 80 * 1024) continue;
+            long c = -(long)sg;  // (no batch given: as many as fit)
+            if (images > 0 && wgrad_blocks > 0 && !getenv("MZLC_WGRAD_SG_MAX")) {
+                int chunks = cus / wgrad_blocks;  // (the towers' layers run paired: wgrad_ops)
+                chunks = chunks < 1 ? 1 : (chunks > images ? images : chunks);
+                const int ipw = cdiv(cdiv(images, chunks), sg) * sg;
+                c = (long)cdiv(cdiv(images, ipw) * wgrad_blocks * 2, 2 * cus) * (ipw / sg) * ns;
+            }
+            if (!have || c <= best_c) { best_c = c; g.SG = sg; have = true; }  // (ties: more images per round)
         }
+    }
     if (g.SG > 1 && !g.stack_rows) g.P4 = 4 * cdiv(g.SG * (g.w + 1), 4);
     g.nsteps = (g.SG > 1 && g.stack_rows) ? cdiv((g.SG * (g.h + 1) - 1) * g.P4, 16) : cdiv(g.h * g.P4, 16);
     g.SPY = 16 * g.nsteps + 4;
@@ -1097,7 +1113,8 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     if (cfg->in_dim != h->C0 * h->obsH * h->obsW) return bad("in_dim must equal in_channels * board_h * board_w");
     if (cfg->value_support_size < 1 || cfg->reward_support_size < 1 || cfg->value_support_size > 1024 || cfg->reward_support_size > 1024) return bad("support sizes must be in [1, 1024]");
     if (h->hw > 240 || h->P > 1024) return bad("conv learner: boards up to 240 points and 1024 planes (larger nets train through muzero_amd.learner.train_step)");
-    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"), getenv("MZLC_DENSE_TILING") ? 0 : h->maxB, cdiv(cdiv(h->P, 16), 4) * 2, h->num_cus, !getenv("MZLC_NO_WGRAD_STACK"))) return bad("board does not fit the conv kernels' tiling");
+    if (!make_geom(h->gm, h->h, h->w, !getenv("MZLC_NO_SIDE"), getenv("MZLC_DENSE_TILING") ? 0 : h->maxB, cdiv(cdiv(h->P, 16), 4) * 2, h->num_cus, !getenv("MZLC_NO_WGRAD_STACK"), false,
+                   cdiv(cdiv(h->P, 16), 2) * cdiv(cdiv(h->P, 16), 2))) return bad("board does not fit the conv kernels' tiling");
     if (wgrad_lds(h->gm) > 160 * 1024 || conv_lds(h->gm.qstride, pad16(h->P + h->A)) > 160 * 1024) return bad("board too large for the conv learner's LDS layout");
     h->wide_tiles = !getenv("MZLC_NO_WIDE_TILES");
     if (h->atari && (!make_geom(h->gt, TILE + 2, TILE + 2, false) || !make_geom(h->g12, TILE, TILE, false) ||
