@@ -86,7 +86,9 @@ const char* mzl_last_error(void);
  *              tiles instead of the tiles' inner positions only: round 5's form), MZLC_NO_OUT_PLANE=1 (those convolutions write inner-only tiles that k_lc_tile_scatter
  *              moves into the plane and takes the BatchNorm statistics of, instead of doing both in their own epilogue), MZLC_NO_RING_ROWS=1 (their weight gradients reduce over every row of the haloed tile,
  *              ring zeroed, instead of the inner rows), MZLC_NO_ROW_STEPS=1 (16 flat positions per reduction step of those instead of one row of a wide tile's inner columns), MZLC_NO_KEEP_TILES=1 (the tiled stages' input tiles gathered again for the weight gradient instead of kept
- *              from the forward pass), MZLC_WGRAD_MIN_IPW=n (least images per weight-gradient workgroup) */
+ *              from the forward pass), MZLC_WGRAD_MIN_IPW=n (least images per weight-gradient workgroup), MZLC_DEFER_WGRAD=0 / 1 (the shared towers' block layers take their weight
+ *              gradient per unroll step / in one launch per layer over all steps; default: one launch where a step's batch is at most four staging rounds per
+ *              workgroup), MZLC_WGRAD_SG=n (at most n images per staging round) */
 
 int mzl_create(const mzl_config* cfg, int device_id, mz_learner** out);
 int mzl_destroy(mz_learner* h);

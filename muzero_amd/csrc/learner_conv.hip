@@ -55,6 +55,7 @@ struct TensorInfo {
 };
 struct AppBufs {  // saved tensors of ONE application of a tower (representation: 1, dynamics / prediction: K)
     std::vector<float*> y, x, fcoef, save, bcoef;
+    std::vector<float*> dz;  // defer_wgrad: dz of every layer's BatchNorm output, kept until the steps' weight gradients run in one launch per layer
 };
 enum OpKind { OP_CONV, OP_WGRAD, OP_WREDUCE, OP_BNFWD, OP_BNBWD, OP_APPLY, OP_WGRAD_ACT };
 struct Op {
@@ -209,6 +210,10 @@ struct mzlc_learner {
     bool par_compact = true;  // the parity planes of conv_1 / conv_2 on their own taps only (MZLC_NO_TAPSETS=1 at create: nine taps, zero weights)
     bool halo_in = true;      // the tiled stages' stride-1 convs compute the inner positions of a tile only (MZLC_NO_HALO_IN=1 at create: whole haloed tiles)
     bool ring_rows = true;    // the tiled stages' weight gradients reduce over the inner rows of a tile only (MZLC_NO_RING_ROWS=1 at create: all rows, ring zeroed)
+    bool defer_wgrad = false; // the shared towers' block layers: weight gradients of all K unroll steps in one launch per layer, after the last step's backward
+                              // (decided at create: where one step's batch is <= 4 staging rounds per workgroup -- small planes; MZLC_DEFER_WGRAD=0 / 1 overrides)
+    LcWgradSrc* d_srcs = nullptr;  // [tower 1, 2][layer][K]
+    int srcs_stride[2] = {0, 0};   // layers of the tower
     bool row_steps = true;    // (with ring_rows) a reduction step of those weight gradients is one row of a wide tile's 16 inner columns (MZLC_NO_ROW_STEPS=1: 16 flat positions)
     bool out_plane = true;    // (with halo_in) the tiled stages' stride-1 convs write their outputs straight into the plane, add the skip from there and sum the
                               // BatchNorm statistics per tile (MZLC_NO_OUT_PLANE=1 at create: inner-only tiles + k_lc_tile_scatter)
@@ -286,9 +291,13 @@ void add_head(mzlc_learner* h, int hi, const std::string& name, int oc, int n_ou
     add_tensor(h, name + ".4.bias", n_out, 0, &H.lb_off);
 }
 
-bool alloc_app(mzlc_learner* h, const TowerInfo& t, AppBufs& a, size_t elems) {
+bool alloc_app(mzlc_learner* h, const TowerInfo& t, AppBufs& a, size_t elems, bool with_dz = false) {
     bool ok = true;
     const int nl = (int)t.layers.size(), nx = t.R + (t.conv0 ? 1 : 0);
+    if (with_dz) {
+        a.dz.resize(nl);
+        for (int i = 0; i < nl; i++) ok = ok && dalloc(h, &a.dz[i], elems) == hipSuccess;
+    }
     a.y.resize(nl); a.fcoef.resize(nl); a.save.resize(nl); a.bcoef.resize(nl); a.x.resize(nx);
     const int cpad = pad16(h->P > 128 ? h->P : 128);
     for (int i = 0; i < nl; i++) {
@@ -442,26 +451,56 @@ struct Sched {
         return const_cast<float*>(cur);
     }
 
+    // weight gradient of a block layer the K unroll steps share, all steps in one launch (LcWgrad::srcs); x_mode: IN_BNRELU (second conv of a block)
+    // or IN_IDENT.  Chunks: as many per step as keep the launch at two workgroups per CU (one with a paired launch), at least one.
+    void wgrad_ops_steps(std::vector<Op>& ops, const LayerInfo& L, const LcWgradSrc* srcs, int nsrc, int x_mode) const {
+        Op o{};
+        o.kind = OP_WGRAD;
+        LcWgrad& g = o.wg;
+        g.srcs = srcs; g.nsrc = nsrc; g.x_mode = x_mode; g.num_actions = h->A;
+        g.cin_real = L.cin_real; g.cin = L.cin; g.cout = L.cout; g.ci_tiles = cdiv(g.cin, 16); g.co_tiles = L.co_tiles;
+        g.cpad_in = pad16(L.cin_real); g.cpad_out = pad16(L.cout);
+        g.B = B; g.h = this->g.h; g.w_img = this->g.w; g.P4 = this->g.P4; g.nsteps = this->g.nsteps; g.SPY = this->g.SPY; g.SPX = this->g.SPX; g.sg = this->g.SG; g.sg_cols = (this->g.SG > 1 && !this->g.stack_rows) ? 1 : 0;
+        g.co_blocks = cdiv(g.co_tiles, 2);
+        const int ci_blocks = cdiv(g.ci_tiles, 2);
+        int cps = (lane_pairs ? 1 : 2) * h->num_cus / (g.co_blocks * ci_blocks) / nsrc;
+        cps = cps < 1 ? 1 : (cps > B ? B : cps);
+        g.ipw = cdiv(B, cps);
+        if (g.ipw < h->wgrad_min_ipw) g.ipw = h->wgrad_min_ipw < B ? h->wgrad_min_ipw : B;
+        g.ipw = cdiv(g.ipw, g.sg) * g.sg;  // whole staging rounds
+        g.cps = cdiv(B, g.ipw);
+        g.part = h->wpart[lane];
+        ops.push_back(o);
+        Op r{};
+        r.kind = OP_WREDUCE;
+        r.wr.part = g.part; r.wr.grad = h->grads + L.w_off; r.wr.chunks = nsrc * g.cps; r.wr.cout = L.cout; r.wr.cin = L.cin;
+        r.wr.co_pad = g.co_tiles * 16; r.wr.ci_pad = g.ci_tiles * 16; r.wr.accumulate = 0;
+        ops.push_back(r);
+    }
+
     // backward of one tower application.  D[lane][0] holds dz of the tower's last BatchNorm, its partial sums are in stat[lane] (entry_groups groups).
     // final_out: where the gradient wrt the tower's input goes (null: not needed -- the representation tower); final_skip: added to it.
     void tower_bwd(std::vector<Op>& ops, const TowerInfo& t, AppBufs& a, const float* x_in, const int* action, int entry_groups, int accumulate,
-                   float* final_out, const float* final_skip) const {
-        float *Da = h->D[lane][0], *Db = h->D[lane][1], *Dc = h->D[lane][2];
+                   float* final_out, const float* final_skip, bool defer = false) const {
+        // defer (h->defer_wgrad, the shared towers): every layer's dz goes to its own buffer of the application (a.dz) and the block layers' weight
+        // gradients are left to wgrad_ops_steps, after the last step's backward; the caller's entry kernel wrote a.dz.back()
+        float *Da = defer ? a.dz.back() : h->D[lane][0], *Db = h->D[lane][1], *Dc = h->D[lane][2];
         const int li = t.conv0 ? 1 : 0, xi = t.conv0 ? 1 : 0;
         int ng = entry_groups;
         for (int r = t.R - 1; r >= 0; r--) {
             const int l1 = li + 2 * r, l2 = l1 + 1;
+            if (defer) { Db = a.dz[l1]; Dc = l1 > 0 ? a.dz[l1 - 1] : h->D[lane][2]; }
             const LayerInfo &L1 = h->layers[t.layers[l1]], &L2 = h->layers[t.layers[l2]];
             const float* xin_blk = r > 0 ? a.x[xi + r - 1] : (t.conv0 ? a.x[0] : x_in);
             ops.push_back(op_bnbwd(L2, a.save[l2], a.bcoef[l2], ng, accumulate));
-            wgrad_ops(ops, L2, Da, a.y[l2], a.bcoef[l2], a.y[l1], IN_BNRELU, a.fcoef[l1], nullptr, accumulate);
+            if (!defer) wgrad_ops(ops, L2, Da, a.y[l2], a.bcoef[l2], a.y[l1], IN_BNRELU, a.fcoef[l1], nullptr, accumulate);
             LcConv c = conv_base(L2, true);
             c.in0 = Da; c.in1 = a.y[l2]; c.coef = a.bcoef[l2]; c.in_mode = IN_BNBWD; c.out = Db;
             c.mask = a.y[l1]; c.mcoef = a.fcoef[l1]; c.partner = a.y[l1]; c.stat_mode = ST_BWD; c.stat_part = h->stat[lane];
             ops.push_back(op_conv(c));
             ng = groups();
             ops.push_back(op_bnbwd(L1, a.save[l1], a.bcoef[l1], ng, accumulate));
-            wgrad_ops(ops, L1, Db, a.y[l1], a.bcoef[l1], xin_blk, IN_IDENT, nullptr, nullptr, accumulate);
+            if (!defer) wgrad_ops(ops, L1, Db, a.y[l1], a.bcoef[l1], xin_blk, IN_IDENT, nullptr, nullptr, accumulate);
             LcConv d = conv_base(L1, true);
             d.in0 = Db; d.in1 = a.y[l1]; d.coef = a.bcoef[l1]; d.in_mode = IN_BNBWD; d.skip = Da;
             if (r > 0 || t.conv0) {  // the block's input is itself a ReLU output behind a BatchNorm: mask + that layer's partial sums
@@ -600,7 +639,8 @@ int launch_ops(mzlc_learner* h, const Op* a, const Op* b, hipStream_t st) {
         case OP_WGRAD: {
             Pair<LcWgrad> pj{};
             pj.a = a->wg;
-            const int ya = a->wg.co_blocks * cdiv(a->wg.B, a->wg.ipw), yb = b ? b->wg.co_blocks * cdiv(b->wg.B, b->wg.ipw) : 0;
+            auto wg_chunks = [](const LcWgrad& g) { return (g.srcs ? g.nsrc : 1) * cdiv(g.B, g.ipw); };
+            const int ya = a->wg.co_blocks * wg_chunks(a->wg), yb = b ? b->wg.co_blocks * wg_chunks(b->wg) : 0;
             pj.na = ya;
             if (b) pj.b = b->wg;
             int x = cdiv(a->wg.ci_tiles, 2);
@@ -1185,9 +1225,40 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     }
     if (!h->atari) ok = ok && alloc_app(h, h->tower[0], h->app_rep, h->T);
     h->app_dyn.resize(h->K); h->app_pred.resize(h->K);
-    for (int t = 0; t < h->K; t++) ok = ok && alloc_app(h, h->tower[1], h->app_dyn[t], h->T) && alloc_app(h, h->tower[2], h->app_pred[t], h->T);
+    {   // one launch per shared layer for the K steps' weight gradients where a single step's share is a few staging rounds per workgroup
+        const int blocks = cdiv(cdiv(h->P, 16), 2) * cdiv(cdiv(h->P, 16), 2);
+        int chunks = (h->paired ? 1 : 2) * h->num_cus / blocks;
+        chunks = chunks < 1 ? 1 : (chunks > h->maxB ? h->maxB : chunks);
+        const int rounds = cdiv(cdiv(h->maxB, chunks), h->gm.SG);
+        h->defer_wgrad = h->K > 1 && rounds <= 4 && h->tower[1].R > 0;
+        if (const char* m = getenv("MZLC_DEFER_WGRAD")) h->defer_wgrad = atoi(m) != 0 && h->K > 1 && h->tower[1].R > 0;
+    }
+    for (int t = 0; t < h->K; t++)
+        ok = ok && alloc_app(h, h->tower[1], h->app_dyn[t], h->T, h->defer_wgrad) && alloc_app(h, h->tower[2], h->app_pred[t], h->T, h->defer_wgrad);
     h->s.resize(h->K);
     for (int t = 0; t < h->K; t++) AL(&h->s[t], h->T);
+    if (h->defer_wgrad && ok) {  // the steps' operand table of every block layer (fixed buffers: written once)
+        std::vector<LcWgradSrc> tab;
+        for (int tw = 0; tw < 2; tw++) {
+            const TowerInfo& T = h->tower[1 + tw];
+            const int nl = (int)T.layers.size(), li = T.conv0 ? 1 : 0, xi = li;
+            h->srcs_stride[tw] = nl;
+            for (int l = 0; l < nl; l++)
+                for (int t = 0; t < h->K; t++) {
+                    const AppBufs& a = tw == 0 ? h->app_dyn[t] : h->app_pred[t];
+                    LcWgradSrc e{};
+                    if (l >= li) {
+                        const int r = (l - li) >> 1;
+                        e.dz = a.dz[l]; e.y = a.y[l]; e.dcoef = a.bcoef[l];
+                        if ((l - li) & 1) { e.x0 = a.y[l - 1]; e.xcoef = a.fcoef[l - 1]; }  // second conv of block r: x = relu(bn(y1)), formed while staging
+                        else { e.x0 = r > 0 ? a.x[xi + r - 1] : (T.conv0 ? a.x[0] : h->s[t]); e.xcoef = nullptr; }
+                    }
+                    tab.push_back(e);
+                }
+        }
+        ok = ok && dalloc(h, &h->d_srcs, tab.size()) == hipSuccess &&
+             hipMemcpy(h->d_srcs, tab.data(), tab.size() * sizeof(LcWgradSrc), hipMemcpyHostToDevice) == hipSuccess;
+    }
     AL(&h->obs, (size_t)h->maxB * h->C0 * h->obsH * h->obsW);
     ok = ok && dalloc(h, &h->act, (size_t)h->K * h->maxB) == hipSuccess;
     {
@@ -1205,6 +1276,11 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
             const int cot = L.co_tiles, cit = cdiv(L.cin, 16), blocks = cdiv(cot, 2) * cdiv(cit, 2);
             int chunks = 2 * h->num_cus / blocks;
             chunks = chunks < 1 ? 1 : (chunks > h->max_imgs ? h->max_imgs : chunks);
+            if (h->defer_wgrad) {  // (wgrad_ops_steps: at least one chunk per step)
+                int cps = 2 * h->num_cus / blocks / h->K;
+                cps = cps < 1 ? 1 : (cps > h->maxB ? h->maxB : cps);
+                chunks = h->K * cps > chunks ? h->K * cps : chunks;
+            }
             const size_t n = (size_t)chunks * 9 * cot * 16 * cit * 16;
             mx = n > mx ? n : mx;
         }
@@ -1491,19 +1567,31 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     for (int t = K - 1; t >= 0; t--) {
         const size_t tb = (size_t)t * B * h->P * h->hw;
         LcEntry ed{};
-        ed.x = g_raw[t]; ed.gs = gs_next; ed.extra = h->dF_rew + tb; ed.partner = h->app_dyn[t].y.back(); ed.dz = h->D[0][0]; ed.stat_part = h->stat[0];
+        ed.x = g_raw[t]; ed.gs = gs_next; ed.extra = h->dF_rew + tb; ed.partner = h->app_dyn[t].y.back(); ed.dz = h->defer_wgrad ? h->app_dyn[t].dz.back() : h->D[0][0]; ed.stat_part = h->stat[0];
         ed.scale = 0.5f; ed.B = B; ed.C = h->P; ed.hw = h->hw; ed.cpad = pad16(h->P);
         launch_entry(h, ed, st);
         LcEntry ep = ed;
-        ep.x = f_out[t]; ep.gs = nullptr; ep.extra = h->dF_pred + tb; ep.partner = h->app_pred[t].y.back(); ep.dz = h->D[1][0]; ep.stat_part = h->stat[1];
+        ep.x = f_out[t]; ep.gs = nullptr; ep.extra = h->dF_pred + tb; ep.partner = h->app_pred[t].y.back(); ep.dz = h->defer_wgrad ? h->app_pred[t].dz.back() : h->D[1][0]; ep.stat_part = h->stat[1];
         launch_entry(h, ep, st);
         float* gs_t = gs_bufs[t & 1];
         const int acc = t == K - 1 ? 0 : 1;
         ops.clear(); ops2.clear();
-        s0.tower_bwd(ops, h->tower[1], h->app_dyn[t], h->s[t], h->act + (size_t)t * B, eg, acc, gs_t, h->GsP);
-        s1.tower_bwd(ops2, h->tower[2], h->app_pred[t], h->s[t], nullptr, eg, acc, h->GsP, nullptr);
+        s0.tower_bwd(ops, h->tower[1], h->app_dyn[t], h->s[t], h->act + (size_t)t * B, eg, acc, gs_t, h->GsP, h->defer_wgrad);
+        s1.tower_bwd(ops2, h->tower[2], h->app_pred[t], h->s[t], nullptr, eg, acc, h->GsP, nullptr, h->defer_wgrad);
         if (run_zip(h, ops, ops2, false, st, paired)) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
         gs_next = gs_t;
+    }
+    if (h->defer_wgrad) {  // the block layers of the two shared towers: K steps per launch, dynamics and prediction layer side by side
+        ops.clear(); ops2.clear();
+        const Sched* sc[2] = {&s0, &s1};
+        std::vector<Op>* ol[2] = {&ops, &ops2};
+        for (int tw = 0; tw < 2; tw++) {
+            const TowerInfo& T = h->tower[1 + tw];
+            const int li = T.conv0 ? 1 : 0, nl = (int)T.layers.size();
+            for (int l = li; l < nl; l++)
+                sc[tw]->wgrad_ops_steps(*ol[tw], h->layers[T.layers[l]], h->d_srcs + ((size_t)tw * h->srcs_stride[0] + l) * K, K, ((l - li) & 1) ? IN_BNRELU : IN_IDENT);
+        }
+        if (run_zip(h, ops, ops2, true, st, paired && ops.size() == ops2.size())) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
     }
     if (h->atari) {
         atari_rep_bwd(h, B, gs_next, st);

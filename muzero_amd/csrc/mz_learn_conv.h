@@ -448,6 +448,9 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
 // a pad position contributes 0.  Lane (i, kq) multiplies positions 16 g + 4 kq + s in k-step s: dy is one aligned 16-byte read, and the tap
 // shifts dx = -1 / +1 of x are the same quad with one element taken from the neighbouring dword -- a register choice.
 // ---------------------------------------------------------------------------------------------------------------------------------
+struct LcWgradSrc {        // one unroll step's operands of a layer the steps share (see LcWgrad::srcs)
+    const float *dz, *y, *dcoef, *x0, *xcoef;
+};
 struct LcWgrad {
     const float* dz;       // [B][cout][hw]
     const float* y;        // [B][cout][hw]
@@ -464,6 +467,10 @@ struct LcWgrad {
     int sg;                // images per staging round (nsteps / SPY / SPX / P4 are the round's)
     int sg_cols;           // 1: the round's images side by side (column offset gi (w + 1)); 0: stacked vertically (row offset gi (h + 1))
     int tapmask;           // 0 / 0x1ff: all nine taps; else only these accumulators exist (a parity plane of a stride-2 conv; see k_lc_conv's TAPMASK)
+    const LcWgradSrc* srcs;  // round 6, or null: the layer's operands of `nsrc` unroll steps (device table) -- the dynamics / prediction towers apply the same
+    int nsrc, cps;           // weights at every step, and on a 6 x 6 plane one step's batch is two staging rounds per workgroup: prologue, write-out and the
+                             // reduce launch cost more than the MFMAs.  All steps in ONE launch: chunk c is chunk c % cps of step c / cps (B images per step;
+                             // dz / y / dcoef / x0 / xcoef above are not read), `cps` chunks per step.
     int ring_zero;         // 1: the outermost ring of every dy image is multiplied by 0 (tiles gathered with their halo: only the inner pixels are outputs)
     int ring_rows;         // round 6, with ring_zero: 1: the dy plane holds rows 1 .. h - 2 only -- the first and last row of a haloed tile are all ring, i.e. all
                            // zeros, and were 2 P4 of the reduction's positions (18 -> 15 steps of 16 positions for a 14 x 18 tile, 14 -> 12 for 14 x 14) --
@@ -492,8 +499,15 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         byy = g * Yc + blk / X;
     }
     const bool second = byy >= PJ.na;
-    const LcWgrad L = second ? PJ.b : PJ.a;
+    LcWgrad L = second ? PJ.b : PJ.a;
     const int by = second ? byy - PJ.na : byy;
+    int lchunk = by / L.co_blocks;  // the chunk within its unroll step
+    if (L.srcs) {
+        const int s = lchunk / L.cps;
+        lchunk -= s * L.cps;
+        const LcWgradSrc S = L.srcs[s];
+        L.dz = S.dz; L.y = S.y; L.dcoef = S.dcoef; L.x0 = S.x0; L.xcoef = S.xcoef;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sm = reinterpret_cast<float*>(smem);
     const int ybuf = 32 * L.SPY, xbuf = 32 * L.SPX;
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     float4 rdz[8], ry[8], rx[8];
     int r_act = -1;
     bool r_ok = false;  // this lane's image of the round in flight belongs to the chunk (the last round may be short: its idle slots are staged as zeros)
-    const int b_lo = chunk * L.ipw, b_hi = (b_lo + L.ipw < L.B) ? b_lo + L.ipw : L.B;
+    const int b_lo = lchunk * L.ipw, b_hi = (b_lo + L.ipw < L.B) ? b_lo + L.ipw : L.B;
     auto fetch = [&](int b) {  // round of images b .. b + sg - 1
         const int bi = b + (s_ok ? gi : 0);
         r_ok = s_ok && bi < b_hi;

@@ -310,6 +310,33 @@ def test_batch_read_from_the_ring_by_index_and_unpaired_launches_agree_bit_for_b
     assert torch.equal(hl.running, hl2.running) and torch.equal(hl.num_batches, hl2.num_batches)
 
 
+def test_weight_gradients_of_all_unroll_steps_in_one_launch_match_the_per_step_launches():
+    """Round 6: where one unroll step's batch is a few staging rounds per weight-gradient workgroup (small planes), the block layers of the
+    dynamics / prediction towers take their weight gradient from ONE launch per layer over all K steps (LcWgrad::srcs, after the last step's
+    backward) instead of K accumulating launches.  Same products, summed in another order: loss and priorities (forward only) are the same
+    bits, the gradient agrees to float32 rounding."""
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(5)
+    for board, planes, blocks, chan, B, K in ((6, 64, 2, 3, 32, 5), (9, 32, 3, 4, 17, 3), (3, 16, 1, 2, 8, 5)):
+        net, A = _net(board, planes, blocks, chan, 40 + board, dev)
+        tr = _batch(rs, B, (chan, board, board), A, K=K)
+        w = torch.from_numpy(rs.uniform(0.3, 1.0, B).astype(np.float32)).to(dev)
+        out = []
+        for flag in ('1', '0'):
+            os.environ['MZLC_DEFER_WGRAD'] = flag
+            try:
+                hl = _hip(copy.deepcopy(net), dev, B, K=K)
+            finally:
+                del os.environ['MZLC_DEFER_WGRAD']
+            la, pa = hl.grad(_ring(tr, dev), None, w, B)
+            out.append((la.clone(), pa.clone(), hl.grad_flat.clone()))
+            hl.close()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        g1, g0 = out[0][2], out[1][2]
+        assert float((g1 - g0).abs().max()) <= 2e-6 * float(g0.abs().max()), (board, float((g1 - g0).abs().max()), float(g0.abs().max()))
+        assert not torch.equal(g1, g0) or B == 1  # (the two forms really are different launches)
+
+
 def test_checkpoint_round_trip_and_inference_after_load_state_dict():
     """weights written through the learner (load_state_dict, apply) must reach the module's inference engine; the
     optimizer / scheduler views keep torch's checkpoint format (pipeline.py:224-230)."""
