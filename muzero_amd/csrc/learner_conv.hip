@@ -214,6 +214,8 @@ struct mzlc_learner {
                               // (decided at create: where one step's batch is <= 4 staging rounds per workgroup -- small planes; MZLC_DEFER_WGRAD=0 / 1 overrides)
     LcWgradSrc* d_srcs = nullptr;  // [tower 1, 2][layer][K]
     int srcs_stride[2] = {0, 0};   // layers of the tower
+    bool fuse_entry = true;   // (with out_plane) the tiled stages' data-gradient convs mask their result and take the BatchNorm-backward sums themselves
+                              // (MZLC_NO_FUSE_ENTRY=1: a gradient plane + k_lc_entry_plain)
     bool row_steps = true;    // (with ring_rows) a reduction step of those weight gradients is one row of a wide tile's 16 inner columns (MZLC_NO_ROW_STEPS=1: 16 flat positions)
     bool out_plane = true;    // (with halo_in) the tiled stages' stride-1 convs write their outputs straight into the plane, add the skip from there and sum the
                               // BatchNorm statistics per tile (MZLC_NO_OUT_PLANE=1 at create: inner-only tiles + k_lc_tile_scatter)
@@ -826,11 +828,16 @@ struct AtariRun {
     // [B][C][H][W] (+ `skip`, a plane of the same shape), and with `stat_part` the BatchNorm forward partial sums are taken per tile (pivoted, the
     // format k_lc_bn_fwd reads).  Returns the statistic groups written, or -1 when this build / shape does not take the route (the caller scatters).
     bool plane_route(int C, int H, int W) const { return h->out_plane && (size_t)B * C * H * W * sizeof(float) < ((size_t)1 << 32); }
-    int conv_tiles_plane(const LayerInfo& L, bool dgrad, int H, int W, const float* in, float* plane, const float* skip, float* stat_part) const {
+    // `mask` (with `partner`): the data gradient's consumer folded in as in the towers -- the result is zeroed where the plane `mask` (a materialised
+    // ReLU output) is <= 0 and the BatchNorm-backward partial sums against `partner` (that layer's raw conv output) are taken per tile: dz of the
+    // layer below leaves the conv directly (before: a gradient plane, then k_lc_entry_plain over it).
+    int conv_tiles_plane(const LayerInfo& L, bool dgrad, int H, int W, const float* in, float* plane, const float* skip, float* stat_part,
+                         const float* mask = nullptr, const float* partner = nullptr) const {
         const Sched s = tiles(dgrad ? L.cout : L.cin_real, H, W);
         LcConv c = s.conv_base(L, dgrad);
         c.in0 = in; c.in_mode = IN_IDENT; c.out = plane; c.skip = skip;
-        c.stat_mode = stat_part ? ST_FWD : ST_NONE; c.stat_part = stat_part;
+        c.stat_mode = stat_part ? (mask ? ST_BWD : ST_FWD) : ST_NONE; c.stat_part = stat_part;
+        c.mask = mask; c.mcoef = nullptr; c.partner = partner;
         Op o = s.op_conv(c);
         const int tw = tile_w(W);
         o.conv.halo_in = 1; o.conv.G = 1; o.conv.h = TILE; o.conv.w_img = tw; o.conv.qstride = (4 * (TILE + 2) * (tw + 2) + 63) & ~63;
@@ -966,22 +973,29 @@ struct AtariRun {
             gather(sb.dzA, sb.y[2 * r + 1], sb.bcoef[2 * r + 1], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             if (!h->keep_tiles) gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L2, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r + 1] : h->TC, nullptr);
-            if (plane_route(C, H, W)) conv_tiles_plane(L2, true, H, W, h->TA, sb.gF, nullptr, nullptr);
+            if (plane_route(C, H, W) && h->fuse_entry) ng = conv_tiles_plane(L2, true, H, W, h->TA, sb.dzB, nullptr, h->stat[0], sb.h1[r], sb.y[2 * r]);
             else {
-                conv_tiles(L2, true, H, W, h->TA, h->TB);
-                scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr, halo_in());
+                if (plane_route(C, H, W)) conv_tiles_plane(L2, true, H, W, h->TA, sb.gF, nullptr, nullptr);
+                else {
+                    conv_tiles(L2, true, H, W, h->TA, h->TB);
+                    scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, nullptr, nullptr, halo_in());
+                }
+                ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
             }
-            ng = entry(sb.h1[r], nullptr, 1.0f, sb.gF, sb.y[2 * r], sb.dzB, C, hw);
             bn_bwd(L1, sb.save[2 * r], sb.bcoef[2 * r], ng, count);
             gather(sb.dzB, sb.y[2 * r], sb.bcoef[2 * r], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             if (!h->keep_tiles) gather(xin_blk, nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L1, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r] : h->TC, nullptr);
-            if (plane_route(C, H, W)) conv_tiles_plane(L1, true, H, W, h->TA, sb.gF, sb.dzA, nullptr);  // + the block's skip gradient
+            if (plane_route(C, H, W) && h->fuse_entry && r > 0)  // (in place: every element of dzA is read -- the skip gradient -- and written by the same lane)
+                ng = conv_tiles_plane(L1, true, H, W, h->TA, sb.dzA, sb.dzA, h->stat[0], xin_blk, sb.y[2 * r - 1]);
             else {
-                conv_tiles(L1, true, H, W, h->TA, h->TB);
-                scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr, halo_in());  // + the block's skip gradient
+                if (plane_route(C, H, W)) conv_tiles_plane(L1, true, H, W, h->TA, sb.gF, sb.dzA, nullptr);  // + the block's skip gradient
+                else {
+                    conv_tiles(L1, true, H, W, h->TA, h->TB);
+                    scatter(h->TB, C, H, W, sb.gF, H, W, 1, 1, 0, 0, sb.dzA, nullptr, halo_in());  // + the block's skip gradient
+                }
+                if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
             }
-            if (r > 0) ng = entry(xin_blk, nullptr, 1.0f, sb.gF, sb.y[2 * r - 1], sb.dzA, C, hw);
         }
     }
 };
@@ -1135,6 +1149,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->keep_tiles = !getenv("MZLC_NO_KEEP_TILES");
     h->out_plane = h->halo_in && !getenv("MZLC_NO_OUT_PLANE");
     h->row_steps = h->ring_rows && !getenv("MZLC_NO_ROW_STEPS");
+    h->fuse_entry = !getenv("MZLC_NO_FUSE_ENTRY");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
