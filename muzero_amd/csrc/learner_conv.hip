@@ -785,6 +785,8 @@ struct AtariRun {
         g.src0 = src0; g.src1 = src1; g.coef = coef; g.dst = dst; g.mode = mode; g.B = B; g.C = C; g.cpad = pad16(C); g.H = H; g.W = W;
         g.srcH = srcH; g.srcW = srcW; g.sy = sy; g.sx = sx; g.py = py; g.px = px; g.Ty = TILE; g.Tx = tw; g.nty = H / TILE; g.ntx = W / tw; g.inner_only = inner_only;
         g.n = (long long)B * g.nty * g.ntx * C * ts2;
+        static const bool xcd = !getenv("MZLC_NO_GATHER_XCD");
+        g.xcd = xcd ? 1 : 0;
         const dim3 grid((unsigned)(B * g.nty * g.ntx), (unsigned)cdiv(C * ts2, 1024));
         if (tw == 16) hipLaunchKernelGGL((k_lc_tile_gather<TILE + 2, 18>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_lc_tile_gather<TILE + 2, TILE + 2>), grid, dim3(256), 0, st, g);

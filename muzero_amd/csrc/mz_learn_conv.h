@@ -1204,13 +1204,19 @@ struct LcTileGather {
     int Ty, Tx, nty, ntx;            // tile size (rows x columns of plane positions) and count
     int inner_only;      // 1: the halo ring is written as zeros (the dy operand of the weight gradient: only the tile's own pixels count)
     long long n;         // elements of dst
+    int xcd;             // 1: XCD-aware tile order (k_lc_tile_gather)
 };
 // grid (tiles, chunks of 1024 tile elements): the tile's coordinates are workgroup-uniform (scalar), the element's (c, ly, lx) divide by compile-time
 // constants; four elements per thread, their loads issued together (one 4-byte load per thread in flight left the kernel latency-bound at 1.5 TB/s)
 template <int TSY, int TSX>
 __global__ __launch_bounds__(256) void k_lc_tile_gather(const LcTileGather L) {
     constexpr int ts2 = TSY * TSX;
-    const int ti = blockIdx.x, j0 = blockIdx.y * 1024 + threadIdx.x, nel = L.C * ts2;
+    // XCD-aware order (round 6): workgroups go to the 8 XCDs round-robin by linear id, and neighbouring tiles share the source plane's cache lines (a
+    // 14 x 18 tile's rows are 72 bytes at a 192-byte pitch): in launch order every line was fetched into two or three L2s.  Remapped, XCD k takes
+    // the k-th eighth of the tiles -- whole images next to each other.
+    int ti = blockIdx.x;
+    if (L.xcd && (gridDim.x & 7) == 0) ti = (ti & 7) * (gridDim.x >> 3) + (ti >> 3);
+    const int j0 = blockIdx.y * 1024 + threadIdx.x, nel = L.C * ts2;
     const int nt = L.nty * L.ntx, b = ti / nt, t = ti - b * nt, tyi = t / L.ntx, txi = t - tyi * L.ntx;
     const float* s0 = L.src0 + (size_t)b * L.C * L.srcH * L.srcW;
     const float* s1 = L.mode == IN_BNBWD ? L.src1 + (size_t)b * L.C * L.srcH * L.srcW : s0;
