@@ -216,6 +216,8 @@ struct mzlc_learner {
     int srcs_stride[2] = {0, 0};   // layers of the tower
     bool fuse_entry = true;   // (with out_plane) the tiled stages' data-gradient convs mask their result and take the BatchNorm-backward sums themselves
                               // (MZLC_NO_FUSE_ENTRY=1: a gradient plane + k_lc_entry_plain)
+    bool skip_h1 = true;      // (with fuse_entry and keep_tiles) the tiled stages' inner activation relu(bn(conv1)) exists as TILES only -- formed by the gather from
+                              // the raw conv output -- and the backward mask is the sign of a y + b as in the towers (MZLC_KEEP_H1=1: the plane too; same bits)
     bool row_steps = true;    // (with ring_rows) a reduction step of those weight gradients is one row of a wide tile's 16 inner columns (MZLC_NO_ROW_STEPS=1: 16 flat positions)
     bool out_plane = true;    // (with halo_in) the tiled stages' stride-1 convs write their outputs straight into the plane, add the skip from there and sum the
                               // BatchNorm statistics per tile (MZLC_NO_OUT_PLANE=1 at create: inner-only tiles + k_lc_tile_scatter)
@@ -834,12 +836,12 @@ struct AtariRun {
     // ReLU output) is <= 0 and the BatchNorm-backward partial sums against `partner` (that layer's raw conv output) are taken per tile: dz of the
     // layer below leaves the conv directly (before: a gradient plane, then k_lc_entry_plain over it).
     int conv_tiles_plane(const LayerInfo& L, bool dgrad, int H, int W, const float* in, float* plane, const float* skip, float* stat_part,
-                         const float* mask = nullptr, const float* partner = nullptr) const {
+                         const float* mask = nullptr, const float* partner = nullptr, const float* mcoef = nullptr) const {
         const Sched s = tiles(dgrad ? L.cout : L.cin_real, H, W);
         LcConv c = s.conv_base(L, dgrad);
         c.in0 = in; c.in_mode = IN_IDENT; c.out = plane; c.skip = skip;
         c.stat_mode = stat_part ? (mask ? ST_BWD : ST_FWD) : ST_NONE; c.stat_part = stat_part;
-        c.mask = mask; c.mcoef = nullptr; c.partner = partner;
+        c.mask = mask; c.mcoef = mcoef; c.partner = partner;  // (mcoef: the mask is where a mask + b > 0 -- a ReLU that was never materialised)
         Op o = s.op_conv(c);
         const int tw = tile_w(W);
         o.conv.halo_in = 1; o.conv.G = 1; o.conv.h = TILE; o.conv.w_img = tw; o.conv.qstride = (4 * (TILE + 2) * (tw + 2) + 63) & ~63;
@@ -951,8 +953,11 @@ struct AtariRun {
                 ng = scatter(h->TB, C, H, W, sb.y[2 * r], H, W, 1, 1, 0, 0, nullptr, h->stat[0], halo_in());
             }
             bn_fwd(L1, sb.fcoef[2 * r], sb.save[2 * r], ng, count);
-            apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
-            gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, xb);
+            if (h->skip_h1 && plane_route(C, H, W)) gather(sb.y[2 * r], nullptr, sb.fcoef[2 * r], IN_BNRELU, C, H, W, H, W, 1, 1, 0, 0, 0, xb);
+            else {
+                apply(sb.y[2 * r], nullptr, sb.fcoef[2 * r], sb.h1[r], C, hw);
+                gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, xb);
+            }
             if (plane_route(C, H, W)) ng = conv_tiles_plane(L2, false, H, W, xb, sb.y[2 * r + 1], nullptr, h->stat[0]);
             else {
                 conv_tiles(L2, false, H, W, xb, h->TB);
@@ -975,7 +980,8 @@ struct AtariRun {
             gather(sb.dzA, sb.y[2 * r + 1], sb.bcoef[2 * r + 1], IN_BNBWD, C, H, W, H, W, 1, 1, 0, 0, 0, h->TA);
             if (!h->keep_tiles) gather(sb.h1[r], nullptr, nullptr, IN_IDENT, C, H, W, H, W, 1, 1, 0, 0, 0, h->TC);
             wgrad_tiles(L2, C, H, W, h->TA, h->keep_tiles ? sb.xt[2 * r + 1] : h->TC, nullptr);
-            if (plane_route(C, H, W) && h->fuse_entry) ng = conv_tiles_plane(L2, true, H, W, h->TA, sb.dzB, nullptr, h->stat[0], sb.h1[r], sb.y[2 * r]);
+            if (plane_route(C, H, W) && h->skip_h1) ng = conv_tiles_plane(L2, true, H, W, h->TA, sb.dzB, nullptr, h->stat[0], sb.y[2 * r], sb.y[2 * r], sb.fcoef[2 * r]);
+            else if (plane_route(C, H, W) && h->fuse_entry) ng = conv_tiles_plane(L2, true, H, W, h->TA, sb.dzB, nullptr, h->stat[0], sb.h1[r], sb.y[2 * r]);
             else {
                 if (plane_route(C, H, W)) conv_tiles_plane(L2, true, H, W, h->TA, sb.gF, nullptr, nullptr);
                 else {
@@ -1152,6 +1158,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->out_plane = h->halo_in && !getenv("MZLC_NO_OUT_PLANE");
     h->row_steps = h->ring_rows && !getenv("MZLC_NO_ROW_STEPS");
     h->fuse_entry = !getenv("MZLC_NO_FUSE_ENTRY");
+    h->skip_h1 = h->out_plane && h->fuse_entry && h->keep_tiles && !getenv("MZLC_KEEP_H1");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;
     if (const char* m = getenv("MZLC_WGRAD_MIN_IPW")) h->wgrad_min_ipw = atoi(m) > 0 ? atoi(m) : 1;
     auto bad = [&](const std::string& m) { err = m; mzlc_destroy(h); return MZL_E_INVALID; };
@@ -1649,7 +1656,8 @@ int mzlc_apply(mzlc_learner* h, double lr, double beta1, double beta2, double ep
 // [3][pad16(C)], rows a, b), "s" (a = t), "dF_pred" / "dF_rew" (a = t).  Round 6 (tests/forced_masks.py: the decisions of THIS forward pass -- ReLU
 // masks, normalisation arg-min / arg-max -- for a float64 reference that takes the same branches): "feat" the heads' post-ReLU features
 // [3 K groups][B][2 hw]; the Atari representation's plane tensors "a1" / "a2" (post-ReLU conv_1 / conv_2), "s48_h1" / "s48_x" / "s24_h1" / "s24_x"
-// (b = block: the block's inner post-ReLU tensor / its output), "hraw" (the pooled 6 x 6 state before normalisation).  *count: floats of the
+// (b = block: the block's inner post-ReLU tensor -- only with MZLC_KEEP_H1=1; else "s48_y1" / "s48_fcoef1" / .., its raw conv output and BatchNorm
+// coefficients as for "y" / "fcoef" -- and the block's output), "hraw" (the pooled 6 x 6 state before normalisation).  *count: floats of the
 // tensor at the last batch where the shape is known here, else the allocation's.
 int mzlc_debug_tensor(const mzlc_learner* h, const char* what, int a, int b, void** ptr, int64_t* count) {
     const std::string w = what;
@@ -1671,6 +1679,10 @@ int mzlc_debug_tensor(const mzlc_learner* h, const char* what, int a, int b, voi
         if (w == "a2") { *ptr = h->a2; *count = n24; return MZL_OK; }
         if (w == "hraw") { *ptr = h->hraw; *count = (int64_t)h->lastB * h->P * h->hw; return MZL_OK; }
         if (b >= 0 && b < 2) {
+            if (w == "s48_y1") { *ptr = h->sb48.y[2 * b]; *count = n48; return MZL_OK; }
+            if (w == "s24_y1") { *ptr = h->sb24.y[2 * b]; *count = n24; return MZL_OK; }
+            if (w == "s48_fcoef1") { *ptr = h->sb48.fcoef[2 * b]; *count = 3 * 128; return MZL_OK; }
+            if (w == "s24_fcoef1") { *ptr = h->sb24.fcoef[2 * b]; *count = 3 * (int64_t)pad16(h->P); return MZL_OK; }
             if (w == "s48_h1") { *ptr = h->sb48.h1[b]; *count = n48; return MZL_OK; }
             if (w == "s48_x") { *ptr = h->sb48.x[b]; *count = n48; return MZL_OK; }
             if (w == "s24_h1") { *ptr = h->sb24.h1[b]; *count = n24; return MZL_OK; }

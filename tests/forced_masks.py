@@ -82,12 +82,12 @@ def hip_decisions(hl, net, B, K):
     if atari:
         H1, H2, H3 = spec['input_shape'][1] // 2, spec['input_shape'][1] // 4, spec['input_shape'][1] // 8
         masks.append(T.get('a1', 0, 0, (B, 128, H1, H1)) > 0)
-        for r in range(2):
-            masks.append(T.get('s48_h1', 0, r, (B, 128, H1, H1)) > 0)
+        for r in range(2):  # (the block's inner ReLU exists as tiles only: its mask is the sign of a y + b, as in the towers)
+            masks.append(_fma_sign(T.get('s48_y1', 0, r, (B, 128, H1, H1)), T.get('s48_fcoef1', 0, r, (3 * 128,)), 128, 128))
             masks.append(T.get('s48_x', 0, r, (B, 128, H1, H1)) > 0)
         masks.append(T.get('a2', 0, 0, (B, P, H2, H2)) > 0)
         for r in range(2):
-            masks.append(T.get('s24_h1', 0, r, (B, P, H2, H2)) > 0)
+            masks.append(_fma_sign(T.get('s24_y1', 0, r, (B, P, H2, H2)), T.get('s24_fcoef1', 0, r, (3 * cpad,)), P, cpad))
             masks.append(T.get('s24_x', 0, r, (B, P, H2, H2)) > 0)
         tower(2 * K + 1, False, 2, H3, H3)
         norm_of(T.get('hraw', 0, 0, (B, P, h, w)))

@@ -375,7 +375,7 @@ def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
     # (every form with MZLC_NO_OUT_PLANE: the plane-writing epilogue sums the BatchNorm statistics per TILE, the scatter per 32 positions --
     # the same numbers in another order; it is held to rounding against these below.  NO_KEEP_TILES: the weight gradient's x tiles gathered
     # again instead of kept from the forward pass)
-    for flags in (('MZLC_NO_OUT_PLANE',), ('MZLC_NO_OUT_PLANE', 'MZLC_NO_HALO_IN'), ('MZLC_NO_OUT_PLANE', 'MZLC_NO_KEEP_TILES'), ()):
+    for flags in (('MZLC_NO_OUT_PLANE',), ('MZLC_NO_OUT_PLANE', 'MZLC_NO_HALO_IN'), ('MZLC_NO_OUT_PLANE', 'MZLC_NO_KEEP_TILES'), (), ('MZLC_KEEP_H1',)):
         for f in flags:
             os.environ[f] = '1'
         try:
@@ -392,6 +392,9 @@ def test_inner_only_tile_convolutions_are_bit_identical_to_whole_haloed_tiles():
         assert torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1]) and torch.equal(out[0][2], o[2])
     # the default build (outputs written straight into the plane by the conv's epilogue, statistics per tile): same arithmetic but for the order
     # of the BatchNorm partial sums
+    # (MZLC_KEEP_H1: the blocks' inner activation as a plane too, masks read from it -- the default forms it in the gather and masks by the sign of
+    # a y + b: the same values, the same bits)
+    assert torch.equal(out[3][0], out[4][0]) and torch.equal(out[3][1], out[4][1]) and torch.equal(out[3][2], out[4][2])
     l0, p0, g0 = out[0]
     l1, p1, g1 = out[3]
     assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0))
