@@ -212,12 +212,6 @@ struct mzlc_learner {
     bool ring_rows = true;    // the tiled stages' weight gradients reduce over the inner rows of a tile only (MZLC_NO_RING_ROWS=1 at create: all rows, ring zeroed)
     bool defer_wgrad = false; // the shared towers' block layers: weight gradients of all K unroll steps in one launch per layer, after the last step's backward
                               // (decided at create: where one step's batch is <= 4 staging rounds per workgroup -- small planes; MZLC_DEFER_WGRAD=0 / 1 overrides)
-    bool two_streams = false; // the dynamics and the prediction tower of a step as two dependency chains on two streams (the caller's and st2, tied by events)
-                              // instead of side by side in paired launches: every launch of a chain waits for the one before through the batch statistics,
-                              // and two chains that drift apart fill each other's ramp-up, finalize and tail gaps.  Same kernels, same sums as MZLC_NO_PAIR=1.
-    hipStream_t st2 = nullptr;
-    std::vector<hipEvent_t> ev;    // [0, K): forward forks, [K, 2K): backward joins per step, 2K .. 2K + 3: join / fork / join
-    std::vector<float*> GsPk;      // two_streams: the prediction tower's input gradient per step (the chains drift: one buffer would be overwritten early)
     LcWgradSrc* d_srcs = nullptr;  // [tower 1, 2][layer][K]
     int srcs_stride[2] = {0, 0};   // layers of the tower
     bool fuse_entry = true;   // (with out_plane) the tiled stages' data-gradient convs mask their result and take the BatchNorm-backward sums themselves
@@ -1263,14 +1257,6 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
         h->defer_wgrad = h->K > 1 && rounds <= 4 && h->tower[1].R > 0;
         if (const char* m = getenv("MZLC_DEFER_WGRAD")) h->defer_wgrad = atoi(m) != 0 && h->K > 1 && h->tower[1].R > 0;
     }
-    h->two_streams = h->paired && getenv("MZLC_TWO_STREAMS") && atoi(getenv("MZLC_TWO_STREAMS")) != 0;
-    if (h->two_streams) {
-        ok = ok && hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) == hipSuccess;
-        h->ev.resize(2 * h->K + 4);
-        for (hipEvent_t& e : h->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        h->GsPk.resize(h->K);
-        for (int t = 0; t < h->K; t++) ok = ok && dalloc(h, &h->GsPk[t], h->T) == hipSuccess;
-    }
     for (int t = 0; t < h->K; t++)
         ok = ok && alloc_app(h, h->tower[1], h->app_dyn[t], h->T, h->defer_wgrad) && alloc_app(h, h->tower[2], h->app_pred[t], h->T, h->defer_wgrad);
     h->s.resize(h->K);
@@ -1454,8 +1440,6 @@ void mzlc_destroy(mzlc_learner* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    if (h->st2) (void)hipStreamDestroy(h->st2);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -1556,23 +1540,14 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
         for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
     }
     launch_normalize(h, hraw, h->s[0], B, st);
-    const bool two = h->two_streams;
-    hipStream_t sB = two ? h->st2 : st;   // the prediction tower's chain
-    bool ev_ok = true;
-    auto tie = [&](int e, hipStream_t from, hipStream_t to) { ev_ok = ev_ok && hipEventRecord(h->ev[e], from) == hipSuccess && hipStreamWaitEvent(to, h->ev[e], 0) == hipSuccess; };
     std::vector<float*> g_raw(K), f_out(K);
     for (int t = 0; t < K; t++) {
         ops.clear(); ops2.clear();
         g_raw[t] = s0.tower_fwd(ops, h->tower[1], h->app_dyn[t], h->s[t], h->act + (size_t)t * B);
         f_out[t] = s1.tower_fwd(ops2, h->tower[2], h->app_pred[t], h->s[t], nullptr);
-        if (two) {
-            tie(t, st, sB);  // s_t exists
-            for (const Op& o : ops2) launch_ops(h, &o, nullptr, sB);
-            for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
-        } else if (run_zip(h, ops, ops2, true, st, paired)) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
+        if (run_zip(h, ops, ops2, true, st, paired)) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
         if (t + 1 < K) launch_normalize(h, g_raw[t], h->s[t + 1], B, st);
     }
-    if (two) tie(2 * K, sB, st);  // the heads read every step's prediction features
     // ---- heads ----
     const int ng = 3 * K;
     h->groups_host.resize(ng);
@@ -1613,34 +1588,23 @@ int mzlc_grad(mzlc_learner* h, const mzl_batch* b, void* stream, std::string& er
     const int eg = entry_groups(h, B);
     const float* gs_next = nullptr;  // gradient wrt s_{t+1}
     float* gs_bufs[2] = {h->GsA, h->GsB};
-    if (two) tie(2 * K + 1, st, sB);  // the heads' gradients exist
     for (int t = K - 1; t >= 0; t--) {
         const size_t tb = (size_t)t * B * h->P * h->hw;
         LcEntry ed{};
         ed.x = g_raw[t]; ed.gs = gs_next; ed.extra = h->dF_rew + tb; ed.partner = h->app_dyn[t].y.back(); ed.dz = h->defer_wgrad ? h->app_dyn[t].dz.back() : h->D[0][0]; ed.stat_part = h->stat[0];
         ed.scale = 0.5f; ed.B = B; ed.C = h->P; ed.hw = h->hw; ed.cpad = pad16(h->P);
+        launch_entry(h, ed, st);
         LcEntry ep = ed;
         ep.x = f_out[t]; ep.gs = nullptr; ep.extra = h->dF_pred + tb; ep.partner = h->app_pred[t].y.back(); ep.dz = h->defer_wgrad ? h->app_pred[t].dz.back() : h->D[1][0]; ep.stat_part = h->stat[1];
+        launch_entry(h, ep, st);
         float* gs_t = gs_bufs[t & 1];
-        float* gsp = two ? h->GsPk[t] : h->GsP;
         const int acc = t == K - 1 ? 0 : 1;
         ops.clear(); ops2.clear();
-        s0.tower_bwd(ops, h->tower[1], h->app_dyn[t], h->s[t], h->act + (size_t)t * B, eg, acc, gs_t, gsp, h->defer_wgrad);
-        s1.tower_bwd(ops2, h->tower[2], h->app_pred[t], h->s[t], nullptr, eg, acc, gsp, nullptr, h->defer_wgrad);
-        if (two) {  // the prediction tower's backward of step t needs nothing of the dynamics tower's: its chain runs ahead, the dynamics chain picks its result up
-            launch_entry(h, ep, sB);
-            for (const Op& o : ops2) launch_ops(h, &o, nullptr, sB);
-            launch_entry(h, ed, st);
-            tie(K + t, sB, st);
-            for (const Op& o : ops) launch_ops(h, &o, nullptr, st);
-        } else {
-            launch_entry(h, ed, st);
-            launch_entry(h, ep, st);
-            if (run_zip(h, ops, ops2, false, st, paired)) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
-        }
+        s0.tower_bwd(ops, h->tower[1], h->app_dyn[t], h->s[t], h->act + (size_t)t * B, eg, acc, gs_t, h->GsP, h->defer_wgrad);
+        s1.tower_bwd(ops2, h->tower[2], h->app_pred[t], h->s[t], nullptr, eg, acc, h->GsP, nullptr, h->defer_wgrad);
+        if (run_zip(h, ops, ops2, false, st, paired)) { err = "internal: op lists of the paired towers do not line up"; return MZL_E_STATE; }
         gs_next = gs_t;
     }
-    if (!ev_ok) { err = "hipEventRecord / hipStreamWaitEvent"; return MZL_E_HIP; }
     if (h->defer_wgrad) {  // the block layers of the two shared towers: K steps per launch, dynamics and prediction layer side by side
         ops.clear(); ops2.clear();
         const Sched* sc[2] = {&s0, &s1};
