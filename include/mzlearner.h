@@ -87,7 +87,7 @@ const char* mzl_last_error(void);
  *              moves into the plane and takes the BatchNorm statistics of, instead of doing both in their own epilogue), MZLC_NO_FUSE_ENTRY=1 (their data gradients leave a gradient plane for k_lc_entry_plain to mask and sum instead of
  *              masking and summing in the epilogue), MZLC_KEEP_H1=1 (a tiled block's inner activation as a plane too, not only as the next conv's input tiles),
  *              MZLC_NO_RING_ROWS=1 (their weight gradients reduce over every row of the haloed tile,
- *              ring zeroed, instead of the inner rows), MZLC_NO_ROW_STEPS=1 (16 flat positions per reduction step of those instead of one row of a wide tile's inner columns), MZLC_NO_KEEP_TILES=1 (the tiled stages' input tiles gathered again for the weight gradient instead of kept
+ *              ring zeroed, instead of the inner rows), MZLC_NO_ROW_STEPS=1 (16 flat positions per reduction step of those instead of one row of a wide tile's inner columns), MZLC_NO_QUAD_STEPS=1 (the 12-wide tiles' weight gradients step over whole pitch rows, pad quad included), MZLC_NO_KEEP_TILES=1 (the tiled stages' input tiles gathered again for the weight gradient instead of kept
  *              from the forward pass), MZLC_WGRAD_MIN_IPW=n (least images per weight-gradient workgroup), MZLC_DEFER_WGRAD=0 / 1 (the shared towers' block layers take their weight
  *              gradient per unroll step / in one launch per layer over all steps; default: one launch where a step's batch is at most four staging rounds per
  *              workgroup), MZLC_WGRAD_SG=n (at most n images per staging round) */

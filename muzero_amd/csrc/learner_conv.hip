@@ -218,6 +218,7 @@ struct mzlc_learner {
                               // (MZLC_NO_FUSE_ENTRY=1: a gradient plane + k_lc_entry_plain)
     bool skip_h1 = true;      // (with fuse_entry and keep_tiles) the tiled stages' inner activation relu(bn(conv1)) exists as TILES only -- formed by the gather from
                               // the raw conv output -- and the backward mask is the sign of a y + b as in the towers (MZLC_KEEP_H1=1: the plane too; same bits)
+    bool quad_steps = true;   // (with ring_rows) 12-wide tiles: a reduction step is four real quads in row order, the rows' pad quads are skipped (MZLC_NO_QUAD_STEPS=1)
     bool row_steps = true;    // (with ring_rows) a reduction step of those weight gradients is one row of a wide tile's 16 inner columns (MZLC_NO_ROW_STEPS=1: 16 flat positions)
     bool out_plane = true;    // (with halo_in) the tiled stages' stride-1 convs write their outputs straight into the plane, add the skip from there and sum the
                               // BatchNorm statistics per tile (MZLC_NO_OUT_PLANE=1 at create: inner-only tiles + k_lc_tile_scatter)
@@ -921,6 +922,9 @@ struct AtariRun {
             if (h->row_steps && g.P4 > 16 && g.w_img - 2 <= 16 && (g.h - 2) * g.P4 + 4 <= g.SPY) {  // one step per tile row (the planes keep their size)
                 g.ring_rows = 2;
                 g.nsteps = g.h - 2;
+            } else if (h->quad_steps && g.P4 == 16 && g.w_img - 2 == 12 && (3 * (g.h - 2)) % 4 == 0 && (g.h - 2) * g.P4 + 4 <= g.SPY) {  // four real quads per step
+                g.ring_rows = 3;
+                g.nsteps = 3 * (g.h - 2) / 4;
             }
         }
         if (tapmap) {
@@ -1157,6 +1161,7 @@ int mzlc_create(const mzl_config* cfg, int device_id, int num_cus, mzlc_learner*
     h->keep_tiles = !getenv("MZLC_NO_KEEP_TILES");
     h->out_plane = h->halo_in && !getenv("MZLC_NO_OUT_PLANE");
     h->row_steps = h->ring_rows && !getenv("MZLC_NO_ROW_STEPS");
+    h->quad_steps = h->ring_rows && !getenv("MZLC_NO_QUAD_STEPS");
     h->fuse_entry = !getenv("MZLC_NO_FUSE_ENTRY");
     h->skip_h1 = h->out_plane && h->fuse_entry && h->keep_tiles && !getenv("MZLC_KEEP_H1");
     h->act_sparse = !getenv("MZLC_ACT_MFMA") && h->A <= 256;

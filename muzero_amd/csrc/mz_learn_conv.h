@@ -479,6 +479,7 @@ struct LcWgrad {
                            // both planes are stored one position to the left, so that the inner columns 1 .. w - 2 are slots 0 .. of their pitch row and
                            // step g reads the aligned quads of row g; the ring columns' dy (zeros) have no slot, the pad slots are never multiplied:
                            // nsteps = h - 2 (a 14 x 18 tile, pitch 20: 12 steps for 15 -- a fifth of the MFMAs were pad and ring columns).
+                           // 3: as 2 for an inner width of 12 (pitch 16), and a step is the next four REAL quads in row order (see `request`): nsteps = 3 (h - 2) / 4.
 };
 
 // ACT: the layer has action-plane input channels (the dynamics net's first conv); the other builds carry none of that code.
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         sx_ok[e] = spos[e] >= 0;
         sposy[e] = spos[e];
         if (RING && L.ring_rows) {  // (one image per round: the launcher checks) row py of the tile is row py - 1 of the planes; rows 0 and h - 1 exist in x only
-            const bool rows2 = L.ring_rows == 2;
+            const bool rows2 = L.ring_rows >= 2;
             spos[e] -= rows2 ? L.P4 + 1 : L.P4;
             sposy[e] = (py >= 1 && py <= L.h - 2 && (!rows2 || (px >= 1 && px <= L.w_img - 2))) ? spos[e] : L.SPY - 4;
         }
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
     const float* py_ = s_y + (wm * 16 + i16) * L.SPY + 4 * kq;             // + 16 g: the lane's dy quad
     const float* px_ = s_x + (wn * 16 + i16) * L.SPX + L.P4 + 4 + 4 * kq;   // + 16 g + dy P4: the centre quad of row dy
     const int P4 = L.P4;
-    const int GS = (RING && L.ring_rows == 2) ? P4 : 16;  // floats from one reduction step's quads to the next one's
+    const int GS = (RING && L.ring_rows >= 2) ? P4 : 16;  // floats from one reduction step's quads to the next one's
     for (int b = b_lo; b < b_hi; b += SGn) {
         __syncthreads();  // the previous round's MFMAs have read the planes (first pass: the zero fill is complete)
         stage();
@@ -657,11 +658,18 @@ __global__ __launch_bounds__(256, 2) void k_lc_wgrad(const Pair<LcWgrad> PJ) {
         struct OpSet { float4 a4; float4 c4[3]; float lf[3], rg[3]; };
         auto request = [&](int g, OpSet& o) {
             const int gc = g < L.nsteps ? g : L.nsteps - 1;
-            o.a4 = *reinterpret_cast<const float4*>(py_ + GS * gc);
+            // (ring_rows == 3: the tile's inner width is 12 -- three quads a row at pitch 16 -- and a step takes the next FOUR REAL quads, row by row: quad
+            // Q = 4 g + kq of the 3 (h - 2) is row Q / 3, columns 4 (Q % 3); the pad quad of every row is never multiplied: 9 steps for 12 at 14 x 14)
+            int og = GS * gc;
+            if (RING && L.ring_rows == 3) {
+                const int Q = 4 * gc + kq, row = (Q * 43691) >> 17;
+                og = row * P4 + 4 * (Q - 3 * row) - 4 * kq;  // (py_ / px_ carry + 4 kq)
+            }
+            o.a4 = *reinterpret_cast<const float4*>(py_ + og);
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
                 if (((TAPMASK >> (3 * dy)) & 7) != 0) {  // (a row none of whose taps exists is not read)
-                    const float* r = px_ + GS * gc + (dy - 1) * P4;
+                    const float* r = px_ + og + (dy - 1) * P4;
                     o.c4[dy] = *reinterpret_cast<const float4*>(r);
                     if ((TAPMASK >> (3 * dy)) & 1) o.lf[dy] = r[-1];
                     if ((TAPMASK >> (3 * dy + 2)) & 1) o.rg[dy] = r[4];
