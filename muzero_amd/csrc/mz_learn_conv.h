@@ -96,6 +96,9 @@ struct LcConv {
                            // skip from there) -- k_lc_tile_scatter's job, without the pass over the tiles; ST_FWD statistics per tile as for any image.
 };
 
+#ifndef MZLC_EPI_PIPE
+#define MZLC_EPI_PIPE 1
+#endif
 // taps of a TAPMASK build: their number and the k-th one (compile-time)
 constexpr int tm_count(int m) { int c = 0; for (int i = 0; i < 9; i++) c += (m >> i) & 1; return c; }
 constexpr int tm_tap(int m, int k) { for (int i = 0; i < 9; i++) if ((m >> i) & 1) { if (k == 0) return i; k--; } return 0; }
@@ -363,8 +366,74 @@ __global__ __launch_bounds__(256, 2) void k_lc_conv(const Pair<LcConv> PJ) {
         }
     }
     constexpr int EC = NPT < 3 ? NPT : 3;
+    constexpr int NB = (NPT + EC - 1) / EC;
+    // Round 6: where a batch of EC tiles is REGULAR -- every lane's four slots are one whole quad of one image, all real or all padding: the image's
+    // pixel count is a multiple of four, or (one image per workgroup) the tiles lie inside it -- its skip / mask / partner operands are loaded with
+    // unconditional 16-byte loads (padding lanes read a clamped address and discard), and the loads of batch it + 1 are issued BEFORE batch it is
+    // finished and stored: the epilogue of a data-gradient conv was five dependent round trips to L2 / HBM (138.9 us against the forward conv's 130.6 on
+    // the 15 x 15 net).  nfast: the leading regular batches (workgroup-uniform; a compile-time fact in the SIDE builds).
+    const bool quads_whole = (hw & 3) == 0;
+    int nfast = 0;
 #pragma unroll
-    for (int pb = 0; pb < NPT; pb += EC) {
+    for (int it = 0; it < NB; it++)
+        if (nfast == it && (quads_whole || (L.G == 1 && (it * EC + EC) * 16 <= hw))) nfast = it + 1;  // (the tile path's tiles are 12 or 16 wide: whole quads)
+    if (MZLC_EPI_PIPE == 0) nfast = 0;
+    struct Bt { f32x4 kv[EC], mv[EC], yv[EC]; unsigned vo[EC]; bool valid[EC]; };
+    auto issue = [&](int pb, Bt& b) {
+#pragma unroll
+        for (int e = 0; e < EC; e++) {
+            const int p = (pb + e) * 16 + 4 * q;
+            const int g = lc_idiv(p, r_hw), pp = p - g * hw;
+            b.valid[e] = co_ok && (pb + e < NPT) && (g < L.G) && (img0 + g < L.B);
+            const int gs = b.valid[e] ? g : 0, cs = co_ok ? co : 0, ps = b.valid[e] ? pp : 0;  // (a real address for every lane)
+            if (oplane) {
+                const int py = lc_idiv(ps, r_iw), px = ps - py * L.w_img;
+                b.vo[e] = (unsigned)(cs * pl_hw + py * L.pl_w + px) * (unsigned)sizeof(float);
+            } else
+            b.vo[e] = (unsigned)((gs * L.cout + cs) * hw + ps) * (unsigned)sizeof(float);
+            b.kv[e] = b.mv[e] = b.yv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pb + e < NPT) {
+                if (L.skip) { const float4 t = ld4(rs_skip, b.vo[e], soff); b.kv[e] = f32x4{t.x, t.y, t.z, t.w}; }
+                if (L.mask) { const float4 t = ld4(rs_mask, b.vo[e], soff); b.mv[e] = f32x4{t.x, t.y, t.z, t.w}; }
+                if (L.partner && !part_is_mask) { const float4 t = ld4(rs_part, b.vo[e], soff); b.yv[e] = f32x4{t.x, t.y, t.z, t.w}; }
+            }
+        }
+    };
+    auto finish = [&](int pb, const Bt& b) {
+#pragma unroll
+        for (int e = 0; e < EC; e++) {
+            if (pb + e >= NPT) continue;
+            f32x4 v = acc[pb + e];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float t = v[r] + (b.valid[e] ? b.kv[e][r] : 0.0f);
+                const float mvr = b.valid[e] ? b.mv[e][r] : 0.0f;
+                if (L.mask && !(fmaf(ma, mvr, mb) > 0.0f)) t = 0.0f;
+                if (!b.valid[e]) t = 0.0f;
+                const float pv = b.valid[e] ? (part_is_mask ? b.mv[e][r] : b.yv[e][r]) : 0.0f;
+                if (L.stat_mode == ST_BWD) {
+                    s1 += t;
+                    s2 = fmaf(t, pv, s2);
+                }
+                v[r] = t;
+            }
+            if (b.valid[e])
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs_out,
+                                                       b.vo[e], soff, 0);
+        }
+    };
+    Bt bt[2];
+    if (nfast > 0) issue(0, bt[0]);
+#pragma unroll
+    for (int it = 0; it < NB; it++) {
+        const int pb = it * EC;
+        if (it < nfast) {
+            if (it + 1 < nfast) issue(pb + EC, bt[(it + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(pb, bt[it & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
         unsigned vo[EC][4];
         bool ok[EC][4], vec[EC];
         f32x4 kv[EC], mv[EC], yv[EC];
