@@ -388,8 +388,66 @@ __global__ __launch_bounds__(256, (NCT * NPT > 15) ? 1 : 2) void k_conv3x3(const
         const int co = cot[c] * 16 + j;
         const bool co_ok = co < L.cout;
         const unsigned soff = (unsigned)((size_t)img0 * L.cout * ohw * sizeof(float));
+        // Round 6 (found on the learner's conv first, mz_learn_conv.h): the residual loads of a batch sat inside per-lane `if (vec)` regions, so every batch
+        // of EC tiles was a dependent round trip to L2 / HBM behind the previous batch's stores.  Whole-image builds: where a batch is regular -- every
+        // lane's four slots are one whole quad of one image (pixel count a multiple of four, or the workgroup's only image and the tiles inside it) --
+        // the residual comes by unconditional 16-byte loads (padding lanes read a clamped address and discard) and batch it + 1's are issued before
+        // batch it is finished and stored.  nfast: the leading regular batches (workgroup-uniform; compile-time in the SIDE builds).
+        constexpr int NB = (NPT + EC - 1) / EC;
+        int nfast = 0;
+        struct Bt { f32x4 rv[EC]; unsigned vo[EC]; bool valid[EC]; };
+        Bt bt[2];
+        [[maybe_unused]] auto issue = [&](int p0, Bt& b) {
+#pragma unroll
+            for (int e = 0; e < EC; e++) {
+                const int p = (p0 + e) * 16 + 4 * q;
+                const int g = conv_idiv(p, r_tp), pp = p - g * TP;
+                b.valid[e] = co_ok && (p0 + e < NPT) && (g < L.G) && (img0 + g < L.B);
+                const int gs = b.valid[e] ? g : 0, cs = co_ok ? co : 0, ps = b.valid[e] ? pp : 0;  // (a real address for every lane)
+                b.vo[e] = (unsigned)((gs * L.cout + cs) * ohw + ps) * (unsigned)sizeof(float);
+                b.rv[e] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (L.residual && p0 + e < NPT) {
+                    const conv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, b.vo[e], soff, 0);
+                    b.rv[e] = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+                }
+            }
+        };
+        [[maybe_unused]] auto finish = [&](int p0, const Bt& b) {
+#pragma unroll
+            for (int e = 0; e < EC; e++) {
+                if (p0 + e >= NPT) continue;
+                f32x4 v = acc[c][p0 + e];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float t = v[r] + (b.valid[e] ? b.rv[e][r] : 0.0f);
+                    if (L.relu && !(t > 0.0f)) t = 0.0f;
+                    v[r] = t;
+                }
+                if (b.valid[e])
+                    __builtin_amdgcn_raw_buffer_store_b128(conv_u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                           rs_out, b.vo[e], soff, 0);
+            }
+        };
+#if !defined(MZC_NO_EPI) && !defined(MZC_NO_EPI_PIPE)
+        if constexpr (WHOLE && !SP) {
+#pragma unroll
+            for (int it = 0; it < NB; it++)
+                if (nfast == it && ((ohw & 3) == 0 || (L.G == 1 && (it * EC + EC) * 16 <= ohw))) nfast = it + 1;
+            if (nfast > 0) issue(0, bt[0]);
+        }
+#endif
 #pragma unroll
         for (int p0 = 0; p0 < NPT; p0 += EC) {
+            if constexpr (WHOLE && !SP) {
+                const int it = p0 / EC;
+                if (it < nfast) {
+                    if (it + 1 < nfast) issue(p0 + EC, bt[(it + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(p0, bt[it & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+            }
             unsigned vo[EC][4];
             bool ok[EC][4], vec[EC];
             f32x4 rv[EC];
